@@ -1,0 +1,141 @@
+/*
+ * tpose_hip.h -- C ABI of the MI355X-native t-pose hot path (libtpose_hip.so).
+ *
+ * Drop-in boundary.  In the reference (weigert/t-pose) this path is not behind a plugin ABI but a
+ * name-bound SSBO contract between C++ and GLSL: the eight global `Buffer*` handles and four host
+ * mirrors of source/triangulation.hpp:578-590, bound by name to the shaders in
+ * software/triangulate/main.cpp:84-101 / software/warp/main.cpp:86-108 and driven by the lambdas
+ * computecolors/doreset, doenergy, doshift (triangulate/main.cpp:121-155, warp/main.cpp:140-178).
+ * Each entry point below names the reference interface it replaces.  Plain pointers and sizes
+ * only; every pointer argument is caller-owned and only touched during the call; the context owns
+ * all device memory.  A context is single-threaded; distinct contexts (distinct GPUs) may be
+ * driven from distinct threads.  Every function returns TP_OK (0) or an error code and records a
+ * message retrievable with tp_last_error().  There is NO CPU fallback: without a HIP device
+ * tp_create fails with TP_ERR_NO_DEVICE.
+ *
+ * Buffer layouts are the reference's: variant-major `id = i*NT + t`, i = 0..12 (TDIV), t = triangle
+ * (triangle.vs:47-48); triangles ivec4 (x,y,z = vertex ids, w unused); points vec2 in t-pose space
+ * x in [-RATIO,RATIO], y in [-1,1], y up; colours ivec4.
+ */
+#ifndef TPOSE_HIP_H
+#define TPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TP_ABI_VERSION 1
+#define TP_MAXT (2 << 18) /* tpose::triangulation::MAXT, source/triangulation.hpp:95; 13*NT <= MAXT */
+
+typedef struct tp_context tp_context;
+
+enum tp_status {
+    TP_OK = 0,
+    TP_ERR_INVALID = 1,   /* bad argument */
+    TP_ERR_NO_DEVICE = 2, /* no HIP device / device index out of range */
+    TP_ERR_HIP = 3,       /* a HIP runtime call failed */
+    TP_ERR_CAPACITY = 4,  /* 13*NT > MAXT, raster too large, or a device-side work list overflowed */
+    TP_ERR_STATE = 5      /* call order violated (e.g. energy before accumulate/upload) */
+};
+
+/* which cost function: software/triangulate/shader/ vs software/warp/shader/ */
+enum tp_flavour { TP_TRIANGULATE = 0, TP_WARP = 1 };
+
+/* image slots: `imageTexture` (triangulate) = slot A; `imageA` / `imageB` (warp triangle.fs:23-24) */
+enum tp_slot { TP_IMAGE_A = 0, TP_IMAGE_B = 1 };
+
+/* buffers readable with tp_retrieve -- the SSBOs of triangle.vs:5-32 */
+enum tp_buffer {
+    TP_BUF_TENERGY = 0,  /* int32[13*NT]      `tenergy`  (tpose::tenergybuf -> terr) */
+    TP_BUF_COLNUM = 1,   /* int32[13*NT]      `colnum`   (tpose::tcolnumbuf -> cn) */
+    TP_BUF_COLACC = 2,   /* int32[4*13*NT]    `colacc`   (tpose::tcolaccbuf) ivec4 */
+    TP_BUF_POINTS = 3,   /* float[2*NP]       `points`   (tpose::pointbuf) */
+    TP_BUF_GRADIENT = 4, /* int32[2*NP]       `gradient` (tpose::pgradbuf) ivec2 */
+    TP_BUF_PENERGY = 5,  /* int32[count]      `penergy`  (dead in the reference: lambda = 0,
+                            triangle.vs:107) -- always zeros */
+    TP_BUF_MOMENTS = 6   /* int64[6*13*NT]    {n, n_odd, sum r, sum g, sum b, sum r^2+g^2+b^2} per
+                            variant: the exact single-sweep moments the energies derive from */
+};
+
+/* parameters of a fused grad-iter; tp_default_params fills the reference's hard-coded values */
+typedef struct tp_params {
+    int32_t flavour;    /* tp_flavour */
+    int32_t image_slot; /* raster swept by the cost function.  triangulate: A.  warp: the OTHER
+                           view (warp/shader/triangle.fs:49-50: warpA -> imageB) */
+    float rate;         /* shift.cs:45 -- 0.00005 (triangulate) / 0.00003 (warp) */
+    float dp;           /* vertex perturbation in t-pose units; <= 0 selects the reference law
+                           0.05/(1+4NT/3000) (triangle.vs:60-62) or 0.05/(1+9NT/1000) (warp :63-65) */
+} tp_params;
+
+/* library / device ------------------------------------------------------------------------- */
+int tp_abi_version(void);
+int tp_device_count(int* count);
+const char* tp_last_error(const tp_context* ctx); /* ctx may be NULL: last error of tp_create */
+
+/* tpose::init() (source/triangulation.hpp:592-608) + Tiny::window/Texture setup: one context per
+ * device, for a width x height raster.  RATIO defaults to (float)width/(float)height
+ * (software/triangulate/main.cpp:54). */
+int tp_create(int device, int width, int height, tp_context** out);
+/* tpose::quit() (source/triangulation.hpp:610-626) */
+int tp_destroy(tp_context* ctx);
+
+/* tpose::RATIO (source/tpose.hpp:12); io::read overwrites it (source/io.hpp:81) */
+int tp_set_ratio(tp_context* ctx, float ratio);
+int tp_get_ratio(const tp_context* ctx, float* ratio);
+/* override the vertex perturbation `dp` (triangle.vs:60-62) for the piecewise calls below;
+ * dp <= 0 restores the reference law.  tp_iterate takes its dp from tp_params instead. */
+int tp_set_dp(tp_context* ctx, float dp);
+
+/* `Texture tex(IMG)` (software/triangulate/main.cpp:74, warp/main.cpp:118-119): RGBA8, row 0 = top,
+ * width x height texels, `stride_bytes` between rows.  Host pointer. */
+int tp_set_image(tp_context* ctx, int slot, const uint8_t* rgba, size_t stride_bytes);
+/* same, source already in device memory of this context's device (e.g. a torch tensor) */
+int tp_set_image_device(tp_context* ctx, int slot, const void* dev_rgba, size_t stride_bytes);
+
+/* tpose::upload(tr, uploadcolor) (source/triangulation.hpp:628-643).  points float[2*NP],
+ * triangles int32[4*NT] (ivec4), colors int32[4*NT] (ivec4) or NULL (= uploadcolor false: `colacc`
+ * keeps its contents).  Colours are replicated into the 13 variant blocks device-side. */
+int tp_upload(tp_context* ctx, const float* points, int NP, const int32_t* triangles, int NT,
+              const int32_t* colors);
+
+/* computecolors() / doreset() -- the mode-0 draw (triangulate/main.cpp:121-130, warp/main.cpp:140-151).
+ * `flavour` says which program's vertex stage applies (its dp law).  One sweep of raster `slot`
+ * -- for TP_WARP the image the following mode-1 pass samples -- yields exact per-variant moments,
+ * from which `colnum`/`colacc` (and the mode-1 energies) derive. */
+int tp_accumulate(tp_context* ctx, int flavour, int slot);
+/* doenergy() -- the mode-1 draw (triangulate/main.cpp:132-141, warp/main.cpp:153-164): fills
+ * `tenergy` (and `colnum`, `colacc` for TP_TRIANGULATE) from the moments of the last tp_accumulate. */
+int tp_energy(tp_context* ctx, int flavour);
+/* doshift() -- gradient.cs + shift.cs (triangulate/main.cpp:143-155, warp/main.cpp:166-178) */
+int tp_shift(tp_context* ctx, float rate);
+
+void tp_default_params(int flavour, tp_params* p);
+/* n_iters x { tp_accumulate(image_slot); tp_energy(flavour); tp_shift(rate) } with no host
+ * round trip (the reference reads back four buffers every frame, triangulate/main.cpp:201-204).
+ * Asynchronous: returns after enqueueing; tp_retrieve / tp_synchronize wait. */
+int tp_iterate(tp_context* ctx, const tp_params* p, int n_iters);
+
+/* Buffer::retrieve (triangulate/main.cpp:201-204, 221): copies `count` elements (int32 / float /
+ * int64 units as listed in tp_buffer) into dst after waiting for enqueued work. */
+int tp_retrieve(tp_context* ctx, int what, void* dst, size_t count);
+int tp_synchronize(tp_context* ctx);
+
+/* measurement hooks (bench.py): the HIP stream the kernels run on, and HIP-event timing of the
+ * dominant kernel (the per-pixel accumulate) accumulated over launches since the last reset.
+ * Timing is only collected on the un-fused path used by tp_profile_iterate. */
+int tp_get_stream(tp_context* ctx, void** hip_stream);
+/* runs n_iters grad-iters eagerly with HIP events around every accumulate launch; returns the
+ * average accumulate-kernel duration in microseconds */
+int tp_profile_iterate(tp_context* ctx, const tp_params* p, int n_iters, double* accumulate_us);
+
+/* introspection for tests/benchmarks: 0 = tiles_x, 1 = tiles_y, 2 = tile width, 3 = tile height,
+ * 4 = (triangle,tile) pairs of the last binning, 5 = device-side overflow flags */
+int tp_get_info(tp_context* ctx, int what, int64_t* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPOSE_HIP_H */

@@ -1,0 +1,89 @@
+// CPU emulation of the k_accumulate / k_finalize data flow (tests only, never shipped):
+// runs the SAME per-lane integer logic (tpose_amd/csrc/tp_raster.h) tile by tile, with the LDS
+// prefix table as a plain array.  Lets the span walker be checked against the oracle without a GPU.
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#include "../../tpose_amd/csrc/tp_raster.h"
+
+#define TW 128
+#define TH 32
+
+extern "C" int emul_moments(const uint8_t* img, size_t stride, int W, int H, const float* points,
+                            const int32_t* tris, int NT, float dp, float ratio, int64_t* mom,
+                            int64_t* npairs) {
+    tp_view vw;
+    vw.dp = dp; vw.ratio = ratio; vw.halfW = 0.5f * (float)W; vw.halfH = 0.5f * (float)H; vw.W = W; vw.H = H;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    memset(mom, 0, sizeof(int64_t) * 6 * 13 * (size_t)NT);
+    std::vector<uint32_t> P((size_t)TH * (TW + 1) * 3);
+    int64_t pairs = 0;
+    for (int ty = 0; ty < tiles_y; ty++)
+        for (int tx = 0; tx < tiles_x; tx++) {
+            // prefix table (zero outside the raster, like the padded device plane)
+            for (int r = 0; r < TH; r++) {
+                uint32_t w0 = 0, w1 = 0, w2 = 0;
+                for (int c = 0; c <= TW; c++) {
+                    uint32_t* e = &P[((size_t)r * (TW + 1) + c) * 3];
+                    e[0] = w0; e[1] = w1; e[2] = w2;
+                    const int ar = ty * TH + r, ac = tx * TW + c;
+                    if (c < TW && ar < H && ac < W) {
+                        const uint8_t* p = img + (size_t)ar * stride + 4 * (size_t)ac;
+                        const uint32_t R = p[0], G = p[1], B = p[2];
+                        w0 += R | (G << 16); w1 += B | (((R + G + B) & 1u) << 16); w2 += R * R + G * G + B * B;
+                    }
+                }
+            }
+            const int row0 = ty * TH, row1 = tp_min(row0 + TH - 1, H - 1);
+            const int col0 = tx * TW, colE = tp_min(col0 + TW, W);
+            for (int t = 0; t < NT; t++) {
+                float p[3][2];
+                for (int s = 0; s < 3; s++) { p[s][0] = points[2 * tris[4 * t + s]]; p[s][1] = points[2 * tris[4 * t + s] + 1]; }
+                tp_bbox bb = tp_triangle_bbox(p, vw);
+                if (bb.c0 > bb.c1 || bb.r0 > bb.r1) continue;
+                if (bb.c1 / TW < tx || bb.c0 / TW > tx || bb.r1 / TH < ty || bb.r0 / TH > ty) continue;
+                pairs++;
+                for (int v = 0; v < 13; v++) {
+                    int32_t X[3], Y[3];
+                    for (int s = 0; s < 3; s++) tp_vertex_stage(p[s][0], p[s][1], v, s, vw, X[s], Y[s]);
+                    tp_span sp = tp_setup_span(X, Y, row0, row1);
+                    uint32_t n = 0, no = 0, sr = 0, sg = 0, sb = 0, q = 0;
+                    for (int r = sp.r0; r <= sp.r1; r++) {
+                        int32_t lo, hi;
+                        tp_span_row(sp, col0, colE, lo, hi);
+                        if (lo < hi) {
+                            const uint32_t* a = &P[((size_t)(r - row0) * (TW + 1) + (lo - col0)) * 3];
+                            const uint32_t* b = &P[((size_t)(r - row0) * (TW + 1) + (hi - col0)) * 3];
+                            const uint32_t d0 = b[0] - a[0], d1 = b[1] - a[1];
+                            n += hi - lo; sr += d0 & 0xffffu; sg += d0 >> 16; sb += d1 & 0xffffu; no += d1 >> 16;
+                            q += b[2] - a[2];
+                        }
+                    }
+                    int64_t* m = mom + 6 * ((size_t)v * NT + t);
+                    m[0] += n; m[1] += no; m[2] += sr; m[3] += sg; m[4] += sb; m[5] += q;
+                }
+            }
+        }
+    if (npairs) *npairs = pairs;
+    return 0;
+}
+
+// finalize exactly as k_finalize does
+extern "C" void emul_finalize(const int64_t* mom, int NT, int flavour, const int32_t* colors, int32_t* ten,
+                              int32_t* cn, int32_t* ca) {
+    for (int id = 0; id < 13 * NT; id++) {
+        const int64_t* p = mom + 6 * (size_t)id;
+        tp_moments m = {p[0], p[1], p[2], p[3], p[4], p[5]};
+        int64_t E;
+        if (flavour == 0) {
+            E = tp_energy_triangulate(m);
+            ca[4 * id] = tp_wrap32(m.sr); ca[4 * id + 1] = tp_wrap32(m.sg); ca[4 * id + 2] = tp_wrap32(m.sb); ca[4 * id + 3] = 0;
+        } else {
+            const int32_t* c = colors + 4 * (id % NT);
+            E = tp_energy64(m, c[0], c[1], c[2]);
+        }
+        ten[id] = tp_wrap32(E); cn[id] = tp_wrap32(m.n);
+    }
+}
+
+extern "C" float emul_reference_dp(int flavour, int NT) { return tp_reference_dp(flavour, NT); }

@@ -1,0 +1,131 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+
+Integer buffers (`colnum`, `colacc`, `tenergy`, `gradient`, moments) must be identical; vertex
+positions are float32 produced by the same sequence of IEEE operations (shift.cs:45) and must be
+BIT-identical too (tolerance 0 ulp, stated here; see DESIGN.md "Numerics").
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tpose_amd import capi, synth
+from util import RATE, case
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (64, 48, (6, 4)), (97, 61, (6, 4)), (300, 200, (15, 5)), (257, 131, (6, 4)),
+    (640, 480, (50, 30)), (128, 32, None), (129, 33, None), (1011, 674, (15, 5)),
+]
+
+
+def run_piecewise(ctx, flavour, slot, rate):
+    ctx.accumulate(flavour, slot)
+    ctx.energy(flavour)
+    out = dict(ten=ctx.retrieve(capi.BUF_TENERGY), cn=ctx.retrieve(capi.BUF_COLNUM),
+               ca=ctx.retrieve(capi.BUF_COLACC), mom=ctx.retrieve(capi.BUF_MOMENTS))
+    ctx.shift(rate)
+    out["gr"] = ctx.retrieve(capi.BUF_GRADIENT)
+    out["points"] = ctx.retrieve(capi.BUF_POINTS)
+    return out
+
+
+@pytest.mark.parametrize("W,H,grid", CASES)
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_single_iteration_matches_oracle(W, H, grid, flavour):
+    img, imgB, pts, tris, ratio, colors = case(W, H, grid)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.set_image(capi.IMAGE_B, imgB)
+    ctx.upload(pts, tris, colors if flavour == 1 else None)
+    slot = capi.IMAGE_B if flavour == 1 else capi.IMAGE_A
+    got = run_piecewise(ctx, flavour, slot, RATE[flavour])
+    sweep = imgB if flavour == 1 else img
+    ref = O.iterate(sweep, pts, tris, flavour, ratio, RATE[flavour], 1,
+                    colors=colors if flavour == 1 else None, literal=True)
+    mom = O.moments(sweep, pts, tris, O.dp(flavour, tris.shape[0]), ratio)
+    assert np.array_equal(got["mom"], mom)
+    assert np.array_equal(got["cn"], ref["cn"])
+    assert np.array_equal(got["ten"], ref["ten"])
+    assert np.array_equal(got["ca"], ref["ca"])
+    assert np.array_equal(got["gr"], ref["gr"])
+    assert np.array_equal(got["points"].view(np.uint32), ref["points"].view(np.uint32))
+    ctx.close()
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+@pytest.mark.parametrize("iters", [1, 10, 50])
+def test_fused_iterations_match_oracle(flavour, iters):
+    W, H, grid = 300, 200, (15, 5)
+    img, imgB, pts, tris, ratio, colors = case(W, H, grid)
+    sweep = imgB if flavour == 1 else img
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.set_image(capi.IMAGE_B, imgB)
+    ctx.upload(pts, tris, colors if flavour == 1 else None)
+    ctx.iterate(capi.default_params(flavour), iters)
+    ref = O.iterate(sweep, pts, tris, flavour, ratio, RATE[flavour], iters,
+                    colors=colors if flavour == 1 else None, literal=False)
+    assert np.array_equal(ctx.retrieve(capi.BUF_TENERGY), ref["ten"])
+    assert np.array_equal(ctx.retrieve(capi.BUF_COLNUM), ref["cn"])
+    assert np.array_equal(ctx.retrieve(capi.BUF_GRADIENT), ref["gr"])
+    assert np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
+    ctx.close()
+
+
+def test_random_soup_and_ties():
+    """Arbitrary (overlapping, inverted, degenerate, out-of-domain, lattice-aligned) triangles."""
+    W, H = 200, 150
+    img = synth.voronoi_raster(W, H, seed=3, sites=10)
+    ratio = float(np.float32(W) / np.float32(H))
+    rng = np.random.default_rng(0)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    for trial in range(12):
+        NP = 30
+        pts = (rng.random((NP, 2)).astype(np.float32) * 2 - 1) * np.float32(1.3)
+        pts[:, 0] *= np.float32(ratio)
+        if trial % 3 == 0:
+            pts = (np.round(pts * 8) / 8).astype(np.float32)
+        tris = np.zeros((40, 4), np.int32)
+        tris[:, :3] = rng.integers(0, NP, (40, 3))
+        dp = [0.05, 0.0078125, 0.3][trial % 3]
+        ctx.upload(pts, tris)
+        ctx.set_dp(dp)
+        ctx.accumulate(0, capi.IMAGE_A)
+        ctx.energy(0)
+        mom = O.moments(img, pts, tris, dp, ratio)
+        assert np.array_equal(ctx.retrieve(capi.BUF_MOMENTS), mom), "trial %d" % trial
+    ctx.close()
+
+
+def test_full_size_properties():
+    """BASELINE.json metric size (2048^2, 3000 triangles): size-independent properties.
+    The base variants of a triangulation tile the raster exactly once (watertight top-left rule), so
+    sum(cn[0:NT]) == W*H and the base colour sums equal the image's channel sums."""
+    W = H = 2048
+    img, pts, tris, he, ratio = synth.workload(W, H, 3000)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts, tris)
+    ctx.accumulate(0, capi.IMAGE_A)
+    ctx.energy(0)
+    NT = tris.shape[0]
+    cn = ctx.retrieve(capi.BUF_COLNUM)
+    ca = ctx.retrieve(capi.BUF_COLACC)
+    mom = ctx.retrieve(capi.BUF_MOMENTS)
+    assert int(cn[:NT].sum()) == W * H
+    assert np.array_equal(ca[:NT, :3].astype(np.int64).sum(axis=0), img[:, :, :3].astype(np.int64).sum(axis=(0, 1)))
+    q = (img[:, :, :3].astype(np.int64) ** 2).sum()
+    assert int(mom[:NT, 5].sum()) == int(q)
+    # spot-check 40 variants against the oracle restricted to those triangles
+    sel = np.arange(0, NT, NT // 40)[:40]
+    sub = tris[sel]
+    om = O.moments(img, pts, sub, O.dp(0, NT), ratio).reshape(13, len(sel), 6)
+    gm = mom.reshape(13, NT, 6)[:, sel]
+    assert np.array_equal(om, gm)
+    # iterate: energy must not increase wildly and points stay finite / inside the domain
+    ctx.iterate(capi.default_params(0), 32)
+    p = ctx.retrieve(capi.BUF_POINTS)
+    assert np.isfinite(p).all()
+    ctx.close()

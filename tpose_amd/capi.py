@@ -1,0 +1,187 @@
+"""ctypes binding of the C ABI in include/tpose_hip.h (libtpose_hip.so).
+
+Thin plumbing for tests, bench.py and the multi-GPU drivers: every call goes straight through the
+C entry points a C++/cgo/JNI host would bind.  There is no fallback: a missing library or a
+missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtpose_hip.so")
+
+TP_OK, TP_ERR_INVALID, TP_ERR_NO_DEVICE, TP_ERR_HIP, TP_ERR_CAPACITY, TP_ERR_STATE = range(6)
+TRIANGULATE, WARP = 0, 1
+IMAGE_A, IMAGE_B = 0, 1
+BUF_TENERGY, BUF_COLNUM, BUF_COLACC, BUF_POINTS, BUF_GRADIENT, BUF_PENERGY, BUF_MOMENTS = range(7)
+
+# every symbol include/tpose_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "tp_abi_version", "tp_device_count", "tp_last_error", "tp_create", "tp_destroy", "tp_set_ratio",
+    "tp_get_ratio", "tp_set_dp", "tp_set_image", "tp_set_image_device", "tp_upload", "tp_accumulate",
+    "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_synchronize",
+    "tp_get_stream", "tp_profile_iterate", "tp_get_info",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("flavour", C.c_int32), ("image_slot", C.c_int32), ("rate", C.c_float), ("dp", C.c_float)]
+
+
+class TposeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("tpose_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libtpose_hip.so; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: build it with `python -m tpose_amd.build` "
+                               "(there is no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.tp_last_error.restype = C.c_char_p
+        lib.tp_last_error.argtypes = [C.c_void_p]
+        lib.tp_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        lib.tp_destroy.argtypes = [C.c_void_p]
+        lib.tp_set_ratio.argtypes = [C.c_void_p, C.c_float]
+        lib.tp_get_ratio.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        lib.tp_set_dp.argtypes = [C.c_void_p, C.c_float]
+        lib.tp_set_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        lib.tp_set_image_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        lib.tp_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        lib.tp_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.tp_energy.argtypes = [C.c_void_p, C.c_int]
+        lib.tp_shift.argtypes = [C.c_void_p, C.c_float]
+        lib.tp_default_params.argtypes = [C.c_int, C.POINTER(Params)]
+        lib.tp_default_params.restype = None
+        lib.tp_iterate.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int]
+        lib.tp_retrieve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        lib.tp_synchronize.argtypes = [C.c_void_p]
+        lib.tp_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.tp_profile_iterate.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_double)]
+        lib.tp_get_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        lib.tp_device_count.argtypes = [C.POINTER(C.c_int)]
+        _lib = lib
+    return _lib
+
+
+def device_count():
+    n = C.c_int(0)
+    load().tp_device_count(C.byref(n))
+    return n.value
+
+
+def default_params(flavour, dp=0.0, rate=None, image_slot=None):
+    p = Params()
+    load().tp_default_params(flavour, C.byref(p))
+    p.dp = dp
+    if rate is not None:
+        p.rate = rate
+    if image_slot is not None:
+        p.image_slot = image_slot
+    return p
+
+
+class Context:
+    """One context per GPU (tpose::init .. tpose::quit)."""
+
+    def __init__(self, device, width, height):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.tp_create(device, width, height, C.byref(self.h))
+        if rc != TP_OK:
+            raise TposeError(rc, self.lib.tp_last_error(None).decode())
+        self.W, self.H = width, height
+        self.NT = self.NP = 0
+
+    def _ck(self, rc):
+        if rc != TP_OK:
+            raise TposeError(rc, self.lib.tp_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.tp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_ratio(self, ratio):
+        self._ck(self.lib.tp_set_ratio(self.h, ratio))
+
+    def set_dp(self, dp):
+        self._ck(self.lib.tp_set_dp(self.h, dp))
+
+    def set_image(self, slot, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.shape == (self.H, self.W, 4)
+        self._ck(self.lib.tp_set_image(self.h, slot, img.ctypes.data, img.strides[0]))
+
+    def set_image_device(self, slot, ptr, stride):
+        self._ck(self.lib.tp_set_image_device(self.h, slot, C.c_void_p(ptr), stride))
+
+    def upload(self, points, tris, colors=None):
+        points = np.ascontiguousarray(points, np.float32)
+        tris = np.ascontiguousarray(tris, np.int32)
+        assert points.ndim == 2 and points.shape[1] == 2 and tris.ndim == 2 and tris.shape[1] == 4
+        cptr = None
+        if colors is not None:
+            colors = np.ascontiguousarray(colors, np.int32)
+            assert colors.shape == tris.shape
+            cptr = colors.ctypes.data
+        self._ck(self.lib.tp_upload(self.h, points.ctypes.data, points.shape[0], tris.ctypes.data,
+                                    tris.shape[0], cptr))
+        self.NP, self.NT = points.shape[0], tris.shape[0]
+
+    def accumulate(self, flavour=TRIANGULATE, slot=IMAGE_A):
+        self._ck(self.lib.tp_accumulate(self.h, flavour, slot))
+
+    def energy(self, flavour=TRIANGULATE):
+        self._ck(self.lib.tp_energy(self.h, flavour))
+
+    def shift(self, rate):
+        self._ck(self.lib.tp_shift(self.h, rate))
+
+    def iterate(self, params, n):
+        self._ck(self.lib.tp_iterate(self.h, C.byref(params), n))
+
+    def profile_iterate(self, params, n):
+        us = C.c_double(0)
+        self._ck(self.lib.tp_profile_iterate(self.h, C.byref(params), n, C.byref(us)))
+        return us.value
+
+    def synchronize(self):
+        self._ck(self.lib.tp_synchronize(self.h))
+
+    def retrieve(self, what, count=None):
+        V = 13 * self.NT
+        shape, dtype = {
+            BUF_TENERGY: ((V,), np.int32), BUF_COLNUM: ((V,), np.int32), BUF_COLACC: ((V, 4), np.int32),
+            BUF_POINTS: ((self.NP, 2), np.float32), BUF_GRADIENT: ((self.NP, 2), np.int32),
+            BUF_PENERGY: ((V,), np.int32), BUF_MOMENTS: ((V, 6), np.int64),
+        }[what]
+        out = np.zeros(shape, dtype)
+        n = out.size if count is None else count
+        self._ck(self.lib.tp_retrieve(self.h, what, out.ctypes.data, n))
+        return out
+
+    def info(self, what):
+        v = C.c_int64(0)
+        self._ck(self.lib.tp_get_info(self.h, what, C.byref(v)))
+        return v.value
+
+    def stream(self):
+        s = C.c_void_p()
+        self._ck(self.lib.tp_get_stream(self.h, C.byref(s)))
+        return s.value

@@ -1,0 +1,535 @@
+// tp_context.hip -- the C ABI of include/tpose_hip.h: context, device memory, launch sequencing,
+// hipGraph-fused iteration.  Host side of the boundary that replaces tpose::init/quit/upload and
+// the computecolors/doenergy/doshift lambdas of the reference (source/triangulation.hpp:576-643,
+// software/triangulate/main.cpp:121-155, software/warp/main.cpp:140-178).
+#include "../../include/tpose_hip.h"
+#include "tp_kernels.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct graph_entry {
+    hipGraphExec_t exec = nullptr;
+    tp_params params{};
+    int iters = 0;
+    uint64_t generation = 0;
+};
+
+}  // namespace
+
+struct tp_context {
+    int device = 0;
+    int W = 0, H = 0, Wp = 0, Hp = 0;
+    float ratio = 1.0f;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    uint8_t* img[2] = {nullptr, nullptr};
+    bool have_img[2] = {false, false};
+
+    // triangulation
+    int NT = 0, NP = 0, capT = 0, capP = 0;
+    float2* points = nullptr;
+    int4* tris = nullptr;
+    int4* colors = nullptr;
+    int* vtx_off = nullptr;
+    int* vtx_adj = nullptr;
+    // work lists
+    int tiles_x = 0, tiles_y = 0;
+    int* tilecount = nullptr;
+    int2* tilelist = nullptr;
+    size_t tilelist_elems = 0;
+    int list_cap = 0;
+    int2* tri_pair = nullptr;
+    uint32_t* partials = nullptr;
+    int pair_cap = 0;
+    tp_device_state* state = nullptr;
+    // outputs
+    int32_t* ten = nullptr;
+    int32_t* cn = nullptr;
+    int4* ca = nullptr;
+    int2* gr = nullptr;
+    int64_t* moments = nullptr;
+
+    bool uploaded = false, accumulated = false, energized = false;
+    int acc_slot = 0, acc_flavour = 0;
+    float dp_override = 0.0f;  // <= 0: reference law
+    int last_flavour = 0;
+    uint64_t generation = 1;
+    std::vector<graph_entry> graphs;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int fail(tp_context* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->error = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, TP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+template <class T>
+hipError_t dev_alloc(T** p, size_t n) {
+    return hipMalloc(reinterpret_cast<void**>(p), (n ? n : 1) * sizeof(T));
+}
+
+void drop_graphs(tp_context* c) {
+    for (auto& g : c->graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+}
+
+void free_triangulation(tp_context* c) {
+    hipFree(c->points); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
+    hipFree(c->tri_pair); hipFree(c->partials); hipFree(c->tilelist);
+    hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments);
+    c->points = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
+    c->tri_pair = nullptr; c->partials = nullptr; c->tilelist = nullptr;
+    c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr;
+    c->capT = c->capP = 0;
+}
+
+tp_launch make_launch(const tp_context* c, int slot, float dp) {
+    tp_launch L{};
+    L.img = c->img[slot];
+    L.pitch = c->Wp * 4;
+    L.vw.dp = dp; L.vw.ratio = c->ratio;
+    L.vw.halfW = 0.5f * (float)c->W; L.vw.halfH = 0.5f * (float)c->H;
+    L.vw.W = c->W; L.vw.H = c->H;
+    L.tiles_x = c->tiles_x; L.tiles_y = c->tiles_y;
+    L.points = c->points; L.tris = c->tris; L.colors = c->colors;
+    L.NT = c->NT; L.NP = c->NP;
+    L.vtx_off = c->vtx_off; L.vtx_adj = c->vtx_adj;
+    L.tilecount = c->tilecount; L.tilelist = c->tilelist; L.list_cap = c->list_cap;
+    L.tri_pair = c->tri_pair; L.partials = c->partials; L.pair_cap = c->pair_cap;
+    L.state = c->state;
+    L.ten = c->ten; L.cn = c->cn; L.ca = c->ca; L.gr = c->gr; L.moments = c->moments;
+    return L;
+}
+
+float resolve_dp(const tp_context* c, int flavour, float dp) {
+    return dp > 0.0f ? dp : tp_reference_dp(flavour, c->NT);
+}
+
+int check_slot(tp_context* c, int slot) {
+    if (slot != TP_IMAGE_A && slot != TP_IMAGE_B) return fail(c, TP_ERR_INVALID, "bad image slot %d", slot);
+    if (!c->have_img[slot]) return fail(c, TP_ERR_STATE, "image slot %d was never set", slot);
+    return TP_OK;
+}
+
+// enqueue one grad-iter on the context stream (no sync)
+void enqueue_iter(tp_context* c, const tp_params& p, float dp, bool first) {
+    tp_launch L = make_launch(c, p.image_slot, dp);
+    if (first) {
+        hipMemsetAsync(c->tilecount, 0, sizeof(int) * (size_t)c->tiles_x * c->tiles_y, c->stream);
+        hipMemsetAsync(&c->state->pair_total, 0, sizeof(uint32_t), c->stream);
+    }
+    tp_launch_bin(L, c->stream);
+    tp_launch_accumulate(L, c->stream);
+    tp_launch_finalize(L, p.flavour, false, c->stream);
+    tp_launch_shift(L, p.rate, c->stream);  // also re-arms tilecount / pair_total
+}
+
+int check_flags(tp_context* c) {
+    tp_device_state st{};
+    HIP_TRY(c, hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
+    if (st.flags) {
+        return fail(c, TP_ERR_CAPACITY, "device work list overflow (flags=%u, list_cap=%d, pair_cap=%d)",
+                    st.flags, c->list_cap, c->pair_cap);
+    }
+    return TP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tp_abi_version(void) { return TP_ABI_VERSION; }
+
+int tp_device_count(int* count) {
+    if (!count) return TP_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(nullptr, TP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return TP_OK;
+}
+
+const char* tp_last_error(const tp_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int tp_create(int device, int width, int height, tp_context** out) {
+    if (!out) return fail(nullptr, TP_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (width < 1 || height < 1 || width > TP_MAX_RASTER || height > TP_MAX_RASTER)
+        return fail(nullptr, TP_ERR_CAPACITY, "raster %dx%d outside 1..%d", width, height, TP_MAX_RASTER);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, TP_ERR_NO_DEVICE, "no HIP device available (the HIP path has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(nullptr, TP_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(nullptr, hipSetDevice(device));
+    tp_context* c = new tp_context();
+    c->device = device; c->W = width; c->H = height;
+    c->tiles_x = (width + TP_TILE_W - 1) / TP_TILE_W;
+    c->tiles_y = (height + TP_TILE_H - 1) / TP_TILE_H;
+    c->Wp = c->tiles_x * TP_TILE_W; c->Hp = c->tiles_y * TP_TILE_H;
+    c->ratio = (float)width / (float)height;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = dev_alloc(&c->tilecount, (size_t)c->tiles_x * c->tiles_y);
+    if (e == hipSuccess) e = dev_alloc(&c->state, 1);
+    if (e == hipSuccess) e = hipMemset(c->state, 0, sizeof(tp_device_state));
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = tp_kernels_init();
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, TP_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+        tp_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return TP_OK;
+}
+
+int tp_destroy(tp_context* c) {
+    if (!c) return TP_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    drop_graphs(c);
+    free_triangulation(c);
+    hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->tilecount); hipFree(c->state);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return TP_OK;
+}
+
+int tp_set_ratio(tp_context* c, float ratio) {
+    if (!c) return TP_ERR_INVALID;
+    if (!(ratio > 0.0f)) return fail(c, TP_ERR_INVALID, "RATIO must be positive");
+    if (ratio != c->ratio) { c->ratio = ratio; c->generation++; c->accumulated = c->energized = false; }
+    return TP_OK;
+}
+
+int tp_set_dp(tp_context* c, float dp) {
+    if (!c) return TP_ERR_INVALID;
+    c->dp_override = dp;
+    c->accumulated = c->energized = false;
+    return TP_OK;
+}
+
+int tp_get_ratio(const tp_context* c, float* ratio) {
+    if (!c || !ratio) return TP_ERR_INVALID;
+    *ratio = c->ratio;
+    return TP_OK;
+}
+
+static int set_image_common(tp_context* c, int slot, const void* src, size_t stride, hipMemcpyKind kind) {
+    if (!c) return TP_ERR_INVALID;
+    if (slot != TP_IMAGE_A && slot != TP_IMAGE_B) return fail(c, TP_ERR_INVALID, "bad image slot %d", slot);
+    if (!src) return fail(c, TP_ERR_INVALID, "image pointer is NULL");
+    if (stride < (size_t)c->W * 4) return fail(c, TP_ERR_INVALID, "stride %zu < 4*width", stride);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->img[slot]) {
+        // padded plane: whole tiles, zero filled, so the accumulate kernel needs no bounds checks
+        HIP_TRY(c, dev_alloc(&c->img[slot], (size_t)c->Wp * c->Hp * 4));
+        HIP_TRY(c, hipMemsetAsync(c->img[slot], 0, (size_t)c->Wp * c->Hp * 4, c->stream));
+    }
+    HIP_TRY(c, hipMemcpy2DAsync(c->img[slot], (size_t)c->Wp * 4, src, stride, (size_t)c->W * 4, c->H, kind, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_img[slot] = true;
+    c->accumulated = c->energized = false;
+    return TP_OK;
+}
+
+int tp_set_image(tp_context* c, int slot, const uint8_t* rgba, size_t stride) {
+    return set_image_common(c, slot, rgba, stride, hipMemcpyHostToDevice);
+}
+
+int tp_set_image_device(tp_context* c, int slot, const void* dev, size_t stride) {
+    return set_image_common(c, slot, dev, stride, hipMemcpyDeviceToDevice);
+}
+
+int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, int NT, const int32_t* colors) {
+    if (!c) return TP_ERR_INVALID;
+    if (!points || !tris || NP < 1 || NT < 1) return fail(c, TP_ERR_INVALID, "upload: bad arguments (NP=%d NT=%d)", NP, NT);
+    if ((size_t)13 * NT > (size_t)TP_MAXT) return fail(c, TP_ERR_CAPACITY, "13*NT = %d exceeds MAXT = %d", 13 * NT, TP_MAXT);
+    if ((size_t)NP > (size_t)TP_MAXT) return fail(c, TP_ERR_CAPACITY, "NP = %d exceeds MAXT = %d", NP, TP_MAXT);
+    for (int t = 0; t < NT; t++)
+        for (int s = 0; s < 3; s++) {
+            const int v = tris[4 * t + s];
+            if (v < 0 || v >= NP) return fail(c, TP_ERR_INVALID, "triangle %d references vertex %d (NP=%d)", t, v, NP);
+        }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+
+    const int ntiles = c->tiles_x * c->tiles_y;
+    if (NT > c->capT || NP > c->capP) {
+        free_triangulation(c);
+        const int capT = NT + NT / 2 + 64, capP = NP + NP / 2 + 64;
+        HIP_TRY(c, dev_alloc(&c->points, capP));
+        HIP_TRY(c, dev_alloc(&c->gr, capP));
+        HIP_TRY(c, dev_alloc(&c->vtx_off, capP + 1));
+        HIP_TRY(c, dev_alloc(&c->tris, capT));
+        HIP_TRY(c, dev_alloc(&c->colors, capT));
+        HIP_TRY(c, dev_alloc(&c->vtx_adj, (size_t)3 * capT));
+        HIP_TRY(c, dev_alloc(&c->tri_pair, capT));
+        HIP_TRY(c, dev_alloc(&c->ten, (size_t)13 * capT));
+        HIP_TRY(c, dev_alloc(&c->cn, (size_t)13 * capT));
+        HIP_TRY(c, dev_alloc(&c->ca, (size_t)13 * capT));
+        HIP_TRY(c, dev_alloc(&c->moments, (size_t)13 * capT * 6));
+        HIP_TRY(c, hipMemset(c->ca, 0, sizeof(int4) * 13 * (size_t)capT));
+        HIP_TRY(c, hipMemset(c->ten, 0, sizeof(int32_t) * 13 * (size_t)capT));
+        HIP_TRY(c, hipMemset(c->cn, 0, sizeof(int32_t) * 13 * (size_t)capT));
+        HIP_TRY(c, hipMemset(c->gr, 0, sizeof(int2) * (size_t)capP));
+        // (triangle, tile) pairs: typical triangles touch a handful of tiles, a few huge ones all
+        size_t pcap = (size_t)capT * 48 + (size_t)ntiles * 8;
+        if (pcap > ((size_t)1 << 26)) pcap = (size_t)1 << 26;
+        HIP_TRY(c, dev_alloc(&c->partials, pcap * TP_NVARIANTS * TP_PARTIAL_WORDS));
+        c->pair_cap = (int)pcap;
+        c->capT = capT; c->capP = capP;
+        c->tilelist_elems = 0;
+    }
+    // per-tile list capacity: never more than NT entries; generous multiple of the mean otherwise
+    {
+        size_t mean = ((size_t)c->capT * 8) / (size_t)ntiles + 8;
+        size_t cap = mean * 16;
+        if (cap < 256) cap = 256;
+        if (cap > (size_t)c->capT) cap = (size_t)c->capT;
+        if (cap * ntiles > c->tilelist_elems) {
+            hipFree(c->tilelist); c->tilelist = nullptr;
+            HIP_TRY(c, dev_alloc(&c->tilelist, cap * ntiles));
+            c->tilelist_elems = cap * ntiles;
+        }
+        c->list_cap = (int)(c->tilelist_elems / ntiles);
+        if (c->list_cap > c->capT) c->list_cap = c->capT;
+    }
+
+    // vertex -> outgoing half-edge ids (3t+s), the gather form of gradient.cs' scatter
+    std::vector<int> off(NP + 1, 0), adj((size_t)3 * NT);
+    for (int t = 0; t < NT; t++) for (int s = 0; s < 3; s++) off[tris[4 * t + s] + 1]++;
+    for (int v = 0; v < NP; v++) off[v + 1] += off[v];
+    {
+        std::vector<int> cur(off.begin(), off.end() - 1);
+        for (int t = 0; t < NT; t++) for (int s = 0; s < 3; s++) adj[cur[tris[4 * t + s]]++] = 3 * t + s;
+    }
+    HIP_TRY(c, hipMemcpy(c->points, points, sizeof(float) * 2 * (size_t)NP, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->tris, tris, sizeof(int32_t) * 4 * (size_t)NT, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->vtx_off, off.data(), sizeof(int) * (size_t)(NP + 1), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->vtx_adj, adj.data(), sizeof(int) * 3 * (size_t)NT, hipMemcpyHostToDevice));
+    c->NT = NT; c->NP = NP;
+    if (colors) {
+        HIP_TRY(c, hipMemcpy(c->colors, colors, sizeof(int32_t) * 4 * (size_t)NT, hipMemcpyHostToDevice));
+        tp_launch L = make_launch(c, 0, 0.0f);
+        tp_launch_replicate_colors(L, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    HIP_TRY(c, hipMemset(c->state, 0, sizeof(tp_device_state)));
+    c->generation++;  // captured graphs bake NT, NP, dp and buffer addresses
+    c->uploaded = true; c->accumulated = c->energized = false;
+    return TP_OK;
+}
+
+int tp_accumulate(tp_context* c, int flavour, int slot) {
+    if (!c) return TP_ERR_INVALID;
+    if (flavour != TP_TRIANGULATE && flavour != TP_WARP) return fail(c, TP_ERR_INVALID, "bad flavour %d", flavour);
+    if (!c->uploaded) return fail(c, TP_ERR_STATE, "accumulate before upload");
+    if (int rc = check_slot(c, slot)) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    tp_launch L = make_launch(c, slot, resolve_dp(c, flavour, c->dp_override));
+    HIP_TRY(c, hipMemsetAsync(c->tilecount, 0, sizeof(int) * (size_t)c->tiles_x * c->tiles_y, c->stream));
+    HIP_TRY(c, hipMemsetAsync(&c->state->pair_total, 0, sizeof(uint32_t), c->stream));
+    tp_launch_bin(L, c->stream);
+    tp_launch_accumulate(L, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    c->acc_slot = slot; c->acc_flavour = flavour;
+    c->accumulated = true; c->energized = false;
+    return TP_OK;
+}
+
+int tp_energy(tp_context* c, int flavour) {
+    if (!c) return TP_ERR_INVALID;
+    if (flavour != TP_TRIANGULATE && flavour != TP_WARP) return fail(c, TP_ERR_INVALID, "bad flavour %d", flavour);
+    if (!c->accumulated) return fail(c, TP_ERR_STATE, "energy before accumulate");
+    if (flavour != c->acc_flavour) return fail(c, TP_ERR_STATE, "energy flavour %d differs from the accumulate pass (%d)", flavour, c->acc_flavour);
+    HIP_TRY(c, hipSetDevice(c->device));
+    tp_launch L = make_launch(c, c->acc_slot, 0.0f);
+    tp_launch_finalize(L, flavour, true, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    c->energized = true; c->last_flavour = flavour;
+    return TP_OK;
+}
+
+int tp_shift(tp_context* c, float rate) {
+    if (!c) return TP_ERR_INVALID;
+    if (!c->energized) return fail(c, TP_ERR_STATE, "shift before energy");
+    HIP_TRY(c, hipSetDevice(c->device));
+    tp_launch L = make_launch(c, c->acc_slot, 0.0f);
+    tp_launch_shift(L, rate, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    c->accumulated = c->energized = false;  // geometry moved
+    return TP_OK;
+}
+
+void tp_default_params(int flavour, tp_params* p) {
+    if (!p) return;
+    p->flavour = flavour;
+    p->image_slot = flavour == TP_WARP ? TP_IMAGE_B : TP_IMAGE_A;
+    p->rate = flavour == TP_WARP ? 0.00003f : 0.00005f;  // shift.cs:45 of each program
+    p->dp = 0.0f;
+}
+
+static int validate_params(tp_context* c, const tp_params* p, int n_iters) {
+    if (!p) return fail(c, TP_ERR_INVALID, "params is NULL");
+    if (n_iters < 0) return fail(c, TP_ERR_INVALID, "n_iters < 0");
+    if (p->flavour != TP_TRIANGULATE && p->flavour != TP_WARP) return fail(c, TP_ERR_INVALID, "bad flavour %d", p->flavour);
+    if (!c->uploaded) return fail(c, TP_ERR_STATE, "iterate before upload");
+    return check_slot(c, p->image_slot);
+}
+
+int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
+    if (!c) return TP_ERR_INVALID;
+    if (int rc = validate_params(c, p, n_iters)) return rc;
+    if (n_iters == 0) return TP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const float dp = resolve_dp(c, p->flavour, p->dp);
+
+    // graphs of CHUNK fused iterations hide the ~10 us replay floor; the remainder runs eagerly
+    const int CHUNK = 16;
+    int left = n_iters;
+    if (left >= CHUNK) {
+        graph_entry* g = nullptr;
+        for (auto& e : c->graphs)
+            if (e.generation == c->generation && e.iters == CHUNK && memcmp(&e.params, p, sizeof *p) == 0) g = &e;
+        if (!g) {
+            hipGraph_t graph = nullptr;
+            HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            for (int k = 0; k < CHUNK; k++) enqueue_iter(c, *p, dp, k == 0);
+            HIP_TRY(c, hipStreamEndCapture(c->stream, &graph));
+            graph_entry e;
+            hipError_t err = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (err != hipSuccess) return fail(c, TP_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(err));
+            e.params = *p; e.iters = CHUNK; e.generation = c->generation;
+            if (c->graphs.size() > 8) drop_graphs(c);
+            c->graphs.push_back(e);
+            g = &c->graphs.back();
+        }
+        while (left >= CHUNK) {
+            HIP_TRY(c, hipGraphLaunch(g->exec, c->stream));
+            left -= CHUNK;
+        }
+    }
+    for (int k = 0; k < left; k++) enqueue_iter(c, *p, dp, true);
+    HIP_TRY(c, hipGetLastError());
+    c->acc_slot = p->image_slot; c->last_flavour = p->flavour;
+    c->accumulated = c->energized = false;
+    return TP_OK;
+}
+
+int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* accumulate_us) {
+    if (!c || !accumulate_us) return TP_ERR_INVALID;
+    if (int rc = validate_params(c, p, n_iters)) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const float dp = resolve_dp(c, p->flavour, p->dp);
+    double total_ms = 0.0;
+    for (int k = 0; k < n_iters; k++) {
+        tp_launch L = make_launch(c, p->image_slot, dp);
+        HIP_TRY(c, hipMemsetAsync(c->tilecount, 0, sizeof(int) * (size_t)c->tiles_x * c->tiles_y, c->stream));
+        HIP_TRY(c, hipMemsetAsync(&c->state->pair_total, 0, sizeof(uint32_t), c->stream));
+        tp_launch_bin(L, c->stream);
+        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        tp_launch_accumulate(L, c->stream);
+        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        tp_launch_finalize(L, p->flavour, false, c->stream);
+        tp_launch_shift(L, p->rate, c->stream);
+        HIP_TRY(c, hipEventSynchronize(c->ev1));
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        total_ms += ms;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *accumulate_us = n_iters ? total_ms * 1000.0 / n_iters : 0.0;
+    c->accumulated = c->energized = false;
+    return check_flags(c);
+}
+
+int tp_synchronize(tp_context* c) {
+    if (!c) return TP_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return check_flags(c);
+}
+
+int tp_retrieve(tp_context* c, int what, void* dst, size_t count) {
+    if (!c) return TP_ERR_INVALID;
+    if (!dst && count) return fail(c, TP_ERR_INVALID, "retrieve: dst is NULL");
+    if (!c->uploaded) return fail(c, TP_ERR_STATE, "retrieve before upload");
+    if (int rc = tp_synchronize(c)) return rc;
+    const size_t V = (size_t)13 * c->NT;
+    const void* src = nullptr;
+    size_t elem = 4, avail = 0;
+    switch (what) {
+        case TP_BUF_TENERGY: src = c->ten; avail = V; break;
+        case TP_BUF_COLNUM: src = c->cn; avail = V; break;
+        case TP_BUF_COLACC: src = c->ca; avail = 4 * V; break;
+        case TP_BUF_POINTS: src = c->points; avail = 2 * (size_t)c->NP; break;
+        case TP_BUF_GRADIENT: src = c->gr; avail = 2 * (size_t)c->NP; break;
+        case TP_BUF_PENERGY: memset(dst, 0, count * 4); return TP_OK;
+        case TP_BUF_MOMENTS:
+            if (!c->energized) return fail(c, TP_ERR_STATE, "moments are only kept by tp_energy (piecewise API)");
+            src = c->moments; avail = 6 * V; elem = 8; break;
+        default: return fail(c, TP_ERR_INVALID, "retrieve: unknown buffer %d", what);
+    }
+    if (count > avail) return fail(c, TP_ERR_INVALID, "retrieve: count %zu > %zu available", count, avail);
+    HIP_TRY(c, hipMemcpy(dst, src, count * elem, hipMemcpyDeviceToHost));
+    return TP_OK;
+}
+
+int tp_get_stream(tp_context* c, void** s) {
+    if (!c || !s) return TP_ERR_INVALID;
+    *s = (void*)c->stream;
+    return TP_OK;
+}
+
+int tp_get_info(tp_context* c, int what, int64_t* value) {
+    if (!c || !value) return TP_ERR_INVALID;
+    switch (what) {
+        case 0: *value = c->tiles_x; return TP_OK;
+        case 1: *value = c->tiles_y; return TP_OK;
+        case 2: *value = TP_TILE_W; return TP_OK;
+        case 3: *value = TP_TILE_H; return TP_OK;
+        case 4:
+        case 5: {
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            tp_device_state st{};
+            HIP_TRY(c, hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
+            *value = what == 4 ? (st.pair_total ? st.pair_total : st.pad[0]) : st.flags;
+            return TP_OK;
+        }
+        default: return fail(c, TP_ERR_INVALID, "unknown info %d", what);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// tp_kernels.h -- launch interface between the C ABI (tp_context.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tp_raster.h"
+
+#define TP_TILE_W 128
+#define TP_TILE_H 32
+#define TP_PARTIAL_WORDS 6 /* n, n_odd, sum r, sum g, sum b, q  (uint32 per (variant, tile)) */
+
+// device-side flag bits (tp_device_state::flags)
+#define TP_FLAG_LIST_OVERFLOW 1u
+#define TP_FLAG_PAIR_OVERFLOW 2u
+
+struct tp_device_state {
+    uint32_t pair_total;  // (triangle, tile) pairs allocated by the last binning
+    uint32_t flags;       // sticky overflow flags
+    uint32_t pad[2];
+};
+
+struct tp_launch {
+    // raster
+    const uint8_t* img;  // padded RGBA8 plane
+    int pitch;           // bytes per padded row
+    tp_view vw;
+    int tiles_x, tiles_y;
+    // triangulation
+    float2* points;
+    const int4* tris;
+    const int4* colors;  // stored colours ivec4[NT] (warp) -- may be null
+    int NT, NP;
+    const int* vtx_off;  // CSR by origin vertex: half-edge ids 3t+s
+    const int* vtx_adj;
+    // work lists
+    int* tilecount;      // [tiles]
+    int2* tilelist;      // [tiles * list_cap] (t, pair)
+    int list_cap;
+    int2* tri_pair;      // [NT] (first pair, #pairs)
+    uint32_t* partials;  // [pair_cap * 13 * 6]
+    int pair_cap;
+    tp_device_state* state;
+    // outputs (reference layout)
+    int32_t* ten;
+    int32_t* cn;
+    int4* ca;
+    int2* gr;
+    int64_t* moments;  // optional int64[13NT][6]
+};
+
+void tp_launch_bin(const tp_launch& L, hipStream_t s);
+void tp_launch_accumulate(const tp_launch& L, hipStream_t s);
+void tp_launch_finalize(const tp_launch& L, int flavour, bool write_moments, hipStream_t s);
+void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s);
+void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s);
+size_t tp_accumulate_lds_bytes();
+hipError_t tp_kernels_init();  // per-device function attributes (dynamic LDS > 64 KiB)

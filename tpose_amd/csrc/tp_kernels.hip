@@ -1,0 +1,278 @@
+// tp_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the t-pose hot path.  wave64 only.
+//
+// One grad-iter of the reference = two instanced draws of 13*NT triangles (mode 0: 4 same-address
+// int atomics per fragment, mode 1: one) + gradient.cs + shift.cs
+// (software/triangulate/main.cpp:121-155).  Here:
+//
+//   k_bin         triangles -> per-tile work lists (conservative bbox of the 13 variants)
+//   k_accumulate  THE hot kernel: one workgroup per 128x32-pixel tile.  The tile's RGBA8 pixels are
+//                 read once, coalesced (16 B per lane), turned into per-row prefix sums of the five
+//                 pixel moments in LDS (DPP wave scans), then every (variant, tile) pair is walked
+//                 by ONE lane: per row an exact column span [lo,hi) from three 32.32 edge walkers
+//                 and two LDS lookups.  No atomics, no per-fragment work; per-pair partial moments
+//                 go out as 24-byte records.
+//   k_finalize    per variant: sum its partials -> exact moments -> `colnum`, `colacc`, `tenergy`
+//                 in the reference layout (replaces triangle.fs mode 0/1).
+//   k_shift       per vertex: gather the central differences of its incident triangles
+//                 (gradient.cs) and take the clamped step (shift.cs).
+#include "tp_kernels.h"
+
+#define TW TP_TILE_W
+#define TH TP_TILE_H
+#define ROWLEN (TW + 1)  // exclusive prefix has TW+1 entries per row
+
+static_assert(TW == 128, "prefix build assumes 32 lanes x 4 pixels per row");
+static_assert(TH % 8 == 0 && TH <= TP_WALK_MAXROWS, "tile height");
+
+size_t tp_accumulate_lds_bytes() { return (size_t)TH * ROWLEN * sizeof(uint4); }
+
+// ------------------------------------------------------------------------------------------------
+// k_bin
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bin(tp_launch L) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int t = wave; t < L.NT; t += nwaves) {
+        const int4 tri = L.tris[t];
+        const float2 a = L.points[tri.x], b = L.points[tri.y], c = L.points[tri.z];
+        const float p[3][2] = {{a.x, a.y}, {b.x, b.y}, {c.x, c.y}};
+        const tp_bbox bb = tp_triangle_bbox(p, L.vw);
+        int cnt = 0, tx0 = 0, ty0 = 0, ntx = 1;
+        if (bb.c0 <= bb.c1 && bb.r0 <= bb.r1) {
+            tx0 = bb.c0 / TW; ty0 = bb.r0 / TH;
+            ntx = bb.c1 / TW - tx0 + 1;
+            cnt = ntx * (bb.r1 / TH - ty0 + 1);
+        }
+        uint32_t base = 0;
+        if (lane == 0) {
+            if (cnt) base = atomicAdd(&L.state->pair_total, (uint32_t)cnt);
+            if (base + (uint32_t)cnt > (uint32_t)L.pair_cap) atomicOr(&L.state->flags, TP_FLAG_PAIR_OVERFLOW);
+            L.tri_pair[t] = make_int2((int)base, cnt);
+        }
+        base = __shfl(base, 0);
+        for (int k = lane; k < cnt; k += 64) {
+            const int ky = k / ntx, kx = k - ky * ntx;
+            const int tile = (ty0 + ky) * L.tiles_x + tx0 + kx;
+            const int slot = atomicAdd(&L.tilecount[tile], 1);
+            if (slot < L.list_cap) L.tilelist[(size_t)tile * L.list_cap + slot] = make_int2(t, (int)base + k);
+            else atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
+        }
+    }
+}
+
+void tp_launch_bin(const tp_launch& L, hipStream_t s) {
+    int waves = L.NT < 8192 ? L.NT : 8192;
+    int blocks = (waves + 3) / 4;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_bin, dim3(blocks), dim3(256), 0, s, L);
+}
+
+// ------------------------------------------------------------------------------------------------
+// DPP inclusive scan over each 32-lane half of the wave (all 64 lanes must be active)
+// ------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t scan32_inclusive(uint32_t v) {
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
+// packed pixel moments: w0 = r | g<<16, w1 = b | odd<<16, w2 = r^2+g^2+b^2.  Over a 128-pixel row
+// every 16-bit field stays below 2^16 (128*255 = 32640), so packed words add without carries.
+struct pix3 { uint32_t w0, w1, w2; };
+
+__device__ __forceinline__ pix3 pixel_moments(uint32_t rgba) {
+    const uint32_t m = rgba & 0x00ffffffu;
+    const uint32_t r = m & 0xffu, g = (m >> 8) & 0xffu, b = m >> 16;
+    pix3 o;
+    o.w0 = r | (g << 16);
+    o.w1 = b | (((r + g + b) & 1u) << 16);
+    o.w2 = r * r + g * g + b * b;
+    return o;
+}
+__device__ __forceinline__ pix3 operator+(pix3 a, pix3 b) { return {a.w0 + b.w0, a.w1 + b.w1, a.w2 + b.w2}; }
+
+// ------------------------------------------------------------------------------------------------
+// k_accumulate
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_accumulate(tp_launch L) {
+    extern __shared__ __attribute__((aligned(16))) uint4 P[];  // [TH][ROWLEN]
+
+    const int tile = blockIdx.x;
+    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
+    int nlist = L.tilecount[tile];
+    if (nlist > L.list_cap) nlist = L.list_cap;
+    if (nlist == 0) return;
+
+    const int tid = threadIdx.x;
+
+    // ---- phase 1: pixels -> row prefix sums in LDS ------------------------------------------
+    {
+        const int l32 = tid & 31, rsub = tid >> 5;  // 8 rows per pass, 32 lanes x 4 px per row
+        const uint8_t* src = L.img + (size_t)(ty * TH + rsub) * L.pitch + (size_t)(tx * TW + l32 * 4) * 4;
+        uint4 px[TH / 8];
+#pragma unroll
+        for (int p = 0; p < TH / 8; p++)
+            px[p] = *reinterpret_cast<const uint4*>(src + (size_t)p * 8 * L.pitch);
+#pragma unroll
+        for (int p = 0; p < TH / 8; p++) {
+            const pix3 e0 = pixel_moments(px[p].x), e1 = pixel_moments(px[p].y),
+                       e2 = pixel_moments(px[p].z), e3 = pixel_moments(px[p].w);
+            const pix3 s1 = e0 + e1, s2 = s1 + e2, s3 = s2 + e3;
+            pix3 ex;  // exclusive prefix of this lane's first pixel
+            ex.w0 = scan32_inclusive(s3.w0) - s3.w0;
+            ex.w1 = scan32_inclusive(s3.w1) - s3.w1;
+            ex.w2 = scan32_inclusive(s3.w2) - s3.w2;
+            uint4* row = P + (p * 8 + rsub) * ROWLEN + l32 * 4;
+            row[0] = make_uint4(ex.w0, ex.w1, ex.w2, 0);
+            row[1] = make_uint4(ex.w0 + e0.w0, ex.w1 + e0.w1, ex.w2 + e0.w2, 0);
+            row[2] = make_uint4(ex.w0 + s1.w0, ex.w1 + s1.w1, ex.w2 + s1.w2, 0);
+            row[3] = make_uint4(ex.w0 + s2.w0, ex.w1 + s2.w1, ex.w2 + s2.w2, 0);
+            if (l32 == 31) row[4] = make_uint4(ex.w0 + s3.w0, ex.w1 + s3.w1, ex.w2 + s3.w2, 0);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: one lane per (triangle, variant) of this tile --------------------------------
+    const int row0 = ty * TH;
+    const int row1 = min(row0 + TH - 1, L.vw.H - 1);
+    const int col0 = tx * TW;
+    const int colE = min(col0 + TW, L.vw.W);
+    const int nitems = nlist * TP_NVARIANTS;
+    const int2* list = L.tilelist + (size_t)tile * L.list_cap;
+
+    for (int item = tid; item < nitems; item += 256) {
+        const int e = item / TP_NVARIANTS, v = item - e * TP_NVARIANTS;
+        const int2 ent = list[e];
+        const int4 tri = L.tris[ent.x];
+        const float2 p0 = L.points[tri.x], p1 = L.points[tri.y], p2 = L.points[tri.z];
+        int32_t X[3], Y[3];
+        tp_vertex_stage(p0.x, p0.y, v, 0, L.vw, X[0], Y[0]);
+        tp_vertex_stage(p1.x, p1.y, v, 1, L.vw, X[1], Y[1]);
+        tp_vertex_stage(p2.x, p2.y, v, 2, L.vw, X[2], Y[2]);
+        tp_span sp = tp_setup_span(X, Y, row0, row1);
+
+        uint32_t n = 0, no = 0, sr = 0, sg = 0, sb = 0, q = 0;
+        const uint4* rowp = P + (sp.r0 - row0) * ROWLEN - col0;
+        for (int r = sp.r0; r <= sp.r1; ++r, rowp += ROWLEN) {
+            int32_t lo, hi;
+            tp_span_row(sp, col0, colE, lo, hi);
+            if (lo < hi) {
+                const uint4 a = rowp[lo], b = rowp[hi];
+                const uint32_t d0 = b.x - a.x, d1 = b.y - a.y;
+                n += (uint32_t)(hi - lo);
+                sr += d0 & 0xffffu; sg += d0 >> 16;
+                sb += d1 & 0xffffu; no += d1 >> 16;
+                q += b.z - a.z;
+            }
+        }
+        if (ent.y < L.pair_cap) {
+            uint32_t* out = L.partials + ((size_t)ent.y * TP_NVARIANTS + v) * TP_PARTIAL_WORDS;
+            reinterpret_cast<uint2*>(out)[0] = make_uint2(n, no);
+            reinterpret_cast<uint2*>(out)[1] = make_uint2(sr, sg);
+            reinterpret_cast<uint2*>(out)[2] = make_uint2(sb, q);
+        }
+    }
+}
+
+hipError_t tp_kernels_init() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_accumulate),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp_accumulate_lds_bytes());
+}
+
+void tp_launch_accumulate(const tp_launch& L, hipStream_t s) {
+    hipLaunchKernelGGL(k_accumulate, dim3(L.tiles_x * L.tiles_y), dim3(256), tp_accumulate_lds_bytes(), s, L);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_finalize: thread per (triangle, variant); id = i*NT + t in the outputs
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(tp_launch L, int flavour, int write_moments) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= L.NT * TP_NVARIANTS) return;
+    const int t = gid / TP_NVARIANTS, i = gid - t * TP_NVARIANTS;
+    const int2 pr = L.tri_pair[t];
+    tp_moments m = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < pr.y; k++) {
+        const int pair = pr.x + k;
+        if (pair >= L.pair_cap) break;
+        const uint2* in = reinterpret_cast<const uint2*>(L.partials + ((size_t)pair * TP_NVARIANTS + i) * TP_PARTIAL_WORDS);
+        const uint2 a = in[0], b = in[1], c = in[2];
+        m.n += a.x; m.nodd += a.y; m.sr += b.x; m.sg += b.y; m.sb += c.x; m.q += c.y;
+    }
+    const int id = i * L.NT + t;
+    int64_t E;
+    if (flavour == 0) {
+        E = tp_energy_triangulate(m);
+        L.ca[id] = make_int4(tp_wrap32(m.sr), tp_wrap32(m.sg), tp_wrap32(m.sb), 0);
+    } else {
+        const int4 col = L.ca[id];  // stored colour, replicated x13 by upload
+        E = tp_energy64(m, col.x, col.y, col.z);
+    }
+    L.ten[id] = tp_wrap32(E);
+    L.cn[id] = tp_wrap32(m.n);
+    if (write_moments) {
+        int64_t* o = L.moments + (size_t)id * 6;
+        o[0] = m.n; o[1] = m.nodd; o[2] = m.sr; o[3] = m.sg; o[4] = m.sb; o[5] = m.q;
+    }
+}
+
+void tp_launch_finalize(const tp_launch& L, int flavour, bool write_moments, hipStream_t s) {
+    const int n = L.NT * TP_NVARIANTS;
+    hipLaunchKernelGGL(k_finalize, dim3((n + 255) / 256), dim3(256), 0, s, L, flavour, write_moments ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shift: gradient.cs gathered per vertex (no atomics) + shift.cs; also re-arms the work lists
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_shift(tp_launch L, float rate) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    for (int k = gid; k < L.tiles_x * L.tiles_y; k += nth) L.tilecount[k] = 0;
+    if (gid == 0) { L.state->pad[0] = L.state->pair_total; L.state->pair_total = 0; }
+
+    if (gid >= L.NP) return;
+    uint32_t gx = 0, gy = 0;  // int32 wrapping sums, like the reference's int atomics
+    const int NT = L.NT;
+    for (int k = L.vtx_off[gid]; k < L.vtx_off[gid + 1]; k++) {
+        const int h = L.vtx_adj[k], t = h / 3, s = h - 3 * t;
+        const int32_t* e = L.ten + t;
+        gx += (uint32_t)e[(4 * s + 1) * NT] - (uint32_t)e[(4 * s + 2) * NT];
+        gy += (uint32_t)e[(4 * s + 3) * NT] - (uint32_t)e[(4 * s + 4) * NT];
+    }
+    L.gr[gid] = make_int2((int)gx, (int)gy);
+    if (gid < 4) return;  // shift.cs:20 -- the four corners never move
+
+    float tgx = (float)(int)gx, tgy = (float)(int)gy;
+    float2 p = L.points[gid];
+    const float R = L.vw.ratio;
+    if (p.x <= -R) { p.x = -R; tgx = 0.0f; } else if (p.x >= R) { p.x = R; tgx = 0.0f; }
+    if (p.y <= -1.0f) { p.y = -1.0f; tgy = 0.0f; } else if (p.y >= 1.0f) { p.y = 1.0f; tgy = 0.0f; }
+    // p -= rate * tgr / 256 / 256  (shift.cs:45), one rounding per operation
+    p.x = tp_fsub(p.x, tp_fdiv(tp_fdiv(tp_fmul(rate, tgx), 256.0f), 256.0f));
+    p.y = tp_fsub(p.y, tp_fdiv(tp_fdiv(tp_fmul(rate, tgy), 256.0f), 256.0f));
+    L.points[gid] = p;
+}
+
+void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s) {
+    hipLaunchKernelGGL(k_shift, dim3((L.NP + 255) / 256), dim3(256), 0, s, L, rate);
+}
+
+// tpose::upload colour replication (source/triangulation.hpp:633-641): col[i*NT + k] = colors[k]
+__global__ void k_replicate_colors(tp_launch L) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= L.NT * TP_NVARIANTS) return;
+    L.ca[gid] = L.colors[gid % L.NT];
+}
+
+void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s) {
+    const int n = L.NT * TP_NVARIANTS;
+    hipLaunchKernelGGL(k_replicate_colors, dim3((n + 255) / 256), dim3(256), 0, s, L);
+}

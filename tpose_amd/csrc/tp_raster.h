@@ -1,0 +1,287 @@
+// tp_raster.h -- per-lane geometry of the t-pose hot path: vertex stage, edge setup and the exact
+// row-span walker used by the HIP kernels (tp_kernels.hip).
+//
+// What it replaces in the reference (weigert/t-pose):
+//   software/triangulate/shader/triangle.vs:45-84  (warp: software/warp/shader/triangle.vs:48-87)
+//       -- the 13-variant vertex stage;
+//   the OpenGL rasteriser between triangle.vs and triangle.fs -- here an explicit, exact rule:
+//       pixel-centre sampling, vertices snapped to 1/256 px, integer edge functions, top-left rule,
+//       orientation agnostic (the reference disables culling, software/triangulate/main.cpp:56).
+//
+// Instead of testing every pixel, a lane walks the rows of ONE variant and gets the covered
+// column span [lo, hi) of each row in O(1) from three 32.32 fixed-point edge walkers whose floor
+// is provably exact (see tp_edge_walker).  Sums over a span come from row prefix sums (LDS).
+//
+// Everything here is __host__ __device__ so that tests can run the same integer logic on the CPU
+// (tests/emul) -- the shipped library never executes it on the host.
+#pragma once
+
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define TP_HD __host__ __device__ __forceinline__
+#else
+#define TP_HD inline
+#endif
+
+// snapped coordinates are clamped to [-2^22, 2^23]: every edge delta fits in 24 bits
+#define TP_COORD_MIN (-4194304.0f)
+#define TP_COORD_MAX (8388608.0f)
+#define TP_MAX_RASTER 16384
+#define TP_NVARIANTS 13
+
+// ---------------------------------------------------------------------------------------------
+// float helpers: each is exactly one IEEE-754 binary32 operation (no contraction)
+// ---------------------------------------------------------------------------------------------
+TP_HD float tp_fadd(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fadd_rn(a, b);
+#else
+    volatile float r = a + b; return r;
+#endif
+}
+TP_HD float tp_fsub(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fsub_rn(a, b);
+#else
+    volatile float r = a - b; return r;
+#endif
+}
+TP_HD float tp_fmul(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fmul_rn(a, b);
+#else
+    volatile float r = a * b; return r;
+#endif
+}
+TP_HD float tp_fdiv(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fdiv_rn(a, b);
+#else
+    volatile float r = a / b; return r;
+#endif
+}
+
+// dp law, triangle.vs:60-62 (triangulate: 4, 3000) / warp triangle.vs:63-65 (9, 1000)
+inline float tp_reference_dp(int flavour, int NT) {
+    volatile float k = flavour ? 9.0f : 4.0f, m = flavour ? 1000.0f : 3000.0f;
+    volatile float a = k * (float)NT;
+    volatile float b = a / m;
+    volatile float c = 1.0f + b;
+    volatile float d = 0.05f / c;
+    return d;
+}
+
+TP_HD int32_t tp_min(int32_t a, int32_t b) { return a < b ? a : b; }
+TP_HD int32_t tp_max(int32_t a, int32_t b) { return a > b ? a : b; }
+
+TP_HD int32_t tp_snap256(float f) {
+    float v = tp_fadd(tp_fmul(f, 256.0f), 0.5f);
+    v = fmaxf(v, TP_COORD_MIN);  // NaN -> lower bound
+    v = fminf(v, TP_COORD_MAX);
+    return (int32_t)floorf(v);
+}
+
+struct tp_view {
+    float dp, ratio, halfW, halfH;  // halfW = 0.5f * W (exact)
+    int W, H;
+};
+
+// Vertex stage for model-vertex `slot` of variant `i` (TDIV): displacement BEFORE x /= RATIO.
+TP_HD void tp_vertex_stage(float px, float py, int i, int slot, const tp_view& vw, int32_t& X,
+                           int32_t& Y) {
+    float Dx = 0.0f, Dy = 0.0f;
+    if (i > 0 && ((i - 1) >> 2) == slot) {
+        int k = (i - 1) & 3;
+        Dx = (k == 0) ? vw.dp : (k == 1) ? -vw.dp : 0.0f;
+        Dy = (k == 2) ? vw.dp : (k == 3) ? -vw.dp : 0.0f;
+    }
+    float tx = tp_fadd(px, Dx);
+    float ty = tp_fadd(py, Dy);
+    float nx = tp_fdiv(tx, vw.ratio);
+    float fx = tp_fmul(tp_fadd(nx, 1.0f), vw.halfW);
+    float fy = tp_fmul(tp_fsub(1.0f, ty), vw.halfH);
+    X = tp_snap256(fx);
+    Y = tp_snap256(fy);
+}
+
+TP_HD int32_t tp_floor_shr8(int32_t v) { return v >> 8; }  // arithmetic shift == floor(v/256)
+
+// pixel (inclusive) range whose centres 256c+128 lie within [vmin, vmax]
+TP_HD int32_t tp_first_centre(int32_t vmin) { return (vmin - 128 + 255) >> 8; }
+TP_HD int32_t tp_last_centre(int32_t vmax) { return (vmax - 128) >> 8; }
+
+// ---------------------------------------------------------------------------------------------
+// Edge walker.  For one edge with d = |a| > 0 the column bound of row r is floor(N_r / d) with
+// N_{r+1} = N_r + step, all integers, d < 2^24.  It is tracked as x_r = x_0 + r*s in 32.32 fixed
+// point:  x_0 = floor(N_0/d)*2^32 + floor(rem*2^32/d) + BIAS,  s = floor(step*2^32/d)  (each
+// fractional part off by at most one unit from the double-precision estimate).  Over at most 32
+// rows the accumulated error lies in (BIAS-66, BIAS+34) units of 2^-32; the exact fractional part
+// of N_r/d is a multiple of 1/d >= 2^-24 = 256 units, so with BIAS = 96 the integer part of x_r
+// IS floor(N_r/d) for every row.  Quotients beyond +-2^30 are clamped (they stay far outside any
+// raster for the whole tile: the per-row drift is < 2^24).
+// ---------------------------------------------------------------------------------------------
+#define TP_WALK_BIAS 96
+#define TP_WALK_MAXROWS 32
+
+struct tp_walker {
+    int64_t x, s;
+};
+
+TP_HD void tp_divmod_floor(int64_t N, int32_t d, double inv, int64_t& q, int64_t& rem) {
+    q = (int64_t)floor((double)N * inv);
+    rem = N - q * (int64_t)d;
+    while (rem < 0) { rem += d; --q; }
+    while (rem >= d) { rem -= d; ++q; }
+}
+
+TP_HD uint32_t tp_frac32(int64_t rem, double inv) {
+    double f = floor((double)rem * 4294967296.0 * inv);
+    if (f > 4294967295.0) f = 4294967295.0;
+    if (f < 0.0) f = 0.0;
+    return (uint32_t)f;
+}
+
+TP_HD tp_walker tp_make_walker(int64_t N0, int32_t step, int32_t d) {
+    const double inv = 1.0 / (double)d;
+    int64_t q, rem, sq, srem;
+    tp_divmod_floor(N0, d, inv, q, rem);
+    uint32_t fr = tp_frac32(rem, inv);
+    const int64_t QMAX = (int64_t)1 << 30;
+    if (q > QMAX) { q = QMAX; fr = 0; }
+    if (q < -QMAX) { q = -QMAX; fr = 0; }
+    tp_divmod_floor((int64_t)step, d, inv, sq, srem);
+    tp_walker w;
+    w.x = q * 4294967296LL + (int64_t)fr + TP_WALK_BIAS;
+    w.s = sq * 4294967296LL + (int64_t)tp_frac32(srem, inv);
+    return w;
+}
+
+TP_HD int32_t tp_walker_value(const tp_walker& w) { return (int32_t)(w.x >> 32); }
+
+// ---------------------------------------------------------------------------------------------
+// Span setup for one variant inside a window of rows [win_r0, win_r1] (inclusive, absolute).
+// Canonical slots: A is a left edge (lower bound), B a right edge (exclusive upper bound), C the
+// third edge (either kind, or neutral when horizontal).
+// ---------------------------------------------------------------------------------------------
+struct tp_span {
+    tp_walker A, B, C;
+    int32_t r0, r1;   // absolute row range (inclusive); empty when r0 > r1
+    int32_t c_is_lo;  // C bounds from the left (1) or the right (0)
+};
+
+TP_HD tp_span tp_setup_span(const int32_t X[3], const int32_t Y[3], int32_t win_r0, int32_t win_r1) {
+    tp_span sp;
+    sp.r0 = 0; sp.r1 = -1; sp.c_is_lo = 1;
+    sp.A.x = sp.A.s = sp.B.x = sp.B.s = sp.C.x = sp.C.s = 0;
+
+    const int64_t area2 = (int64_t)(X[1] - X[0]) * (Y[2] - Y[0]) - (int64_t)(Y[1] - Y[0]) * (X[2] - X[0]);
+    if (area2 == 0) return sp;
+    const int32_t sg = area2 > 0 ? 1 : -1;
+
+    int32_t ymin = tp_min(Y[0], tp_min(Y[1], Y[2]));
+    int32_t ymax = tp_max(Y[0], tp_max(Y[1], Y[2]));
+
+    int32_t a[3], b[3];
+    int bottom_flat = 0;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const int j = (e == 2) ? 0 : e + 1;
+        a[e] = -(Y[j] - Y[e]) * sg;
+        b[e] = (X[j] - X[e]) * sg;
+        // horizontal edge with the interior above it: a centre exactly on it is excluded
+        if (a[e] == 0 && b[e] < 0) bottom_flat = 1;
+    }
+    int32_t r0 = tp_max(win_r0, tp_first_centre(ymin));
+    int32_t r1 = tp_min(win_r1, tp_last_centre(ymax - bottom_flat));
+    if (r0 > r1) return sp;
+
+    tp_walker w[3];
+    int kind[3];  // 1 = lower bound, 0 = upper bound, 2 = neutral
+    const int64_t cy = 256LL * r0 + 128;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        if (a[e] == 0) {
+            kind[e] = 2;
+            w[e].x = -((int64_t)1 << 62); w[e].s = 0;
+            continue;
+        }
+        const int32_t tl = (a[e] > 0) ? 1 : 0;  // a != 0 here: left edges own their boundary
+        // E(c,r) >= 0 (with tie rule)  <=>  a*256*c + K >= 0
+        const int64_t K = (int64_t)a[e] * (128 - X[e]) + (int64_t)b[e] * (cy - Y[e]) + tl - 1;
+        const int64_t Kf = K >> 8;  // floor(K/256); steps by b per row
+        if (a[e] > 0) {             // c >= ceil(-Kf / a) = floor((-Kf + a - 1) / a)
+            kind[e] = 1;
+            w[e] = tp_make_walker(-Kf + a[e] - 1, -b[e], a[e]);
+        } else {                    // c <= floor(Kf / d)  ->  exclusive bound floor((Kf + d) / d)
+            kind[e] = 0;
+            w[e] = tp_make_walker(Kf - a[e], b[e], -a[e]);
+        }
+    }
+    // canonical slots
+    int ia = (kind[0] == 1) ? 0 : (kind[1] == 1) ? 1 : (kind[2] == 1) ? 2 : -1;
+    int ib = (kind[0] == 0) ? 0 : (kind[1] == 0) ? 1 : (kind[2] == 0) ? 2 : -1;
+    if (ia < 0 || ib < 0) return sp;  // cannot happen for area2 != 0
+    int ic = 3 - ia - ib;
+    sp.A = (ia == 0) ? w[0] : (ia == 1) ? w[1] : w[2];
+    sp.B = (ib == 0) ? w[0] : (ib == 1) ? w[1] : w[2];
+    sp.C = (ic == 0) ? w[0] : (ic == 1) ? w[1] : w[2];
+    const int kc = (ic == 0) ? kind[0] : (ic == 1) ? kind[1] : kind[2];
+    sp.c_is_lo = (kc != 0);
+    sp.r0 = r0; sp.r1 = r1;
+    return sp;
+}
+
+// column span of the current row, clipped to [clip_lo, clip_hi); then advance one row
+TP_HD void tp_span_row(tp_span& sp, int32_t clip_lo, int32_t clip_hi, int32_t& lo, int32_t& hi) {
+    const int32_t va = tp_walker_value(sp.A), vb = tp_walker_value(sp.B), vc = tp_walker_value(sp.C);
+    lo = tp_max(tp_max(va, sp.c_is_lo ? vc : INT32_MIN), clip_lo);
+    hi = tp_min(tp_min(vb, sp.c_is_lo ? INT32_MAX : vc), clip_hi);
+    sp.A.x += sp.A.s; sp.B.x += sp.B.s; sp.C.x += sp.C.s;
+}
+
+// conservative pixel bounding box of all 13 variants of a triangle (inclusive; may be empty)
+struct tp_bbox { int32_t c0, c1, r0, r1; };
+
+TP_HD tp_bbox tp_triangle_bbox(const float p[3][2], const tp_view& vw) {
+    int32_t xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {  // k = 0: unmoved, 1..4: the four displacements of slot s
+            int32_t X, Y;
+            tp_vertex_stage(p[s][0], p[s][1], k == 0 ? 0 : 4 * s + k, s, vw, X, Y);
+            xmin = tp_min(xmin, X); xmax = tp_max(xmax, X);
+            ymin = tp_min(ymin, Y); ymax = tp_max(ymax, Y);
+        }
+    }
+    tp_bbox bb;
+    bb.c0 = tp_max(0, tp_first_centre(xmin)); bb.c1 = tp_min(vw.W - 1, tp_last_centre(xmax));
+    bb.r0 = tp_max(0, tp_first_centre(ymin)); bb.r1 = tp_min(vw.H - 1, tp_last_centre(ymax));
+    return bb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Moments -> energy (replaces the mode-1 pass, triangle.fs:37-43 / warp :46-53).
+// For an integer reference colour a:  sum_i (|I_i - a|^2 >> 1) = (S - n_oddS) / 2 with
+// S = Q - 2 a.sumI + n |a|^2 and |I_i - a|^2 odd  <=>  (r+g+b) + |a|^2 odd.
+// ---------------------------------------------------------------------------------------------
+struct tp_moments { int64_t n, nodd, sr, sg, sb, q; };
+
+TP_HD int32_t tp_wrap32(int64_t v) { return (int32_t)(uint32_t)(uint64_t)v; }
+
+TP_HD int64_t tp_energy64(const tp_moments& m, int64_t ar, int64_t ag, int64_t ab) {
+    const int64_t a2 = ar * ar + ag * ag + ab * ab;
+    const int64_t S = m.q - 2 * (ar * m.sr + ag * m.sg + ab * m.sb) + m.n * a2;
+    const int64_t nodd = (a2 & 1) ? (m.n - m.nodd) : m.nodd;
+    return (S - nodd) / 2;
+}
+
+// triangulate flavour: a = ca.rgb / cn with the int32 (wrapped) sums of the reference SSBO;
+// energy 0 when cn == 0 (triangle.fs:40)
+TP_HD int64_t tp_energy_triangulate(const tp_moments& m) {
+    const int32_t n32 = tp_wrap32(m.n);
+    if (n32 <= 0) return 0;
+    return tp_energy64(m, tp_wrap32(m.sr) / n32, tp_wrap32(m.sg) / n32, tp_wrap32(m.sb) / n32);
+}
