@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the t-pose hot path on MI355X.
+
+Metric (BASELINE.json): triangles*grad-iters / second at a 2048x2048 RGBA8 raster, 3000 triangles,
+plus the achieved fraction of the HBM roofline of the dominant kernel (the per-pixel accumulate).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one grad-iter: accumulate (one sweep of the raster, 13 variants of every triangle) ->
+energy -> gradient -> shift, on inputs already resident in HBM, with no host round trip inside the
+timed region.  N > 1 (launched by torch.distributed.run, one rank per GPU) runs independent
+replicas -- one image + triangulation per GPU, no data-path collective -- and
+reports the whole-job aggregate ("weak" scaling).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+W = H = 2048
+NT = 3000
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(W, H, NT, NP):
+    """one read of the RGBA8 plane + triangle indices + per-variant outputs
+    in reference layout (ca 16 B + cn 4 B + ten 4 B) + points r/w and gradient."""
+    return 4 * W * H + 16 * NT + 24 * 13 * NT + 24 * NP
+
+
+def cpu_baseline(img, pts, tris, ratio, budget_s=12.0):
+    """The oracle in reference form (13 variants x 2 passes, per-fragment loops) on the host cores.
+    Baseline only; this is the one place bench.py touches oracle/."""
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    O.iterate(img, pts, tris, O.TRIANGULATE, ratio, 0.00005, 1, literal=True, nthreads=cores)  # warm-up
+    iters, t0 = 0, time.perf_counter()
+    p = pts
+    while True:
+        out = O.iterate(img, p, tris, O.TRIANGULATE, ratio, 0.00005, 1, literal=True, nthreads=cores)
+        p = out["points"]
+        iters += 1
+        dt = time.perf_counter() - t0
+        if (dt >= budget_s and iters >= 3) or iters >= 200:
+            break
+    return {
+        "value": NT * iters / dt, "unit": "triangles*grad-iters/s", "cores": cores, "kind": "port",
+        "sample": "%d grad-iters of the same 2048x2048 / 3000-triangle workload, oracle/tp_oracle.c "
+                  "literal two-pass form, OpenMP over variants (%.1f s)" % (iters, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flavour", type=int, default=0, help="0 triangulate (metric), 1 warp")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from tpose_amd import capi, synth
+
+    # independent replica per rank: its own image (seeded by rank) and triangulation
+    img, pts, tris, he, ratio = synth.workload(W, H, NT, seed=1234 + rank)
+    NP = pts.shape[0]
+    ctx = capi.Context(local_rank, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    imgB = None
+    colors = None
+    if args.flavour == 1:
+        imgB = synth.displaced_raster(img)
+        ctx.set_image(capi.IMAGE_B, imgB)
+        colors = synth.mean_colors(img, pts, tris, ratio)
+    ctx.upload(pts, tris, colors)
+    params = capi.default_params(args.flavour)
+
+    def sync_all():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ctx.iterate(params, args.warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    ctx.iterate(params, args.steps)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.barrier()
+
+    # dominant kernel: average accumulate-launch duration, HIP events on the library's own stream,
+    # same workload and state, eager launches (events cannot bracket kernels inside a graph replay)
+    acc_us = ctx.profile_iterate(params, 200)
+    bytes_iter = algorithmic_bytes(W, H, NT, NP)
+    achieved = bytes_iter / (acc_us * 1e-6) / 1e9
+
+    if rank == 0:
+        line = {
+            "metric": "triangles*grad-iters/sec at 2048^2/3000 tris; HBM GB/s vs roofline",
+            "value": NT * args.steps * world / dt,
+            "unit": "triangles*grad-iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {
+                "workload": "2048x2048 RGBA8 synthetic Voronoi+noise raster, 3000-triangle jittered grid "
+                            "(50x30x2), %s flavour, one replica per GPU" % ("warp" if args.flavour else "triangulate"),
+                "raster": [W, H], "triangles": NT, "points": NP, "variants": 13 * NT,
+                "parallelism": "replicas x%d (no data-path collective)" % world,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_accumulate", "kernel_us": acc_us, "algorithmic_bytes": bytes_iter,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(img if args.flavour == 0 else imgB, pts, tris, ratio)
+        print(json.dumps(line), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

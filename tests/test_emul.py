@@ -1,0 +1,80 @@
+"""The per-lane integer logic the HIP kernels run (tpose_amd/csrc/tp_raster.h: vertex stage, edge
+walkers, row spans, prefix-sum lookups, finalize) compiled for the CPU and checked against the oracle.
+This is a test harness around shared __host__ __device__ code -- not a product path."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tpose_amd import synth
+from util import case
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def em():
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    so = os.path.join(HERE, "_build", "libtp_emul.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", so,
+                           os.path.join(HERE, "emul", "emul.cpp")])
+    lib = C.CDLL(so)
+    lib.emul_reference_dp.restype = C.c_float
+    return lib
+
+
+def emul_moments(em, img, pts, tris, dp, ratio):
+    NT = tris.shape[0]
+    H, W = img.shape[:2]
+    mom = np.zeros((13 * NT, 6), np.int64)
+    em.emul_moments(img.ctypes.data_as(C.c_void_p), C.c_size_t(img.strides[0]), W, H,
+                    pts.ctypes.data_as(C.c_void_p), tris.ctypes.data_as(C.c_void_p), NT,
+                    C.c_float(dp), C.c_float(ratio), mom.ctypes.data_as(C.c_void_p), None)
+    return mom
+
+
+@pytest.mark.parametrize("W,H,grid", [(97, 61, (6, 4)), (300, 200, (15, 5)), (257, 131, (6, 4)),
+                                      (640, 480, (50, 30)), (200, 150, None)])
+@pytest.mark.parametrize("dp", [None, 0.2])
+def test_span_walker_matches_oracle(em, W, H, grid, dp):
+    img, _, pts, tris, ratio, colors = case(W, H, grid)
+    NT = tris.shape[0]
+    d = O.dp(0, NT) if dp is None else dp
+    mom = emul_moments(em, img, pts, tris, d, ratio)
+    assert np.array_equal(mom, O.moments(img, pts, tris, d, ratio))
+    for fl in (0, 1):
+        ten = np.zeros(13 * NT, np.int32); cn = np.zeros(13 * NT, np.int32); ca = np.zeros((13 * NT, 4), np.int32)
+        em.emul_finalize(mom.ctypes.data_as(C.c_void_p), NT, fl, colors.ctypes.data_as(C.c_void_p),
+                         ten.ctypes.data_as(C.c_void_p), cn.ctypes.data_as(C.c_void_p), ca.ctypes.data_as(C.c_void_p))
+        rt, rc, rca, _ = O.finalize(mom, NT, fl, colors)
+        assert np.array_equal(ten, rt) and np.array_equal(cn, rc)
+        if fl == 0:
+            assert np.array_equal(ca, rca)
+
+
+def test_span_walker_on_triangle_soup(em):
+    W, H = 200, 150
+    img = synth.voronoi_raster(W, H, seed=3, sites=10)
+    ratio = float(np.float32(W) / np.float32(H))
+    rng = np.random.default_rng(1)
+    for trial in range(30):
+        NP = 30
+        pts = (rng.random((NP, 2)).astype(np.float32) * 2 - 1) * np.float32(1.3)
+        pts[:, 0] *= np.float32(ratio)
+        if trial % 3 == 0:
+            pts = (np.round(pts * 8) / 8).astype(np.float32)   # exact ties, horizontal/vertical edges
+        if trial % 5 == 0:
+            pts[:5] = pts[5:10]                                  # degenerate triangles
+        tris = np.zeros((40, 4), np.int32)
+        tris[:, :3] = rng.integers(0, NP, (40, 3))
+        dp = [0.05, 0.0078125, 0.3][trial % 3]
+        assert np.array_equal(emul_moments(em, img, pts, tris, dp, ratio), O.moments(img, pts, tris, dp, ratio)), trial
+
+
+def test_reference_dp_matches_oracle(em):
+    for fl in (0, 1):
+        for NT in (2, 150, 3000, 12000, 40329):
+            assert np.float32(em.emul_reference_dp(fl, NT)) == np.float32(O.dp(fl, NT))
