@@ -135,6 +135,11 @@ int tp_profile_iterate(tp_context* ctx, const tp_params* p, int n_iters, double*
  * 4 = (triangle,tile) pairs of the last binning, 5 = device-side overflow flags */
 int tp_get_info(tp_context* ctx, int what, int64_t* value);
 
+/* device self-test of the exact span walker (tp_raster.h): for each (N0, step, d), the 32 values
+ * floor((N0 + r*step)/d), r = 0..31, as the accumulate kernel derives them.  out = int32[32*n]. */
+int tp_selftest_walker(tp_context* ctx, const int64_t* N0, const int32_t* step, const int32_t* d,
+                       int n, int32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,3 +87,9 @@ extern "C" void emul_finalize(const int64_t* mom, int NT, int flavour, const int
 }
 
 extern "C" float emul_reference_dp(int flavour, int NT) { return tp_reference_dp(flavour, NT); }
+
+// walker values for rows 0..rows-1 (tests the exactness claim of tp_make_walker directly)
+extern "C" void emul_walker(int64_t N0, int32_t step, int32_t d, int rows, int32_t* out) {
+    tp_walker w = tp_make_walker(N0, step, d);
+    for (int r = 0; r < rows; r++) { out[r] = tp_walker_value(w); w.x += w.s; }
+}

@@ -78,3 +78,37 @@ def test_reference_dp_matches_oracle(em):
     for fl in (0, 1):
         for NT in (2, 150, 3000, 12000, 40329):
             assert np.float32(em.emul_reference_dp(fl, NT)) == np.float32(O.dp(fl, NT))
+
+
+def test_walker_floor_is_exact(em):
+    """floor(x_r) == floor((N0 + r*step)/d) for 32 rows, including exact multiples, d = 1, the
+    largest d, and the clamp region."""
+    rng = np.random.default_rng(5)
+    out = np.zeros(32, np.int32)
+    em.emul_walker.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int, C.c_void_p]
+    cases = []
+    for _ in range(20000):
+        d = int(rng.choice([1, 2, 3, 255, 256, 257, (1 << 24) - 1, int(rng.integers(1, 1 << 24))]))
+        step = int(rng.integers(-(1 << 24) + 1, 1 << 24))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            N0 = int(rng.integers(-(1 << 40), 1 << 40))
+        elif kind == 1:   # exact multiples of d: the floor sits on the knife edge
+            N0 = d * int(rng.integers(-(1 << 15), 1 << 15))
+            step = d * int(rng.integers(-3, 4)) if rng.integers(0, 2) else step
+        elif kind == 2:   # just below / above a multiple
+            N0 = d * int(rng.integers(-(1 << 15), 1 << 15)) + int(rng.choice([-1, 1]))
+        else:
+            N0 = int(rng.integers(-(1 << 30), 1 << 30)) * max(1, d // 7)
+        if abs(N0) >= 1 << 41:
+            continue
+        cases.append((N0, step, d))
+    for N0, step, d in cases:
+        em.emul_walker(N0, step, d, 32, out.ctypes.data)
+        for r in range(32):
+            exact = (N0 + r * step) // d
+            if abs(N0 // d) > (1 << 30):
+                # clamped: only the side (far left / far right of any raster) matters
+                assert (out[r] > (1 << 28)) == (exact > 0) and abs(int(out[r])) > (1 << 28)
+            else:
+                assert int(out[r]) == exact, (N0, step, d, r, int(out[r]), exact)

@@ -129,3 +129,24 @@ def test_full_size_properties():
     p = ctx.retrieve(capi.BUF_POINTS)
     assert np.isfinite(p).all()
     ctx.close()
+
+
+def test_device_walker_floor_is_exact():
+    """The division-free edge walker on the GPU (v_rcp_f64 + Newton) against exact integer floors."""
+    rng = np.random.default_rng(11)
+    n = 200000
+    d = rng.integers(1, 1 << 24, n)
+    d[: n // 8] = rng.choice([1, 2, 3, 255, 256, 257, (1 << 24) - 1], n // 8)
+    step = rng.integers(-(1 << 24) + 1, 1 << 24, n)
+    N0 = rng.integers(-(1 << 40), 1 << 40, n)
+    k = n // 2
+    N0[:k] = d[:k] * rng.integers(-(1 << 15), 1 << 15, k) + rng.integers(-1, 2, k)   # knife edges
+    step[: k // 2] = d[: k // 2] * rng.integers(-3, 4, k // 2)
+    ctx = capi.Context(0, 64, 64)
+    got = ctx.selftest_walker(N0, step, d).astype(np.int64)
+    exact = (N0[:, None] + np.arange(32)[None, :] * step[:, None].astype(np.int64)) // d[:, None]
+    inside = np.abs(N0 // d) <= (1 << 30)
+    assert np.array_equal(got[inside], exact[inside])
+    far = ~inside
+    assert np.all((got[far] > (1 << 28)) == (exact[far] > 0)) and np.all(np.abs(got[far]) > (1 << 28))
+    ctx.close()

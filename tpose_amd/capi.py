@@ -22,7 +22,7 @@ SYMBOLS = [
     "tp_abi_version", "tp_device_count", "tp_last_error", "tp_create", "tp_destroy", "tp_set_ratio",
     "tp_get_ratio", "tp_set_dp", "tp_set_image", "tp_set_image_device", "tp_upload", "tp_accumulate",
     "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_synchronize",
-    "tp_get_stream", "tp_profile_iterate", "tp_get_info",
+    "tp_get_stream", "tp_profile_iterate", "tp_get_info", "tp_selftest_walker",
 ]
 
 
@@ -69,6 +69,7 @@ def load():
         lib.tp_profile_iterate.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_double)]
         lib.tp_get_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         lib.tp_device_count.argtypes = [C.POINTER(C.c_int)]
+        lib.tp_selftest_walker.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -180,6 +181,15 @@ class Context:
         v = C.c_int64(0)
         self._ck(self.lib.tp_get_info(self.h, what, C.byref(v)))
         return v.value
+
+    def selftest_walker(self, N0, step, d):
+        N0 = np.ascontiguousarray(N0, np.int64)
+        step = np.ascontiguousarray(step, np.int32)
+        d = np.ascontiguousarray(d, np.int32)
+        out = np.zeros((N0.shape[0], 32), np.int32)
+        self._ck(self.lib.tp_selftest_walker(self.h, N0.ctypes.data, step.ctypes.data, d.ctypes.data,
+                                             N0.shape[0], out.ctypes.data))
+        return out
 
     def stream(self):
         s = C.c_void_p()

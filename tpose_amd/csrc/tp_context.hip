@@ -512,6 +512,22 @@ int tp_get_stream(tp_context* c, void** s) {
     return TP_OK;
 }
 
+int tp_selftest_walker(tp_context* c, const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out) {
+    if (!c || !N0 || !step || !d || !out || n < 0) return TP_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int64_t* dN = nullptr; int32_t *ds = nullptr, *dd = nullptr, *dout = nullptr;
+    HIP_TRY(c, dev_alloc(&dN, n)); HIP_TRY(c, dev_alloc(&ds, n)); HIP_TRY(c, dev_alloc(&dd, n));
+    HIP_TRY(c, dev_alloc(&dout, (size_t)n * 32));
+    HIP_TRY(c, hipMemcpy(dN, N0, sizeof(int64_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(ds, step, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(dd, d, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    tp_launch_selftest_walker(dN, ds, dd, n, dout, c->stream);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, dout, sizeof(int32_t) * 32 * (size_t)n, hipMemcpyDeviceToHost));
+    hipFree(dN); hipFree(ds); hipFree(dd); hipFree(dout);
+    return TP_OK;
+}
+
 int tp_get_info(tp_context* c, int what, int64_t* value) {
     if (!c || !value) return TP_ERR_INVALID;
     switch (what) {

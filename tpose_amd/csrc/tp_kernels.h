@@ -54,3 +54,4 @@ void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s);
 void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s);
 size_t tp_accumulate_lds_bytes();
 hipError_t tp_kernels_init();  // per-device function attributes (dynamic LDS > 64 KiB)
+void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s);

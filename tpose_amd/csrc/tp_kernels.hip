@@ -22,50 +22,78 @@
 #define ROWLEN (TW + 1)  // exclusive prefix has TW+1 entries per row
 
 static_assert(TW == 128, "prefix build assumes 32 lanes x 4 pixels per row");
-static_assert(TH % 8 == 0 && TH <= TP_WALK_MAXROWS, "tile height");
+#define ACC_THREADS 512
+#define ACC_ROWS_PER_PASS (ACC_THREADS / 32)
+static_assert(TH % ACC_ROWS_PER_PASS == 0 && TH <= TP_WALK_MAXROWS, "tile height");
 
 size_t tp_accumulate_lds_bytes() { return (size_t)TH * ROWLEN * sizeof(uint4); }
 
 // ------------------------------------------------------------------------------------------------
 // k_bin
 // ------------------------------------------------------------------------------------------------
+#define BIN_TRIS 64  // triangles per 256-thread block
+
 __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int t = wave; t < L.NT; t += nwaves) {
-        const int4 tri = L.tris[t];
-        const float2 a = L.points[tri.x], b = L.points[tri.y], c = L.points[tri.z];
-        const float p[3][2] = {{a.x, a.y}, {b.x, b.y}, {c.x, c.y}};
-        const tp_bbox bb = tp_triangle_bbox(p, L.vw);
-        int cnt = 0, tx0 = 0, ty0 = 0, ntx = 1;
-        if (bb.c0 <= bb.c1 && bb.r0 <= bb.r1) {
-            tx0 = bb.c0 / TW; ty0 = bb.r0 / TH;
-            ntx = bb.c1 / TW - tx0 + 1;
-            cnt = ntx * (bb.r1 / TH - ty0 + 1);
+    __shared__ int s_excl[BIN_TRIS + 1];  // exclusive scan of pair counts
+    __shared__ int s_rect[BIN_TRIS][3];   // tx0, ty0, ntx
+    __shared__ uint32_t s_base;
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x * BIN_TRIS + tid;
+    int cnt = 0;
+    if (tid < BIN_TRIS) {
+        int tx0 = 0, ty0 = 0, ntx = 1;
+        if (t < L.NT) {
+            const int4 tri = L.tris[t];
+            const float2 a = L.points[tri.x], b = L.points[tri.y], c = L.points[tri.z];
+            const float p[3][2] = {{a.x, a.y}, {b.x, b.y}, {c.x, c.y}};
+            const tp_bbox bb = tp_triangle_bbox(p, L.vw);
+            if (bb.c0 <= bb.c1 && bb.r0 <= bb.r1) {
+                tx0 = bb.c0 / TW; ty0 = bb.r0 / TH;
+                ntx = bb.c1 / TW - tx0 + 1;
+                cnt = ntx * (bb.r1 / TH - ty0 + 1);
+            }
         }
-        uint32_t base = 0;
-        if (lane == 0) {
-            if (cnt) base = atomicAdd(&L.state->pair_total, (uint32_t)cnt);
-            if (base + (uint32_t)cnt > (uint32_t)L.pair_cap) atomicOr(&L.state->flags, TP_FLAG_PAIR_OVERFLOW);
-            L.tri_pair[t] = make_int2((int)base, cnt);
+        s_rect[tid][0] = tx0; s_rect[tid][1] = ty0; s_rect[tid][2] = ntx;
+        // wave 0 holds all BIN_TRIS counts: inclusive scan by shuffles
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(inc, o);
+            if (tid >= o) inc += v;
         }
-        base = __shfl(base, 0);
-        for (int k = lane; k < cnt; k += 64) {
-            const int ky = k / ntx, kx = k - ky * ntx;
-            const int tile = (ty0 + ky) * L.tiles_x + tx0 + kx;
-            const int slot = atomicAdd(&L.tilecount[tile], 1);
-            if (slot < L.list_cap) L.tilelist[(size_t)tile * L.list_cap + slot] = make_int2(t, (int)base + k);
-            else atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
+        s_excl[tid + 1] = inc;
+        if (tid == 0) s_excl[0] = 0;
+        if (tid == BIN_TRIS - 1) {
+            uint32_t base = 0;
+            if (inc) base = atomicAdd(&L.state->pair_total, (uint32_t)inc);
+            if (base + (uint32_t)inc > (uint32_t)L.pair_cap) atomicOr(&L.state->flags, TP_FLAG_PAIR_OVERFLOW);
+            s_base = base;
         }
+    }
+    __syncthreads();
+    const int total = s_excl[BIN_TRIS];
+    const uint32_t base = s_base;
+    if (tid < BIN_TRIS && t < L.NT) L.tri_pair[t] = make_int2((int)base + s_excl[tid], cnt);
+    for (int p = tid; p < total; p += 256) {
+        int lo = 0, hi = BIN_TRIS;  // largest j with s_excl[j] <= p
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int mid = (lo + hi) >> 1;
+            if (s_excl[mid] <= p) lo = mid; else hi = mid;
+        }
+        const int k = p - s_excl[lo], ntx = s_rect[lo][2];
+        const int ky = k / ntx, kx = k - ky * ntx;
+        const int tile = (s_rect[lo][1] + ky) * L.tiles_x + s_rect[lo][0] + kx;
+        const int slot = atomicAdd(&L.tilecount[tile], 1);
+        if (slot < L.list_cap)
+            L.tilelist[(size_t)tile * L.list_cap + slot] = make_int2(blockIdx.x * BIN_TRIS + lo, (int)base + p);
+        else
+            atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
     }
 }
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s) {
-    int waves = L.NT < 8192 ? L.NT : 8192;
-    int blocks = (waves + 3) / 4;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_bin, dim3(blocks), dim3(256), 0, s, L);
+    hipLaunchKernelGGL(k_bin, dim3((L.NT + BIN_TRIS - 1) / BIN_TRIS), dim3(256), 0, s, L);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -102,7 +130,7 @@ __device__ __forceinline__ pix3 operator+(pix3 a, pix3 b) { return {a.w0 + b.w0,
 // ------------------------------------------------------------------------------------------------
 // k_accumulate
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_accumulate(tp_launch L) {
+__global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
     extern __shared__ __attribute__((aligned(16))) uint4 P[];  // [TH][ROWLEN]
 
     const int tile = blockIdx.x;
@@ -115,14 +143,15 @@ __global__ __launch_bounds__(256) void k_accumulate(tp_launch L) {
 
     // ---- phase 1: pixels -> row prefix sums in LDS ------------------------------------------
     {
-        const int l32 = tid & 31, rsub = tid >> 5;  // 8 rows per pass, 32 lanes x 4 px per row
+        const int l32 = tid & 31, rsub = tid >> 5;  // 32 lanes x 4 px per row, ACC_ROWS_PER_PASS rows per pass
         const uint8_t* src = L.img + (size_t)(ty * TH + rsub) * L.pitch + (size_t)(tx * TW + l32 * 4) * 4;
-        uint4 px[TH / 8];
+        constexpr int NPASS = TH / ACC_ROWS_PER_PASS;
+        uint4 px[NPASS];
 #pragma unroll
-        for (int p = 0; p < TH / 8; p++)
-            px[p] = *reinterpret_cast<const uint4*>(src + (size_t)p * 8 * L.pitch);
+        for (int p = 0; p < NPASS; p++)
+            px[p] = *reinterpret_cast<const uint4*>(src + (size_t)p * ACC_ROWS_PER_PASS * L.pitch);
 #pragma unroll
-        for (int p = 0; p < TH / 8; p++) {
+        for (int p = 0; p < NPASS; p++) {
             const pix3 e0 = pixel_moments(px[p].x), e1 = pixel_moments(px[p].y),
                        e2 = pixel_moments(px[p].z), e3 = pixel_moments(px[p].w);
             const pix3 s1 = e0 + e1, s2 = s1 + e2, s3 = s2 + e3;
@@ -130,7 +159,7 @@ __global__ __launch_bounds__(256) void k_accumulate(tp_launch L) {
             ex.w0 = scan32_inclusive(s3.w0) - s3.w0;
             ex.w1 = scan32_inclusive(s3.w1) - s3.w1;
             ex.w2 = scan32_inclusive(s3.w2) - s3.w2;
-            uint4* row = P + (p * 8 + rsub) * ROWLEN + l32 * 4;
+            uint4* row = P + (p * ACC_ROWS_PER_PASS + rsub) * ROWLEN + l32 * 4;
             row[0] = make_uint4(ex.w0, ex.w1, ex.w2, 0);
             row[1] = make_uint4(ex.w0 + e0.w0, ex.w1 + e0.w1, ex.w2 + e0.w2, 0);
             row[2] = make_uint4(ex.w0 + s1.w0, ex.w1 + s1.w1, ex.w2 + s1.w2, 0);
@@ -148,7 +177,7 @@ __global__ __launch_bounds__(256) void k_accumulate(tp_launch L) {
     const int nitems = nlist * TP_NVARIANTS;
     const int2* list = L.tilelist + (size_t)tile * L.list_cap;
 
-    for (int item = tid; item < nitems; item += 256) {
+    for (int item = tid; item < nitems; item += ACC_THREADS) {
         const int e = item / TP_NVARIANTS, v = item - e * TP_NVARIANTS;
         const int2 ent = list[e];
         const int4 tri = L.tris[ent.x];
@@ -188,7 +217,7 @@ hipError_t tp_kernels_init() {
 }
 
 void tp_launch_accumulate(const tp_launch& L, hipStream_t s) {
-    hipLaunchKernelGGL(k_accumulate, dim3(L.tiles_x * L.tiles_y), dim3(256), tp_accumulate_lds_bytes(), s, L);
+    hipLaunchKernelGGL(k_accumulate, dim3(L.tiles_x * L.tiles_y), dim3(ACC_THREADS), tp_accumulate_lds_bytes(), s, L);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -275,4 +304,16 @@ __global__ void k_replicate_colors(tp_launch L) {
 void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s) {
     const int n = L.NT * TP_NVARIANTS;
     hipLaunchKernelGGL(k_replicate_colors, dim3((n + 255) / 256), dim3(256), 0, s, L);
+}
+
+// device-side self-test of the edge walker (tp_selftest_walker): 32 row values per (N0, step, d)
+__global__ void k_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n) return;
+    tp_walker w = tp_make_walker(N0[gid], step[gid], d[gid]);
+    for (int r = 0; r < 32; r++) { out[(size_t)gid * 32 + r] = tp_walker_value(w); w.x += w.s; }
+}
+
+void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest_walker, dim3((n + 255) / 256), dim3(256), 0, s, N0, step, d, n, out);
 }

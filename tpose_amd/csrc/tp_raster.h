@@ -113,48 +113,55 @@ TP_HD int32_t tp_first_centre(int32_t vmin) { return (vmin - 128 + 255) >> 8; }
 TP_HD int32_t tp_last_centre(int32_t vmax) { return (vmax - 128) >> 8; }
 
 // ---------------------------------------------------------------------------------------------
-// Edge walker.  For one edge with d = |a| > 0 the column bound of row r is floor(N_r / d) with
-// N_{r+1} = N_r + step, all integers, d < 2^24.  It is tracked as x_r = x_0 + r*s in 32.32 fixed
-// point:  x_0 = floor(N_0/d)*2^32 + floor(rem*2^32/d) + BIAS,  s = floor(step*2^32/d)  (each
-// fractional part off by at most one unit from the double-precision estimate).  Over at most 32
-// rows the accumulated error lies in (BIAS-66, BIAS+34) units of 2^-32; the exact fractional part
-// of N_r/d is a multiple of 1/d >= 2^-24 = 256 units, so with BIAS = 96 the integer part of x_r
-// IS floor(N_r/d) for every row.  Quotients beyond +-2^30 are clamped (they stay far outside any
-// raster for the whole tile: the per-row drift is < 2^24).
+// Edge walker.  For one edge with d = |a| (1 <= d < 2^24) the column bound of row r is
+// floor(N_r / d) with N_{r+1} = N_r + step, integers, |N| < 2^41, |step| < 2^24.  It is tracked as
+// x_r = x_0 + r*s in 32.32 fixed point, built WITHOUT integer division:
+//     inv = 1/d (double),  t = N_0*inv,  x_0 = floor(t)*2^32 + trunc(frac(t)*2^32) + BIAS,
+//     ts = step*inv,       s   = floor(ts)*2^32 + trunc(frac(ts)*2^32),   BIAS = floor(2^31*inv).
+// Error budget in units of 2^-32, with u = 2^32/d >= 256 the spacing of the possible exact
+// fractional parts of N_r/d:  t and ts carry relative error <= 2^-50 (|t| <= 2^41/d -> < 2^-9 u),
+// each truncation loses < 1 unit, so after at most 32 rows  x_r - BIAS  lies in
+// (N_r/d - 34 units - 2^-8 u,  N_r/d + 2^-8 u]  -- within (-u/4, +u/4) of the exact value.  Adding
+// BIAS = u/2 puts x_r strictly between N_r/d and N_r/d + u whenever N_r/d is a multiple of 1/d,
+// hence  floor(x_r) == floor(N_r/d)  for every row: the span ends are EXACT.
+// Quotients beyond +-2^30 are clamped (per-row drift < 2^24, so they stay far outside any raster
+// for the whole <= 32-row window and int32 never overflows).
 // ---------------------------------------------------------------------------------------------
-#define TP_WALK_BIAS 96
 #define TP_WALK_MAXROWS 32
 
 struct tp_walker {
     int64_t x, s;
 };
 
-TP_HD void tp_divmod_floor(int64_t N, int32_t d, double inv, int64_t& q, int64_t& rem) {
-    q = (int64_t)floor((double)N * inv);
-    rem = N - q * (int64_t)d;
-    while (rem < 0) { rem += d; --q; }
-    while (rem >= d) { rem -= d; ++q; }
+TP_HD double tp_rcp_exact(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);  // v_rcp_f64 (reduced precision) + two Newton steps
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+#else
+    return 1.0 / d;
+#endif
 }
 
-TP_HD uint32_t tp_frac32(int64_t rem, double inv) {
-    double f = floor((double)rem * 4294967296.0 * inv);
-    if (f > 4294967295.0) f = 4294967295.0;
-    if (f < 0.0) f = 0.0;
-    return (uint32_t)f;
+// floor(t)*2^32 + trunc(frac(t)*2^32) for |t| <= 2^30
+TP_HD int64_t tp_fix32(double t) {
+    const double q = floor(t);
+    const double f = (t - q) * 4294967296.0;  // exact subtraction, in [0, 2^32)
+    const int32_t qi = (int32_t)q;
+    uint32_t fi = (f >= 4294967295.0) ? 4294967295u : (uint32_t)f;
+    return (int64_t)(((uint64_t)(uint32_t)qi << 32) | fi);
 }
 
 TP_HD tp_walker tp_make_walker(int64_t N0, int32_t step, int32_t d) {
-    const double inv = 1.0 / (double)d;
-    int64_t q, rem, sq, srem;
-    tp_divmod_floor(N0, d, inv, q, rem);
-    uint32_t fr = tp_frac32(rem, inv);
-    const int64_t QMAX = (int64_t)1 << 30;
-    if (q > QMAX) { q = QMAX; fr = 0; }
-    if (q < -QMAX) { q = -QMAX; fr = 0; }
-    tp_divmod_floor((int64_t)step, d, inv, sq, srem);
+    const double inv = tp_rcp_exact((double)d);
+    double t = (double)N0 * inv;
+    t = fmin(fmax(t, -1073741824.0), 1073741824.0);
     tp_walker w;
-    w.x = q * 4294967296LL + (int64_t)fr + TP_WALK_BIAS;
-    w.s = sq * 4294967296LL + (int64_t)tp_frac32(srem, inv);
+    w.x = tp_fix32(t) + (int64_t)(uint32_t)(2147483648.0 * inv);  // d = 1: bias 2^31 = half a unit step
+    w.s = tp_fix32((double)step * inv);
     return w;
 }
 
