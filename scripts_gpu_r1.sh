@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -8
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r1 -o r1 -- python bench.py --steps 512 --warmup 64 --no-cpu-baseline > gpurun_out/prof_r1.log 2>&1
-tail -1 gpurun_out/prof_r1.log | cut -c1-400
+tail -1 gpurun_out/prof_r1.log | cut -c1-300
 f=$(find gpurun_out/prof_r1 -name "*kernel_stats.csv" | head -1); cat "$f" | head -8

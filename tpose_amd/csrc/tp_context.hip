@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -45,7 +46,7 @@ struct tp_context {
     // work lists
     int tiles_x = 0, tiles_y = 0;
     int* tilecount = nullptr;
-    int2* tilelist = nullptr;
+    tp_list_entry* tilelist = nullptr;
     size_t tilelist_elems = 0;
     int list_cap = 0;
     int2* tri_pair = nullptr;
@@ -58,6 +59,7 @@ struct tp_context {
     int4* ca = nullptr;
     int2* gr = nullptr;
     int64_t* moments = nullptr;
+    unsigned long long* gacc = nullptr;
 
     bool uploaded = false, accumulated = false, energized = false;
     int acc_slot = 0, acc_flavour = 0;
@@ -102,10 +104,10 @@ void drop_graphs(tp_context* c) {
 void free_triangulation(tp_context* c) {
     hipFree(c->points); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
     hipFree(c->tri_pair); hipFree(c->partials); hipFree(c->tilelist);
-    hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments);
+    hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
     c->points = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
     c->tri_pair = nullptr; c->partials = nullptr; c->tilelist = nullptr;
-    c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr;
+    c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
     c->capT = c->capP = 0;
 }
 
@@ -124,6 +126,9 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.tri_pair = c->tri_pair; L.partials = c->partials; L.pair_cap = c->pair_cap;
     L.state = c->state;
     L.ten = c->ten; L.cn = c->cn; L.ca = c->ca; L.gr = c->gr; L.moments = c->moments;
+    L.gacc = c->gacc;
+    static const int dbg = getenv("TPOSE_DEBUG_ACC") ? atoi(getenv("TPOSE_DEBUG_ACC")) : 0;
+    L.debug = dbg;
     return L;
 }
 
@@ -146,8 +151,7 @@ void enqueue_iter(tp_context* c, const tp_params& p, float dp, bool first) {
     }
     tp_launch_bin(L, c->stream);
     tp_launch_accumulate(L, c->stream);
-    tp_launch_finalize(L, p.flavour, false, c->stream);
-    tp_launch_shift(L, p.rate, c->stream);  // also re-arms tilecount / pair_total
+    tp_launch_update(L, p.flavour, p.rate, c->stream);  // finalize + gradient + shift; re-arms the lists
 }
 
 int check_flags(tp_context* c) {
@@ -288,6 +292,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         const int capT = NT + NT / 2 + 64, capP = NP + NP / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->points, capP));
         HIP_TRY(c, dev_alloc(&c->gr, capP));
+        HIP_TRY(c, dev_alloc(&c->gacc, (size_t)2 * capP));
         HIP_TRY(c, dev_alloc(&c->vtx_off, capP + 1));
         HIP_TRY(c, dev_alloc(&c->tris, capT));
         HIP_TRY(c, dev_alloc(&c->colors, capT));
@@ -345,6 +350,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     HIP_TRY(c, hipMemset(c->state, 0, sizeof(tp_device_state)));
+    HIP_TRY(c, hipMemset(c->gacc, 0, sizeof(unsigned long long) * 2 * (size_t)c->capP));
     c->generation++;  // captured graphs bake NT, NP, dp and buffer addresses
     c->uploaded = true; c->accumulated = c->energized = false;
     return TP_OK;
@@ -461,8 +467,7 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         tp_launch_accumulate(L, c->stream);
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-        tp_launch_finalize(L, p->flavour, false, c->stream);
-        tp_launch_shift(L, p->rate, c->stream);
+        tp_launch_update(L, p->flavour, p->rate, c->stream);
         HIP_TRY(c, hipEventSynchronize(c->ev1));
         float ms = 0.0f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));

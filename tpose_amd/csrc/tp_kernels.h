@@ -18,6 +18,13 @@ struct tp_device_state {
     uint32_t pad[2];
 };
 
+// One (triangle, tile) work item, self-contained so the accumulate kernel has no dependent loads:
+// where its partial record goes and the triangle's three vertices (t-pose space).
+struct __attribute__((aligned(16))) tp_list_entry {
+    int pair, tri;
+    float x0, y0, x1, y1, x2, y2;
+};
+
 struct tp_launch {
     // raster
     const uint8_t* img;  // padded RGBA8 plane
@@ -33,7 +40,7 @@ struct tp_launch {
     const int* vtx_adj;
     // work lists
     int* tilecount;      // [tiles]
-    int2* tilelist;      // [tiles * list_cap] (t, pair)
+    tp_list_entry* tilelist;  // [tiles * list_cap]
     int list_cap;
     int2* tri_pair;      // [NT] (first pair, #pairs)
     uint32_t* partials;  // [pair_cap * 13 * 6]
@@ -45,12 +52,15 @@ struct tp_launch {
     int4* ca;
     int2* gr;
     int64_t* moments;  // optional int64[13NT][6]
+    unsigned long long* gacc;  // [NP][2] fused-update accumulators: (gradient component << 32) | arrivals
+    int debug;         // ablation knobs (TPOSE_DEBUG_ACC), 0 in production
 };
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s);
 void tp_launch_accumulate(const tp_launch& L, hipStream_t s);
 void tp_launch_finalize(const tp_launch& L, int flavour, bool write_moments, hipStream_t s);
 void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s);
+void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s);
 void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s);
 size_t tp_accumulate_lds_bytes();
 hipError_t tp_kernels_init();  // per-device function attributes (dynamic LDS > 64 KiB)

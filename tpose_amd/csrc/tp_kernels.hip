@@ -36,6 +36,7 @@ size_t tp_accumulate_lds_bytes() { return (size_t)TH * ROWLEN * sizeof(uint4); }
 __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
     __shared__ int s_excl[BIN_TRIS + 1];  // exclusive scan of pair counts
     __shared__ int s_rect[BIN_TRIS][3];   // tx0, ty0, ntx
+    __shared__ float s_pts[BIN_TRIS][6];
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x;
     const int t = blockIdx.x * BIN_TRIS + tid;
@@ -47,6 +48,8 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
             const float2 a = L.points[tri.x], b = L.points[tri.y], c = L.points[tri.z];
             const float p[3][2] = {{a.x, a.y}, {b.x, b.y}, {c.x, c.y}};
             const tp_bbox bb = tp_triangle_bbox(p, L.vw);
+            s_pts[tid][0] = a.x; s_pts[tid][1] = a.y; s_pts[tid][2] = b.x; s_pts[tid][3] = b.y;
+            s_pts[tid][4] = c.x; s_pts[tid][5] = c.y;
             if (bb.c0 <= bb.c1 && bb.r0 <= bb.r1) {
                 tx0 = bb.c0 / TW; ty0 = bb.r0 / TH;
                 ntx = bb.c1 / TW - tx0 + 1;
@@ -85,9 +88,13 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
         const int ky = k / ntx, kx = k - ky * ntx;
         const int tile = (s_rect[lo][1] + ky) * L.tiles_x + s_rect[lo][0] + kx;
         const int slot = atomicAdd(&L.tilecount[tile], 1);
-        if (slot < L.list_cap)
-            L.tilelist[(size_t)tile * L.list_cap + slot] = make_int2(blockIdx.x * BIN_TRIS + lo, (int)base + p);
-        else
+        if (slot < L.list_cap) {
+            tp_list_entry e;
+            e.pair = (int)base + p; e.tri = blockIdx.x * BIN_TRIS + lo;
+            e.x0 = s_pts[lo][0]; e.y0 = s_pts[lo][1]; e.x1 = s_pts[lo][2]; e.y1 = s_pts[lo][3];
+            e.x2 = s_pts[lo][4]; e.y2 = s_pts[lo][5];
+            L.tilelist[(size_t)tile * L.list_cap + slot] = e;
+        } else
             atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
     }
 }
@@ -135,21 +142,28 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
 
     const int tile = blockIdx.x;
     const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
-    int nlist = L.tilecount[tile];
-    if (nlist > L.list_cap) nlist = L.list_cap;
-    if (nlist == 0) return;
-
     const int tid = threadIdx.x;
+    constexpr int NPASS = TH / ACC_ROWS_PER_PASS;
 
-    // ---- phase 1: pixels -> row prefix sums in LDS ------------------------------------------
+    // issue every global load up front: the tile's pixels, the list length, this lane's first item
+    const int l32 = tid & 31, rsub = tid >> 5;  // 32 lanes x 4 px per row, ACC_ROWS_PER_PASS rows per pass
+    uint4 px[NPASS];
     {
-        const int l32 = tid & 31, rsub = tid >> 5;  // 32 lanes x 4 px per row, ACC_ROWS_PER_PASS rows per pass
         const uint8_t* src = L.img + (size_t)(ty * TH + rsub) * L.pitch + (size_t)(tx * TW + l32 * 4) * 4;
-        constexpr int NPASS = TH / ACC_ROWS_PER_PASS;
-        uint4 px[NPASS];
 #pragma unroll
         for (int p = 0; p < NPASS; p++)
             px[p] = *reinterpret_cast<const uint4*>(src + (size_t)p * ACC_ROWS_PER_PASS * L.pitch);
+    }
+    int nlist = L.tilecount[tile];
+    if (nlist > L.list_cap) nlist = L.list_cap;
+    if (nlist == 0) return;
+    const int nitems = nlist * TP_NVARIANTS;
+    const tp_list_entry* list = L.tilelist + (size_t)tile * L.list_cap;
+    int item = tid;
+    tp_list_entry ent = list[item < nitems ? item / TP_NVARIANTS : 0];
+
+    // ---- phase 1: pixels -> row prefix sums in LDS ------------------------------------------
+    if (!(L.debug & 1)) {
 #pragma unroll
         for (int p = 0; p < NPASS; p++) {
             const pix3 e0 = pixel_moments(px[p].x), e1 = pixel_moments(px[p].y),
@@ -168,42 +182,52 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
         }
     }
     __syncthreads();
+    if (L.debug & 2) return;
 
     // ---- phase 2: one lane per (triangle, variant) of this tile --------------------------------
     const int row0 = ty * TH;
     const int row1 = min(row0 + TH - 1, L.vw.H - 1);
     const int col0 = tx * TW;
     const int colE = min(col0 + TW, L.vw.W);
-    const int nitems = nlist * TP_NVARIANTS;
-    const int2* list = L.tilelist + (size_t)tile * L.list_cap;
 
-    for (int item = tid; item < nitems; item += ACC_THREADS) {
+    for (; item < nitems; item += ACC_THREADS) {
         const int e = item / TP_NVARIANTS, v = item - e * TP_NVARIANTS;
-        const int2 ent = list[e];
-        const int4 tri = L.tris[ent.x];
-        const float2 p0 = L.points[tri.x], p1 = L.points[tri.y], p2 = L.points[tri.z];
+        if (item != tid) ent = list[e];
         int32_t X[3], Y[3];
-        tp_vertex_stage(p0.x, p0.y, v, 0, L.vw, X[0], Y[0]);
-        tp_vertex_stage(p1.x, p1.y, v, 1, L.vw, X[1], Y[1]);
-        tp_vertex_stage(p2.x, p2.y, v, 2, L.vw, X[2], Y[2]);
+        tp_vertex_stage(ent.x0, ent.y0, v, 0, L.vw, X[0], Y[0]);
+        tp_vertex_stage(ent.x1, ent.y1, v, 1, L.vw, X[1], Y[1]);
+        tp_vertex_stage(ent.x2, ent.y2, v, 2, L.vw, X[2], Y[2]);
         tp_span sp = tp_setup_span(X, Y, row0, row1);
+        if (L.debug & 4) sp.r1 = sp.r0 - 1 + (int)(sp.A.x & 1);
 
         uint32_t n = 0, no = 0, sr = 0, sg = 0, sb = 0, q = 0;
-        const uint4* rowp = P + (sp.r0 - row0) * ROWLEN - col0;
-        for (int r = sp.r0; r <= sp.r1; ++r, rowp += ROWLEN) {
-            int32_t lo, hi;
-            tp_span_row(sp, col0, colE, lo, hi);
-            if (lo < hi) {
-                const uint4 a = rowp[lo], b = rowp[hi];
-                const uint32_t d0 = b.x - a.x, d1 = b.y - a.y;
-                n += (uint32_t)(hi - lo);
+        // four rows per trip: all eight LDS reads are issued before any result is consumed; rows
+        // past the end (or empty spans) read P[row][0] twice and contribute zero
+        for (int r = sp.r0; r <= sp.r1; r += 4) {
+            uint4 a[4], b[4];
+            int32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int32_t lo, hi;
+                tp_span_row(sp, col0, colE, lo, hi);
+                const bool ok = (r + j <= sp.r1) && (lo < hi);
+                lo = ok ? lo - col0 : 0;
+                hi = ok ? hi - col0 : 0;
+                const uint4* rowp = P + min(r + j - row0, TH - 1) * ROWLEN;
+                a[j] = rowp[lo]; b[j] = rowp[hi];
+                w[j] = hi - lo;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t d0 = b[j].x - a[j].x, d1 = b[j].y - a[j].y;
+                n += (uint32_t)w[j];
                 sr += d0 & 0xffffu; sg += d0 >> 16;
                 sb += d1 & 0xffffu; no += d1 >> 16;
-                q += b.z - a.z;
+                q += b[j].z - a[j].z;
             }
         }
-        if (ent.y < L.pair_cap) {
-            uint32_t* out = L.partials + ((size_t)ent.y * TP_NVARIANTS + v) * TP_PARTIAL_WORDS;
+        if (ent.pair < L.pair_cap) {
+            uint32_t* out = L.partials + ((size_t)ent.pair * TP_NVARIANTS + v) * TP_PARTIAL_WORDS;
             reinterpret_cast<uint2*>(out)[0] = make_uint2(n, no);
             reinterpret_cast<uint2*>(out)[1] = make_uint2(sr, sg);
             reinterpret_cast<uint2*>(out)[2] = make_uint2(sb, q);
@@ -292,6 +316,103 @@ __global__ __launch_bounds__(256) void k_shift(tp_launch L, float rate) {
 
 void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s) {
     hipLaunchKernelGGL(k_shift, dim3((L.NP + 255) / 256), dim3(256), 0, s, L, rate);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_update: k_finalize + k_shift in ONE launch (used by tp_iterate).  Thread (g, t): g = 0 handles
+// the base variant of triangle t, g = 1..3 the four variants that displace vertex slot s = g-1.
+// After writing the reference-layout outputs, a slot thread adds its central differences to its
+// vertex with one returning 64-bit atomic per component -- (difference << 32) + 1 -- so the thread
+// that completes the vertex's arrival count already holds the whole (wrapping int32) gradient
+// component and takes the shift.cs step for it.  x and y never interact in shift.cs, so they are
+// settled independently.  Integer sums commute: the result does not depend on arrival order.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ tp_moments sum_partials(const tp_launch& L, int2 pr, int i) {
+    tp_moments m = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < pr.y; k++) {
+        const int pair = pr.x + k;
+        if (pair >= L.pair_cap) break;
+        const uint2* in = reinterpret_cast<const uint2*>(L.partials + ((size_t)pair * TP_NVARIANTS + i) * TP_PARTIAL_WORDS);
+        const uint2 a = in[0], b = in[1], c = in[2];
+        m.n += a.x; m.nodd += a.y; m.sr += b.x; m.sg += b.y; m.sb += c.x; m.q += c.y;
+    }
+    return m;
+}
+
+__device__ __forceinline__ int32_t emit_variant(const tp_launch& L, int flavour, int t, int i, const tp_moments& m) {
+    const int id = i * L.NT + t;
+    int64_t E;
+    if (flavour == 0) {
+        E = tp_energy_triangulate(m);
+        L.ca[id] = make_int4(tp_wrap32(m.sr), tp_wrap32(m.sg), tp_wrap32(m.sb), 0);
+    } else {
+        const int4 col = L.ca[id];
+        E = tp_energy64(m, col.x, col.y, col.z);
+    }
+    const int32_t e32 = tp_wrap32(E);
+    L.ten[id] = e32;
+    L.cn[id] = tp_wrap32(m.n);
+    return e32;
+}
+
+// settle one gradient component; returns true (and the total) for the last arriver
+__device__ __forceinline__ bool arrive(unsigned long long* slot, uint32_t contrib, int degree, uint32_t& total) {
+    const unsigned long long old = atomicAdd(slot, ((unsigned long long)contrib << 32) + 1ull);
+    if ((int)(old & 0xffffffffull) != degree - 1) return false;
+    total = (uint32_t)(old >> 32) + contrib;
+    *slot = 0ull;  // re-armed for the next launch (nobody else touches it any more)
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float rate) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    for (int k = gid; k < L.tiles_x * L.tiles_y; k += nth) L.tilecount[k] = 0;
+    if (gid == 0) { L.state->pad[0] = L.state->pair_total; L.state->pair_total = 0; }
+
+    // one thread per variant.  Threads [0, 12 NT): quads (t, s, k) = the four displacements of
+    // vertex slot s, adjacent lanes; threads [12 NT, 13 NT): the base variants.
+    const int NT = L.NT;
+    const bool live = gid < 13 * NT;
+    int t, i;
+    if (gid < 12 * NT) { t = gid / 12; i = gid - 12 * t + 1; }
+    else { t = gid - 12 * NT; i = 0; }
+    int32_t e = 0;
+    if (live) e = emit_variant(L, flavour, t, i, sum_partials(L, L.tri_pair[t], i));
+    // central differences inside the quad: lanes 4q+0/1 hold E(+dx)/E(-dx), 4q+2/3 E(+dy)/E(-dy)
+    const uint32_t e1 = (uint32_t)__shfl_xor(e, 1);
+    const uint32_t gxy = (uint32_t)e - e1;                 // valid on even lanes of the quad
+    const uint32_t gy = (uint32_t)__shfl_down((int)gxy, 2);  // lane 4q+0 fetches lane 4q+2's value
+    if (!live || i == 0 || ((i - 1) & 3) != 0) return;
+    const int s = (i - 1) >> 2;
+    const int4 tri = L.tris[t];
+    const int v = s == 0 ? tri.x : s == 1 ? tri.y : tri.z;
+    const int deg = L.vtx_off[v + 1] - L.vtx_off[v];
+    const float R = L.vw.ratio;
+    uint32_t tot;
+    if (arrive(&L.gacc[2 * v], gxy, deg, tot)) {
+        reinterpret_cast<int*>(L.gr)[2 * v] = (int)tot;
+        if (v >= 4) {
+            float* px = reinterpret_cast<float*>(L.points) + 2 * v;
+            float x = *px, tg = (float)(int)tot;
+            if (x <= -R) { x = -R; tg = 0.0f; } else if (x >= R) { x = R; tg = 0.0f; }
+            *px = tp_fsub(x, tp_fdiv(tp_fdiv(tp_fmul(rate, tg), 256.0f), 256.0f));
+        }
+    }
+    if (arrive(&L.gacc[2 * v + 1], gy, deg, tot)) {
+        reinterpret_cast<int*>(L.gr)[2 * v + 1] = (int)tot;
+        if (v >= 4) {
+            float* py = reinterpret_cast<float*>(L.points) + 2 * v + 1;
+            float y = *py, tg = (float)(int)tot;
+            if (y <= -1.0f) { y = -1.0f; tg = 0.0f; } else if (y >= 1.0f) { y = 1.0f; tg = 0.0f; }
+            *py = tp_fsub(y, tp_fdiv(tp_fdiv(tp_fmul(rate, tg), 256.0f), 256.0f));
+        }
+    }
+}
+
+void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s) {
+    const int n = 13 * L.NT;
+    hipLaunchKernelGGL(k_update, dim3((n + 255) / 256), dim3(256), 0, s, L, flavour, rate);
 }
 
 // tpose::upload colour replication (source/triangulation.hpp:633-641): col[i*NT + k] = colors[k]
