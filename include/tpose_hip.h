@@ -89,6 +89,11 @@ int tp_get_ratio(const tp_context* ctx, float* ratio);
  * dp <= 0 restores the reference law.  tp_iterate takes its dp from tp_params instead. */
 int tp_set_dp(tp_context* ctx, float dp);
 
+/* tuning: the fused iteration keeps its per-tile work lists while no vertex has moved more than
+ * margin_px - 1 pixels since they were built (lists are built over bounding boxes inflated by
+ * margin_px); 0 or 1 rebuilds them every iteration.  Results are identical for every margin. */
+int tp_set_margin(tp_context* ctx, int margin_px);
+
 /* `Texture tex(IMG)` (software/triangulate/main.cpp:74, warp/main.cpp:118-119): RGBA8, row 0 = top,
  * width x height texels, `stride_bytes` between rows.  Host pointer. */
 int tp_set_image(tp_context* ctx, int slot, const uint8_t* rgba, size_t stride_bytes);
@@ -132,7 +137,8 @@ int tp_get_stream(tp_context* ctx, void** hip_stream);
 int tp_profile_iterate(tp_context* ctx, const tp_params* p, int n_iters, double* accumulate_us);
 
 /* introspection for tests/benchmarks: 0 = tiles_x, 1 = tiles_y, 2 = tile width, 3 = tile height,
- * 4 = (triangle,tile) pairs of the last binning, 5 = device-side overflow flags */
+ * 4 = (triangle,tile) pairs of the current work lists, 5 = device-side overflow flags,
+ * 6 = number of work-list rebuilds requested by the device so far */
 int tp_get_info(tp_context* ctx, int what, int64_t* value);
 
 /* device self-test of the exact span walker (tp_raster.h): for each (N0, step, d), the 32 values

@@ -16,21 +16,21 @@ extern "C" int emul_moments(const uint8_t* img, size_t stride, int W, int H, con
     vw.dp = dp; vw.ratio = ratio; vw.halfW = 0.5f * (float)W; vw.halfH = 0.5f * (float)H; vw.W = W; vw.H = H;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     memset(mom, 0, sizeof(int64_t) * 6 * 13 * (size_t)NT);
-    std::vector<uint32_t> P((size_t)TH * (TW + 1) * 3);
+    std::vector<uint64_t> P((size_t)TH * (TW + 1) * 2);  // entry = {x | y<<32, z | w<<32} like the LDS table
     int64_t pairs = 0;
     for (int ty = 0; ty < tiles_y; ty++)
         for (int tx = 0; tx < tiles_x; tx++) {
             // prefix table (zero outside the raster, like the padded device plane)
             for (int r = 0; r < TH; r++) {
-                uint32_t w0 = 0, w1 = 0, w2 = 0;
+                uint32_t x = 0, y = 0, z = 0, w = 0;
                 for (int c = 0; c <= TW; c++) {
-                    uint32_t* e = &P[((size_t)r * (TW + 1) + c) * 3];
-                    e[0] = w0; e[1] = w1; e[2] = w2;
+                    uint64_t* e = &P[((size_t)r * (TW + 1) + c) * 2];
+                    e[0] = (uint64_t)x | ((uint64_t)y << 32); e[1] = (uint64_t)z | ((uint64_t)w << 32);
                     const int ar = ty * TH + r, ac = tx * TW + c;
                     if (c < TW && ar < H && ac < W) {
                         const uint8_t* p = img + (size_t)ar * stride + 4 * (size_t)ac;
                         const uint32_t R = p[0], G = p[1], B = p[2];
-                        w0 += R | (G << 16); w1 += B | (((R + G + B) & 1u) << 16); w2 += R * R + G * G + B * B;
+                        x += R; y += G; z += B | (((R + G + B) & 1u) << 20); w += (R * R + G * G + B * B) << 2;
                     }
                 }
             }
@@ -46,19 +46,21 @@ extern "C" int emul_moments(const uint8_t* img, size_t stride, int W, int H, con
                 for (int v = 0; v < 13; v++) {
                     int32_t X[3], Y[3];
                     for (int s = 0; s < 3; s++) tp_vertex_stage(p[s][0], p[s][1], v, s, vw, X[s], Y[s]);
-                    tp_span sp = tp_setup_span(X, Y, row0, row1);
-                    uint32_t n = 0, no = 0, sr = 0, sg = 0, sb = 0, q = 0;
+                    tp_span sp;
+        tp_setup_span(X, Y, row0, row1, sp);
+                    uint64_t bxy = 0, bzw = 0, axy = 0, azw = 0;
+                    uint32_t n = 0;
                     for (int r = sp.r0; r <= sp.r1; r++) {
                         int32_t lo, hi;
                         tp_span_row(sp, col0, colE, lo, hi);
-                        if (lo < hi) {
-                            const uint32_t* a = &P[((size_t)(r - row0) * (TW + 1) + (lo - col0)) * 3];
-                            const uint32_t* b = &P[((size_t)(r - row0) * (TW + 1) + (hi - col0)) * 3];
-                            const uint32_t d0 = b[0] - a[0], d1 = b[1] - a[1];
-                            n += hi - lo; sr += d0 & 0xffffu; sg += d0 >> 16; sb += d1 & 0xffffu; no += d1 >> 16;
-                            q += b[2] - a[2];
-                        }
+                        const uint64_t* a = &P[((size_t)(r - row0) * (TW + 1) + (lo - col0)) * 2];
+                        const uint64_t* b = &P[((size_t)(r - row0) * (TW + 1) + (hi - col0)) * 2];
+                        n += hi - lo; bxy += b[0]; bzw += b[1]; axy += a[0]; azw += a[1];
                     }
+                    const uint64_t dxy = bxy - axy, dzw = bzw - azw;
+                    const uint32_t sr = (uint32_t)dxy, sg = (uint32_t)(dxy >> 32);
+                    const uint32_t sb = (uint32_t)dzw & 0xfffffu, no = (uint32_t)(dzw >> 20) & 0x3fffu;
+                    const uint32_t q = (uint32_t)(dzw >> 34);
                     int64_t* m = mom + 6 * ((size_t)v * NT + t);
                     m[0] += n; m[1] += no; m[2] += sr; m[3] += sg; m[4] += sb; m[5] += q;
                 }

@@ -150,3 +150,29 @@ def test_device_walker_floor_is_exact():
     far = ~inside
     assert np.all((got[far] > (1 << 28)) == (exact[far] > 0)) and np.all(np.abs(got[far]) > (1 << 28))
     ctx.close()
+
+
+@pytest.mark.parametrize("margin", [0, 2, 6, 40])
+def test_work_list_reuse_never_changes_results(margin):
+    """The fused iteration reuses its per-tile work lists while vertices stay inside a margin; any
+    margin must give the oracle's bits.  A high step rate makes vertices travel many pixels."""
+    W, H, grid = 300, 200, (15, 5)
+    img, imgB, pts, tris, ratio, colors = case(W, H, grid)
+    ctx = capi.Context(0, W, H)
+    ctx.set_margin(margin)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts, tris)
+    rate = 0.0004
+    params = capi.default_params(0, rate=rate)
+    ctx.iterate(params, 40)
+    ref = O.iterate(img, pts, tris, 0, ratio, rate, 40, literal=False)
+    assert np.array_equal(ctx.retrieve(capi.BUF_TENERGY), ref["ten"])
+    assert np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
+    moved = np.abs(ref["points"] - pts).max() * H / 2
+    rebuilds = ctx.info(6)
+    assert moved > 3.0, moved                      # the test really moves vertices
+    if margin < 2:
+        assert rebuilds >= 39                      # margin off: rebuilt every iteration
+    elif margin == 40:
+        assert rebuilds == 0
+    ctx.close()

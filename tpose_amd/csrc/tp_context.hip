@@ -39,6 +39,9 @@ struct tp_context {
     // triangulation
     int NT = 0, NP = 0, capT = 0, capP = 0;
     float2* points = nullptr;
+    float2* points_binned = nullptr;
+    int margin_px = 0;  // 0: rebuild the work lists every iteration (tp_set_margin)
+    float lists_dp = -1.0f, lists_ratio = -1.0f;  // geometry parameters the current work lists were built for
     int4* tris = nullptr;
     int4* colors = nullptr;
     int* vtx_off = nullptr;
@@ -102,10 +105,10 @@ void drop_graphs(tp_context* c) {
 }
 
 void free_triangulation(tp_context* c) {
-    hipFree(c->points); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
+    hipFree(c->points); hipFree(c->points_binned); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
     hipFree(c->tri_pair); hipFree(c->partials); hipFree(c->tilelist);
     hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
-    c->points = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
+    c->points = nullptr; c->points_binned = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
     c->tri_pair = nullptr; c->partials = nullptr; c->tilelist = nullptr;
     c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
     c->capT = c->capP = 0;
@@ -119,7 +122,8 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.vw.halfW = 0.5f * (float)c->W; L.vw.halfH = 0.5f * (float)c->H;
     L.vw.W = c->W; L.vw.H = c->H;
     L.tiles_x = c->tiles_x; L.tiles_y = c->tiles_y;
-    L.points = c->points; L.tris = c->tris; L.colors = c->colors;
+    L.points = c->points; L.points_binned = c->points_binned; L.margin_px = c->margin_px;
+    L.tris = c->tris; L.colors = c->colors;
     L.NT = c->NT; L.NP = c->NP;
     L.vtx_off = c->vtx_off; L.vtx_adj = c->vtx_adj;
     L.tilecount = c->tilecount; L.tilelist = c->tilelist; L.list_cap = c->list_cap;
@@ -142,14 +146,20 @@ int check_slot(tp_context* c, int slot) {
     return TP_OK;
 }
 
+// make the next k_bin rebuild the work lists (host side: upload, changed dp / RATIO, piecewise API)
+hipError_t force_rebin(tp_context* c) {
+    hipError_t e = hipMemsetAsync(c->tilecount, 0, sizeof(int) * (size_t)c->tiles_x * c->tiles_y, c->stream);
+    if (e != hipSuccess) return e;
+    static const uint32_t zero_one[3] = {0u, 0u, 1u};
+    e = hipMemcpyAsync(&c->state->pair_total, &zero_one[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(&c->state->rebin_req, &zero_one[2], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+}
+
 // enqueue one grad-iter on the context stream (no sync)
-void enqueue_iter(tp_context* c, const tp_params& p, float dp, bool first) {
+void enqueue_iter(tp_context* c, const tp_params& p, float dp) {
     tp_launch L = make_launch(c, p.image_slot, dp);
-    if (first) {
-        hipMemsetAsync(c->tilecount, 0, sizeof(int) * (size_t)c->tiles_x * c->tiles_y, c->stream);
-        hipMemsetAsync(&c->state->pair_total, 0, sizeof(uint32_t), c->stream);
-    }
-    tp_launch_bin(L, c->stream);
+    tp_launch_bin(L, c->stream);  // early-exits unless a rebuild was requested
     tp_launch_accumulate(L, c->stream);
     tp_launch_update(L, p.flavour, p.rate, c->stream);  // finalize + gradient + shift; re-arms the lists
 }
@@ -241,6 +251,13 @@ int tp_set_dp(tp_context* c, float dp) {
     return TP_OK;
 }
 
+int tp_set_margin(tp_context* c, int margin_px) {
+    if (!c) return TP_ERR_INVALID;
+    if (margin_px < 0 || margin_px > 1024) return fail(c, TP_ERR_INVALID, "margin %d outside 0..1024", margin_px);
+    if (margin_px != c->margin_px) { c->margin_px = margin_px; c->lists_dp = -1.0f; c->generation++; }
+    return TP_OK;
+}
+
 int tp_get_ratio(const tp_context* c, float* ratio) {
     if (!c || !ratio) return TP_ERR_INVALID;
     *ratio = c->ratio;
@@ -291,6 +308,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         free_triangulation(c);
         const int capT = NT + NT / 2 + 64, capP = NP + NP / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->points, capP));
+        HIP_TRY(c, dev_alloc(&c->points_binned, capP));
         HIP_TRY(c, dev_alloc(&c->gr, capP));
         HIP_TRY(c, dev_alloc(&c->gacc, (size_t)2 * capP));
         HIP_TRY(c, dev_alloc(&c->vtx_off, capP + 1));
@@ -350,6 +368,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     HIP_TRY(c, hipMemset(c->state, 0, sizeof(tp_device_state)));
+    c->lists_dp = -1.0f;  // forces a rebuild of the work lists at the next use
     HIP_TRY(c, hipMemset(c->gacc, 0, sizeof(unsigned long long) * 2 * (size_t)c->capP));
     c->generation++;  // captured graphs bake NT, NP, dp and buffer addresses
     c->uploaded = true; c->accumulated = c->energized = false;
@@ -363,8 +382,8 @@ int tp_accumulate(tp_context* c, int flavour, int slot) {
     if (int rc = check_slot(c, slot)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     tp_launch L = make_launch(c, slot, resolve_dp(c, flavour, c->dp_override));
-    HIP_TRY(c, hipMemsetAsync(c->tilecount, 0, sizeof(int) * (size_t)c->tiles_x * c->tiles_y, c->stream));
-    HIP_TRY(c, hipMemsetAsync(&c->state->pair_total, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, force_rebin(c));  // the piecewise API rebuilds the work lists on every sweep
+    c->lists_dp = L.vw.dp; c->lists_ratio = c->ratio;
     tp_launch_bin(L, c->stream);
     tp_launch_accumulate(L, c->stream);
     HIP_TRY(c, hipGetLastError());
@@ -420,6 +439,10 @@ int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
     HIP_TRY(c, hipSetDevice(c->device));
     const float dp = resolve_dp(c, p->flavour, p->dp);
 
+    if (c->lists_dp != dp || c->lists_ratio != c->ratio) {
+        HIP_TRY(c, force_rebin(c));
+        c->lists_dp = dp; c->lists_ratio = c->ratio;
+    }
     // graphs of CHUNK fused iterations hide the ~10 us replay floor; the remainder runs eagerly
     const int CHUNK = 16;
     int left = n_iters;
@@ -430,7 +453,7 @@ int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
         if (!g) {
             hipGraph_t graph = nullptr;
             HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            for (int k = 0; k < CHUNK; k++) enqueue_iter(c, *p, dp, k == 0);
+            for (int k = 0; k < CHUNK; k++) enqueue_iter(c, *p, dp);
             HIP_TRY(c, hipStreamEndCapture(c->stream, &graph));
             graph_entry e;
             hipError_t err = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
@@ -446,7 +469,7 @@ int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
             left -= CHUNK;
         }
     }
-    for (int k = 0; k < left; k++) enqueue_iter(c, *p, dp, true);
+    for (int k = 0; k < left; k++) enqueue_iter(c, *p, dp);
     HIP_TRY(c, hipGetLastError());
     c->acc_slot = p->image_slot; c->last_flavour = p->flavour;
     c->accumulated = c->energized = false;
@@ -461,8 +484,10 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
     double total_ms = 0.0;
     for (int k = 0; k < n_iters; k++) {
         tp_launch L = make_launch(c, p->image_slot, dp);
-        HIP_TRY(c, hipMemsetAsync(c->tilecount, 0, sizeof(int) * (size_t)c->tiles_x * c->tiles_y, c->stream));
-        HIP_TRY(c, hipMemsetAsync(&c->state->pair_total, 0, sizeof(uint32_t), c->stream));
+        if (k == 0 && (c->lists_dp != dp || c->lists_ratio != c->ratio)) {
+            HIP_TRY(c, force_rebin(c));
+            c->lists_dp = dp; c->lists_ratio = c->ratio;
+        }
         tp_launch_bin(L, c->stream);
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         tp_launch_accumulate(L, c->stream);
@@ -541,12 +566,13 @@ int tp_get_info(tp_context* c, int what, int64_t* value) {
         case 2: *value = TP_TILE_W; return TP_OK;
         case 3: *value = TP_TILE_H; return TP_OK;
         case 4:
-        case 5: {
+        case 5:
+        case 6: {
             HIP_TRY(c, hipSetDevice(c->device));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             tp_device_state st{};
             HIP_TRY(c, hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
-            *value = what == 4 ? (st.pair_total ? st.pair_total : st.pad[0]) : st.flags;
+            *value = what == 4 ? st.pair_total : what == 5 ? st.flags : st.rebin_count;
             return TP_OK;
         }
         default: return fail(c, TP_ERR_INVALID, "unknown info %d", what);

@@ -13,16 +13,18 @@
 #define TP_FLAG_PAIR_OVERFLOW 2u
 
 struct tp_device_state {
-    uint32_t pair_total;  // (triangle, tile) pairs allocated by the last binning
-    uint32_t flags;       // sticky overflow flags
-    uint32_t pad[2];
+    uint32_t pair_total;   // (triangle, tile) pairs of the current work lists
+    uint32_t flags;        // sticky overflow flags
+    uint32_t rebin_req;    // 1: k_bin must rebuild the work lists (upload, or a vertex left its margin)
+    uint32_t arrive;       // k_update: blocks arrived | (blocks voting for a rebuild) << 16
+    uint32_t rebin_count;  // statistics: rebuilds so far
+    uint32_t pad[3];
 };
 
-// One (triangle, tile) work item, self-contained so the accumulate kernel has no dependent loads:
-// where its partial record goes and the triangle's three vertices (t-pose space).
+// One (triangle, tile) work item: where its partial record goes and the triangle's vertex ids
+// (positions are read fresh every iteration -- the lists outlive many vertex updates).
 struct __attribute__((aligned(16))) tp_list_entry {
-    int pair, tri;
-    float x0, y0, x1, y1, x2, y2;
+    int pair, v0, v1, v2;
 };
 
 struct tp_launch {
@@ -33,6 +35,8 @@ struct tp_launch {
     int tiles_x, tiles_y;
     // triangulation
     float2* points;
+    float2* points_binned;  // vertex positions when the work lists were last built
+    int margin_px;          // work lists stay valid while no vertex moved more than margin_px - 1 pixels
     const int4* tris;
     const int4* colors;  // stored colours ivec4[NT] (warp) -- may be null
     int NT, NP;

@@ -36,10 +36,12 @@ size_t tp_accumulate_lds_bytes() { return (size_t)TH * ROWLEN * sizeof(uint4); }
 __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
     __shared__ int s_excl[BIN_TRIS + 1];  // exclusive scan of pair counts
     __shared__ int s_rect[BIN_TRIS][3];   // tx0, ty0, ntx
-    __shared__ float s_pts[BIN_TRIS][6];
+    __shared__ int s_vid[BIN_TRIS][3];
     __shared__ uint32_t s_base;
+    if (!L.state->rebin_req) return;  // lists still valid: nothing moved past its margin
     const int tid = threadIdx.x;
     const int t = blockIdx.x * BIN_TRIS + tid;
+    for (int v = blockIdx.x * 256 + tid; v < L.NP; v += gridDim.x * 256) L.points_binned[v] = L.points[v];
     int cnt = 0;
     if (tid < BIN_TRIS) {
         int tx0 = 0, ty0 = 0, ntx = 1;
@@ -47,9 +49,10 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
             const int4 tri = L.tris[t];
             const float2 a = L.points[tri.x], b = L.points[tri.y], c = L.points[tri.z];
             const float p[3][2] = {{a.x, a.y}, {b.x, b.y}, {c.x, c.y}};
-            const tp_bbox bb = tp_triangle_bbox(p, L.vw);
-            s_pts[tid][0] = a.x; s_pts[tid][1] = a.y; s_pts[tid][2] = b.x; s_pts[tid][3] = b.y;
-            s_pts[tid][4] = c.x; s_pts[tid][5] = c.y;
+            tp_bbox bb = tp_triangle_bbox(p, L.vw);
+            bb.c0 = max(bb.c0 - L.margin_px, 0); bb.c1 = min(bb.c1 + L.margin_px, L.vw.W - 1);
+            bb.r0 = max(bb.r0 - L.margin_px, 0); bb.r1 = min(bb.r1 + L.margin_px, L.vw.H - 1);
+            s_vid[tid][0] = tri.x; s_vid[tid][1] = tri.y; s_vid[tid][2] = tri.z;
             if (bb.c0 <= bb.c1 && bb.r0 <= bb.r1) {
                 tx0 = bb.c0 / TW; ty0 = bb.r0 / TH;
                 ntx = bb.c1 / TW - tx0 + 1;
@@ -90,9 +93,8 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
         const int slot = atomicAdd(&L.tilecount[tile], 1);
         if (slot < L.list_cap) {
             tp_list_entry e;
-            e.pair = (int)base + p; e.tri = blockIdx.x * BIN_TRIS + lo;
-            e.x0 = s_pts[lo][0]; e.y0 = s_pts[lo][1]; e.x1 = s_pts[lo][2]; e.y1 = s_pts[lo][3];
-            e.x2 = s_pts[lo][4]; e.y2 = s_pts[lo][5];
+            e.pair = (int)base + p;
+            e.v0 = s_vid[lo][0]; e.v1 = s_vid[lo][1]; e.v2 = s_vid[lo][2];
             L.tilelist[(size_t)tile * L.list_cap + slot] = e;
         } else
             atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
@@ -119,20 +121,24 @@ __device__ __forceinline__ uint32_t scan32_inclusive(uint32_t v) {
     return v;
 }
 
-// packed pixel moments: w0 = r | g<<16, w1 = b | odd<<16, w2 = r^2+g^2+b^2.  Over a 128-pixel row
-// every 16-bit field stays below 2^16 (128*255 = 32640), so packed words add without carries.
-struct pix3 { uint32_t w0, w1, w2; };
+// LDS prefix entry (uint4), per row exclusive prefix over the tile's 128 columns:
+//   x = sum r,  y = sum g,  z = sum b | n_odd << 20,  w = (sum r^2+g^2+b^2) << 2
+// Read as two u64 {x,y} and {z,w}: sums of entries over up to 32 rows never carry between the
+// fields that matter -- sum b < 2^20 (4096*255), n_odd <= 4096 spills at most into bit 32, which
+// the << 2 on q keeps free -- so a lane accumulates whole entries with 64-bit adds and unpacks once.
+struct pix4 { uint32_t x, y, z, w; };
 
-__device__ __forceinline__ pix3 pixel_moments(uint32_t rgba) {
+__device__ __forceinline__ pix4 pixel_moments(uint32_t rgba) {
     const uint32_t m = rgba & 0x00ffffffu;
     const uint32_t r = m & 0xffu, g = (m >> 8) & 0xffu, b = m >> 16;
-    pix3 o;
-    o.w0 = r | (g << 16);
-    o.w1 = b | (((r + g + b) & 1u) << 16);
-    o.w2 = r * r + g * g + b * b;
+    pix4 o;
+    o.x = r; o.y = g;
+    o.z = b | (((r + g + b) & 1u) << 20);
+    o.w = (r * r + g * g + b * b) << 2;
     return o;
 }
-__device__ __forceinline__ pix3 operator+(pix3 a, pix3 b) { return {a.w0 + b.w0, a.w1 + b.w1, a.w2 + b.w2}; }
+__device__ __forceinline__ pix4 operator+(pix4 a, pix4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__device__ __forceinline__ uint4 as_uint4(pix4 a) { return make_uint4(a.x, a.y, a.z, a.w); }
 
 // ------------------------------------------------------------------------------------------------
 // k_accumulate
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
     }
     int nlist = L.tilecount[tile];
     if (nlist > L.list_cap) nlist = L.list_cap;
+    if (tile == 0 && tid == 0) L.state->rebin_req = 0;  // consumed by the k_bin that ran before us
     if (nlist == 0) return;
     const int nitems = nlist * TP_NVARIANTS;
     const tp_list_entry* list = L.tilelist + (size_t)tile * L.list_cap;
@@ -166,19 +173,20 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
     if (!(L.debug & 1)) {
 #pragma unroll
         for (int p = 0; p < NPASS; p++) {
-            const pix3 e0 = pixel_moments(px[p].x), e1 = pixel_moments(px[p].y),
+            const pix4 e0 = pixel_moments(px[p].x), e1 = pixel_moments(px[p].y),
                        e2 = pixel_moments(px[p].z), e3 = pixel_moments(px[p].w);
-            const pix3 s1 = e0 + e1, s2 = s1 + e2, s3 = s2 + e3;
-            pix3 ex;  // exclusive prefix of this lane's first pixel
-            ex.w0 = scan32_inclusive(s3.w0) - s3.w0;
-            ex.w1 = scan32_inclusive(s3.w1) - s3.w1;
-            ex.w2 = scan32_inclusive(s3.w2) - s3.w2;
+            const pix4 s1 = e0 + e1, s2 = s1 + e2, s3 = s2 + e3;
+            pix4 ex;  // exclusive prefix of this lane's first pixel
+            ex.x = scan32_inclusive(s3.x) - s3.x;
+            ex.y = scan32_inclusive(s3.y) - s3.y;
+            ex.z = scan32_inclusive(s3.z) - s3.z;
+            ex.w = scan32_inclusive(s3.w) - s3.w;
             uint4* row = P + (p * ACC_ROWS_PER_PASS + rsub) * ROWLEN + l32 * 4;
-            row[0] = make_uint4(ex.w0, ex.w1, ex.w2, 0);
-            row[1] = make_uint4(ex.w0 + e0.w0, ex.w1 + e0.w1, ex.w2 + e0.w2, 0);
-            row[2] = make_uint4(ex.w0 + s1.w0, ex.w1 + s1.w1, ex.w2 + s1.w2, 0);
-            row[3] = make_uint4(ex.w0 + s2.w0, ex.w1 + s2.w1, ex.w2 + s2.w2, 0);
-            if (l32 == 31) row[4] = make_uint4(ex.w0 + s3.w0, ex.w1 + s3.w1, ex.w2 + s3.w2, 0);
+            row[0] = as_uint4(ex);
+            row[1] = as_uint4(ex + e0);
+            row[2] = as_uint4(ex + s1);
+            row[3] = as_uint4(ex + s2);
+            if (l32 == 31) row[4] = as_uint4(ex + s3);
         }
     }
     __syncthreads();
@@ -193,39 +201,30 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
     for (; item < nitems; item += ACC_THREADS) {
         const int e = item / TP_NVARIANTS, v = item - e * TP_NVARIANTS;
         if (item != tid) ent = list[e];
+        const float2 p0 = L.points[ent.v0], p1 = L.points[ent.v1], p2 = L.points[ent.v2];
         int32_t X[3], Y[3];
-        tp_vertex_stage(ent.x0, ent.y0, v, 0, L.vw, X[0], Y[0]);
-        tp_vertex_stage(ent.x1, ent.y1, v, 1, L.vw, X[1], Y[1]);
-        tp_vertex_stage(ent.x2, ent.y2, v, 2, L.vw, X[2], Y[2]);
-        tp_span sp = tp_setup_span(X, Y, row0, row1);
+        tp_vertex_stage(p0.x, p0.y, v, 0, L.vw, X[0], Y[0]);
+        tp_vertex_stage(p1.x, p1.y, v, 1, L.vw, X[1], Y[1]);
+        tp_vertex_stage(p2.x, p2.y, v, 2, L.vw, X[2], Y[2]);
+        tp_span sp;
+        tp_setup_span(X, Y, row0, row1, sp);
         if (L.debug & 4) sp.r1 = sp.r0 - 1 + (int)(sp.A.x & 1);
-
-        uint32_t n = 0, no = 0, sr = 0, sg = 0, sb = 0, q = 0;
-        // four rows per trip: all eight LDS reads are issued before any result is consumed; rows
-        // past the end (or empty spans) read P[row][0] twice and contribute zero
-        for (int r = sp.r0; r <= sp.r1; r += 4) {
-            uint4 a[4], b[4];
-            int32_t w[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int32_t lo, hi;
-                tp_span_row(sp, col0, colE, lo, hi);
-                const bool ok = (r + j <= sp.r1) && (lo < hi);
-                lo = ok ? lo - col0 : 0;
-                hi = ok ? hi - col0 : 0;
-                const uint4* rowp = P + min(r + j - row0, TH - 1) * ROWLEN;
-                a[j] = rowp[lo]; b[j] = rowp[hi];
-                w[j] = hi - lo;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t d0 = b[j].x - a[j].x, d1 = b[j].y - a[j].y;
-                n += (uint32_t)w[j];
-                sr += d0 & 0xffffu; sg += d0 >> 16;
-                sb += d1 & 0xffffu; no += d1 >> 16;
-                q += b[j].z - a[j].z;
-            }
+        // one row per trip, branch-free: an empty row has hi == lo and its two reads cancel.
+        // Whole entries are accumulated with 64-bit adds, hi-side and lo-side apart.
+        uint64_t bxy = 0, bzw = 0, axy = 0, azw = 0;
+        uint32_t n = 0;
+        const ulonglong2* rowp = reinterpret_cast<const ulonglong2*>(P) + (sp.r0 - row0) * ROWLEN - col0;
+        for (int r = sp.r0; r <= sp.r1; ++r, rowp += ROWLEN) {
+            int32_t lo, hi;
+            tp_span_row(sp, col0, colE, lo, hi);
+            const ulonglong2 a = rowp[lo], b = rowp[hi];
+            n += (uint32_t)(hi - lo);
+            bxy += b.x; bzw += b.y; axy += a.x; azw += a.y;
         }
+        const uint64_t dxy = bxy - axy, dzw = bzw - azw;
+        const uint32_t sr = (uint32_t)dxy, sg = (uint32_t)(dxy >> 32);
+        const uint32_t sb = (uint32_t)dzw & 0xfffffu, no = (uint32_t)(dzw >> 20) & 0x3fffu;
+        const uint32_t q = (uint32_t)(dzw >> 34);
         if (ent.pair < L.pair_cap) {
             uint32_t* out = L.partials + ((size_t)ent.pair * TP_NVARIANTS + v) * TP_PARTIAL_WORDS;
             reinterpret_cast<uint2*>(out)[0] = make_uint2(n, no);
@@ -287,10 +286,6 @@ void tp_launch_finalize(const tp_launch& L, int flavour, bool write_moments, hip
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_shift(tp_launch L, float rate) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nth = gridDim.x * blockDim.x;
-    for (int k = gid; k < L.tiles_x * L.tiles_y; k += nth) L.tilecount[k] = 0;
-    if (gid == 0) { L.state->pad[0] = L.state->pair_total; L.state->pair_total = 0; }
-
     if (gid >= L.NP) return;
     uint32_t gx = 0, gy = 0;  // int32 wrapping sums, like the reference's int atomics
     const int NT = L.NT;
@@ -365,47 +360,81 @@ __device__ __forceinline__ bool arrive(unsigned long long* slot, uint32_t contri
 }
 
 __global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float rate) {
+    __shared__ int s_last;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nth = gridDim.x * blockDim.x;
-    for (int k = gid; k < L.tiles_x * L.tiles_y; k += nth) L.tilecount[k] = 0;
-    if (gid == 0) { L.state->pad[0] = L.state->pair_total; L.state->pair_total = 0; }
 
     // one thread per variant.  Threads [0, 12 NT): quads (t, s, k) = the four displacements of
     // vertex slot s, adjacent lanes; threads [12 NT, 13 NT): the base variants.
     const int NT = L.NT;
     const bool live = gid < 13 * NT;
-    int t, i;
+    int t = 0, i = 0;
     if (gid < 12 * NT) { t = gid / 12; i = gid - 12 * t + 1; }
-    else { t = gid - 12 * NT; i = 0; }
+    else if (live) { t = gid - 12 * NT; i = 0; }
+    const bool leader = live && i > 0 && ((i - 1) & 3) == 0;
+    // the quad leader's vertex data does not depend on the energies: fetch it early
+    int v = 0, deg = 0;
+    float2 p = make_float2(0.0f, 0.0f), pb = p;
+    if (leader) {
+        const int s = (i - 1) >> 2;
+        const int4 tri = L.tris[t];
+        v = s == 0 ? tri.x : s == 1 ? tri.y : tri.z;
+        deg = L.vtx_off[v + 1] - L.vtx_off[v];
+        p = L.points[v];
+        pb = L.points_binned[v];
+    }
     int32_t e = 0;
     if (live) e = emit_variant(L, flavour, t, i, sum_partials(L, L.tri_pair[t], i));
     // central differences inside the quad: lanes 4q+0/1 hold E(+dx)/E(-dx), 4q+2/3 E(+dy)/E(-dy)
     const uint32_t e1 = (uint32_t)__shfl_xor(e, 1);
-    const uint32_t gxy = (uint32_t)e - e1;                 // valid on even lanes of the quad
-    const uint32_t gy = (uint32_t)__shfl_down((int)gxy, 2);  // lane 4q+0 fetches lane 4q+2's value
-    if (!live || i == 0 || ((i - 1) & 3) != 0) return;
-    const int s = (i - 1) >> 2;
-    const int4 tri = L.tris[t];
-    const int v = s == 0 ? tri.x : s == 1 ? tri.y : tri.z;
-    const int deg = L.vtx_off[v + 1] - L.vtx_off[v];
-    const float R = L.vw.ratio;
-    uint32_t tot;
-    if (arrive(&L.gacc[2 * v], gxy, deg, tot)) {
-        reinterpret_cast<int*>(L.gr)[2 * v] = (int)tot;
-        if (v >= 4) {
-            float* px = reinterpret_cast<float*>(L.points) + 2 * v;
-            float x = *px, tg = (float)(int)tot;
-            if (x <= -R) { x = -R; tg = 0.0f; } else if (x >= R) { x = R; tg = 0.0f; }
-            *px = tp_fsub(x, tp_fdiv(tp_fdiv(tp_fmul(rate, tg), 256.0f), 256.0f));
+    const uint32_t gx = (uint32_t)e - e1;                     // valid on even lanes of the quad
+    const uint32_t gy = (uint32_t)__shfl_down((int)gx, 2);    // lane 4q+0 fetches lane 4q+2's value
+    int need = L.margin_px < 2;                                // margin off: rebuild every iteration
+    if (leader) {
+        const float R = L.vw.ratio;
+        const float lim = (float)(L.margin_px - 1);
+        // both components settle with one returning atomic each, issued back to back
+        const unsigned long long ox = atomicAdd(&L.gacc[2 * v], ((unsigned long long)gx << 32) + 1ull);
+        const unsigned long long oy = atomicAdd(&L.gacc[2 * v + 1], ((unsigned long long)gy << 32) + 1ull);
+        if ((int)(ox & 0xffffffffull) == deg - 1) {
+            const uint32_t tot = (uint32_t)(ox >> 32) + gx;
+            L.gacc[2 * v] = 0ull;
+            reinterpret_cast<int*>(L.gr)[2 * v] = (int)tot;
+            if (v >= 4) {
+                float x = p.x, tg = (float)(int)tot;
+                if (x <= -R) { x = -R; tg = 0.0f; } else if (x >= R) { x = R; tg = 0.0f; }
+                x = tp_fsub(x, tp_fdiv(tp_fdiv(tp_fmul(rate, tg), 256.0f), 256.0f));
+                reinterpret_cast<float*>(L.points)[2 * v] = x;
+                need |= !(fabsf(x - pb.x) * (L.vw.halfW / R) <= lim);
+            }
+        }
+        if ((int)(oy & 0xffffffffull) == deg - 1) {
+            const uint32_t tot = (uint32_t)(oy >> 32) + gy;
+            L.gacc[2 * v + 1] = 0ull;
+            reinterpret_cast<int*>(L.gr)[2 * v + 1] = (int)tot;
+            if (v >= 4) {
+                float y = p.y, tg = (float)(int)tot;
+                if (y <= -1.0f) { y = -1.0f; tg = 0.0f; } else if (y >= 1.0f) { y = 1.0f; tg = 0.0f; }
+                y = tp_fsub(y, tp_fdiv(tp_fdiv(tp_fmul(rate, tg), 256.0f), 256.0f));
+                reinterpret_cast<float*>(L.points)[2 * v + 1] = y;
+                need |= !(fabsf(y - pb.y) * L.vw.halfH <= lim);
+            }
         }
     }
-    if (arrive(&L.gacc[2 * v + 1], gy, deg, tot)) {
-        reinterpret_cast<int*>(L.gr)[2 * v + 1] = (int)tot;
-        if (v >= 4) {
-            float* py = reinterpret_cast<float*>(L.points) + 2 * v + 1;
-            float y = *py, tg = (float)(int)tot;
-            if (y <= -1.0f) { y = -1.0f; tg = 0.0f; } else if (y >= 1.0f) { y = 1.0f; tg = 0.0f; }
-            *py = tp_fsub(y, tp_fdiv(tp_fdiv(tp_fmul(rate, tg), 256.0f), 256.0f));
+    // grid-wide arrival: the last block knows whether ANY vertex left its margin and, if so,
+    // re-arms the work lists so that the next k_bin rebuilds them
+    need = __syncthreads_or(need);
+    if (threadIdx.x == 0) {
+        const uint32_t old = atomicAdd(&L.state->arrive, 1u + (need ? 0x10000u : 0u));
+        const uint32_t now = old + 1u + (need ? 0x10000u : 0u);
+        s_last = ((now & 0xffffu) == gridDim.x) ? ((now >> 16) ? 2 : 1) : 0;
+    }
+    __syncthreads();
+    if (s_last) {
+        if (s_last == 2)
+            for (int k = threadIdx.x; k < L.tiles_x * L.tiles_y; k += blockDim.x) L.tilecount[k] = 0;
+        if (threadIdx.x == 0) {
+            L.state->arrive = 0;
+            if (s_last == 2) { L.state->pair_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
         }
     }
 }

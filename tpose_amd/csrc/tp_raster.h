@@ -173,79 +173,74 @@ TP_HD int32_t tp_walker_value(const tp_walker& w) { return (int32_t)(w.x >> 32);
 // third edge (either kind, or neutral when horizontal).
 // ---------------------------------------------------------------------------------------------
 struct tp_span {
-    tp_walker A, B, C;
-    int32_t r0, r1;   // absolute row range (inclusive); empty when r0 > r1
-    int32_t c_is_lo;  // C bounds from the left (1) or the right (0)
+    tp_walker A, B;    // a left edge (inclusive lower bound) and a right edge (exclusive upper bound)
+    tp_walker Cl, Ch;  // the third edge, filed under the side it bounds; the other one is inert
+    int32_t r0, r1;    // absolute row range (inclusive); empty when r0 > r1
 };
 
-TP_HD tp_span tp_setup_span(const int32_t X[3], const int32_t Y[3], int32_t win_r0, int32_t win_r1) {
-    tp_span sp;
-    sp.r0 = 0; sp.r1 = -1; sp.c_is_lo = 1;
-    sp.A.x = sp.A.s = sp.B.x = sp.B.s = sp.C.x = sp.C.s = 0;
+#define TP_INERT_LO (-((int64_t)1 << 62))  // walker value -2^30: never the max
+#define TP_INERT_HI (((int64_t)1 << 62))   // walker value +2^30: never the min
 
+// straight-line (single exit, no early returns: keeps everything in registers on the GPU)
+TP_HD void tp_setup_span(const int32_t X[3], const int32_t Y[3], int32_t win_r0, int32_t win_r1, tp_span& sp) {
     const int64_t area2 = (int64_t)(X[1] - X[0]) * (Y[2] - Y[0]) - (int64_t)(Y[1] - Y[0]) * (X[2] - X[0]);
-    if (area2 == 0) return sp;
     const int32_t sg = area2 > 0 ? 1 : -1;
 
-    int32_t ymin = tp_min(Y[0], tp_min(Y[1], Y[2]));
-    int32_t ymax = tp_max(Y[0], tp_max(Y[1], Y[2]));
+    const int32_t ymin = tp_min(Y[0], tp_min(Y[1], Y[2]));
+    const int32_t ymax = tp_max(Y[0], tp_max(Y[1], Y[2]));
 
-    int32_t a[3], b[3];
-    int bottom_flat = 0;
-#pragma unroll
-    for (int e = 0; e < 3; e++) {
-        const int j = (e == 2) ? 0 : e + 1;
-        a[e] = -(Y[j] - Y[e]) * sg;
-        b[e] = (X[j] - X[e]) * sg;
-        // horizontal edge with the interior above it: a centre exactly on it is excluded
-        if (a[e] == 0 && b[e] < 0) bottom_flat = 1;
-    }
-    int32_t r0 = tp_max(win_r0, tp_first_centre(ymin));
-    int32_t r1 = tp_min(win_r1, tp_last_centre(ymax - bottom_flat));
-    if (r0 > r1) return sp;
-
-    tp_walker w[3];
-    int kind[3];  // 1 = lower bound, 0 = upper bound, 2 = neutral
+    const int32_t a0 = -(Y[1] - Y[0]) * sg, b0 = (X[1] - X[0]) * sg;
+    const int32_t a1 = -(Y[2] - Y[1]) * sg, b1 = (X[2] - X[1]) * sg;
+    const int32_t a2 = -(Y[0] - Y[2]) * sg, b2 = (X[0] - X[2]) * sg;
+    // horizontal edge with the interior above it: a centre exactly on it is excluded
+    const int bottom_flat = ((a0 == 0) & (b0 < 0)) | ((a1 == 0) & (b1 < 0)) | ((a2 == 0) & (b2 < 0));
+    const int32_t r0 = tp_max(win_r0, tp_first_centre(ymin));
+    const int32_t r1 = tp_min(win_r1, tp_last_centre(ymax - bottom_flat));
     const int64_t cy = 256LL * r0 + 128;
-#pragma unroll
-    for (int e = 0; e < 3; e++) {
-        if (a[e] == 0) {
-            kind[e] = 2;
-            w[e].x = -((int64_t)1 << 62); w[e].s = 0;
-            continue;
-        }
-        const int32_t tl = (a[e] > 0) ? 1 : 0;  // a != 0 here: left edges own their boundary
-        // E(c,r) >= 0 (with tie rule)  <=>  a*256*c + K >= 0
-        const int64_t K = (int64_t)a[e] * (128 - X[e]) + (int64_t)b[e] * (cy - Y[e]) + tl - 1;
-        const int64_t Kf = K >> 8;  // floor(K/256); steps by b per row
-        if (a[e] > 0) {             // c >= ceil(-Kf / a) = floor((-Kf + a - 1) / a)
-            kind[e] = 1;
-            w[e] = tp_make_walker(-Kf + a[e] - 1, -b[e], a[e]);
-        } else {                    // c <= floor(Kf / d)  ->  exclusive bound floor((Kf + d) / d)
-            kind[e] = 0;
-            w[e] = tp_make_walker(Kf - a[e], b[e], -a[e]);
-        }
+
+    // per edge: E(c,r) >= 0 (with the tie rule)  <=>  a*256*c + K >= 0,  Kf = floor(K/256) steps by b
+    //   a > 0 (left edge):   c >= ceil(-Kf / a)  =  floor((-Kf + a - 1) / a)
+    //   a < 0 (right edge):  c <= floor(Kf / d)   ->  exclusive bound floor((Kf + d) / d),  d = -a
+    //   a == 0: horizontal, already folded into r0 / r1
+    tp_walker w0, w1, w2;
+#define TP_EDGE(W, A, B, XE, YE)                                                                 \
+    {                                                                                            \
+        const int32_t left = (A) > 0;                                                            \
+        const int64_t K = (int64_t)(A) * (128 - (XE)) + (int64_t)(B) * (cy - (YE)) + left - 1;   \
+        const int64_t Kf = K >> 8;                                                               \
+        const int32_t d = (A) == 0 ? 1 : ((A) > 0 ? (A) : -(A));                                 \
+        W = tp_make_walker(left ? (-Kf + d - 1) : (Kf + d), left ? -(B) : (B), d);               \
     }
-    // canonical slots
-    int ia = (kind[0] == 1) ? 0 : (kind[1] == 1) ? 1 : (kind[2] == 1) ? 2 : -1;
-    int ib = (kind[0] == 0) ? 0 : (kind[1] == 0) ? 1 : (kind[2] == 0) ? 2 : -1;
-    if (ia < 0 || ib < 0) return sp;  // cannot happen for area2 != 0
-    int ic = 3 - ia - ib;
-    sp.A = (ia == 0) ? w[0] : (ia == 1) ? w[1] : w[2];
-    sp.B = (ib == 0) ? w[0] : (ib == 1) ? w[1] : w[2];
-    sp.C = (ic == 0) ? w[0] : (ic == 1) ? w[1] : w[2];
-    const int kc = (ic == 0) ? kind[0] : (ic == 1) ? kind[1] : kind[2];
-    sp.c_is_lo = (kc != 0);
-    sp.r0 = r0; sp.r1 = r1;
-    return sp;
+    TP_EDGE(w0, a0, b0, X[0], Y[0])
+    TP_EDGE(w1, a1, b1, X[1], Y[1])
+    TP_EDGE(w2, a2, b2, X[2], Y[2])
+#undef TP_EDGE
+    // canonical slots: A = first left edge, B = first right edge, C = the remaining one
+    const int l0 = a0 > 0, l1 = a1 > 0, l2 = a2 > 0;
+    const int u0 = a0 < 0, u1 = a1 < 0, u2 = a2 < 0;
+    const int ia = l0 ? 0 : l1 ? 1 : 2;
+    const int ib = u0 ? 0 : u1 ? 1 : 2;
+    const int ic = 3 - ia - ib;
+    sp.A = ia == 0 ? w0 : ia == 1 ? w1 : w2;
+    sp.B = ib == 0 ? w0 : ib == 1 ? w1 : w2;
+    const tp_walker wc = ic == 0 ? w0 : ic == 1 ? w1 : w2;
+    const int cl = ic == 0 ? l0 : ic == 1 ? l1 : l2;
+    const int cu = ic == 0 ? u0 : ic == 1 ? u1 : u2;
+    sp.Cl.x = cl ? wc.x : TP_INERT_LO; sp.Cl.s = cl ? wc.s : 0;
+    sp.Ch.x = cu ? wc.x : TP_INERT_HI; sp.Ch.s = cu ? wc.s : 0;
+    // degenerate: zero area, or (never for area != 0) no left / no right edge
+    const int ok = (area2 != 0) & ((l0 | l1 | l2) != 0) & ((u0 | u1 | u2) != 0) & (ia != ib);
+    sp.r0 = ok ? r0 : 0;
+    sp.r1 = ok ? r1 : -1;
 }
 
-// column span of the current row, clipped to [clip_lo, clip_hi); then advance one row
+// column span of the current row, clipped to [clip_lo, clip_hi); hi >= lo always (hi == lo: empty);
+// then advance one row
 TP_HD void tp_span_row(tp_span& sp, int32_t clip_lo, int32_t clip_hi, int32_t& lo, int32_t& hi) {
-    const int32_t va = tp_walker_value(sp.A), vb = tp_walker_value(sp.B), vc = tp_walker_value(sp.C);
-    lo = tp_max(tp_max(va, sp.c_is_lo ? vc : INT32_MIN), clip_lo);
-    hi = tp_min(tp_min(vb, sp.c_is_lo ? INT32_MAX : vc), clip_hi);
-    sp.A.x += sp.A.s; sp.B.x += sp.B.s; sp.C.x += sp.C.s;
+    lo = tp_max(tp_max(tp_walker_value(sp.A), tp_walker_value(sp.Cl)), clip_lo);
+    hi = tp_min(tp_min(tp_walker_value(sp.B), tp_walker_value(sp.Ch)), clip_hi);
+    hi = tp_max(hi, lo);
+    sp.A.x += sp.A.s; sp.B.x += sp.B.s; sp.Cl.x += sp.Cl.s; sp.Ch.x += sp.Ch.s;
 }
 
 // conservative pixel bounding box of all 13 variants of a triangle (inclusive; may be empty)
