@@ -1,0 +1,155 @@
+// Host-mirror known-answer tests (CPU only).  Expected values are the fixtures SURVEY.md section 8c
+// lists for the host half of the path -- (i) initial state, (ii) flip, (iii)/(iv) split, (v) warp,
+// (v') collapse, (vi) geterr, (vii) .tri layout / stacked read.
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tpose/io.hpp"
+#include "tpose/triangulation.hpp"
+
+using namespace tpose;
+
+static int fails = 0;
+#define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); fails++; } } while (0)
+static bool near(float a, float b, float tol = 1e-5f) { return std::fabs(a - b) <= tol; }
+static bool tri_eq(const triangulation& tr, std::vector<std::vector<int>> v) {
+    if ((int)v.size() != tr.NT) return false;
+    for (int t = 0; t < tr.NT; t++)
+        for (int k = 0; k < 3; k++) if (tr.triangles[t][k] != v[t][k]) return false;
+    return true;
+}
+static bool he_eq(const triangulation& tr, std::vector<int> h) {
+    return tr.halfedges == h;
+}
+
+int main(int argc, char** argv) {
+    const std::string tmp = argc > 1 ? argv[1] : "/tmp";
+    io::verbose = false;
+    RATIO = 1.5f;
+    {   // (i) initial state
+        triangulation tr;
+        CHECK(tr.NT == 2 && tr.NP == 4);
+        CHECK(tri_eq(tr, {{0, 1, 2}, {2, 1, 3}}));
+        CHECK(he_eq(tr, {-1, 3, -1, 1, -1, -1}));
+        CHECK(near(tr.angle(0), 0.588003f) && near(tr.angle(1), 1.5708f, 1e-4f) && near(tr.angle(2), 0.982794f));
+        CHECK(near(tr.hlength(0), 2.0f) && near(tr.hlength(1), 3.60555f, 1e-4f) && near(tr.hlength(2), 3.0f));
+        CHECK(tr.points[0] == vec2(-1.5f, -1) && tr.points[3] == vec2(1.5f, 1));
+        CHECK(tr.colors.size() == triangulation::MAXT && tr.colors[0].w == 1);
+        CHECK(tr.boundary(0) == 3);
+    }
+    {   // (ii) flip(1, 0), and flipping back restores the edge ids
+        triangulation tr;
+        CHECK(tr.flip(1, 0.0f));
+        CHECK(tri_eq(tr, {{1, 3, 0}, {0, 3, 2}}));
+        CHECK(he_eq(tr, {-1, 3, -1, 1, -1, -1}));
+        CHECK(tr.flip(1, 0.0f));
+        CHECK(tri_eq(tr, {{3, 2, 1}, {1, 2, 0}}));
+        CHECK(!tr.flip(0, 0.0f));           // no twin
+    }
+    {   // (iii) split(0)
+        triangulation tr;
+        CHECK(tr.split(0));
+        CHECK(tr.NT == 4 && tr.NP == 5);
+        CHECK(tri_eq(tr, {{0, 1, 4}, {2, 1, 3}, {1, 2, 4}, {2, 0, 4}}));
+        CHECK(he_eq(tr, {-1, 8, 10, 6, -1, -1, 3, 11, 1, -1, 2, 7}));
+        CHECK(near(tr.points[4].x, -0.5f) && near(tr.points[4].y, -0.333333f));
+        // (iv) split(0); split(1)
+        CHECK(tr.split(1));
+        CHECK(tr.NT == 6 && tr.NP == 6);
+        CHECK(he_eq(tr, {-1, 8, 10, 6, 14, 16, 3, 11, 1, -1, 2, 7, -1, 17, 4, -1, 5, 13}));
+        // (v) warp through state (iv)
+        tr.originpoints = tr.points;
+        tr.points[4] += vec2(0.1f, 0.05f);
+        std::vector<vec2> q = {vec2(-0.4f, -0.2f), vec2(0.3f, 0.3f)};
+        tr.warp(q);
+        CHECK(near(q[0].x, -0.33f, 1e-4f) && near(q[0].y, -0.165f, 1e-4f));
+        CHECK(near(q[1].x, 0.3f) && near(q[1].y, 0.3f));
+        tr.reversewarp(q);
+        CHECK(near(q[0].x, -0.4f, 1e-4f) && near(q[0].y, -0.2f, 1e-4f));
+    }
+    {   // (v') collapse
+        triangulation tr;
+        tr.split(0);
+        tr.points[4] = tr.points[0] + vec2(0.005f, 0.0f);
+        CHECK(tr.collapse(2));
+        CHECK(tr.NT == 2 && tr.NP == 4);
+        CHECK(tri_eq(tr, {{1, 0, 2}, {0, 1, 3}}));
+        CHECK(he_eq(tr, {3, -1, -1, 0, -1, -1}));
+        CHECK(tr.points[0] == vec2(-1.5f, 1) && tr.points[1] == vec2(1.5f, -1) && tr.points[2] == vec2(1.5f, 1));
+        CHECK(near(tr.points[3].x, -1.4975f) && near(tr.points[3].y, -1.0f));
+        triangulation far;
+        far.split(0);
+        CHECK(!far.collapse(2));             // edge longer than 0.01
+    }
+    {   // prune / eraset / erasep bookkeeping
+        triangulation tr;
+        tr.split(0); tr.split(1);
+        const int NT = tr.NT;
+        CHECK(!tr.prune(0));                 // proper triangle
+        tr.points[4] = vec2(-1.5f, 0.0f);    // triangle 0 = (0,1,4) becomes flat on the hull
+        CHECK(tr.prune(0));
+        CHECK(tr.NT == NT - 1 && (int)tr.halfedges.size() == 3 * tr.NT);
+        for (int h = 0; h < 3 * tr.NT; h++) {
+            const int w = tr.halfedges[h];
+            CHECK(w < 3 * tr.NT);
+            if (w >= 0) CHECK(tr.halfedges[w] == h);   // twins stay mutual
+        }
+    }
+    {   // (vi) geterr / maxerrid
+        triangulation tr;
+        tpose::terr = new int[16]();
+        tpose::terr[0] = 100; tpose::terr[1] = 400;
+        tpose::toterr = 1.0f;
+        CHECK(geterr(&tr) == 499.0f);
+        CHECK(geterr(&tr) == 0.0f);
+        CHECK(tpose::maxerr == 20.0f);
+        CHECK(maxerrid(&tr) == 1);
+        CHECK(gettoterr(&tr) == 500.0f);
+        delete[] tpose::terr; tpose::terr = nullptr;
+    }
+    {   // (vii) .tri byte layout, stacked write / read
+        const std::string f = tmp + "/tp_host_test.tri";
+        std::remove(f.c_str());
+        {
+            triangulation tr;
+            tr.colors[0] = ivec4(10, 20, 30, 1);
+            io::write(&tr, f);               // record 1: NT 2 / NP 4
+            tr.split(0);
+            io::write(&tr, f);               // record 2: NT 4 / NP 5
+        }
+        std::ifstream s(f, std::ios::binary | std::ios::ate);
+        const long sz = (long)s.tellg();
+        CHECK(sz == (4 + 4 + 2 * 36 + 4 + 4 * 16) + (4 + 4 + 4 * 36 + 4 + 5 * 16));
+        triangulation rd;
+        RATIO = 9.0f;
+        CHECK(io::read(&rd, f));
+        CHECK(RATIO == 1.5f && rd.NT == 2 && rd.NP == 4 && rd.colors.size() == 2 && rd.colors[0] == ivec4(10, 20, 30, 1));
+        CHECK(io::read(&rd, f));
+        CHECK(rd.NT == 4 && rd.NP == 5 && rd.triangles[2] == ivec4(1, 2, 4, 0));
+        CHECK(!io::read(&rd, f));
+        CHECK(!rd.in.is_open());
+        // 6-triangle record is 324 bytes (SURVEY probe)
+        const std::string g = tmp + "/tp_host_test6.tri";
+        std::remove(g.c_str());
+        { triangulation tr; tr.split(0); tr.split(1); io::write(&tr, g); }
+        std::ifstream s6(g, std::ios::binary | std::ios::ate);
+        CHECK((long)s6.tellg() == 324);
+    }
+    {   // optimize() keeps the half-edge structure consistent on a perturbed mesh
+        RATIO = 1.5f;
+        triangulation tr;
+        for (int k = 0; k < 6; k++) tr.split(k % tr.NT);
+        tr.optimize();
+        CHECK((int)tr.triangles.size() == tr.NT && (int)tr.points.size() == tr.NP);
+        for (int h = 0; h < 3 * tr.NT; h++) {
+            const int w = tr.halfedges[h];
+            if (w >= 0) { CHECK(tr.halfedges[w] == h); CHECK(tr.org(h) == tr.dst(w) && tr.dst(h) == tr.org(w)); }
+        }
+    }
+    std::printf(fails ? "%d FAILED\n" : "host mirror OK\n", fails);
+    return fails ? 1 : 0;
+}
