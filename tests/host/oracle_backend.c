@@ -1,0 +1,94 @@
+/* oracle_backend.c -- TEST INFRASTRUCTURE: the subset of the C ABI (include/tpose_hip.h) that the
+ * headless harnesses use, implemented on the CPU oracle (oracle/tp_oracle.c, literal reference form).
+ * Linking a harness against this instead of libtpose_hip.so gives a schedule-level reference run:
+ * tests compare the .tri files the two builds write, byte for byte.  Never shipped, never linked by
+ * the product. */
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/tpose_hip.h"
+#include "../../oracle/tp_oracle.h"
+
+struct tp_context {
+    int W, H;
+    float ratio, dp_override;
+    uint8_t* img[2];
+    float* points; int NP;
+    int32_t* tris; int NT;
+    int32_t *ca, *cn, *ten, *gr;
+    int acc_flavour, acc_slot;
+};
+
+static const char* g_err = "";
+
+int tp_abi_version(void) { return TP_ABI_VERSION; }
+const char* tp_last_error(const tp_context* c) { (void)c; return g_err; }
+
+int tp_create(int device, int width, int height, tp_context** out) {
+    (void)device;
+    tp_context* c = (tp_context*)calloc(1, sizeof *c);
+    c->W = width; c->H = height; c->ratio = (float)width / (float)height;
+    *out = c;
+    return TP_OK;
+}
+int tp_destroy(tp_context* c) {
+    if (!c) return TP_OK;
+    free(c->img[0]); free(c->img[1]); free(c->points); free(c->tris); free(c->ca); free(c->cn); free(c->ten); free(c->gr);
+    free(c);
+    return TP_OK;
+}
+int tp_set_ratio(tp_context* c, float r) { c->ratio = r; return TP_OK; }
+int tp_set_image(tp_context* c, int slot, const uint8_t* rgba, size_t stride) {
+    free(c->img[slot]);
+    c->img[slot] = (uint8_t*)malloc((size_t)c->W * c->H * 4);
+    for (int y = 0; y < c->H; y++) memcpy(c->img[slot] + (size_t)y * c->W * 4, rgba + (size_t)y * stride, (size_t)c->W * 4);
+    return TP_OK;
+}
+int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, int NT, const int32_t* colors) {
+    if (NT != c->NT) {
+        int32_t* ca = (int32_t*)calloc((size_t)13 * NT * 4, 4);
+        if (c->ca && c->NT) {  /* colacc persists across uploads in the reference (one big SSBO) */
+            /* variant-major layout changes with NT: the stale contents are never read before the
+             * next mode-0 pass in triangulate, and warp always uploads colours */
+        }
+        free(c->ca); c->ca = ca;
+        free(c->cn); c->cn = (int32_t*)calloc((size_t)13 * NT, 4);
+        free(c->ten); c->ten = (int32_t*)calloc((size_t)13 * NT, 4);
+    }
+    if (NP != c->NP) { free(c->gr); c->gr = (int32_t*)calloc((size_t)2 * NP, 4); }
+    free(c->points); c->points = (float*)malloc(sizeof(float) * 2 * NP); memcpy(c->points, points, sizeof(float) * 2 * NP);
+    free(c->tris); c->tris = (int32_t*)malloc(sizeof(int32_t) * 4 * NT); memcpy(c->tris, tris, sizeof(int32_t) * 4 * NT);
+    c->NP = NP; c->NT = NT;
+    if (colors)
+        for (int i = 0; i < 13; i++) memcpy(c->ca + (size_t)4 * i * NT, colors, sizeof(int32_t) * 4 * NT);
+    return TP_OK;
+}
+static float the_dp(tp_context* c, int flavour) { return c->dp_override > 0 ? c->dp_override : tpo_dp(flavour, c->NT); }
+int tp_accumulate(tp_context* c, int flavour, int slot) {
+    tpo_raster r = {c->img[slot], (size_t)c->W * 4, c->W, c->H};
+    tpo_accumulate_literal(&r, c->points, c->tris, c->NT, the_dp(c, flavour), c->ratio, flavour == TP_WARP, c->cn, c->ca, 1);
+    c->acc_flavour = flavour; c->acc_slot = slot;
+    return TP_OK;
+}
+int tp_energy(tp_context* c, int flavour) {
+    tpo_raster r = {c->img[c->acc_slot], (size_t)c->W * 4, c->W, c->H};
+    tpo_energy_literal(&r, c->points, c->tris, c->NT, the_dp(c, flavour), c->ratio, flavour, c->cn, c->ca, c->ten, 1);
+    return TP_OK;
+}
+int tp_shift(tp_context* c, float rate) {
+    tpo_gradient(c->ten, c->tris, c->NT, c->NP, c->gr);
+    tpo_shift(c->points, c->NP, c->gr, c->ratio, rate);
+    return TP_OK;
+}
+int tp_retrieve(tp_context* c, int what, void* dst, size_t count) {
+    switch (what) {
+        case TP_BUF_TENERGY: memcpy(dst, c->ten, count * 4); break;
+        case TP_BUF_COLNUM: memcpy(dst, c->cn, count * 4); break;
+        case TP_BUF_COLACC: memcpy(dst, c->ca, count * 4); break;
+        case TP_BUF_POINTS: memcpy(dst, c->points, count * 4); break;
+        case TP_BUF_GRADIENT: memcpy(dst, c->gr, count * 4); break;
+        case TP_BUF_PENERGY: memset(dst, 0, count * 4); break;
+        default: return TP_ERR_INVALID;
+    }
+    return TP_OK;
+}

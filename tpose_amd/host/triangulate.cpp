@@ -1,0 +1,148 @@
+// triangulate -- headless counterpart of the reference's software/triangulate program: energy-based
+// image triangulation with the reference's frame schedule (software/triangulate/main.cpp:190-353),
+// driven through the tpose:: host mirror (include/tpose/) on top of the HIP C ABI.
+//
+//   triangulate -i image.ppm [-o out.tri] [-window 1.5] [-maxframes N] [-maxtris N] [-device D] [-quiet]
+//
+// One frame = doenergy, doshift, read back tenergy/penergy/colnum/points, then -- once the relative
+// energy change drops below 1e-4 -- export (on the 50,100,...,1000 ladder), energy-sorted flip set with
+// flip-back, split of the worst triangle; every frame: prune, wide-angle flips, short-edge collapses;
+// then computecolors at the new positions.  No window, no GL: `-window f` only selects the raster
+// (image size / f, like the reference's Tiny::window(w/1.5, h/1.5)); default f = 1 (raster == image).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "tpose/io.hpp"
+#include "tpose/triangulation.hpp"
+#include "image_io.hpp"
+
+using namespace tpose;
+
+int main(int argc, char** argv) {
+    std::string input, output;
+    float window = 1.0f;
+    long maxframes = 1L << 40;
+    int maxtris = 1 << 30, device = 0;
+    bool quiet = false;
+    for (int a = 1; a < argc; a++) {
+        const std::string k = argv[a];
+        auto val = [&]() -> const char* { if (a + 1 >= argc) { std::cerr << "missing value for " << k << "\n"; std::exit(2); } return argv[++a]; };
+        if (k == "-i") input = val();
+        else if (k == "-o") output = val();
+        else if (k == "-window") window = (float)std::atof(val());
+        else if (k == "-maxframes") maxframes = std::atol(val());
+        else if (k == "-maxtris") maxtris = std::atoi(val());
+        else if (k == "-device") device = std::atoi(val());
+        else if (k == "-quiet") quiet = true;
+        else { std::cerr << "unknown option " << k << "\n"; return 2; }
+    }
+    if (input.empty()) { std::cout << "Please specify an input image with -i." << std::endl; return 0; }
+    Raster img;
+    if (!load_raster(input, img)) { std::cout << "Failed to load image." << std::endl; return 0; }
+    if (output.empty()) output = input + ".tri";
+    io::verbose = !quiet;
+
+    std::vector<int> exportlist = {1000, 900, 800, 700, 600, 500, 400, 300, 200, 100, 50};  // consumed from the back
+
+    RATIO = (float)img.w / (float)img.h;
+    Raster raster = img;
+    if (window != 1.0f) raster = resample(img, (int)((float)img.w / window), (int)((float)img.h / window));
+
+    tpose::init(raster.w, raster.h, device);
+    tpose::flavour = TP_TRIANGULATE;
+    tpose::image(TP_IMAGE_A, raster.rgba.data(), (size_t)raster.w * 4);
+
+    triangulation tr;
+    tpose::upload(&tr, false);
+    if (!quiet) std::cout << "Number of Triangles: " << tr.NT << std::endl;
+    tpose::computecolors();
+
+    long frame = 0;
+    bool done = false;
+    while (!done && frame < maxframes) {
+        frame++;
+        tpose::doenergy();
+        tpose::doshift();
+        tpose::retrieve(&tr);
+
+        bool updated = false;
+        if (tpose::geterr(&tr) < 1E-4) {
+            if (exportlist.empty() || tr.NT > maxtris) { done = true; break; }
+            if (tr.NT >= exportlist.back()) {
+                tpose::retrieve_colors(&tr);
+                for (int i = 0; i < tr.NT; i++)
+                    if (tpose::cn[i] > 0) tr.colors[i] /= tpose::cn[i];
+                tr.originpoints = tr.points;
+                io::write(&tr, output);
+                exportlist.pop_back();
+            }
+
+            // half-edges ordered by the energy of their triangle pair (ties are dropped, like the
+            // reference's std::set keyed on energy alone)
+            struct by_energy {
+                bool operator()(const std::pair<int, float>& l, const std::pair<int, float>& r) const { return l.second > r.second; }
+            };
+            std::set<std::pair<int, float>, by_energy> ranked;
+            for (int t = 0; t < (int)tr.triangles.size(); t++)
+                for (int k = 0; k < 3; k++) {
+                    const int w = tr.halfedges[3 * t + k];
+                    if (w >= 0) ranked.emplace(3 * t + k, tpose::terr[t] + tpose::terr[w / 3]);
+                }
+            std::set<int> locked;            // half-edges whose triangle already takes part in a flip
+            std::map<int, float> chosen;     // half-edge -> pair energy before the flip
+            for (auto& h : ranked) {
+                if (locked.count(h.first)) continue;
+                const int w = tr.halfedges[h.first];
+                if (w < 0) continue;
+                if (locked.count(w)) continue;
+                chosen[h.first] = h.second;
+                for (int k = 0; k < 3; k++) { locked.insert(3 * (h.first / 3) + k); locked.insert(3 * (w / 3) + k); }
+            }
+            for (auto& h : chosen) tr.flip(h.first, 0.0f);
+            tpose::upload(&tr, false);
+            tpose::computecolors();
+            tpose::doenergy();
+            tpose::retrieve_energy(&tr);
+            for (auto& h : chosen)       // undo the flips that raised their pair's energy
+                if (tpose::terr[h.first / 3] + tpose::terr[tr.halfedges[h.first] / 3] > h.second) tr.flip(h.first, 0.0f);
+            tpose::upload(&tr, false);
+            tpose::computecolors();
+            tpose::doenergy();
+            tpose::retrieve_energy(&tr);
+
+            const int worst = tpose::maxerrid(&tr);
+            if (worst >= 0 && tr.split(worst)) updated = true;
+        }
+
+        for (size_t t = 0; t < (size_t)tr.NT; t++)
+            if (tr.boundary((int)t) == 3)
+                if (tr.prune((int)t)) updated = true;
+        for (size_t t = 0; t < (size_t)tr.NT; t++)
+            for (int k = 0; k < 3; k++)
+                if (tr.angle(3 * (int)t + k) > 0.8 * tpose::PI) tr.flip(3 * (int)t + k, 0.0);
+        for (size_t t = 0; t < tr.triangles.size(); t++) {
+            int h = 3 * (int)t;
+            float shortest = tr.hlength(h);
+            if (tr.hlength(h + 1) < shortest) shortest = tr.hlength(++h);
+            if (tr.hlength(h + 1) < shortest) shortest = tr.hlength(++h);
+            if (tr.collapse(h)) updated = true;
+        }
+        if (updated) {
+            const float e = tpose::gettoterr(&tr);
+            if (!quiet) std::cout << tr.NT << " " << std::setprecision(16) << e << std::endl;
+            tpose::upload(&tr, false);
+        }
+        tpose::computecolors();  // the reference's render pipeline: colours at the new positions
+    }
+    std::cout << "frames " << frame << " triangles " << tr.NT << " points " << tr.NP << " levels written "
+              << (11 - (int)exportlist.size()) << std::endl;
+    tpose::quit();
+    return 0;
+}

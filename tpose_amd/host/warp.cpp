@@ -1,0 +1,101 @@
+// warp -- headless counterpart of the reference's software/warp program: hierarchical two-view warp of
+// a pair of stacked triangulations (software/warp/main.cpp:214-283) through the tpose:: host mirror.
+//
+//   warp -ia A.ppm -ib B.ppm -ta A.tri -tb B.tri [-schedule as_written|two_way]
+//        [-maxframes N] [-levelframes N] [-device D] [-quiet]
+//
+// Per frame: doreset (count), doenergy against the OTHER image with the stored triangle colours,
+// doshift; when the relative energy change falls below 1e-6 the optimised triangulation's reverse
+// warp seeds the other one and the direction flips.
+//   as_written: exactly one direction per level (the reference's `NWARPA < 1 && NWARPB < 1` test is
+//               never true after the first convergence), then both triangulations are written to
+//               <tri>.warp and the next finer level is read, warped on read.
+//   two_way:    both directions per level (the README's description; `||` instead of `&&`).
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+#include "tpose/io.hpp"
+#include "tpose/triangulation.hpp"
+#include "image_io.hpp"
+
+using namespace tpose;
+
+int main(int argc, char** argv) {
+    std::string ia, ib, ta, tb, schedule = "as_written";
+    long maxframes = 1L << 40, levelframes = 1L << 40;
+    int device = 0;
+    bool quiet = false;
+    for (int a = 1; a < argc; a++) {
+        const std::string k = argv[a];
+        auto val = [&]() -> const char* { if (a + 1 >= argc) { std::cerr << "missing value for " << k << "\n"; std::exit(2); } return argv[++a]; };
+        if (k == "-ia") ia = val();
+        else if (k == "-ib") ib = val();
+        else if (k == "-ta") ta = val();
+        else if (k == "-tb") tb = val();
+        else if (k == "-schedule") schedule = val();
+        else if (k == "-maxframes") maxframes = std::atol(val());
+        else if (k == "-levelframes") levelframes = std::atol(val());
+        else if (k == "-device") device = std::atoi(val());
+        else if (k == "-quiet") quiet = true;
+        else { std::cerr << "unknown option " << k << "\n"; return 2; }
+    }
+    if (ia.empty() || ib.empty()) { std::cout << "Please specify two input images with -ia, -ib." << std::endl; return 0; }
+    if (ta.empty() || tb.empty()) { std::cout << "Please specify two input triangulations with -ta, -tb." << std::endl; return 0; }
+    const bool two_way = schedule == "two_way";
+    Raster A, B;
+    if (!load_raster(ia, A) || !load_raster(ib, B)) { std::cout << "Failed to load image." << std::endl; return 0; }
+    if (A.w != B.w || A.h != B.h) { std::cout << "Images don't have the same dimension" << std::endl; return 0; }
+    io::verbose = !quiet;
+
+    RATIO = (float)A.w / (float)A.h;
+    tpose::init(A.w, A.h, device);
+    tpose::flavour = TP_WARP;
+    tpose::image(TP_IMAGE_A, A.rgba.data(), (size_t)A.w * 4);
+    tpose::image(TP_IMAGE_B, B.rgba.data(), (size_t)B.w * 4);
+
+    triangulation trA, trB;
+    io::read(&trA, ta);
+    io::read(&trB, tb);
+    tpose::warpA = true;
+    triangulation* tr = &trA;
+    tpose::upload(tr);
+    tpose::doreset();
+
+    int nwarpa = 0, nwarpb = 0, level = 0;
+    long frame = 0, inlevel = 0;
+    while (frame < maxframes) {
+        frame++; inlevel++;
+        tpose::doreset();
+        tpose::doenergy();
+        tpose::doshift();
+        tpose::retrieve(tr);
+        if (tpose::geterr(tr) < 1E-6 || inlevel >= levelframes) {
+            inlevel = 0;
+            if (tpose::warpA) {
+                trB.points = trB.originpoints;
+                trA.reversewarp(trB.points);
+                nwarpa++;
+            } else {
+                trA.points = trA.originpoints;
+                trB.reversewarp(trA.points);
+                nwarpb++;
+            }
+            tpose::warpA = !tpose::warpA;
+            tr = tpose::warpA ? &trA : &trB;
+            const bool more = two_way ? (nwarpa < 1 || nwarpb < 1) : (nwarpa < 1 && nwarpb < 1);
+            if (more) { tpose::upload(tr); continue; }
+            nwarpa = nwarpb = 0;
+            io::write(&trA, ta + ".warp");
+            io::write(&trB, tb + ".warp");
+            level++;
+            if (!io::read(&trA, ta, true)) break;
+            if (!io::read(&trB, tb, true)) break;
+            tpose::upload(tr);
+        }
+    }
+    std::cout << "frames " << frame << " levels " << level << std::endl;
+    tpose::quit();
+    return 0;
+}
