@@ -74,17 +74,13 @@ def main():
         args.gpus = world
 
     import torch
-    dist = None
+    from tpose_amd import capi, dist_util, synth
+    dist, device = None, None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from tpose_amd import capi, synth
+        dist, rank, world, device = dist_util.init("nccl")  # RCCL; one rank per GPU
 
     # independent replica per rank: its own image (seeded by rank) and triangulation
-    img, pts, tris, he, ratio = synth.workload(W, H, NT, seed=1234 + rank)
+    img, pts, tris, he, ratio = synth.workload(W, H, NT, seed=dist_util.replica_seed(rank))
     NP = pts.shape[0]
     ctx = capi.Context(local_rank, W, H)
     ctx.set_image(capi.IMAGE_A, img)
@@ -112,9 +108,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = dist_util.max_over_ranks(dist, dt, device)  # the job is as slow as its slowest rank
         dist.barrier()
 
     # dominant kernel: average accumulate-launch duration, HIP events on the library's own stream,

@@ -1,0 +1,74 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU path: the two-way warp driver's per-level exchange of
+vertex buffers, pairing, and the bench's max-over-ranks reduction."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from tpose_amd import hostlib, synth, warp_dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def write_stack(path, img, ratio, grids):
+    """a stacked .tri hierarchy (coarse to fine) with stored colours, originpoints = points"""
+    if os.path.exists(path):
+        os.remove(path)
+    hostlib.set_ratio(ratio)
+    t = hostlib.Triangulation()
+    for g in grids:
+        pts, tris, he = synth.grid_triangulation(g[0], g[1], ratio=ratio, jitter=0.15)
+        t.assign(tris, pts, pts, he, synth.mean_colors(img, pts, tris, ratio))
+        t.write(path)
+
+
+def test_pack_unpack_roundtrip():
+    hostlib.set_ratio(1.5)
+    t = hostlib.Triangulation()
+    t.split(0)
+    u = warp_dist.unpack(warp_dist.pack(t))
+    assert u.NT == t.NT and u.NP == t.NP
+    assert np.array_equal(u.triangles, t.triangles) and np.array_equal(u.points, t.points)
+    assert np.array_equal(u.originpoints, t.originpoints)
+
+
+def test_two_way_warp_world_size_2_gloo(tmp_path):
+    W, H = 96, 64
+    ratio = float(np.float32(W) / np.float32(H))
+    A = synth.voronoi_raster(W, H, seed=5, sites=6, noise=2)
+    B = synth.displaced_raster(A, amp=3.0)
+    np.save(str(tmp_path / "A.npy"), A)
+    np.save(str(tmp_path / "B.npy"), B)
+    write_stack(str(tmp_path / "A.tri"), A, ratio, [(3, 2), (6, 4)])
+    write_stack(str(tmp_path / "B.tri"), B, ratio, [(3, 2), (6, 4)])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(tmp_path), "24"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    outs = [json.load(open(str(tmp_path / ("out%d.json" % r)))) for r in range(2)]
+    assert outs[0]["worst"] == outs[1]["worst"] == 11.0          # MAX over ranks
+    assert outs[0]["seed"] != outs[1]["seed"]                    # one replica per rank
+    for r, name in enumerate(("A.tri", "B.tri")):
+        lv = outs[r]["levels"]
+        assert [l["NT"] for l in lv] == [12, 48]                 # both hierarchy levels processed
+        assert all(np.isfinite(l["residual"]) for l in lv)
+        # one record per level appended to <tri>.warp, same sizes as the input stack
+        data = open(str(tmp_path / (name + ".warp")), "rb").read()
+        assert len(data) == os.path.getsize(str(tmp_path / name))
+    # the finer level was read warped-on-read: its origin points are untouched, its points moved
+    hostlib.set_ratio(ratio)
+    t = hostlib.Triangulation()
+    assert t.read(str(tmp_path / "A.tri.warp")) and t.read(str(tmp_path / "A.tri.warp"))
+    assert t.NT == 48 and not np.array_equal(t.points, t.originpoints)
