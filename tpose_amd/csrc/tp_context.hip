@@ -489,9 +489,7 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
             c->lists_dp = dp; c->lists_ratio = c->ratio;
         }
         tp_launch_bin(L, c->stream);
-        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-        tp_launch_accumulate(L, c->stream);
-        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        tp_launch_accumulate_timed(L, c->stream, c->ev0, c->ev1);  // the dispatch's own begin/end stamps
         tp_launch_update(L, p->flavour, p->rate, c->stream);
         HIP_TRY(c, hipEventSynchronize(c->ev1));
         float ms = 0.0f;

@@ -62,6 +62,7 @@ struct tp_launch {
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s);
 void tp_launch_accumulate(const tp_launch& L, hipStream_t s);
+void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t start, hipEvent_t stop);
 void tp_launch_finalize(const tp_launch& L, int flavour, bool write_moments, hipStream_t s);
 void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s);
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s);

@@ -16,6 +16,7 @@
 //   k_shift       per vertex: gather the central differences of its incident triangles
 //                 (gradient.cs) and take the clamped step (shift.cs).
 #include "tp_kernels.h"
+#include <hip/hip_ext.h>
 
 #define TW TP_TILE_W
 #define TH TP_TILE_H
@@ -241,6 +242,12 @@ hipError_t tp_kernels_init() {
 
 void tp_launch_accumulate(const tp_launch& L, hipStream_t s) {
     hipLaunchKernelGGL(k_accumulate, dim3(L.tiles_x * L.tiles_y), dim3(ACC_THREADS), tp_accumulate_lds_bytes(), s, L);
+}
+
+// same launch with the dispatch's own begin/end timestamps recorded into two events
+void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+    hipExtLaunchKernelGGL(k_accumulate, dim3(L.tiles_x * L.tiles_y), dim3(ACC_THREADS), tp_accumulate_lds_bytes(), s,
+                          start, stop, 0, L);
 }
 
 // ------------------------------------------------------------------------------------------------
