@@ -53,6 +53,8 @@ struct tp_context {
     size_t tilelist_elems = 0;
     int list_cap = 0;
     int2* tri_pair = nullptr;
+    int2* vsnap = nullptr;
+    unsigned long long* tri_mask = nullptr;
     uint32_t* partials = nullptr;
     int pair_cap = 0;
     tp_device_state* state = nullptr;
@@ -106,10 +108,10 @@ void drop_graphs(tp_context* c) {
 
 void free_triangulation(tp_context* c) {
     hipFree(c->points); hipFree(c->points_binned); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
-    hipFree(c->tri_pair); hipFree(c->partials); hipFree(c->tilelist);
+    hipFree(c->tri_pair); hipFree(c->vsnap); hipFree(c->tri_mask); hipFree(c->partials); hipFree(c->tilelist);
     hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
     c->points = nullptr; c->points_binned = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
-    c->tri_pair = nullptr; c->partials = nullptr; c->tilelist = nullptr;
+    c->tri_pair = nullptr; c->vsnap = nullptr; c->tri_mask = nullptr; c->partials = nullptr; c->tilelist = nullptr;
     c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
     c->capT = c->capP = 0;
 }
@@ -127,7 +129,7 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.NT = c->NT; L.NP = c->NP;
     L.vtx_off = c->vtx_off; L.vtx_adj = c->vtx_adj;
     L.tilecount = c->tilecount; L.tilelist = c->tilelist; L.list_cap = c->list_cap;
-    L.tri_pair = c->tri_pair; L.partials = c->partials; L.pair_cap = c->pair_cap;
+    L.tri_pair = c->tri_pair; L.vsnap = c->vsnap; L.tri_mask = c->tri_mask; L.partials = c->partials; L.pair_cap = c->pair_cap;
     L.state = c->state;
     L.ten = c->ten; L.cn = c->cn; L.ca = c->ca; L.gr = c->gr; L.moments = c->moments;
     L.gacc = c->gacc;
@@ -316,6 +318,8 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         HIP_TRY(c, dev_alloc(&c->colors, capT));
         HIP_TRY(c, dev_alloc(&c->vtx_adj, (size_t)3 * capT));
         HIP_TRY(c, dev_alloc(&c->tri_pair, capT));
+        HIP_TRY(c, dev_alloc(&c->vsnap, (size_t)capT * TP_VSNAP_STRIDE));
+        HIP_TRY(c, dev_alloc(&c->tri_mask, capT));
         HIP_TRY(c, dev_alloc(&c->ten, (size_t)13 * capT));
         HIP_TRY(c, dev_alloc(&c->cn, (size_t)13 * capT));
         HIP_TRY(c, dev_alloc(&c->ca, (size_t)13 * capT));

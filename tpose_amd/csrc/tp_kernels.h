@@ -21,11 +21,12 @@ struct tp_device_state {
     uint32_t pad[3];
 };
 
-// One (triangle, tile) work item: where its partial record goes and the triangle's vertex ids
-// (positions are read fresh every iteration -- the lists outlive many vertex updates).
-struct __attribute__((aligned(16))) tp_list_entry {
-    int pair, v0, v1, v2;
+// One (triangle, tile) work item: where its partial record goes and which triangle it is (the
+// triangle's 15 snapped vertex positions are read from `vsnap`, refreshed every iteration).
+struct __attribute__((aligned(8))) tp_list_entry {
+    int pair, tri;
 };
+#define TP_VSNAP_STRIDE 16  // int2 per triangle: [0..2] base vertices, [2+i] the moved vertex of variant i
 
 struct tp_launch {
     // raster
@@ -47,6 +48,8 @@ struct tp_launch {
     tp_list_entry* tilelist;  // [tiles * list_cap]
     int list_cap;
     int2* tri_pair;      // [NT] (first pair, #pairs)
+    unsigned long long* tri_mask;  // [NT] which tiles of the rectangle carry a partial record (<= 64 tiles)
+    int2* vsnap;         // [NT][TP_VSNAP_STRIDE] snapped 24.8 vertex positions of the 13 variants
     uint32_t* partials;  // [pair_cap * 13 * 6]
     int pair_cap;
     tp_device_state* state;

@@ -34,35 +34,88 @@ size_t tp_accumulate_lds_bytes() { return (size_t)TH * ROWLEN * sizeof(uint4); }
 // ------------------------------------------------------------------------------------------------
 #define BIN_TRIS 64  // triangles per 256-thread block
 
+// Can any variant of the triangle cover a pixel of the rectangle [c0,c1] x [r0,r1]?  Conservative:
+// every variant lies inside base (+) box(dX, dY), so it suffices that for one base edge the whole
+// rectangle sits more than dX|a| + dY|b| outside.  Integer arithmetic on the snapped vertices.
+__device__ __forceinline__ bool may_touch(const int32_t X[3], const int32_t Y[3], int64_t dX, int64_t dY,
+                                          int c0, int c1, int r0, int r1) {
+    const int64_t area2 = (int64_t)(X[1] - X[0]) * (Y[2] - Y[0]) - (int64_t)(Y[1] - Y[0]) * (X[2] - X[0]);
+    if (area2 == 0) return true;
+    const int64_t sg = area2 > 0 ? 1 : -1;
+    bool touch = true;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const int j = e == 2 ? 0 : e + 1;
+        const int64_t a = -(int64_t)(Y[j] - Y[e]) * sg, b = (int64_t)(X[j] - X[e]) * sg;
+        const int64_t xs = 256LL * (a > 0 ? c1 : c0) + 128, ys = 256LL * (b > 0 ? r1 : r0) + 128;
+        const int64_t emax = a * (xs - X[e]) + b * (ys - Y[e]);
+        const int64_t slack = dX * (a < 0 ? -a : a) + dY * (b < 0 ? -b : b);
+        touch = touch && (emax >= -slack);
+    }
+    return touch;
+}
+
 __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
-    __shared__ int s_excl[BIN_TRIS + 1];  // exclusive scan of pair counts
-    __shared__ int s_rect[BIN_TRIS][3];   // tx0, ty0, ntx
-    __shared__ int s_vid[BIN_TRIS][3];
+    __shared__ int s_excl[BIN_TRIS + 1];             // exclusive scan of rectangle sizes
+    __shared__ int s_rect[BIN_TRIS][4];              // tx0, ty0, ntx, #tiles
+    __shared__ int s_X[BIN_TRIS][3], s_Y[BIN_TRIS][3];
+    __shared__ int s_infl[BIN_TRIS][2];              // dX, dY: how far a displaced vertex strays (1/256 px)
+    __shared__ unsigned long long s_keep[BIN_TRIS];  // tiles of the rectangle some variant can reach
     __shared__ uint32_t s_base;
-    if (!L.state->rebin_req) return;  // lists still valid: nothing moved past its margin
+    const bool rebin = L.state->rebin_req != 0;      // lists still valid otherwise (tp_set_margin)
     const int tid = threadIdx.x;
-    const int t = blockIdx.x * BIN_TRIS + tid;
-    for (int v = blockIdx.x * 256 + tid; v < L.NP; v += gridDim.x * 256) L.points_binned[v] = L.points[v];
-    int cnt = 0;
-    if (tid < BIN_TRIS) {
-        int tx0 = 0, ty0 = 0, ntx = 1;
+    if (rebin)
+        for (int v = blockIdx.x * 256 + tid; v < L.NP; v += gridDim.x * 256) L.points_binned[v] = L.points[v];
+
+    // ---- vertex stage of all 13 variants, once per triangle per iteration: 4 lanes per triangle,
+    //      lane q < 3 transforms vertex slot q (unmoved + its four displacements)
+    const int j = tid >> 2, q = tid & 3;
+    const int t = blockIdx.x * BIN_TRIS + j;
+    int32_t xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN, dX = 0, dY = 0;
+    if (t < L.NT && q < 3) {
+        const int4 tri = L.tris[t];
+        const float2 p = L.points[q == 0 ? tri.x : q == 1 ? tri.y : tri.z];
+        int2* vs = L.vsnap + (size_t)t * TP_VSNAP_STRIDE;
+        int32_t bx, by;
+        tp_vertex_stage(p.x, p.y, 0, q, L.vw, bx, by);
+        vs[q] = make_int2(bx, by);
+        s_X[j][q] = bx; s_Y[j][q] = by;
+        xmin = xmax = bx; ymin = ymax = by;
+#pragma unroll
+        for (int k = 1; k <= 4; k++) {
+            int32_t mx, my;
+            tp_vertex_stage(p.x, p.y, 4 * q + k, q, L.vw, mx, my);
+            vs[2 + 4 * q + k] = make_int2(mx, my);
+            xmin = min(xmin, mx); xmax = max(xmax, mx); ymin = min(ymin, my); ymax = max(ymax, my);
+            dX = max(dX, abs(mx - bx)); dY = max(dY, abs(my - by));
+        }
+    }
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {  // reduce over the triangle's four lanes
+        xmin = min(xmin, __shfl_xor(xmin, o)); xmax = max(xmax, __shfl_xor(xmax, o));
+        ymin = min(ymin, __shfl_xor(ymin, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+        dX = max(dX, __shfl_xor(dX, o)); dY = max(dY, __shfl_xor(dY, o));
+    }
+    if (!rebin) return;
+    if (q == 0) {
+        int tx0 = 0, ty0 = 0, ntx = 1, cnt = 0;
         if (t < L.NT) {
-            const int4 tri = L.tris[t];
-            const float2 a = L.points[tri.x], b = L.points[tri.y], c = L.points[tri.z];
-            const float p[3][2] = {{a.x, a.y}, {b.x, b.y}, {c.x, c.y}};
-            tp_bbox bb = tp_triangle_bbox(p, L.vw);
-            bb.c0 = max(bb.c0 - L.margin_px, 0); bb.c1 = min(bb.c1 + L.margin_px, L.vw.W - 1);
-            bb.r0 = max(bb.r0 - L.margin_px, 0); bb.r1 = min(bb.r1 + L.margin_px, L.vw.H - 1);
-            s_vid[tid][0] = tri.x; s_vid[tid][1] = tri.y; s_vid[tid][2] = tri.z;
-            if (bb.c0 <= bb.c1 && bb.r0 <= bb.r1) {
-                tx0 = bb.c0 / TW; ty0 = bb.r0 / TH;
-                ntx = bb.c1 / TW - tx0 + 1;
-                cnt = ntx * (bb.r1 / TH - ty0 + 1);
+            const int m = L.margin_px;
+            const int c0 = max(tp_first_centre(xmin) - m, 0), c1 = min(tp_last_centre(xmax) + m, L.vw.W - 1);
+            const int r0 = max(tp_first_centre(ymin) - m, 0), r1 = min(tp_last_centre(ymax) + m, L.vw.H - 1);
+            if (c0 <= c1 && r0 <= r1) {
+                tx0 = c0 / TW; ty0 = r0 / TH;
+                ntx = c1 / TW - tx0 + 1;
+                cnt = ntx * (r1 / TH - ty0 + 1);
             }
         }
-        s_rect[tid][0] = tx0; s_rect[tid][1] = ty0; s_rect[tid][2] = ntx;
-        // wave 0 holds all BIN_TRIS counts: inclusive scan by shuffles
-        int inc = cnt;
+        s_rect[j][0] = tx0; s_rect[j][1] = ty0; s_rect[j][2] = ntx; s_rect[j][3] = cnt;
+        s_infl[j][0] = dX + 256 * L.margin_px; s_infl[j][1] = dY + 256 * L.margin_px;
+        s_keep[j] = 0ull;
+    }
+    __syncthreads();
+    if (tid < BIN_TRIS) {  // wave 0: inclusive scan of the rectangle sizes by shuffles
+        int inc = s_rect[tid][3];
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int v = __shfl_up(inc, o);
@@ -80,9 +133,9 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
     __syncthreads();
     const int total = s_excl[BIN_TRIS];
     const uint32_t base = s_base;
-    if (tid < BIN_TRIS && t < L.NT) L.tri_pair[t] = make_int2((int)base + s_excl[tid], cnt);
+    // ---- one thread per (triangle, tile of its rectangle): keep it if some variant can reach it
     for (int p = tid; p < total; p += 256) {
-        int lo = 0, hi = BIN_TRIS;  // largest j with s_excl[j] <= p
+        int lo = 0, hi = BIN_TRIS;  // largest jj with s_excl[jj] <= p
 #pragma unroll
         for (int it = 0; it < 6; it++) {
             const int mid = (lo + hi) >> 1;
@@ -90,15 +143,28 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
         }
         const int k = p - s_excl[lo], ntx = s_rect[lo][2];
         const int ky = k / ntx, kx = k - ky * ntx;
-        const int tile = (s_rect[lo][1] + ky) * L.tiles_x + s_rect[lo][0] + kx;
+        const int txx = s_rect[lo][0] + kx, tyy = s_rect[lo][1] + ky;
+        const int32_t X[3] = {s_X[lo][0], s_X[lo][1], s_X[lo][2]}, Y[3] = {s_Y[lo][0], s_Y[lo][1], s_Y[lo][2]};
+        const bool dense = s_rect[lo][3] > 64;  // huge triangles: no culling, no mask
+        if (!dense && !may_touch(X, Y, s_infl[lo][0], s_infl[lo][1], txx * TW, min(txx * TW + TW - 1, L.vw.W - 1),
+                                 tyy * TH, min(tyy * TH + TH - 1, L.vw.H - 1)))
+            continue;
+        if (!dense) atomicOr(&s_keep[lo], 1ull << k);
+        const int tile = tyy * L.tiles_x + txx;
         const int slot = atomicAdd(&L.tilecount[tile], 1);
         if (slot < L.list_cap) {
             tp_list_entry e;
             e.pair = (int)base + p;
-            e.v0 = s_vid[lo][0]; e.v1 = s_vid[lo][1]; e.v2 = s_vid[lo][2];
+            e.tri = blockIdx.x * BIN_TRIS + lo;
             L.tilelist[(size_t)tile * L.list_cap + slot] = e;
         } else
             atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
+    }
+    __syncthreads();
+    if (q == 0 && t < L.NT) {
+        const int cnt = s_rect[j][3];
+        L.tri_pair[t] = make_int2((int)base + s_excl[j], cnt);
+        L.tri_mask[t] = cnt > 64 ? ~0ull : s_keep[j];
     }
 }
 
@@ -202,11 +268,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
     for (; item < nitems; item += ACC_THREADS) {
         const int e = item / TP_NVARIANTS, v = item - e * TP_NVARIANTS;
         if (item != tid) ent = list[e];
-        const float2 p0 = L.points[ent.v0], p1 = L.points[ent.v1], p2 = L.points[ent.v2];
-        int32_t X[3], Y[3];
-        tp_vertex_stage(p0.x, p0.y, v, 0, L.vw, X[0], Y[0]);
-        tp_vertex_stage(p1.x, p1.y, v, 1, L.vw, X[1], Y[1]);
-        tp_vertex_stage(p2.x, p2.y, v, 2, L.vw, X[2], Y[2]);
+        // snapped vertices of this variant: two base vertices + (v > 0) the displaced one
+        const int2* vs = L.vsnap + (size_t)ent.tri * TP_VSNAP_STRIDE;
+        const int ms = v > 0 ? (v - 1) >> 2 : 3;
+        const int2 q0 = vs[ms == 0 ? 2 + v : 0], q1 = vs[ms == 1 ? 2 + v : 1], q2 = vs[ms == 2 ? 2 + v : 2];
+        const int32_t X[3] = {q0.x, q1.x, q2.x}, Y[3] = {q0.y, q1.y, q2.y};
         tp_span sp;
         tp_setup_span(X, Y, row0, row1, sp);
         if (L.debug & 4) sp.r1 = sp.r0 - 1 + (int)(sp.A.x & 1);
@@ -250,6 +316,19 @@ void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t st
                           start, stop, 0, L);
 }
 
+__device__ __forceinline__ tp_moments sum_partials(const tp_launch& L, int2 pr, unsigned long long mask, int i) {
+    tp_moments m = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < pr.y; k++) {
+        if (pr.y <= 64 && !((mask >> k) & 1ull)) continue;  // tile culled by k_bin: no record
+        const int pair = pr.x + k;
+        if (pair >= L.pair_cap) break;
+        const uint2* in = reinterpret_cast<const uint2*>(L.partials + ((size_t)pair * TP_NVARIANTS + i) * TP_PARTIAL_WORDS);
+        const uint2 a = in[0], b = in[1], c = in[2];
+        m.n += a.x; m.nodd += a.y; m.sr += b.x; m.sg += b.y; m.sb += c.x; m.q += c.y;
+    }
+    return m;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_finalize: thread per (triangle, variant); id = i*NT + t in the outputs
 // ------------------------------------------------------------------------------------------------
@@ -257,15 +336,7 @@ __global__ __launch_bounds__(256) void k_finalize(tp_launch L, int flavour, int 
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= L.NT * TP_NVARIANTS) return;
     const int t = gid / TP_NVARIANTS, i = gid - t * TP_NVARIANTS;
-    const int2 pr = L.tri_pair[t];
-    tp_moments m = {0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < pr.y; k++) {
-        const int pair = pr.x + k;
-        if (pair >= L.pair_cap) break;
-        const uint2* in = reinterpret_cast<const uint2*>(L.partials + ((size_t)pair * TP_NVARIANTS + i) * TP_PARTIAL_WORDS);
-        const uint2 a = in[0], b = in[1], c = in[2];
-        m.n += a.x; m.nodd += a.y; m.sr += b.x; m.sg += b.y; m.sb += c.x; m.q += c.y;
-    }
+    const tp_moments m = sum_partials(L, L.tri_pair[t], L.tri_mask[t], i);
     const int id = i * L.NT + t;
     int64_t E;
     if (flavour == 0) {
@@ -329,18 +400,6 @@ void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s) {
 // component and takes the shift.cs step for it.  x and y never interact in shift.cs, so they are
 // settled independently.  Integer sums commute: the result does not depend on arrival order.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ tp_moments sum_partials(const tp_launch& L, int2 pr, int i) {
-    tp_moments m = {0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < pr.y; k++) {
-        const int pair = pr.x + k;
-        if (pair >= L.pair_cap) break;
-        const uint2* in = reinterpret_cast<const uint2*>(L.partials + ((size_t)pair * TP_NVARIANTS + i) * TP_PARTIAL_WORDS);
-        const uint2 a = in[0], b = in[1], c = in[2];
-        m.n += a.x; m.nodd += a.y; m.sr += b.x; m.sg += b.y; m.sb += c.x; m.q += c.y;
-    }
-    return m;
-}
-
 __device__ __forceinline__ int32_t emit_variant(const tp_launch& L, int flavour, int t, int i, const tp_moments& m) {
     const int id = i * L.NT + t;
     int64_t E;
@@ -390,7 +449,7 @@ __global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float 
         pb = L.points_binned[v];
     }
     int32_t e = 0;
-    if (live) e = emit_variant(L, flavour, t, i, sum_partials(L, L.tri_pair[t], i));
+    if (live) e = emit_variant(L, flavour, t, i, sum_partials(L, L.tri_pair[t], L.tri_mask[t], i));
     // central differences inside the quad: lanes 4q+0/1 hold E(+dx)/E(-dx), 4q+2/3 E(+dy)/E(-dy)
     const uint32_t e1 = (uint32_t)__shfl_xor(e, 1);
     const uint32_t gx = (uint32_t)e - e1;                     // valid on even lanes of the quad
