@@ -210,95 +210,126 @@ __device__ __forceinline__ uint4 as_uint4(pix4 a) { return make_uint4(a.x, a.y, 
 // ------------------------------------------------------------------------------------------------
 // k_accumulate
 // ------------------------------------------------------------------------------------------------
+// Phase-1 lane mapping (waves 0..3 only): wave w owns tile rows 8w..8w+7; lane = seg*8 + rl walks the
+// 16 pixels [16 seg, 16 seg + 16) of row 8w + rl sequentially, and the eight segments of a row are
+// combined by a 3-step scan at lane distance 8.  Consecutive lanes belong to consecutive ROWS, whose
+// LDS rows are 2064 B = 16 B (mod 128) apart, so every ds_write_b128 lane group hits 8 distinct
+// 16-byte slots: the prefix table is written without bank conflicts.
+#define P1_WAVES 4
+#define P1_PX 16
+
+__device__ __forceinline__ uint32_t scan8_stride8(uint32_t v, int seg) {
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, 8 * d);
+        v += seg >= d ? o : 0u;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
     extern __shared__ __attribute__((aligned(16))) uint4 P[];  // [TH][ROWLEN]
 
-    const int tile = blockIdx.x;
-    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
     const int tid = threadIdx.x;
-    constexpr int NPASS = TH / ACC_ROWS_PER_PASS;
+    const int ntiles = L.tiles_x * L.tiles_y;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int rl = lane & 7, seg = lane >> 3, prow = wave * 8 + rl;  // phase-1 role (wave < P1_WAVES)
+    if (blockIdx.x == 0 && tid == 0) L.state->rebin_req = 0;  // consumed by the k_bin that ran before us
 
-    // issue every global load up front: the tile's pixels, the list length, this lane's first item
-    const int l32 = tid & 31, rsub = tid >> 5;  // 32 lanes x 4 px per row, ACC_ROWS_PER_PASS rows per pass
-    uint4 px[NPASS];
-    {
-        const uint8_t* src = L.img + (size_t)(ty * TH + rsub) * L.pitch + (size_t)(tx * TW + l32 * 4) * 4;
+    // the block walks tiles blockIdx.x, +gridDim.x, ...; the pixels of the next tile are fetched into
+    // registers while the spans of the current one are walked
+    uint4 px[P1_PX / 4];
+    auto fetch = [&](int tile) {
+        const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
+        const uint8_t* src = L.img + (size_t)(ty * TH + prow) * L.pitch + (size_t)(tx * TW + seg * P1_PX) * 4;
 #pragma unroll
-        for (int p = 0; p < NPASS; p++)
-            px[p] = *reinterpret_cast<const uint4*>(src + (size_t)p * ACC_ROWS_PER_PASS * L.pitch);
-    }
-    int nlist = L.tilecount[tile];
-    if (nlist > L.list_cap) nlist = L.list_cap;
-    if (tile == 0 && tid == 0) L.state->rebin_req = 0;  // consumed by the k_bin that ran before us
-    if (nlist == 0) return;
-    const int nitems = nlist * TP_NVARIANTS;
-    const tp_list_entry* list = L.tilelist + (size_t)tile * L.list_cap;
-    int item = tid;
-    tp_list_entry ent = list[item < nitems ? item / TP_NVARIANTS : 0];
+        for (int k = 0; k < P1_PX / 4; k++) px[k] = reinterpret_cast<const uint4*>(src)[k];
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles && wave < P1_WAVES) fetch(tile);
 
-    // ---- phase 1: pixels -> row prefix sums in LDS ------------------------------------------
-    if (!(L.debug & 1)) {
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
+        int nlist = L.tilecount[tile];
+        if (nlist > L.list_cap) nlist = L.list_cap;
+        const int nitems = nlist * TP_NVARIANTS;
+        const tp_list_entry* list = L.tilelist + (size_t)tile * L.list_cap;
+        int item = tid;
+        tp_list_entry ent = list[item < nitems ? item / TP_NVARIANTS : 0];
+        const int next = tile + gridDim.x;
+
+        // ---- phase 1: pixels -> row prefix sums in LDS --------------------------------------
+        if (wave < P1_WAVES && nlist > 0 && !(L.debug & 1)) {
+            pix4 loc[P1_PX];  // exclusive prefix inside the lane's 16-pixel segment
+            pix4 run = {0, 0, 0, 0};
 #pragma unroll
-        for (int p = 0; p < NPASS; p++) {
-            const pix4 e0 = pixel_moments(px[p].x), e1 = pixel_moments(px[p].y),
-                       e2 = pixel_moments(px[p].z), e3 = pixel_moments(px[p].w);
-            const pix4 s1 = e0 + e1, s2 = s1 + e2, s3 = s2 + e3;
-            pix4 ex;  // exclusive prefix of this lane's first pixel
-            ex.x = scan32_inclusive(s3.x) - s3.x;
-            ex.y = scan32_inclusive(s3.y) - s3.y;
-            ex.z = scan32_inclusive(s3.z) - s3.z;
-            ex.w = scan32_inclusive(s3.w) - s3.w;
-            uint4* row = P + (p * ACC_ROWS_PER_PASS + rsub) * ROWLEN + l32 * 4;
-            row[0] = as_uint4(ex);
-            row[1] = as_uint4(ex + e0);
-            row[2] = as_uint4(ex + s1);
-            row[3] = as_uint4(ex + s2);
-            if (l32 == 31) row[4] = as_uint4(ex + s3);
+            for (int k = 0; k < P1_PX; k++) {
+                const uint32_t w = k % 4 == 0 ? px[k / 4].x : k % 4 == 1 ? px[k / 4].y : k % 4 == 2 ? px[k / 4].z : px[k / 4].w;
+                loc[k] = run;
+                run = run + pixel_moments(w);
+            }
+            pix4 ex;  // everything left of the segment
+            ex.x = scan8_stride8(run.x, seg) - run.x;
+            ex.y = scan8_stride8(run.y, seg) - run.y;
+            ex.z = scan8_stride8(run.z, seg) - run.z;
+            ex.w = scan8_stride8(run.w, seg) - run.w;
+            uint4* row = P + prow * ROWLEN + seg * P1_PX;
+#pragma unroll
+            for (int k = 0; k < P1_PX; k++) row[k] = as_uint4(ex + loc[k]);
+            if (seg == 7) row[P1_PX] = as_uint4(ex + run);
         }
-    }
-    __syncthreads();
-    if (L.debug & 2) return;
+        if (next < ntiles && wave < P1_WAVES) fetch(next);  // in flight during phase 2
+        __syncthreads();
 
-    // ---- phase 2: one lane per (triangle, variant) of this tile --------------------------------
-    const int row0 = ty * TH;
-    const int row1 = min(row0 + TH - 1, L.vw.H - 1);
-    const int col0 = tx * TW;
-    const int colE = min(col0 + TW, L.vw.W);
+        // ---- phase 2: one lane per (triangle, variant) of this tile ----------------------------
+        const int row0 = ty * TH;
+        const int row1 = min(row0 + TH - 1, L.vw.H - 1);
+        const int col0 = tx * TW;
+        const int colE = min(col0 + TW, L.vw.W);
 
-    for (; item < nitems; item += ACC_THREADS) {
-        const int e = item / TP_NVARIANTS, v = item - e * TP_NVARIANTS;
-        if (item != tid) ent = list[e];
-        // snapped vertices of this variant: two base vertices + (v > 0) the displaced one
-        const int2* vs = L.vsnap + (size_t)ent.tri * TP_VSNAP_STRIDE;
-        const int ms = v > 0 ? (v - 1) >> 2 : 3;
-        const int2 q0 = vs[ms == 0 ? 2 + v : 0], q1 = vs[ms == 1 ? 2 + v : 1], q2 = vs[ms == 2 ? 2 + v : 2];
-        const int32_t X[3] = {q0.x, q1.x, q2.x}, Y[3] = {q0.y, q1.y, q2.y};
-        tp_span sp;
-        tp_setup_span(X, Y, row0, row1, sp);
-        if (L.debug & 4) sp.r1 = sp.r0 - 1 + (int)(sp.A.x & 1);
-        // one row per trip, branch-free: an empty row has hi == lo and its two reads cancel.
-        // Whole entries are accumulated with 64-bit adds, hi-side and lo-side apart.
-        uint64_t bxy = 0, bzw = 0, axy = 0, azw = 0;
-        uint32_t n = 0;
-        const ulonglong2* rowp = reinterpret_cast<const ulonglong2*>(P) + (sp.r0 - row0) * ROWLEN - col0;
-        for (int r = sp.r0; r <= sp.r1; ++r, rowp += ROWLEN) {
-            int32_t lo, hi;
-            tp_span_row(sp, col0, colE, lo, hi);
-            const ulonglong2 a = rowp[lo], b = rowp[hi];
-            n += (uint32_t)(hi - lo);
-            bxy += b.x; bzw += b.y; axy += a.x; azw += a.y;
+        if (!(L.debug & 2))
+        for (; item < nitems; item += ACC_THREADS) {
+            const int e = item / TP_NVARIANTS, v = item - e * TP_NVARIANTS;
+            if (item != tid) ent = list[e];
+            // snapped vertices of this variant: two base vertices + (v > 0) the displaced one
+            const int2* vs = L.vsnap + (size_t)ent.tri * TP_VSNAP_STRIDE;
+            const int ms = v > 0 ? (v - 1) >> 2 : 3;
+            const int2 q0 = vs[ms == 0 ? 2 + v : 0], q1 = vs[ms == 1 ? 2 + v : 1], q2 = vs[ms == 2 ? 2 + v : 2];
+            const int32_t X[3] = {q0.x, q1.x, q2.x}, Y[3] = {q0.y, q1.y, q2.y};
+            tp_span sp;
+            tp_setup_span(X, Y, row0, row1, sp);
+            if (L.debug & 4) sp.r1 = sp.r0 - 1 + (int)(sp.A.x & 1);
+            // one row per trip, branch-free: an empty row has hi == lo and its two reads cancel.
+            // Whole entries are accumulated with 64-bit adds, hi-side and lo-side apart.
+            uint64_t bxy = 0, bzw = 0, axy = 0, azw = 0;
+            uint32_t n = 0;
+            const ulonglong2* rowp = reinterpret_cast<const ulonglong2*>(P) + (sp.r0 - row0) * ROWLEN - col0;
+            for (int r = sp.r0; r <= sp.r1; ++r, rowp += ROWLEN) {
+                int32_t lo, hi;
+                tp_span_row(sp, col0, colE, lo, hi);
+                const ulonglong2 a = rowp[lo], b = rowp[hi];
+                n += (uint32_t)(hi - lo);
+                bxy += b.x; bzw += b.y; axy += a.x; azw += a.y;
+            }
+            const uint64_t dxy = bxy - axy, dzw = bzw - azw;
+            const uint32_t sr = (uint32_t)dxy, sg = (uint32_t)(dxy >> 32);
+            const uint32_t sb = (uint32_t)dzw & 0xfffffu, no = (uint32_t)(dzw >> 20) & 0x3fffu;
+            const uint32_t q = (uint32_t)(dzw >> 34);
+            if (ent.pair < L.pair_cap) {
+                uint32_t* out = L.partials + ((size_t)ent.pair * TP_NVARIANTS + v) * TP_PARTIAL_WORDS;
+                reinterpret_cast<uint2*>(out)[0] = make_uint2(n, no);
+                reinterpret_cast<uint2*>(out)[1] = make_uint2(sr, sg);
+                reinterpret_cast<uint2*>(out)[2] = make_uint2(sb, q);
+            }
         }
-        const uint64_t dxy = bxy - axy, dzw = bzw - azw;
-        const uint32_t sr = (uint32_t)dxy, sg = (uint32_t)(dxy >> 32);
-        const uint32_t sb = (uint32_t)dzw & 0xfffffu, no = (uint32_t)(dzw >> 20) & 0x3fffu;
-        const uint32_t q = (uint32_t)(dzw >> 34);
-        if (ent.pair < L.pair_cap) {
-            uint32_t* out = L.partials + ((size_t)ent.pair * TP_NVARIANTS + v) * TP_PARTIAL_WORDS;
-            reinterpret_cast<uint2*>(out)[0] = make_uint2(n, no);
-            reinterpret_cast<uint2*>(out)[1] = make_uint2(sr, sg);
-            reinterpret_cast<uint2*>(out)[2] = make_uint2(sb, q);
-        }
+        if (next < ntiles) __syncthreads();  // the table is rebuilt for the next tile
     }
+}
+
+static int accumulate_grid(const tp_launch& L) {
+    // every workgroup resident at once (2 per CU by LDS); each walks its tiles with prefetch
+    const int ntiles = L.tiles_x * L.tiles_y;
+    return ntiles < 512 ? ntiles : 512;
 }
 
 hipError_t tp_kernels_init() {
@@ -307,12 +338,12 @@ hipError_t tp_kernels_init() {
 }
 
 void tp_launch_accumulate(const tp_launch& L, hipStream_t s) {
-    hipLaunchKernelGGL(k_accumulate, dim3(L.tiles_x * L.tiles_y), dim3(ACC_THREADS), tp_accumulate_lds_bytes(), s, L);
+    hipLaunchKernelGGL(k_accumulate, dim3(accumulate_grid(L)), dim3(ACC_THREADS), tp_accumulate_lds_bytes(), s, L);
 }
 
 // same launch with the dispatch's own begin/end timestamps recorded into two events
 void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
-    hipExtLaunchKernelGGL(k_accumulate, dim3(L.tiles_x * L.tiles_y), dim3(ACC_THREADS), tp_accumulate_lds_bytes(), s,
+    hipExtLaunchKernelGGL(k_accumulate, dim3(accumulate_grid(L)), dim3(ACC_THREADS), tp_accumulate_lds_bytes(), s,
                           start, stop, 0, L);
 }
 
