@@ -95,3 +95,77 @@ extern "C" void emul_walker(int64_t N0, int32_t step, int32_t d, int rows, int32
     tp_walker w = tp_make_walker(N0, step, d);
     for (int r = 0; r < rows; r++) { out[r] = tp_walker_value(w); w.x += w.s; }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Edge-centric form: W for every distinct edge line (walked in 32-row windows like the tiles do,
+// one full-row prefix lookup per row), then each variant = signed sum of three lines.
+// ---------------------------------------------------------------------------------------------
+#include <map>
+extern "C" int emul_moments_edges(const uint8_t* img, size_t stride, int W, int H, const float* points,
+                                  const int32_t* tris, int NT, int NP, float dp, float ratio, int64_t* mom) {
+    tp_view vw;
+    vw.dp = dp; vw.ratio = ratio; vw.halfW = 0.5f * (float)W; vw.halfH = 0.5f * (float)H; vw.W = W; vw.H = H;
+    // full-row prefix sums of the six per-pixel quantities (index 0: pixel count -> P = x itself)
+    std::vector<int64_t> P((size_t)H * (W + 1) * 5, 0);
+    for (int r = 0; r < H; r++)
+        for (int c = 0; c < W; c++) {
+            const uint8_t* p = img + (size_t)r * stride + 4 * (size_t)c;
+            const int64_t R = p[0], G = p[1], B = p[2];
+            const int64_t v[5] = {(R + G + B) & 1, R, G, B, R * R + G * G + B * B};
+            for (int k = 0; k < 5; k++) P[((size_t)r * (W + 1) + c + 1) * 5 + k] = P[((size_t)r * (W + 1) + c) * 5 + k] + v[k];
+        }
+    // per-vertex snapped positions for the five moves
+    std::vector<int32_t> vx((size_t)NP * 5), vy((size_t)NP * 5);
+    for (int v = 0; v < NP; v++)
+        for (int m = 0; m < 5; m++)
+            tp_vertex_stage(points[2 * v], points[2 * v + 1], m == 0 ? 0 : m, 0, vw, vx[v * 5 + m], vy[v * 5 + m]);
+    // undirected edges
+    std::map<std::pair<int, int>, int> eid;
+    std::vector<std::pair<int, int>> edges;
+    std::vector<int> he_edge(3 * (size_t)NT);
+    for (int t = 0; t < NT; t++)
+        for (int k = 0; k < 3; k++) {
+            const int o = tris[4 * t + k], d = tris[4 * t + (k + 1) % 3];
+            const std::pair<int, int> key(o < d ? o : d, o < d ? d : o);
+            auto it = eid.find(key);
+            if (it == eid.end()) { it = eid.emplace(key, (int)edges.size()).first; edges.push_back(key); }
+            he_edge[3 * t + k] = it->second * 2 + (o != key.first ? 1 : 0);
+        }
+    // W[edge][ver][6]
+    std::vector<int64_t> Wt(edges.size() * 9 * 6, 0);
+    for (size_t e = 0; e < edges.size(); e++)
+        for (int ver = 0; ver < 9; ver++) {
+            const int u = edges[e].first, v = edges[e].second;
+            const int mu = ver >= 1 && ver <= 4 ? ver : 0, mv = ver >= 5 ? ver - 4 : 0;
+            int64_t* w = &Wt[(e * 9 + ver) * 6];
+            for (int win = 0; win < H; win += 32) {
+                tp_edge_walk ew;
+                tp_setup_edge(vx[u * 5 + mu], vy[u * 5 + mu], vx[v * 5 + mv], vy[v * 5 + mv], win, tp_min(win + 31, H - 1), ew);
+                for (int r = ew.ra; r <= ew.rb; r++) {
+                    int32_t x = tp_walker_value(ew.w);
+                    ew.w.x += ew.w.s;
+                    x = x < 0 ? 0 : (x > W ? W : x);
+                    w[0] += x;
+                    for (int k = 0; k < 5; k++) w[1 + k] += P[((size_t)r * (W + 1) + x) * 5 + k];
+                }
+            }
+        }
+    for (int t = 0; t < NT; t++)
+        for (int i = 0; i < 13; i++) {
+            int32_t X[3], Y[3], c[3];
+            for (int s = 0; s < 3; s++) {
+                const int v = tris[4 * t + s];
+                const int m = (i > 0 && ((i - 1) >> 2) == s) ? ((i - 1) & 3) + 1 : 0;
+                X[s] = vx[v * 5 + m]; Y[s] = vy[v * 5 + m];
+            }
+            tp_variant_coeffs(X, Y, c);
+            int64_t* m = mom + 6 * ((size_t)i * NT + t);
+            for (int q = 0; q < 6; q++) m[q] = 0;
+            for (int k = 0; k < 3; k++) {
+                const int he = he_edge[3 * t + k];
+                const int64_t* w = &Wt[((size_t)(he >> 1) * 9 + tp_edge_version(i, k, he & 1)) * 6];
+                for (int q = 0; q < 6; q++) m[q] += c[k] * w[q];
+            }
+        }
+    return 0;
+}

@@ -112,3 +112,41 @@ def test_walker_floor_is_exact(em):
                 assert (out[r] > (1 << 28)) == (exact > 0) and abs(int(out[r])) > (1 << 28)
             else:
                 assert int(out[r]) == exact, (N0, step, d, r, int(out[r]), exact)
+
+
+def emul_moments_edges(em, img, pts, tris, dp, ratio):
+    NT, NP = tris.shape[0], pts.shape[0]
+    H, W = img.shape[:2]
+    mom = np.zeros((13 * NT, 6), np.int64)
+    em.emul_moments_edges(img.ctypes.data_as(C.c_void_p), C.c_size_t(img.strides[0]), W, H,
+                          pts.ctypes.data_as(C.c_void_p), tris.ctypes.data_as(C.c_void_p), NT, NP,
+                          C.c_float(dp), C.c_float(ratio), mom.ctypes.data_as(C.c_void_p))
+    return mom
+
+
+@pytest.mark.parametrize("W,H,grid", [(97, 61, (6, 4)), (300, 200, (15, 5)), (257, 131, (6, 4)), (200, 150, None)])
+@pytest.mark.parametrize("dp", [None, 0.2])
+def test_edge_centric_form_matches_oracle(em, W, H, grid, dp):
+    """moment(variant) = signed sum of three edge-line sums (one prefix lookup per line and row)"""
+    img, _, pts, tris, ratio, _ = case(W, H, grid)
+    d = O.dp(0, tris.shape[0]) if dp is None else dp
+    assert np.array_equal(emul_moments_edges(em, img, pts, tris, d, ratio), O.moments(img, pts, tris, d, ratio))
+
+
+def test_edge_centric_form_on_triangle_soup(em):
+    W, H = 200, 150
+    img = synth.voronoi_raster(W, H, seed=3, sites=10)
+    ratio = float(np.float32(W) / np.float32(H))
+    rng = np.random.default_rng(2)
+    for trial in range(30):
+        NP = 30
+        pts = (rng.random((NP, 2)).astype(np.float32) * 2 - 1) * np.float32(1.3)
+        pts[:, 0] *= np.float32(ratio)
+        if trial % 3 == 0:
+            pts = (np.round(pts * 8) / 8).astype(np.float32)
+        if trial % 5 == 0:
+            pts[:5] = pts[5:10]
+        tris = np.zeros((40, 4), np.int32)
+        tris[:, :3] = rng.integers(0, NP, (40, 3))
+        dp = [0.05, 0.0078125, 0.3][trial % 3]
+        assert np.array_equal(emul_moments_edges(em, img, pts, tris, dp, ratio), O.moments(img, pts, tris, dp, ratio)), trial

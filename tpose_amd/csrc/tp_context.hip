@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -52,11 +53,16 @@ struct tp_context {
     tp_list_entry* tilelist = nullptr;
     size_t tilelist_elems = 0;
     int list_cap = 0;
-    int2* tri_pair = nullptr;
-    int2* vsnap = nullptr;
-    unsigned long long* tri_mask = nullptr;
-    uint32_t* partials = nullptr;
-    int pair_cap = 0;
+    int NE = 0, capE = 0;
+    int2* edge_uv = nullptr;
+    int* he_edge = nullptr;
+    int2* vpos = nullptr;
+    int2* edge_visit = nullptr;
+    int64_t* visits = nullptr;
+    int visit_cap = 0;
+    int64_t* wline = nullptr;
+    int64_t* t2[2] = {nullptr, nullptr};   // static per-image tables
+    uint32_t* seg_scratch = nullptr;
     tp_device_state* state = nullptr;
     // outputs
     int32_t* ten = nullptr;
@@ -108,10 +114,12 @@ void drop_graphs(tp_context* c) {
 
 void free_triangulation(tp_context* c) {
     hipFree(c->points); hipFree(c->points_binned); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
-    hipFree(c->tri_pair); hipFree(c->vsnap); hipFree(c->tri_mask); hipFree(c->partials); hipFree(c->tilelist);
+    hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->edge_visit); hipFree(c->visits);
+    hipFree(c->wline); hipFree(c->tilelist);
     hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
     c->points = nullptr; c->points_binned = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
-    c->tri_pair = nullptr; c->vsnap = nullptr; c->tri_mask = nullptr; c->partials = nullptr; c->tilelist = nullptr;
+    c->edge_uv = nullptr; c->he_edge = nullptr; c->vpos = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
+    c->wline = nullptr; c->tilelist = nullptr; c->capE = 0;
     c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
     c->capT = c->capP = 0;
 }
@@ -129,7 +137,9 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.NT = c->NT; L.NP = c->NP;
     L.vtx_off = c->vtx_off; L.vtx_adj = c->vtx_adj;
     L.tilecount = c->tilecount; L.tilelist = c->tilelist; L.list_cap = c->list_cap;
-    L.tri_pair = c->tri_pair; L.vsnap = c->vsnap; L.tri_mask = c->tri_mask; L.partials = c->partials; L.pair_cap = c->pair_cap;
+    L.edge_uv = c->edge_uv; L.he_edge = c->he_edge; L.vpos = c->vpos; L.NE = c->NE;
+    L.edge_visit = c->edge_visit; L.visits = c->visits; L.visit_cap = c->visit_cap; L.wline = c->wline;
+    L.t2 = c->t2[slot];
     L.state = c->state;
     L.ten = c->ten; L.cn = c->cn; L.ca = c->ca; L.gr = c->gr; L.moments = c->moments;
     L.gacc = c->gacc;
@@ -153,7 +163,7 @@ hipError_t force_rebin(tp_context* c) {
     hipError_t e = hipMemsetAsync(c->tilecount, 0, sizeof(int) * (size_t)c->tiles_x * c->tiles_y, c->stream);
     if (e != hipSuccess) return e;
     static const uint32_t zero_one[3] = {0u, 0u, 1u};
-    e = hipMemcpyAsync(&c->state->pair_total, &zero_one[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    e = hipMemcpyAsync(&c->state->visit_total, &zero_one[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) return e;
     return hipMemcpyAsync(&c->state->rebin_req, &zero_one[2], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
 }
@@ -161,8 +171,9 @@ hipError_t force_rebin(tp_context* c) {
 // enqueue one grad-iter on the context stream (no sync)
 void enqueue_iter(tp_context* c, const tp_params& p, float dp) {
     tp_launch L = make_launch(c, p.image_slot, dp);
-    tp_launch_bin(L, c->stream);  // early-exits unless a rebuild was requested
+    tp_launch_bin(L, c->stream);  // vertex stage; rebuilds the work lists when requested
     tp_launch_accumulate(L, c->stream);
+    tp_launch_reduce(L, c->stream);
     tp_launch_update(L, p.flavour, p.rate, c->stream);  // finalize + gradient + shift; re-arms the lists
 }
 
@@ -170,8 +181,8 @@ int check_flags(tp_context* c) {
     tp_device_state st{};
     HIP_TRY(c, hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
     if (st.flags) {
-        return fail(c, TP_ERR_CAPACITY, "device work list overflow (flags=%u, list_cap=%d, pair_cap=%d)",
-                    st.flags, c->list_cap, c->pair_cap);
+        return fail(c, TP_ERR_CAPACITY, "device work list overflow (flags=%u, list_cap=%d, visit_cap=%d)",
+                    st.flags, c->list_cap, c->visit_cap);
     }
     return TP_OK;
 }
@@ -232,6 +243,7 @@ int tp_destroy(tp_context* c) {
     drop_graphs(c);
     free_triangulation(c);
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->tilecount); hipFree(c->state);
+    hipFree(c->t2[0]); hipFree(c->t2[1]); hipFree(c->seg_scratch);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -278,6 +290,11 @@ static int set_image_common(tp_context* c, int slot, const void* src, size_t str
         HIP_TRY(c, hipMemsetAsync(c->img[slot], 0, (size_t)c->Wp * c->Hp * 4, c->stream));
     }
     HIP_TRY(c, hipMemcpy2DAsync(c->img[slot], (size_t)c->Wp * 4, src, stride, (size_t)c->W * 4, c->H, kind, c->stream));
+    // static table of this image: moments of everything above a row and left of a tile column
+    if (!c->t2[slot]) HIP_TRY(c, dev_alloc(&c->t2[slot], (size_t)(c->H + 1) * (c->tiles_x + 1) * TP_T2_WORDS));
+    if (!c->seg_scratch) HIP_TRY(c, dev_alloc(&c->seg_scratch, (size_t)c->H * c->tiles_x * 5));
+    tp_launch_static_table(c->img[slot], c->Wp * 4, c->W, c->H, c->tiles_x, c->seg_scratch, c->t2[slot], c->stream);
+    HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_img[slot] = true;
     c->accumulated = c->energized = false;
@@ -317,9 +334,8 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         HIP_TRY(c, dev_alloc(&c->tris, capT));
         HIP_TRY(c, dev_alloc(&c->colors, capT));
         HIP_TRY(c, dev_alloc(&c->vtx_adj, (size_t)3 * capT));
-        HIP_TRY(c, dev_alloc(&c->tri_pair, capT));
-        HIP_TRY(c, dev_alloc(&c->vsnap, (size_t)capT * TP_VSNAP_STRIDE));
-        HIP_TRY(c, dev_alloc(&c->tri_mask, capT));
+        HIP_TRY(c, dev_alloc(&c->he_edge, (size_t)3 * capT));
+        HIP_TRY(c, dev_alloc(&c->vpos, (size_t)5 * capP));
         HIP_TRY(c, dev_alloc(&c->ten, (size_t)13 * capT));
         HIP_TRY(c, dev_alloc(&c->cn, (size_t)13 * capT));
         HIP_TRY(c, dev_alloc(&c->ca, (size_t)13 * capT));
@@ -328,28 +344,61 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         HIP_TRY(c, hipMemset(c->ten, 0, sizeof(int32_t) * 13 * (size_t)capT));
         HIP_TRY(c, hipMemset(c->cn, 0, sizeof(int32_t) * 13 * (size_t)capT));
         HIP_TRY(c, hipMemset(c->gr, 0, sizeof(int2) * (size_t)capP));
-        // (triangle, tile) pairs: typical triangles touch a handful of tiles, a few huge ones all
-        size_t pcap = (size_t)capT * 48 + (size_t)ntiles * 8;
-        if (pcap > ((size_t)1 << 26)) pcap = (size_t)1 << 26;
-        HIP_TRY(c, dev_alloc(&c->partials, pcap * TP_NVARIANTS * TP_PARTIAL_WORDS));
-        c->pair_cap = (int)pcap;
         c->capT = capT; c->capP = capP;
         c->tilelist_elems = 0;
     }
-    // per-tile list capacity: never more than NT entries; generous multiple of the mean otherwise
+    // undirected edges: every half-edge (o -> d) maps to the edge {min, max} and a direction bit
+    std::vector<int> he_edge((size_t)3 * NT);
+    std::vector<int> edge_uv;  // 2 ints per edge
     {
-        size_t mean = ((size_t)c->capT * 8) / (size_t)ntiles + 8;
+        std::unordered_map<uint64_t, int> ids;
+        ids.reserve((size_t)3 * NT);
+        for (int t = 0; t < NT; t++)
+            for (int k = 0; k < 3; k++) {
+                const int o = tris[4 * t + k], d = tris[4 * t + (k + 1) % 3];
+                const int u = o < d ? o : d, v = o < d ? d : o;
+                const uint64_t key = ((uint64_t)(uint32_t)u << 32) | (uint32_t)v;
+                auto it = ids.find(key);
+                if (it == ids.end()) {
+                    it = ids.emplace(key, (int)(edge_uv.size() / 2)).first;
+                    edge_uv.push_back(u); edge_uv.push_back(v);
+                }
+                he_edge[(size_t)3 * t + k] = it->second * 2 + (o != u ? 1 : 0);
+            }
+    }
+    const int NE = (int)(edge_uv.size() / 2);
+    if (NE > c->capE) {
+        hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->wline);
+        c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr; c->wline = nullptr;
+        const int capE = NE + NE / 2 + 64;
+        HIP_TRY(c, dev_alloc(&c->edge_uv, capE));
+        HIP_TRY(c, dev_alloc(&c->edge_visit, capE));
+        HIP_TRY(c, dev_alloc(&c->wline, (size_t)capE * TP_NLINES * TP_W_WORDS));
+        // (edge, tile) visits: typical edges cross a handful of tiles, a few long ones many
+        size_t vcap = (size_t)capE * 24 + (size_t)ntiles * 8;
+        if (vcap > ((size_t)1 << 24)) vcap = (size_t)1 << 24;
+        HIP_TRY(c, dev_alloc(&c->visits, vcap * TP_NLINES * TP_W_WORDS));
+        c->visit_cap = (int)vcap;
+        c->capE = capE;
+        c->tilelist_elems = 0;
+    }
+    c->NE = NE;
+    // per-tile list capacity: never more than NE entries; generous multiple of the mean otherwise
+    {
+        size_t mean = ((size_t)c->capE * 6) / (size_t)ntiles + 8;
         size_t cap = mean * 16;
         if (cap < 256) cap = 256;
-        if (cap > (size_t)c->capT) cap = (size_t)c->capT;
+        if (cap > (size_t)c->capE) cap = (size_t)c->capE;
         if (cap * ntiles > c->tilelist_elems) {
             hipFree(c->tilelist); c->tilelist = nullptr;
             HIP_TRY(c, dev_alloc(&c->tilelist, cap * ntiles));
             c->tilelist_elems = cap * ntiles;
         }
         c->list_cap = (int)(c->tilelist_elems / ntiles);
-        if (c->list_cap > c->capT) c->list_cap = c->capT;
+        if (c->list_cap > c->capE) c->list_cap = c->capE;
     }
+    HIP_TRY(c, hipMemcpy(c->edge_uv, edge_uv.data(), sizeof(int) * 2 * (size_t)NE, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->he_edge, he_edge.data(), sizeof(int) * 3 * (size_t)NT, hipMemcpyHostToDevice));
 
     // vertex -> outgoing half-edge ids (3t+s), the gather form of gradient.cs' scatter
     std::vector<int> off(NP + 1, 0), adj((size_t)3 * NT);
@@ -390,6 +439,7 @@ int tp_accumulate(tp_context* c, int flavour, int slot) {
     c->lists_dp = L.vw.dp; c->lists_ratio = c->ratio;
     tp_launch_bin(L, c->stream);
     tp_launch_accumulate(L, c->stream);
+    tp_launch_reduce(L, c->stream);
     HIP_TRY(c, hipGetLastError());
     c->acc_slot = slot; c->acc_flavour = flavour;
     c->accumulated = true; c->energized = false;
@@ -494,6 +544,7 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
         }
         tp_launch_bin(L, c->stream);
         tp_launch_accumulate_timed(L, c->stream, c->ev0, c->ev1);  // the dispatch's own begin/end stamps
+        tp_launch_reduce(L, c->stream);
         tp_launch_update(L, p->flavour, p->rate, c->stream);
         HIP_TRY(c, hipEventSynchronize(c->ev1));
         float ms = 0.0f;
@@ -574,7 +625,7 @@ int tp_get_info(tp_context* c, int what, int64_t* value) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             tp_device_state st{};
             HIP_TRY(c, hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
-            *value = what == 4 ? st.pair_total : what == 5 ? st.flags : st.rebin_count;
+            *value = what == 4 ? st.visit_total : what == 5 ? st.flags : st.rebin_count;
             return TP_OK;
         }
         default: return fail(c, TP_ERR_INVALID, "unknown info %d", what);

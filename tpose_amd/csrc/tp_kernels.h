@@ -6,14 +6,16 @@
 
 #define TP_TILE_W 128
 #define TP_TILE_H 32
-#define TP_PARTIAL_WORDS 6 /* n, n_odd, sum r, sum g, sum b, q  (uint32 per (variant, tile)) */
+#define TP_NLINES 9        /* lines per undirected edge: base + 4 moves of either endpoint */
+#define TP_W_WORDS 6       /* int64 per line sum: sum x, n_odd, sum r, sum g, sum b, q */
+#define TP_T2_WORDS 5      /* int64 per static-table entry: n_odd, sum r, sum g, sum b, q */
 
 // device-side flag bits (tp_device_state::flags)
 #define TP_FLAG_LIST_OVERFLOW 1u
-#define TP_FLAG_PAIR_OVERFLOW 2u
+#define TP_FLAG_VISIT_OVERFLOW 2u
 
 struct tp_device_state {
-    uint32_t pair_total;   // (triangle, tile) pairs of the current work lists
+    uint32_t visit_total;  // (edge, tile) visits of the current work lists
     uint32_t flags;        // sticky overflow flags
     uint32_t rebin_req;    // 1: k_bin must rebuild the work lists (upload, or a vertex left its margin)
     uint32_t arrive;       // k_update: blocks arrived | (blocks voting for a rebuild) << 16
@@ -21,17 +23,16 @@ struct tp_device_state {
     uint32_t pad[3];
 };
 
-// One (triangle, tile) work item: where its partial record goes and which triangle it is (the
-// triangle's 15 snapped vertex positions are read from `vsnap`, refreshed every iteration).
+// One (edge, tile) work item: which undirected edge, and where its nine line records go.
 struct __attribute__((aligned(8))) tp_list_entry {
-    int pair, tri;
+    int visit, edge;
 };
-#define TP_VSNAP_STRIDE 16  // int2 per triangle: [0..2] base vertices, [2+i] the moved vertex of variant i
 
 struct tp_launch {
     // raster
     const uint8_t* img;  // padded RGBA8 plane
     int pitch;           // bytes per padded row
+    const int64_t* t2;   // static table of the swept image: [H+1][tiles_x+1][TP_T2_WORDS]
     tp_view vw;
     int tiles_x, tiles_y;
     // triangulation
@@ -39,37 +40,43 @@ struct tp_launch {
     float2* points_binned;  // vertex positions when the work lists were last built
     int margin_px;          // work lists stay valid while no vertex moved more than margin_px - 1 pixels
     const int4* tris;
-    const int4* colors;  // stored colours ivec4[NT] (warp) -- may be null
-    int NT, NP;
-    const int* vtx_off;  // CSR by origin vertex: half-edge ids 3t+s
+    const int4* colors;     // stored colours ivec4[NT] (warp) -- may be null
+    int NT, NP, NE;
+    const int* vtx_off;     // CSR by origin vertex: half-edge ids 3t+s
     const int* vtx_adj;
+    const int2* edge_uv;    // [NE] endpoints of every undirected edge, u <= v
+    const int* he_edge;     // [3 NT] edge id * 2 + (half-edge runs v -> u)
+    int2* vpos;             // [NP][5] snapped 24.8 position of every vertex: unmoved, +dx, -dx, +dy, -dy
     // work lists
-    int* tilecount;      // [tiles]
+    int* tilecount;           // [tiles]
     tp_list_entry* tilelist;  // [tiles * list_cap]
     int list_cap;
-    int2* tri_pair;      // [NT] (first pair, #pairs)
-    unsigned long long* tri_mask;  // [NT] which tiles of the rectangle carry a partial record (<= 64 tiles)
-    int2* vsnap;         // [NT][TP_VSNAP_STRIDE] snapped 24.8 vertex positions of the 13 variants
-    uint32_t* partials;  // [pair_cap * 13 * 6]
-    int pair_cap;
+    int2* edge_visit;         // [NE] (first visit, #visits)
+    int64_t* visits;          // [visit_cap][TP_NLINES][TP_W_WORDS] per-tile line sums
+    int visit_cap;
+    int64_t* wline;           // [NE][TP_NLINES][TP_W_WORDS] line sums over the whole raster
     tp_device_state* state;
     // outputs (reference layout)
     int32_t* ten;
     int32_t* cn;
     int4* ca;
     int2* gr;
-    int64_t* moments;  // optional int64[13NT][6]
+    int64_t* moments;          // optional int64[13NT][6]
     unsigned long long* gacc;  // [NP][2] fused-update accumulators: (gradient component << 32) | arrivals
-    int debug;         // ablation knobs (TPOSE_DEBUG_ACC), 0 in production
+    int debug;                 // ablation knobs (TPOSE_DEBUG_ACC), 0 in production
 };
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s);
 void tp_launch_accumulate(const tp_launch& L, hipStream_t s);
 void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t start, hipEvent_t stop);
+void tp_launch_reduce(const tp_launch& L, hipStream_t s);
 void tp_launch_finalize(const tp_launch& L, int flavour, bool write_moments, hipStream_t s);
 void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s);
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s);
 void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s);
+// static per-image table: t2[r][tc] = moments of all pixels in rows < r and columns < tc * TP_TILE_W
+void tp_launch_static_table(const uint8_t* img, int pitch, int W, int H, int tiles_x, uint32_t* seg_scratch,
+                            int64_t* t2, hipStream_t s);
 size_t tp_accumulate_lds_bytes();
 hipError_t tp_kernels_init();  // per-device function attributes (dynamic LDS > 64 KiB)
 void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s);

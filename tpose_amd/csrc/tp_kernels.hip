@@ -2,119 +2,135 @@
 //
 // One grad-iter of the reference = two instanced draws of 13*NT triangles (mode 0: 4 same-address
 // int atomics per fragment, mode 1: one) + gradient.cs + shift.cs
-// (software/triangulate/main.cpp:121-155).  Here:
+// (software/triangulate/main.cpp:121-155).  Here the work is organised around EDGE LINES
+// (tp_raster.h, "edge-centric form"): a variant's pixel moments are the signed sum of three line
+// sums W(e) = sum over the line's rows of the row-prefix sum at the line's crossing column, and the
+// 13 variants of all triangles share 9 lines per undirected edge.
 //
-//   k_bin         triangles -> per-tile work lists (conservative bbox of the 13 variants)
-//   k_accumulate  THE hot kernel: one workgroup per 128x32-pixel tile.  The tile's RGBA8 pixels are
-//                 read once, coalesced (16 B per lane), turned into per-row prefix sums of the five
-//                 pixel moments in LDS (DPP wave scans), then every (variant, tile) pair is walked
-//                 by ONE lane: per row an exact column span [lo,hi) from three 32.32 edge walkers
-//                 and two LDS lookups.  No atomics, no per-fragment work; per-pair partial moments
-//                 go out as 24-byte records.
-//   k_finalize    per variant: sum its partials -> exact moments -> `colnum`, `colacc`, `tenergy`
-//                 in the reference layout (replaces triangle.fs mode 0/1).
-//   k_shift       per vertex: gather the central differences of its incident triangles
-//                 (gradient.cs) and take the clamped step (shift.cs).
+//   k_bin         per edge: snapped endpoint positions for the five vertex moves (-> vpos), bounding
+//                 box of its nine lines -> the tiles it may cross -> per-tile work lists
+//   k_accumulate  THE hot kernel: workgroups walk 128x32-pixel tiles; a tile's RGBA8 pixels are read
+//                 once (16 B per lane, prefetched during the previous tile's walk), turned into
+//                 per-row prefix sums of the pixel moments in LDS without bank conflicts, and every
+//                 (edge line, tile) pair is walked by ONE lane: per row one exact crossing column
+//                 from a 32.32 edge walker and ONE LDS lookup.  No atomics, no per-fragment work.
+//   k_reduce      per line: sum its per-tile records -> W(e)
+//   k_update      per variant: signed sum of three W(e) -> exact moments -> `colnum`, `colacc`,
+//                 `tenergy` (reference layout); central differences; per-vertex arrival atomics;
+//                 shift.cs step.  (k_finalize + k_shift: the same as two launches, piecewise API.)
 #include "tp_kernels.h"
 #include <hip/hip_ext.h>
 
 #define TW TP_TILE_W
 #define TH TP_TILE_H
 #define ROWLEN (TW + 1)  // exclusive prefix has TW+1 entries per row
-
-static_assert(TW == 128, "prefix build assumes 32 lanes x 4 pixels per row");
 #define ACC_THREADS 512
-#define ACC_ROWS_PER_PASS (ACC_THREADS / 32)
-static_assert(TH % ACC_ROWS_PER_PASS == 0 && TH <= TP_WALK_MAXROWS, "tile height");
+
+static_assert(TW == 128, "prefix build assumes 8 lanes x 16 pixels per row");
+static_assert(TH == 32 && TH <= TP_WALK_MAXROWS, "tile height");
 
 size_t tp_accumulate_lds_bytes() { return (size_t)TH * ROWLEN * sizeof(uint4); }
 
-// ------------------------------------------------------------------------------------------------
-// k_bin
-// ------------------------------------------------------------------------------------------------
-#define BIN_TRIS 64  // triangles per 256-thread block
+__device__ __forceinline__ int tile_col_of(int x, int tiles_x) { return min(x / TW, tiles_x - 1); }
 
-// Can any variant of the triangle cover a pixel of the rectangle [c0,c1] x [r0,r1]?  Conservative:
-// every variant lies inside base (+) box(dX, dY), so it suffices that for one base edge the whole
-// rectangle sits more than dX|a| + dY|b| outside.  Integer arithmetic on the snapped vertices.
-__device__ __forceinline__ bool may_touch(const int32_t X[3], const int32_t Y[3], int64_t dX, int64_t dY,
-                                          int c0, int c1, int r0, int r1) {
-    const int64_t area2 = (int64_t)(X[1] - X[0]) * (Y[2] - Y[0]) - (int64_t)(Y[1] - Y[0]) * (X[2] - X[0]);
-    if (area2 == 0) return true;
-    const int64_t sg = area2 > 0 ? 1 : -1;
-    bool touch = true;
-#pragma unroll
-    for (int e = 0; e < 3; e++) {
-        const int j = e == 2 ? 0 : e + 1;
-        const int64_t a = -(int64_t)(Y[j] - Y[e]) * sg, b = (int64_t)(X[j] - X[e]) * sg;
-        const int64_t xs = 256LL * (a > 0 ? c1 : c0) + 128, ys = 256LL * (b > 0 ? r1 : r0) + 128;
-        const int64_t emax = a * (xs - X[e]) + b * (ys - Y[e]);
-        const int64_t slack = dX * (a < 0 ? -a : a) + dY * (b < 0 ? -b : b);
-        touch = touch && (emax >= -slack);
-    }
-    return touch;
+// ------------------------------------------------------------------------------------------------
+// static per-image table (built once per tp_set_image)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void px_moments5(uint32_t rgba, uint32_t m[5]) {
+    const uint32_t r = rgba & 0xffu, g = (rgba >> 8) & 0xffu, b = (rgba >> 16) & 0xffu;
+    m[0] += (r + g + b) & 1u; m[1] += r; m[2] += g; m[3] += b; m[4] += r * r + g * g + b * b;
 }
 
+// seg[r][tc][5]: moments of row r inside tile column tc
+__global__ void k_static_seg(const uint8_t* img, int pitch, int W, int H, int tiles_x, uint32_t* seg) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= H * tiles_x) return;
+    const int r = gid / tiles_x, tc = gid - r * tiles_x;
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(img + (size_t)r * pitch);
+    uint32_t m[5] = {0, 0, 0, 0, 0};
+    const int c1 = min((tc + 1) * TW, W);
+    for (int c = tc * TW; c < c1; c++) px_moments5(row[c], m);
+    for (int k = 0; k < 5; k++) seg[(size_t)gid * 5 + k] = m[k];
+}
+// column prefix over rows, stored shifted by one tile column: t2[r][tc+1] = sum_{r' < r} seg[r'][tc]
+__global__ void k_static_cols(const uint32_t* seg, int H, int tiles_x, int64_t* t2) {
+    const int tc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tc >= tiles_x) return;
+    int64_t acc[5] = {0, 0, 0, 0, 0};
+    for (int r = 0; r <= H; r++) {
+        int64_t* o = t2 + ((size_t)r * (tiles_x + 1) + tc + 1) * TP_T2_WORDS;
+        for (int k = 0; k < 5; k++) o[k] = acc[k];
+        if (r < H) for (int k = 0; k < 5; k++) acc[k] += seg[((size_t)r * tiles_x + tc) * 5 + k];
+    }
+}
+// prefix over tile columns in place: t2[r][tc] = moments of rows < r, columns < tc*TW
+__global__ void k_static_rows(int H, int tiles_x, int64_t* t2) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > H) return;
+    int64_t run[5] = {0, 0, 0, 0, 0};
+    int64_t* row = t2 + (size_t)r * (tiles_x + 1) * TP_T2_WORDS;
+    for (int k = 0; k < 5; k++) row[k] = 0;
+    for (int tc = 1; tc <= tiles_x; tc++)
+        for (int k = 0; k < 5; k++) { run[k] += row[tc * TP_T2_WORDS + k]; row[tc * TP_T2_WORDS + k] = run[k]; }
+}
+void tp_launch_static_table(const uint8_t* img, int pitch, int W, int H, int tiles_x, uint32_t* seg, int64_t* t2, hipStream_t s) {
+    hipLaunchKernelGGL(k_static_seg, dim3((H * tiles_x + 255) / 256), dim3(256), 0, s, img, pitch, W, H, tiles_x, seg);
+    hipLaunchKernelGGL(k_static_cols, dim3((tiles_x + 63) / 64), dim3(64), 0, s, seg, H, tiles_x, t2);
+    hipLaunchKernelGGL(k_static_rows, dim3((H + 1 + 255) / 256), dim3(256), 0, s, H, tiles_x, t2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_bin: 64 edges per 256-thread block, 4 lanes per edge (lanes 0/1 transform the two endpoints)
+// ------------------------------------------------------------------------------------------------
+#define BIN_EDGES 64
+
 __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
-    __shared__ int s_excl[BIN_TRIS + 1];             // exclusive scan of rectangle sizes
-    __shared__ int s_rect[BIN_TRIS][4];              // tx0, ty0, ntx, #tiles
-    __shared__ int s_X[BIN_TRIS][3], s_Y[BIN_TRIS][3];
-    __shared__ int s_infl[BIN_TRIS][2];              // dX, dY: how far a displaced vertex strays (1/256 px)
-    __shared__ unsigned long long s_keep[BIN_TRIS];  // tiles of the rectangle some variant can reach
+    __shared__ int s_excl[BIN_EDGES + 1];  // exclusive scan of rectangle sizes
+    __shared__ int s_rect[BIN_EDGES][4];   // tx0, ty0, ntx, #tiles
     __shared__ uint32_t s_base;
-    const bool rebin = L.state->rebin_req != 0;      // lists still valid otherwise (tp_set_margin)
+    const bool rebin = L.state->rebin_req != 0;  // lists still valid otherwise (tp_set_margin)
     const int tid = threadIdx.x;
     if (rebin)
         for (int v = blockIdx.x * 256 + tid; v < L.NP; v += gridDim.x * 256) L.points_binned[v] = L.points[v];
 
-    // ---- vertex stage of all 13 variants, once per triangle per iteration: 4 lanes per triangle,
-    //      lane q < 3 transforms vertex slot q (unmoved + its four displacements)
     const int j = tid >> 2, q = tid & 3;
-    const int t = blockIdx.x * BIN_TRIS + j;
-    int32_t xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN, dX = 0, dY = 0;
-    if (t < L.NT && q < 3) {
-        const int4 tri = L.tris[t];
-        const float2 p = L.points[q == 0 ? tri.x : q == 1 ? tri.y : tri.z];
-        int2* vs = L.vsnap + (size_t)t * TP_VSNAP_STRIDE;
-        int32_t bx, by;
-        tp_vertex_stage(p.x, p.y, 0, q, L.vw, bx, by);
-        vs[q] = make_int2(bx, by);
-        s_X[j][q] = bx; s_Y[j][q] = by;
-        xmin = xmax = bx; ymin = ymax = by;
+    const int e = blockIdx.x * BIN_EDGES + j;
+    int32_t xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN;
+    if (e < L.NE && q < 2) {
+        const int2 uv = L.edge_uv[e];
+        const int v = q == 0 ? uv.x : uv.y;
+        const float2 p = L.points[v];
 #pragma unroll
-        for (int k = 1; k <= 4; k++) {
-            int32_t mx, my;
-            tp_vertex_stage(p.x, p.y, 4 * q + k, q, L.vw, mx, my);
-            vs[2 + 4 * q + k] = make_int2(mx, my);
-            xmin = min(xmin, mx); xmax = max(xmax, mx); ymin = min(ymin, my); ymax = max(ymax, my);
-            dX = max(dX, abs(mx - bx)); dY = max(dY, abs(my - by));
+        for (int m = 0; m < 5; m++) {  // vertex stage for the five moves (several edges write the same values)
+            int32_t X, Y;
+            tp_vertex_stage(p.x, p.y, m, 0, L.vw, X, Y);
+            L.vpos[(size_t)v * 5 + m] = make_int2(X, Y);
+            xmin = min(xmin, X); xmax = max(xmax, X); ymin = min(ymin, Y); ymax = max(ymax, Y);
         }
     }
 #pragma unroll
-    for (int o = 1; o <= 2; o <<= 1) {  // reduce over the triangle's four lanes
+    for (int o = 1; o <= 2; o <<= 1) {
         xmin = min(xmin, __shfl_xor(xmin, o)); xmax = max(xmax, __shfl_xor(xmax, o));
         ymin = min(ymin, __shfl_xor(ymin, o)); ymax = max(ymax, __shfl_xor(ymax, o));
-        dX = max(dX, __shfl_xor(dX, o)); dY = max(dY, __shfl_xor(dY, o));
     }
     if (!rebin) return;
     if (q == 0) {
         int tx0 = 0, ty0 = 0, ntx = 1, cnt = 0;
-        if (t < L.NT) {
+        if (e < L.NE) {
             const int m = L.margin_px;
-            const int c0 = max(tp_first_centre(xmin) - m, 0), c1 = min(tp_last_centre(xmax) + m, L.vw.W - 1);
-            const int r0 = max(tp_first_centre(ymin) - m, 0), r1 = min(tp_last_centre(ymax) + m, L.vw.H - 1);
-            if (c0 <= c1 && r0 <= r1) {
-                tx0 = c0 / TW; ty0 = r0 / TH;
-                ntx = c1 / TW - tx0 + 1;
+            // rows whose centre lies in [ymin, ymax), crossing columns in [first_centre(xmin), first_centre(xmax)]
+            const int r0 = max(tp_first_centre(ymin) - m, 0), r1 = min(tp_first_centre(ymax) - 1 + m, L.vw.H - 1);
+            const int c0 = min(max(tp_first_centre(xmin) - m, 0), L.vw.W), c1 = min(max(tp_first_centre(xmax) + m, 0), L.vw.W);
+            if (r0 <= r1) {
+                tx0 = tile_col_of(c0, L.tiles_x); ty0 = r0 / TH;
+                ntx = tile_col_of(c1, L.tiles_x) - tx0 + 1;
                 cnt = ntx * (r1 / TH - ty0 + 1);
             }
         }
         s_rect[j][0] = tx0; s_rect[j][1] = ty0; s_rect[j][2] = ntx; s_rect[j][3] = cnt;
-        s_infl[j][0] = dX + 256 * L.margin_px; s_infl[j][1] = dY + 256 * L.margin_px;
-        s_keep[j] = 0ull;
     }
     __syncthreads();
-    if (tid < BIN_TRIS) {  // wave 0: inclusive scan of the rectangle sizes by shuffles
+    if (tid < BIN_EDGES) {  // wave 0: inclusive scan of the rectangle sizes by shuffles
         int inc = s_rect[tid][3];
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -123,19 +139,19 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
         }
         s_excl[tid + 1] = inc;
         if (tid == 0) s_excl[0] = 0;
-        if (tid == BIN_TRIS - 1) {
+        if (tid == BIN_EDGES - 1) {
             uint32_t base = 0;
-            if (inc) base = atomicAdd(&L.state->pair_total, (uint32_t)inc);
-            if (base + (uint32_t)inc > (uint32_t)L.pair_cap) atomicOr(&L.state->flags, TP_FLAG_PAIR_OVERFLOW);
+            if (inc) base = atomicAdd(&L.state->visit_total, (uint32_t)inc);
+            if (base + (uint32_t)inc > (uint32_t)L.visit_cap) atomicOr(&L.state->flags, TP_FLAG_VISIT_OVERFLOW);
             s_base = base;
         }
     }
     __syncthreads();
-    const int total = s_excl[BIN_TRIS];
+    const int total = s_excl[BIN_EDGES];
     const uint32_t base = s_base;
-    // ---- one thread per (triangle, tile of its rectangle): keep it if some variant can reach it
+    if (q == 0 && e < L.NE) L.edge_visit[e] = make_int2((int)base + s_excl[j], s_rect[j][3]);
     for (int p = tid; p < total; p += 256) {
-        int lo = 0, hi = BIN_TRIS;  // largest jj with s_excl[jj] <= p
+        int lo = 0, hi = BIN_EDGES;  // largest jj with s_excl[jj] <= p
 #pragma unroll
         for (int it = 0; it < 6; it++) {
             const int mid = (lo + hi) >> 1;
@@ -143,49 +159,20 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
         }
         const int k = p - s_excl[lo], ntx = s_rect[lo][2];
         const int ky = k / ntx, kx = k - ky * ntx;
-        const int txx = s_rect[lo][0] + kx, tyy = s_rect[lo][1] + ky;
-        const int32_t X[3] = {s_X[lo][0], s_X[lo][1], s_X[lo][2]}, Y[3] = {s_Y[lo][0], s_Y[lo][1], s_Y[lo][2]};
-        const bool dense = s_rect[lo][3] > 64;  // huge triangles: no culling, no mask
-        if (!dense && !may_touch(X, Y, s_infl[lo][0], s_infl[lo][1], txx * TW, min(txx * TW + TW - 1, L.vw.W - 1),
-                                 tyy * TH, min(tyy * TH + TH - 1, L.vw.H - 1)))
-            continue;
-        if (!dense) atomicOr(&s_keep[lo], 1ull << k);
-        const int tile = tyy * L.tiles_x + txx;
+        const int tile = (s_rect[lo][1] + ky) * L.tiles_x + s_rect[lo][0] + kx;
         const int slot = atomicAdd(&L.tilecount[tile], 1);
         if (slot < L.list_cap) {
-            tp_list_entry e;
-            e.pair = (int)base + p;
-            e.tri = blockIdx.x * BIN_TRIS + lo;
-            L.tilelist[(size_t)tile * L.list_cap + slot] = e;
+            tp_list_entry en;
+            en.visit = (int)base + p;
+            en.edge = blockIdx.x * BIN_EDGES + lo;
+            L.tilelist[(size_t)tile * L.list_cap + slot] = en;
         } else
             atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
-    }
-    __syncthreads();
-    if (q == 0 && t < L.NT) {
-        const int cnt = s_rect[j][3];
-        L.tri_pair[t] = make_int2((int)base + s_excl[j], cnt);
-        L.tri_mask[t] = cnt > 64 ? ~0ull : s_keep[j];
     }
 }
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s) {
-    hipLaunchKernelGGL(k_bin, dim3((L.NT + BIN_TRIS - 1) / BIN_TRIS), dim3(256), 0, s, L);
-}
-
-// ------------------------------------------------------------------------------------------------
-// DPP inclusive scan over each 32-lane half of the wave (all 64 lanes must be active)
-// ------------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
-    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ uint32_t scan32_inclusive(uint32_t v) {
-    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);  // row_shr:8
-    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-    return v;
+    hipLaunchKernelGGL(k_bin, dim3((L.NE + BIN_EDGES - 1) / BIN_EDGES), dim3(256), 0, s, L);
 }
 
 // LDS prefix entry (uint4), per row exclusive prefix over the tile's 128 columns:
@@ -237,7 +224,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
     if (blockIdx.x == 0 && tid == 0) L.state->rebin_req = 0;  // consumed by the k_bin that ran before us
 
     // the block walks tiles blockIdx.x, +gridDim.x, ...; the pixels of the next tile are fetched into
-    // registers while the spans of the current one are walked
+    // registers while the lines of the current one are walked
     uint4 px[P1_PX / 4];
     auto fetch = [&](int tile) {
         const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
@@ -252,10 +239,10 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
         const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
         int nlist = L.tilecount[tile];
         if (nlist > L.list_cap) nlist = L.list_cap;
-        const int nitems = nlist * TP_NVARIANTS;
+        const int nitems = nlist * TP_NLINES;
         const tp_list_entry* list = L.tilelist + (size_t)tile * L.list_cap;
         int item = tid;
-        tp_list_entry ent = list[item < nitems ? item / TP_NVARIANTS : 0];
+        tp_list_entry ent = list[item < nitems ? item / TP_NLINES : 0];
         const int next = tile + gridDim.x;
 
         // ---- phase 1: pixels -> row prefix sums in LDS --------------------------------------
@@ -281,45 +268,56 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
         if (next < ntiles && wave < P1_WAVES) fetch(next);  // in flight during phase 2
         __syncthreads();
 
-        // ---- phase 2: one lane per (triangle, variant) of this tile ----------------------------
+        // ---- phase 2: one lane per (edge line, tile) -------------------------------------------
         const int row0 = ty * TH;
         const int row1 = min(row0 + TH - 1, L.vw.H - 1);
         const int col0 = tx * TW;
-        const int colE = min(col0 + TW, L.vw.W);
+        const int W = L.vw.W;
 
         if (!(L.debug & 2))
         for (; item < nitems; item += ACC_THREADS) {
-            const int e = item / TP_NVARIANTS, v = item - e * TP_NVARIANTS;
-            if (item != tid) ent = list[e];
-            // snapped vertices of this variant: two base vertices + (v > 0) the displaced one
-            const int2* vs = L.vsnap + (size_t)ent.tri * TP_VSNAP_STRIDE;
-            const int ms = v > 0 ? (v - 1) >> 2 : 3;
-            const int2 q0 = vs[ms == 0 ? 2 + v : 0], q1 = vs[ms == 1 ? 2 + v : 1], q2 = vs[ms == 2 ? 2 + v : 2];
-            const int32_t X[3] = {q0.x, q1.x, q2.x}, Y[3] = {q0.y, q1.y, q2.y};
-            tp_span sp;
-            tp_setup_span(X, Y, row0, row1, sp);
-            if (L.debug & 4) sp.r1 = sp.r0 - 1 + (int)(sp.A.x & 1);
-            // one row per trip, branch-free: an empty row has hi == lo and its two reads cancel.
-            // Whole entries are accumulated with 64-bit adds, hi-side and lo-side apart.
-            uint64_t bxy = 0, bzw = 0, axy = 0, azw = 0;
-            uint32_t n = 0;
-            const ulonglong2* rowp = reinterpret_cast<const ulonglong2*>(P) + (sp.r0 - row0) * ROWLEN - col0;
-            for (int r = sp.r0; r <= sp.r1; ++r, rowp += ROWLEN) {
-                int32_t lo, hi;
-                tp_span_row(sp, col0, colE, lo, hi);
-                const ulonglong2 a = rowp[lo], b = rowp[hi];
-                n += (uint32_t)(hi - lo);
-                bxy += b.x; bzw += b.y; axy += a.x; azw += a.y;
+            const int en = item / TP_NLINES, ver = item - en * TP_NLINES;
+            if (item != tid) ent = list[en];
+            // the line's two snapped endpoints: base, or one endpoint displaced by move 1..4
+            const int2 uv = L.edge_uv[ent.edge];
+            const int mu = (ver >= 1 && ver <= 4) ? ver : 0, mv = ver >= 5 ? ver - 4 : 0;
+            const int2 A = L.vpos[(size_t)uv.x * 5 + mu], B = L.vpos[(size_t)uv.y * 5 + mv];
+            tp_edge_walk ew;
+            tp_setup_edge(A.x, A.y, B.x, B.y, row0, row1, ew);
+            // one row per trip, branch-free: rows whose crossing column falls into another tile
+            // column read the all-zero entry P[r][0] and are not counted
+            uint64_t axy = 0, azw = 0;
+            uint32_t sx = 0, nin = 0;
+            int32_t first = INT32_MAX;
+            const ulonglong2* rowp = reinterpret_cast<const ulonglong2*>(P) + (ew.ra - row0) * ROWLEN;
+            for (int r = ew.ra; r <= ew.rb; ++r, rowp += ROWLEN) {
+                int32_t x = tp_walker_value(ew.w);
+                ew.w.x += ew.w.s;
+                x = min(max(x, 0), W);
+                const bool in = tile_col_of(x, L.tiles_x) == tx;
+                const ulonglong2 a = rowp[in ? x - col0 : 0];
+                axy += a.x; azw += a.y;
+                sx += in ? (uint32_t)x : 0u;
+                nin += in ? 1u : 0u;
+                first = min(first, in ? r : INT32_MAX);
             }
-            const uint64_t dxy = bxy - axy, dzw = bzw - azw;
-            const uint32_t sr = (uint32_t)dxy, sg = (uint32_t)(dxy >> 32);
-            const uint32_t sb = (uint32_t)dzw & 0xfffffu, no = (uint32_t)(dzw >> 20) & 0x3fffu;
-            const uint32_t q = (uint32_t)(dzw >> 34);
-            if (ent.pair < L.pair_cap) {
-                uint32_t* out = L.partials + ((size_t)ent.pair * TP_NVARIANTS + v) * TP_PARTIAL_WORDS;
-                reinterpret_cast<uint2*>(out)[0] = make_uint2(n, no);
-                reinterpret_cast<uint2*>(out)[1] = make_uint2(sr, sg);
-                reinterpret_cast<uint2*>(out)[2] = make_uint2(sb, q);
+            // rows that count are contiguous (the line is monotone): add everything left of this tile
+            // column for them from the static table
+            int64_t st[TP_T2_WORDS] = {0, 0, 0, 0, 0};
+            if (nin) {
+                const int64_t* t0 = L.t2 + ((size_t)first * (L.tiles_x + 1) + tx) * TP_T2_WORDS;
+                const int64_t* t1 = L.t2 + ((size_t)(first + (int)nin) * (L.tiles_x + 1) + tx) * TP_T2_WORDS;
+#pragma unroll
+                for (int k = 0; k < TP_T2_WORDS; k++) st[k] = t1[k] - t0[k];
+            }
+            if (ent.visit < L.visit_cap) {
+                int64_t* out = L.visits + ((size_t)ent.visit * TP_NLINES + ver) * TP_W_WORDS;
+                out[0] = (int64_t)sx;
+                out[1] = (int64_t)((azw >> 20) & 0x3fffu) + st[0];
+                out[2] = (int64_t)(uint32_t)axy + st[1];
+                out[3] = (int64_t)(axy >> 32) + st[2];
+                out[4] = (int64_t)(azw & 0xfffffu) + st[3];
+                out[5] = (int64_t)(azw >> 34) + st[4];
             }
         }
         if (next < ntiles) __syncthreads();  // the table is rebuilt for the next tile
@@ -347,27 +345,56 @@ void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t st
                           start, stop, 0, L);
 }
 
-__device__ __forceinline__ tp_moments sum_partials(const tp_launch& L, int2 pr, unsigned long long mask, int i) {
-    tp_moments m = {0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < pr.y; k++) {
-        if (pr.y <= 64 && !((mask >> k) & 1ull)) continue;  // tile culled by k_bin: no record
-        const int pair = pr.x + k;
-        if (pair >= L.pair_cap) break;
-        const uint2* in = reinterpret_cast<const uint2*>(L.partials + ((size_t)pair * TP_NVARIANTS + i) * TP_PARTIAL_WORDS);
-        const uint2 a = in[0], b = in[1], c = in[2];
-        m.n += a.x; m.nodd += a.y; m.sr += b.x; m.sg += b.y; m.sb += c.x; m.q += c.y;
+// ------------------------------------------------------------------------------------------------
+// k_reduce: W(line) = sum of its per-tile records; one thread per (edge, line, word)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reduce(tp_launch L) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_edge = TP_NLINES * TP_W_WORDS;  // 54 consecutive int64 per record
+    if (gid >= L.NE * per_edge) return;
+    const int e = gid / per_edge, w = gid - e * per_edge;
+    const int2 ev = L.edge_visit[e];
+    int64_t acc = 0;
+    for (int k = 0; k < ev.y; k++) {
+        const int vis = ev.x + k;
+        if (vis >= L.visit_cap) break;
+        acc += L.visits[(size_t)vis * per_edge + w];
     }
-    return m;
+    L.wline[gid] = acc;
+}
+void tp_launch_reduce(const tp_launch& L, hipStream_t s) {
+    const int n = L.NE * TP_NLINES * TP_W_WORDS;
+    hipLaunchKernelGGL(k_reduce, dim3((n + 255) / 256), dim3(256), 0, s, L);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_finalize: thread per (triangle, variant); id = i*NT + t in the outputs
+// per-variant moments = signed sum of three line sums
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize(tp_launch L, int flavour, int write_moments) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= L.NT * TP_NVARIANTS) return;
-    const int t = gid / TP_NVARIANTS, i = gid - t * TP_NVARIANTS;
-    const tp_moments m = sum_partials(L, L.tri_pair[t], L.tri_mask[t], i);
+__device__ __forceinline__ tp_moments variant_moments(const tp_launch& L, int t, int i) {
+    const int4 tri = L.tris[t];
+    const int vid[3] = {tri.x, tri.y, tri.z};
+    const int ms = i > 0 ? (i - 1) >> 2 : 3, mm = i > 0 ? ((i - 1) & 3) + 1 : 0;
+    int32_t X[3], Y[3], c[3];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const int2 q = L.vpos[(size_t)vid[s] * 5 + (s == ms ? mm : 0)];
+        X[s] = q.x; Y[s] = q.y;
+    }
+    tp_variant_coeffs(X, Y, c);
+    int64_t m[TP_W_WORDS] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int he = L.he_edge[3 * t + k];
+        const int64_t* w = L.wline + ((size_t)(he >> 1) * TP_NLINES + tp_edge_version(i, k, he & 1)) * TP_W_WORDS;
+#pragma unroll
+        for (int q = 0; q < TP_W_WORDS; q++) m[q] += (int64_t)c[k] * w[q];
+    }
+    tp_moments r = {m[0], m[1], m[2], m[3], m[4], m[5]};
+    return r;
+}
+
+__device__ __forceinline__ int32_t emit_variant(const tp_launch& L, int flavour, int t, int i, const tp_moments& m,
+                                                bool write_moments) {
     const int id = i * L.NT + t;
     int64_t E;
     if (flavour == 0) {
@@ -377,21 +404,30 @@ __global__ __launch_bounds__(256) void k_finalize(tp_launch L, int flavour, int 
         const int4 col = L.ca[id];  // stored colour, replicated x13 by upload
         E = tp_energy64(m, col.x, col.y, col.z);
     }
-    L.ten[id] = tp_wrap32(E);
+    const int32_t e32 = tp_wrap32(E);
+    L.ten[id] = e32;
     L.cn[id] = tp_wrap32(m.n);
     if (write_moments) {
         int64_t* o = L.moments + (size_t)id * 6;
         o[0] = m.n; o[1] = m.nodd; o[2] = m.sr; o[3] = m.sg; o[4] = m.sb; o[5] = m.q;
     }
+    return e32;
 }
 
+// k_finalize (tp_energy): thread per (triangle, variant); id = i*NT + t in the outputs
+__global__ __launch_bounds__(256) void k_finalize(tp_launch L, int flavour, int write_moments) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= L.NT * TP_NVARIANTS) return;
+    const int t = gid / TP_NVARIANTS, i = gid - t * TP_NVARIANTS;
+    emit_variant(L, flavour, t, i, variant_moments(L, t, i), write_moments != 0);
+}
 void tp_launch_finalize(const tp_launch& L, int flavour, bool write_moments, hipStream_t s) {
     const int n = L.NT * TP_NVARIANTS;
     hipLaunchKernelGGL(k_finalize, dim3((n + 255) / 256), dim3(256), 0, s, L, flavour, write_moments ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_shift: gradient.cs gathered per vertex (no atomics) + shift.cs; also re-arms the work lists
+// k_shift (tp_shift): gradient.cs gathered per vertex (no atomics) + shift.cs
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_shift(tp_launch L, float rate) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -417,51 +453,25 @@ __global__ __launch_bounds__(256) void k_shift(tp_launch L, float rate) {
     p.y = tp_fsub(p.y, tp_fdiv(tp_fdiv(tp_fmul(rate, tgy), 256.0f), 256.0f));
     L.points[gid] = p;
 }
-
 void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s) {
     hipLaunchKernelGGL(k_shift, dim3((L.NP + 255) / 256), dim3(256), 0, s, L, rate);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_update: k_finalize + k_shift in ONE launch (used by tp_iterate).  Thread (g, t): g = 0 handles
-// the base variant of triangle t, g = 1..3 the four variants that displace vertex slot s = g-1.
-// After writing the reference-layout outputs, a slot thread adds its central differences to its
-// vertex with one returning 64-bit atomic per component -- (difference << 32) + 1 -- so the thread
-// that completes the vertex's arrival count already holds the whole (wrapping int32) gradient
-// component and takes the shift.cs step for it.  x and y never interact in shift.cs, so they are
-// settled independently.  Integer sums commute: the result does not depend on arrival order.
+// k_update: k_finalize + k_shift in ONE launch (used by tp_iterate).  One thread per variant; the
+// four displacements of a vertex slot sit in adjacent lanes, so the central differences are two
+// shuffles.  The quad leader adds them to its vertex with one returning 64-bit atomic per component
+// -- (difference << 32) + 1 -- so the thread that completes the vertex's arrival count already
+// holds the whole (wrapping int32) gradient component and takes the shift.cs step for it.  x and y
+// never interact in shift.cs, so they settle independently; integer sums commute, so the result
+// does not depend on arrival order.  The last block to finish knows whether any vertex left its
+// work-list margin and re-arms the lists for the next k_bin.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int32_t emit_variant(const tp_launch& L, int flavour, int t, int i, const tp_moments& m) {
-    const int id = i * L.NT + t;
-    int64_t E;
-    if (flavour == 0) {
-        E = tp_energy_triangulate(m);
-        L.ca[id] = make_int4(tp_wrap32(m.sr), tp_wrap32(m.sg), tp_wrap32(m.sb), 0);
-    } else {
-        const int4 col = L.ca[id];
-        E = tp_energy64(m, col.x, col.y, col.z);
-    }
-    const int32_t e32 = tp_wrap32(E);
-    L.ten[id] = e32;
-    L.cn[id] = tp_wrap32(m.n);
-    return e32;
-}
-
-// settle one gradient component; returns true (and the total) for the last arriver
-__device__ __forceinline__ bool arrive(unsigned long long* slot, uint32_t contrib, int degree, uint32_t& total) {
-    const unsigned long long old = atomicAdd(slot, ((unsigned long long)contrib << 32) + 1ull);
-    if ((int)(old & 0xffffffffull) != degree - 1) return false;
-    total = (uint32_t)(old >> 32) + contrib;
-    *slot = 0ull;  // re-armed for the next launch (nobody else touches it any more)
-    return true;
-}
-
 __global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float rate) {
     __shared__ int s_last;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
 
-    // one thread per variant.  Threads [0, 12 NT): quads (t, s, k) = the four displacements of
-    // vertex slot s, adjacent lanes; threads [12 NT, 13 NT): the base variants.
+    // threads [0, 12 NT): quads (t, s, k); threads [12 NT, 13 NT): the base variants
     const int NT = L.NT;
     const bool live = gid < 13 * NT;
     int t = 0, i = 0;
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float 
         pb = L.points_binned[v];
     }
     int32_t e = 0;
-    if (live) e = emit_variant(L, flavour, t, i, sum_partials(L, L.tri_pair[t], L.tri_mask[t], i));
+    if (live) e = emit_variant(L, flavour, t, i, variant_moments(L, t, i), false);
     // central differences inside the quad: lanes 4q+0/1 hold E(+dx)/E(-dx), 4q+2/3 E(+dy)/E(-dy)
     const uint32_t e1 = (uint32_t)__shfl_xor(e, 1);
     const uint32_t gx = (uint32_t)e - e1;                     // valid on even lanes of the quad
@@ -517,8 +527,6 @@ __global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float 
             }
         }
     }
-    // grid-wide arrival: the last block knows whether ANY vertex left its margin and, if so,
-    // re-arms the work lists so that the next k_bin rebuilds them
     need = __syncthreads_or(need);
     if (threadIdx.x == 0) {
         const uint32_t old = atomicAdd(&L.state->arrive, 1u + (need ? 0x10000u : 0u));
@@ -531,11 +539,10 @@ __global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float 
             for (int k = threadIdx.x; k < L.tiles_x * L.tiles_y; k += blockDim.x) L.tilecount[k] = 0;
         if (threadIdx.x == 0) {
             L.state->arrive = 0;
-            if (s_last == 2) { L.state->pair_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
+            if (s_last == 2) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
         }
     }
 }
-
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s) {
     const int n = 13 * L.NT;
     hipLaunchKernelGGL(k_update, dim3((n + 255) / 256), dim3(256), 0, s, L, flavour, rate);
@@ -547,7 +554,6 @@ __global__ void k_replicate_colors(tp_launch L) {
     if (gid >= L.NT * TP_NVARIANTS) return;
     L.ca[gid] = L.colors[gid % L.NT];
 }
-
 void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s) {
     const int n = L.NT * TP_NVARIANTS;
     hipLaunchKernelGGL(k_replicate_colors, dim3((n + 255) / 256), dim3(256), 0, s, L);
@@ -560,7 +566,6 @@ __global__ void k_selftest_walker(const int64_t* N0, const int32_t* step, const 
     tp_walker w = tp_make_walker(N0[gid], step[gid], d[gid]);
     for (int r = 0; r < 32; r++) { out[(size_t)gid * 32 + r] = tp_walker_value(w); w.x += w.s; }
 }
-
 void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s) {
     hipLaunchKernelGGL(k_selftest_walker, dim3((n + 255) / 256), dim3(256), 0, s, N0, step, d, n, out);
 }

@@ -287,3 +287,61 @@ TP_HD int64_t tp_energy_triangulate(const tp_moments& m) {
     if (n32 <= 0) return 0;
     return tp_energy64(m, tp_wrap32(m.sr) / n32, tp_wrap32(m.sg) / n32, tp_wrap32(m.sb) / n32);
 }
+
+// =============================================================================================
+// Edge-centric form.  The covered span of a triangle row is [f(left edge), f(right edge)) where,
+// for ANY edge line through snapped points T (top) and B (bottom), dy = Yb - Yt > 0,
+//     f(r) = the first column c whose centre satisfies (256c + 128 - Xt) * dy >= dx * (256r + 128 - Yt)
+// -- left edges include a centre lying exactly on the line, right edges exclude it, and both rules
+// give this same f (that is what makes the rasterisation watertight).  Rows belong to an edge when
+// Yt <= 256r + 128 < Yb; the non-horizontal edges on either side of a triangle partition its rows.
+// With P_r(x) the full-row prefix sum of any pixel moment,
+//     moment(triangle) = sum_{right edges} W(e) - sum_{left edges} W(e),   W(e) = sum_{rows of e} P_r(clamp(f(r), 0, W))
+// so the 13 variants of all triangles only need W for each distinct edge line: per undirected edge
+// the base line + 4 displacements of either endpoint.  A line is walked once, with ONE prefix
+// lookup per row, and both triangles sharing it reuse the result.
+// =============================================================================================
+struct tp_edge_walk {
+    tp_walker w;     // value = f(r), advanced one row per step
+    int32_t ra, rb;  // absolute rows (inclusive) inside the window; empty when ra > rb
+};
+
+TP_HD void tp_setup_edge(int32_t Xa, int32_t Ya, int32_t Xb, int32_t Yb, int32_t win_r0, int32_t win_r1,
+                         tp_edge_walk& ew) {
+    const bool swap = Ya > Yb;
+    const int32_t Xt = swap ? Xb : Xa, Yt = swap ? Yb : Ya, Xq = swap ? Xa : Xb, Yq = swap ? Ya : Yb;
+    const int32_t dy = Yq - Yt, dx = Xq - Xt;
+    const int32_t ra = tp_max(win_r0, tp_first_centre(Yt));       // Yt <= 256r + 128
+    const int32_t rb = tp_min(win_r1, tp_first_centre(Yq) - 1);   // 256r + 128 < Yb
+    const int32_t d = dy > 0 ? dy : 1;
+    // (256c + 128 - Xt) dy >= dx (yc - Yt)   <=>   256 dy c >= N1,   N1 = dx (yc - Yt) + (Xt - 128) dy
+    const int64_t N1 = (int64_t)dx * (256LL * ra + 128 - Yt) + (int64_t)(Xt - 128) * dy;
+    const int64_t Nc = -((-N1) >> 8);  // ceil(N1 / 256); steps by dx per row
+    ew.w = tp_make_walker(Nc + d - 1, dx, d);  // floor((Nc + d - 1) / d) = ceil(Nc / d)
+    ew.ra = dy > 0 ? ra : 0;
+    ew.rb = dy > 0 ? rb : -1;
+}
+
+// signs with which the three edge sums enter a variant's moments: +1 right edge, -1 left edge, 0
+// horizontal or degenerate.  Edge k runs from vertex k to vertex (k+1)%3.
+TP_HD void tp_variant_coeffs(const int32_t X[3], const int32_t Y[3], int32_t c[3]) {
+    const int64_t area2 = (int64_t)(X[1] - X[0]) * (Y[2] - Y[0]) - (int64_t)(Y[1] - Y[0]) * (X[2] - X[0]);
+    const int32_t sg = area2 > 0 ? 1 : (area2 < 0 ? -1 : 0);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int j = k == 2 ? 0 : k + 1;
+        const int32_t a = -(Y[j] - Y[k]) * sg;  // > 0: interior to the right of the edge (left edge)
+        c[k] = (a < 0) - (a > 0);
+    }
+}
+
+// which of an edge's nine lines a variant uses for its edge k (origin = vertex slot k, destination =
+// slot (k+1)%3): 0 base, 1..4 canonical first endpoint displaced by move m, 5..8 the second.
+// `flipped`: the half-edge runs from the edge's second endpoint to its first.
+TP_HD int tp_edge_version(int variant, int k, int flipped) {
+    if (variant == 0) return 0;
+    const int s = (variant - 1) >> 2, m = ((variant - 1) & 3) + 1;
+    if (s == k) return flipped ? 4 + m : m;                       // origin displaced
+    if (s == (k == 2 ? 0 : k + 1)) return flipped ? m : 4 + m;   // destination displaced
+    return 0;
+}
