@@ -1,9 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r1 -o r1 -- python bench.py --steps 512 --warmup 64 --no-cpu-baseline > gpurun_out/prof_r1.log 2>&1
-tail -1 gpurun_out/prof_r1.log | cut -c1-300
-f=$(find gpurun_out/prof_r1 -name "*kernel_stats.csv" | head -1); cat "$f" | head -8
+mkdir -p gpurun_out/pmc
 cat > /tmp/t.py <<'PY'
 import sys, time, os
 sys.path.insert(0,'.')
@@ -13,7 +10,16 @@ W=H=2048
 img,pts,tris,he,ratio=synth.workload(W,H,3000)
 ctx=capi.Context(0,W,H); ctx.set_image(0,img); ctx.upload(pts,tris)
 p=capi.default_params(0)
-us=ctx.profile_iterate(p,100)
-print('DEBUG',os.environ.get('TPOSE_DEBUG_ACC','0'),'acc us %.2f'%us, 'visits', ctx.info(4))
+ctx.iterate(p,40); ctx.synchronize()
 PY
-for d in 0 2; do TPOSE_DEBUG_ACC=$d python /tmp/t.py; done
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d gpurun_out/pmc -o p1 -- python /tmp/t.py > /dev/null 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/pmc -o p2 -- python /tmp/t.py > /dev/null 2>&1
+python - <<'PY'
+import csv, collections, glob
+for f in sorted(glob.glob('gpurun_out/pmc/*counter_collection.csv')):
+    acc=collections.defaultdict(lambda: collections.defaultdict(float))
+    for row in csv.DictReader(open(f)):
+        k=row['Kernel_Name'][:14]; acc[k][row['Counter_Name']]+=float(row['Counter_Value'])
+    for k,v in acc.items():
+        if k.startswith('k_'): print(k, {c: round(x/40) for c,x in v.items()})
+PY

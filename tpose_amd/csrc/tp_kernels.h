@@ -23,9 +23,10 @@ struct tp_device_state {
     uint32_t pad[3];
 };
 
-// One (edge, tile) work item: which undirected edge, and where its nine line records go.
-struct __attribute__((aligned(8))) tp_list_entry {
-    int visit, edge;
+// One (edge, tile) work item: which undirected edge (nine lanes walk its nine lines), where the
+// nine records go, and the edge's endpoints so that the walk needs no dependent index load.
+struct __attribute__((aligned(16))) tp_list_entry {
+    int visit, edge, u, v;
 };
 
 struct tp_launch {
@@ -51,7 +52,8 @@ struct tp_launch {
     int* tilecount;           // [tiles]
     tp_list_entry* tilelist;  // [tiles * list_cap]
     int list_cap;
-    int2* edge_visit;         // [NE] (first visit, #visits)
+    int2* edge_visit;         // [NE] (first visit, #tiles of its rectangle)
+    unsigned long long* edge_mask;  // [NE] which tiles of the rectangle carry records (<= 64 tiles)
     int64_t* visits;          // [visit_cap][TP_NLINES][TP_W_WORDS] per-tile line sums
     int visit_cap;
     int64_t* wline;           // [NE][TP_NLINES][TP_W_WORDS] line sums over the whole raster

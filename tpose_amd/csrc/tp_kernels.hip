@@ -87,6 +87,9 @@ void tp_launch_static_table(const uint8_t* img, int pitch, int W, int H, int til
 __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
     __shared__ int s_excl[BIN_EDGES + 1];  // exclusive scan of rectangle sizes
     __shared__ int s_rect[BIN_EDGES][4];   // tx0, ty0, ntx, #tiles
+    __shared__ int s_geom[BIN_EDGES][6];   // base endpoints (Xa, Ya, Xb, Yb) and the moves' reach (dX, dY), 1/256 px
+    __shared__ int s_uv[BIN_EDGES][2];
+    __shared__ unsigned long long s_keep[BIN_EDGES];  // tiles of the rectangle some line can cross
     __shared__ uint32_t s_base;
     const bool rebin = L.state->rebin_req != 0;  // lists still valid otherwise (tp_set_margin)
     const int tid = threadIdx.x;
@@ -95,23 +98,27 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
 
     const int j = tid >> 2, q = tid & 3;
     const int e = blockIdx.x * BIN_EDGES + j;
-    int32_t xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN;
+    int32_t xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN, dX = 0, dY = 0;
     if (e < L.NE && q < 2) {
         const int2 uv = L.edge_uv[e];
         const int v = q == 0 ? uv.x : uv.y;
         const float2 p = L.points[v];
+        int32_t bx = 0, by = 0;
 #pragma unroll
         for (int m = 0; m < 5; m++) {  // vertex stage for the five moves (several edges write the same values)
             int32_t X, Y;
             tp_vertex_stage(p.x, p.y, m, 0, L.vw, X, Y);
             L.vpos[(size_t)v * 5 + m] = make_int2(X, Y);
+            if (m == 0) { bx = X; by = Y; s_geom[j][2 * q] = X; s_geom[j][2 * q + 1] = Y; s_uv[j][q] = v; }
             xmin = min(xmin, X); xmax = max(xmax, X); ymin = min(ymin, Y); ymax = max(ymax, Y);
+            dX = max(dX, abs(X - bx)); dY = max(dY, abs(Y - by));
         }
     }
 #pragma unroll
     for (int o = 1; o <= 2; o <<= 1) {
         xmin = min(xmin, __shfl_xor(xmin, o)); xmax = max(xmax, __shfl_xor(xmax, o));
         ymin = min(ymin, __shfl_xor(ymin, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+        dX = max(dX, __shfl_xor(dX, o)); dY = max(dY, __shfl_xor(dY, o));
     }
     if (!rebin) return;
     if (q == 0) {
@@ -128,6 +135,8 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
             }
         }
         s_rect[j][0] = tx0; s_rect[j][1] = ty0; s_rect[j][2] = ntx; s_rect[j][3] = cnt;
+        s_geom[j][4] = dX + 256 * L.margin_px; s_geom[j][5] = dY + 256 * L.margin_px;
+        s_keep[j] = 0ull;
     }
     __syncthreads();
     if (tid < BIN_EDGES) {  // wave 0: inclusive scan of the rectangle sizes by shuffles
@@ -149,7 +158,6 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
     __syncthreads();
     const int total = s_excl[BIN_EDGES];
     const uint32_t base = s_base;
-    if (q == 0 && e < L.NE) L.edge_visit[e] = make_int2((int)base + s_excl[j], s_rect[j][3]);
     for (int p = tid; p < total; p += 256) {
         int lo = 0, hi = BIN_EDGES;  // largest jj with s_excl[jj] <= p
 #pragma unroll
@@ -159,15 +167,41 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
         }
         const int k = p - s_excl[lo], ntx = s_rect[lo][2];
         const int ky = k / ntx, kx = k - ky * ntx;
-        const int tile = (s_rect[lo][1] + ky) * L.tiles_x + s_rect[lo][0] + kx;
+        const int txx = s_rect[lo][0] + kx, tyy = s_rect[lo][1] + ky;
+        const bool dense = s_rect[lo][3] > 64;  // long edges: no culling, no mask
+        if (!dense) {
+            // Every sample (row, crossing column) of the nine lines lies within the base segment
+            // (+) box(dX, dY) (+) [0, 1 px) in x.  A tile strictly on one side of that band is never
+            // crossed.  Tiles of the first/last tile column also receive the clamped columns: kept.
+            const int64_t a = (int64_t)s_geom[lo][3] - s_geom[lo][1], b = -((int64_t)s_geom[lo][2] - s_geom[lo][0]);
+            const int64_t slack = (a < 0 ? -a : a) * ((int64_t)s_geom[lo][4] + 256) + (b < 0 ? -b : b) * (int64_t)s_geom[lo][5];
+            const int64_t x0 = 256LL * (txx * TW) + 128, x1 = 256LL * min(txx * TW + TW - 1, L.vw.W - 1) + 128;
+            const int64_t y0 = 256LL * (tyy * TH) + 128, y1 = 256LL * min(tyy * TH + TH - 1, L.vw.H - 1) + 128;
+            const int64_t ex0 = a * (x0 - s_geom[lo][0]), ex1 = a * (x1 - s_geom[lo][0]);
+            const int64_t ey0 = b * (y0 - s_geom[lo][1]), ey1 = b * (y1 - s_geom[lo][1]);
+            const int64_t emin = min(ex0, ex1) + min(ey0, ey1), emax = max(ex0, ex1) + max(ey0, ey1);
+            const bool edge_col = txx == 0 || txx == L.tiles_x - 1;
+            if (!edge_col && (emin > slack || emax < -slack)) continue;
+            atomicOr(&s_keep[lo], 1ull << k);
+        }
+        const int tile = tyy * L.tiles_x + txx;
         const int slot = atomicAdd(&L.tilecount[tile], 1);
         if (slot < L.list_cap) {
             tp_list_entry en;
             en.visit = (int)base + p;
             en.edge = blockIdx.x * BIN_EDGES + lo;
+            en.u = s_uv[lo][0]; en.v = s_uv[lo][1];
             L.tilelist[(size_t)tile * L.list_cap + slot] = en;
         } else
             atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
+    }
+    __syncthreads();
+    if (q == 0 && e < L.NE) {
+        const int cnt = s_rect[j][3];
+        int first = (int)base + s_excl[j], n = cnt;
+        if (first + n > L.visit_cap) n = max(0, L.visit_cap - first);  // overflow is flagged; stay in bounds
+        L.edge_visit[e] = make_int2(first, n);
+        L.edge_mask[e] = cnt > 64 ? ~0ull : s_keep[j];
     }
 }
 
@@ -279,7 +313,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
             const int en = item / TP_NLINES, ver = item - en * TP_NLINES;
             if (item != tid) ent = list[en];
             // the line's two snapped endpoints: base, or one endpoint displaced by move 1..4
-            const int2 uv = L.edge_uv[ent.edge];
+            const int2 uv = make_int2(ent.u, ent.v);
             const int mu = (ver >= 1 && ver <= 4) ? ver : 0, mv = ver >= 5 ? ver - 4 : 0;
             const int2 A = L.vpos[(size_t)uv.x * 5 + mu], B = L.vpos[(size_t)uv.y * 5 + mv];
             tp_edge_walk ew;
@@ -353,12 +387,15 @@ __global__ __launch_bounds__(256) void k_reduce(tp_launch L) {
     const int per_edge = TP_NLINES * TP_W_WORDS;  // 54 consecutive int64 per record
     if (gid >= L.NE * per_edge) return;
     const int e = gid / per_edge, w = gid - e * per_edge;
-    const int2 ev = L.edge_visit[e];
+    const int2 ev = L.edge_visit[e];  // k_bin keeps first + count inside the visit buffer
+    const unsigned long long mask = ev.y > 64 ? ~0ull : L.edge_mask[e];
+    const int64_t* src = L.visits + (size_t)ev.x * per_edge + w;
     int64_t acc = 0;
-    for (int k = 0; k < ev.y; k++) {
-        const int vis = ev.x + k;
-        if (vis >= L.visit_cap) break;
-        acc += L.visits[(size_t)vis * per_edge + w];
+    if (ev.y > 64) {
+        for (int k = 0; k < ev.y; k++) acc += src[(size_t)k * per_edge];
+    } else {
+        for (unsigned long long m = mask; m; m &= m - 1)  // only the tiles that carry records
+            acc += src[(size_t)(__ffsll((long long)m) - 1) * per_edge];
     }
     L.wline[gid] = acc;
 }
