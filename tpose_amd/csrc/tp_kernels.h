@@ -27,6 +27,7 @@ struct tp_device_state {
 // nine records go, and the edge's endpoints so that the walk needs no dependent index load.
 struct __attribute__((aligned(16))) tp_list_entry {
     int visit, edge, u, v;
+    int2 a[5], b[5];  // snapped positions of endpoint u / v for the five moves (valid for this iteration)
 };
 
 struct tp_launch {

@@ -29,7 +29,9 @@
 static_assert(TW == 128, "prefix build assumes 8 lanes x 16 pixels per row");
 static_assert(TH == 32 && TH <= TP_WALK_MAXROWS, "tile height");
 
-size_t tp_accumulate_lds_bytes() { return (size_t)TH * ROWLEN * sizeof(uint4); }
+// LDS: the prefix table + the static-table rows bounding the tile's 32 rows (33 x 5 int64)
+#define T2_LDS_WORDS ((TH + 1) * TP_T2_WORDS)
+size_t tp_accumulate_lds_bytes() { return (size_t)TH * ROWLEN * sizeof(uint4) + T2_LDS_WORDS * sizeof(int64_t); }
 
 __device__ __forceinline__ int tile_col_of(int x, int tiles_x) { return min(x / TW, tiles_x - 1); }
 
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
     __shared__ int s_rect[BIN_EDGES][4];   // tx0, ty0, ntx, #tiles
     __shared__ int s_geom[BIN_EDGES][6];   // base endpoints (Xa, Ya, Xb, Yb) and the moves' reach (dX, dY), 1/256 px
     __shared__ int s_uv[BIN_EDGES][2];
+    __shared__ int2 s_pos[BIN_EDGES][2][5];
     __shared__ unsigned long long s_keep[BIN_EDGES];  // tiles of the rectangle some line can cross
     __shared__ uint32_t s_base;
     const bool rebin = L.state->rebin_req != 0;  // lists still valid otherwise (tp_set_margin)
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
             int32_t X, Y;
             tp_vertex_stage(p.x, p.y, m, 0, L.vw, X, Y);
             L.vpos[(size_t)v * 5 + m] = make_int2(X, Y);
+            s_pos[j][q][m] = make_int2(X, Y);
             if (m == 0) { bx = X; by = Y; s_geom[j][2 * q] = X; s_geom[j][2 * q + 1] = Y; s_uv[j][q] = v; }
             xmin = min(xmin, X); xmax = max(xmax, X); ymin = min(ymin, Y); ymax = max(ymax, Y);
             dX = max(dX, abs(X - bx)); dY = max(dY, abs(Y - by));
@@ -191,6 +195,8 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
             en.visit = (int)base + p;
             en.edge = blockIdx.x * BIN_EDGES + lo;
             en.u = s_uv[lo][0]; en.v = s_uv[lo][1];
+#pragma unroll
+            for (int m = 0; m < 5; m++) { en.a[m] = s_pos[lo][0][m]; en.b[m] = s_pos[lo][1][m]; }
             L.tilelist[(size_t)tile * L.list_cap + slot] = en;
         } else
             atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
@@ -249,7 +255,8 @@ __device__ __forceinline__ uint32_t scan8_stride8(uint32_t v, int seg) {
 }
 
 __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
-    extern __shared__ __attribute__((aligned(16))) uint4 P[];  // [TH][ROWLEN]
+    extern __shared__ __attribute__((aligned(16))) uint4 P[];  // [TH][ROWLEN], then int64 T2s[TH+1][5]
+    int64_t* T2s = reinterpret_cast<int64_t*>(P + TH * ROWLEN);
 
     const int tid = threadIdx.x;
     const int ntiles = L.tiles_x * L.tiles_y;
@@ -276,8 +283,21 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
         const int nitems = nlist * TP_NLINES;
         const tp_list_entry* list = L.tilelist + (size_t)tile * L.list_cap;
         int item = tid;
-        tp_list_entry ent = list[item < nitems ? item / TP_NLINES : 0];
+        // this lane's first work item: record slot and the two endpoints of its line, fetched now
+        // so that nothing after the barrier waits on global memory
+        const tp_list_entry* e0 = list + (item < nitems ? item / TP_NLINES : 0);
+        const int ver0 = item % TP_NLINES;
+        int visit = e0->visit;
+        int2 A = e0->a[(ver0 >= 1 && ver0 <= 4) ? ver0 : 0], B = e0->b[ver0 >= 5 ? ver0 - 4 : 0];
+        const bool stale = L.margin_px >= 2;  // lists reused across iterations: positions come from vpos
+        const int eu = stale ? e0->u : 0, ev = stale ? e0->v : 0;
         const int next = tile + gridDim.x;
+        // static-table rows for this tile's row boundaries -> LDS (waves 4..7 are idle in phase 1)
+        if (tid >= 256 && tid < 256 + T2_LDS_WORDS && nlist > 0) {
+            const int k = tid - 256, rr = k / TP_T2_WORDS, ww = k - rr * TP_T2_WORDS;
+            const int rabs = min(ty * TH + rr, L.vw.H);
+            T2s[k] = L.t2[((size_t)rabs * (L.tiles_x + 1) + tx) * TP_T2_WORDS + ww];
+        }
 
         // ---- phase 1: pixels -> row prefix sums in LDS --------------------------------------
         if (wave < P1_WAVES && nlist > 0 && !(L.debug & 1)) {
@@ -311,11 +331,15 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
         if (!(L.debug & 2))
         for (; item < nitems; item += ACC_THREADS) {
             const int en = item / TP_NLINES, ver = item - en * TP_NLINES;
-            if (item != tid) ent = list[en];
-            // the line's two snapped endpoints: base, or one endpoint displaced by move 1..4
-            const int2 uv = make_int2(ent.u, ent.v);
             const int mu = (ver >= 1 && ver <= 4) ? ver : 0, mv = ver >= 5 ? ver - 4 : 0;
-            const int2 A = L.vpos[(size_t)uv.x * 5 + mu], B = L.vpos[(size_t)uv.y * 5 + mv];
+            if (item != tid) {  // rare: more than 512 lines in this tile
+                const tp_list_entry* ee = list + en;
+                visit = ee->visit;
+                A = stale ? L.vpos[(size_t)ee->u * 5 + mu] : ee->a[mu];
+                B = stale ? L.vpos[(size_t)ee->v * 5 + mv] : ee->b[mv];
+            } else if (stale) {
+                A = L.vpos[(size_t)eu * 5 + mu]; B = L.vpos[(size_t)ev * 5 + mv];
+            }
             tp_edge_walk ew;
             tp_setup_edge(A.x, A.y, B.x, B.y, row0, row1, ew);
             // one row per trip, branch-free: rows whose crossing column falls into another tile
@@ -339,13 +363,13 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
             // column for them from the static table
             int64_t st[TP_T2_WORDS] = {0, 0, 0, 0, 0};
             if (nin) {
-                const int64_t* t0 = L.t2 + ((size_t)first * (L.tiles_x + 1) + tx) * TP_T2_WORDS;
-                const int64_t* t1 = L.t2 + ((size_t)(first + (int)nin) * (L.tiles_x + 1) + tx) * TP_T2_WORDS;
+                const int64_t* t0 = T2s + (first - row0) * TP_T2_WORDS;
+                const int64_t* t1 = T2s + (first - row0 + (int)nin) * TP_T2_WORDS;
 #pragma unroll
                 for (int k = 0; k < TP_T2_WORDS; k++) st[k] = t1[k] - t0[k];
             }
-            if (ent.visit < L.visit_cap) {
-                int64_t* out = L.visits + ((size_t)ent.visit * TP_NLINES + ver) * TP_W_WORDS;
+            if (visit < L.visit_cap) {
+                int64_t* out = L.visits + ((size_t)visit * TP_NLINES + ver) * TP_W_WORDS;
                 out[0] = (int64_t)sx;
                 out[1] = (int64_t)((azw >> 20) & 0x3fffu) + st[0];
                 out[2] = (int64_t)(uint32_t)axy + st[1];
