@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "FAILED|passed|failed" | head
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-260

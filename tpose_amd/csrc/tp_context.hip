@@ -146,6 +146,9 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.gacc = c->gacc;
     static const int dbg = getenv("TPOSE_DEBUG_ACC") ? atoi(getenv("TPOSE_DEBUG_ACC")) : 0;
     L.debug = dbg;
+    static unsigned long long* dbgbuf = nullptr;
+    if ((dbg & 8) && !dbgbuf) { hipMalloc((void**)&dbgbuf, 512 * 16 * sizeof(unsigned long long)); hipMemset(dbgbuf, 0, 512 * 16 * 8); }
+    L.dbg = dbgbuf;
     return L;
 }
 
@@ -610,6 +613,14 @@ int tp_selftest_walker(tp_context* c, const int64_t* N0, const int32_t* step, co
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(out, dout, sizeof(int32_t) * 32 * (size_t)n, hipMemcpyDeviceToHost));
     hipFree(dN); hipFree(ds); hipFree(dd); hipFree(dout);
+    return TP_OK;
+}
+
+int tp_debug_dump(tp_context* c, unsigned long long* out, int n) {
+    tp_launch L = make_launch(c, 0, 0.0f);
+    if (!L.dbg) return TP_ERR_STATE;
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(out, L.dbg, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
     return TP_OK;
 }
 

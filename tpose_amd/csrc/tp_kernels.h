@@ -67,6 +67,7 @@ struct tp_launch {
     int64_t* moments;          // optional int64[13NT][6]
     unsigned long long* gacc;  // [NP][2] fused-update accumulators: (gradient component << 32) | arrivals
     int debug;                 // ablation knobs (TPOSE_DEBUG_ACC), 0 in production
+    unsigned long long* dbg;   // per-block phase timestamps when (debug & 8)
 };
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s);

@@ -275,18 +275,26 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
     };
     int tile = blockIdx.x;
     if (tile < ntiles && wave < P1_WAVES) fetch(tile);
+    int dbgk = 0;
+#define TP_STAMP() do { if ((L.debug & 8) && tid == 0 && dbgk < 16) L.dbg[blockIdx.x * 16 + dbgk++] = wall_clock64(); } while (0)
+    TP_STAMP();
 
     for (; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
         int nlist = L.tilecount[tile];
         if (nlist > L.list_cap) nlist = L.list_cap;
-        const int nitems = nlist * TP_NLINES;
+        // work unit = (edge, line, 1/split of the tile's rows): `split` adjacent lanes share a line; as
+        // many as fit the workgroup in one pass, so short lists finish sooner
+        const int nlines = nlist * TP_NLINES;
+        const int lsplit = nlines * 4 <= ACC_THREADS ? 2 : nlines * 2 <= ACC_THREADS ? 1 : 0;  // log2(split)
+        const int split = 1 << lsplit;
+        const int nitems = nlines << lsplit;
         const tp_list_entry* list = L.tilelist + (size_t)tile * L.list_cap;
         int item = tid;
         // this lane's first work item: record slot and the two endpoints of its line, fetched now
         // so that nothing after the barrier waits on global memory
-        const tp_list_entry* e0 = list + (item < nitems ? item / TP_NLINES : 0);
-        const int ver0 = item % TP_NLINES;
+        const tp_list_entry* e0 = list + (item < nitems ? (item >> lsplit) / TP_NLINES : 0);
+        const int ver0 = (item >> lsplit) % TP_NLINES;
         int visit = e0->visit;
         int2 A = e0->a[(ver0 >= 1 && ver0 <= 4) ? ver0 : 0], B = e0->b[ver0 >= 5 ? ver0 - 4 : 0];
         const bool stale = L.margin_px >= 2;  // lists reused across iterations: positions come from vpos
@@ -320,7 +328,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
             if (seg == 7) row[P1_PX] = as_uint4(ex + run);
         }
         if (next < ntiles && wave < P1_WAVES) fetch(next);  // in flight during phase 2
+        TP_STAMP();
         __syncthreads();
+        TP_STAMP();
 
         // ---- phase 2: one lane per (edge line, tile) -------------------------------------------
         const int row0 = ty * TH;
@@ -330,7 +340,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
 
         if (!(L.debug & 2))
         for (; item < nitems; item += ACC_THREADS) {
-            const int en = item / TP_NLINES, ver = item - en * TP_NLINES;
+            const int part = item & (split - 1), line = item >> lsplit;
+            const int en = line / TP_NLINES, ver = line - en * TP_NLINES;
             const int mu = (ver >= 1 && ver <= 4) ? ver : 0, mv = ver >= 5 ? ver - 4 : 0;
             if (item != tid) {  // rare: more than 512 lines in this tile
                 const tp_list_entry* ee = list + en;
@@ -341,7 +352,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
                 A = L.vpos[(size_t)eu * 5 + mu]; B = L.vpos[(size_t)ev * 5 + mv];
             }
             tp_edge_walk ew;
-            tp_setup_edge(A.x, A.y, B.x, B.y, row0, row1, ew);
+            const int pr = TH >> lsplit;  // rows per part
+            tp_setup_edge(A.x, A.y, B.x, B.y, row0 + pr * part, min(row0 + pr * part + pr - 1, row1), ew);
             // one row per trip, branch-free: rows whose crossing column falls into another tile
             // column read the all-zero entry P[r][0] and are not counted
             uint64_t axy = 0, azw = 0;
@@ -359,6 +371,15 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
                 nin += in ? 1u : 0u;
                 first = min(first, in ? r : INT32_MAX);
             }
+            // combine the parts (adjacent lanes; a line's lanes are always active together)
+            for (int o = 1; o < split; o <<= 1) {
+                sx += (uint32_t)__shfl_xor((int)sx, o);
+                nin += (uint32_t)__shfl_xor((int)nin, o);
+                first = min(first, __shfl_xor(first, o));
+                axy += ((uint64_t)(uint32_t)__shfl_xor((int)(axy >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)axy, o);
+                azw += ((uint64_t)(uint32_t)__shfl_xor((int)(azw >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)azw, o);
+            }
+            if (part != 0) continue;
             // rows that count are contiguous (the line is monotone): add everything left of this tile
             // column for them from the static table
             int64_t st[TP_T2_WORDS] = {0, 0, 0, 0, 0};
@@ -378,7 +399,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
                 out[5] = (int64_t)(azw >> 34) + st[4];
             }
         }
+        TP_STAMP();
         if (next < ntiles) __syncthreads();  // the table is rebuilt for the next tile
+        TP_STAMP();
     }
 }
 
