@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-260
+timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -3

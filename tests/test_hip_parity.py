@@ -176,3 +176,42 @@ def test_work_list_reuse_never_changes_results(margin):
     elif margin == 40:
         assert rebuilds == 0
     ctx.close()
+
+
+@pytest.mark.parametrize("W,H", [(1011, 674), (2048, 2048)])
+def test_two_triangle_start_state_large_raster(W, H):
+    """The reference's 2-triangle start state on big rasters: edges spanning hundreds of tiles
+    (the un-culled, un-masked work-list path) against the oracle's moments."""
+    img = synth.voronoi_raster(W, H, seed=11, sites=24)
+    ratio = float(np.float32(W) / np.float32(H))
+    pts, tris, _ = synth.two_triangle(ratio)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts, tris)
+    ctx.accumulate(0, capi.IMAGE_A)
+    ctx.energy(0)
+    mom = O.moments(img, pts, tris, O.dp(0, 2), ratio)
+    assert np.array_equal(ctx.retrieve(capi.BUF_MOMENTS), mom)
+    assert int(ctx.retrieve(capi.BUF_COLNUM)[:2].sum()) == W * H
+    ctx.close()
+
+
+def test_batch_config_properties():
+    """BASELINE.json batch configuration (4096^2, 12000 triangles): size-independent properties."""
+    W = H = 4096
+    img, pts, tris, he, ratio = synth.workload(W, H, 12000)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts, tris)
+    ctx.accumulate(0, capi.IMAGE_A)
+    ctx.energy(0)
+    NT = tris.shape[0]
+    mom = ctx.retrieve(capi.BUF_MOMENTS)
+    assert int(mom[:NT, 0].sum()) == W * H
+    assert np.array_equal(mom[:NT, 2:5].sum(axis=0), img[:, :, :3].astype(np.int64).sum(axis=(0, 1)))
+    sel = np.arange(0, NT, NT // 24)[:24]
+    om = O.moments(img, pts, tris[sel], O.dp(0, NT), ratio).reshape(13, len(sel), 6)
+    assert np.array_equal(om, mom.reshape(13, NT, 6)[:, sel])
+    ctx.iterate(capi.default_params(0), 20)
+    assert np.isfinite(ctx.retrieve(capi.BUF_POINTS)).all()
+    ctx.close()

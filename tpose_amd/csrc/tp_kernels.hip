@@ -84,7 +84,7 @@ void tp_launch_static_table(const uint8_t* img, int pitch, int W, int H, int til
 // ------------------------------------------------------------------------------------------------
 // k_bin: 64 edges per 256-thread block, 4 lanes per edge (lanes 0/1 transform the two endpoints)
 // ------------------------------------------------------------------------------------------------
-#define BIN_EDGES 64
+#define BIN_EDGES 32  // edges per 256-thread block, 8 lanes each (lanes 0/1 transform the endpoints)
 
 __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
     __shared__ int s_excl[BIN_EDGES + 1];  // exclusive scan of rectangle sizes
@@ -94,12 +94,13 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
     __shared__ int2 s_pos[BIN_EDGES][2][5];
     __shared__ unsigned long long s_keep[BIN_EDGES];  // tiles of the rectangle some line can cross
     __shared__ uint32_t s_base;
-    const bool rebin = L.state->rebin_req != 0;  // lists still valid otherwise (tp_set_margin)
     const int tid = threadIdx.x;
-    if (rebin)
-        for (int v = blockIdx.x * 256 + tid; v < L.NP; v += gridDim.x * 256) L.points_binned[v] = L.points[v];
+    const uint32_t rebin_word = L.state->rebin_req;  // consumed late: the loads below do not wait for it
+    int dbgk = 0;
+#define TPB_STAMP() do { if ((L.debug & 16) && tid == 0 && blockIdx.x < 512 && dbgk < 16) L.dbg[blockIdx.x * 16 + dbgk++] = wall_clock64(); } while (0)
+    TPB_STAMP();
 
-    const int j = tid >> 2, q = tid & 3;
+    const int j = tid >> 3, q = tid & 7;
     const int e = blockIdx.x * BIN_EDGES + j;
     int32_t xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN, dX = 0, dY = 0;
     if (e < L.NE && q < 2) {
@@ -118,13 +119,15 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
             dX = max(dX, abs(X - bx)); dY = max(dY, abs(Y - by));
         }
     }
-#pragma unroll
-    for (int o = 1; o <= 2; o <<= 1) {
-        xmin = min(xmin, __shfl_xor(xmin, o)); xmax = max(xmax, __shfl_xor(xmax, o));
-        ymin = min(ymin, __shfl_xor(ymin, o)); ymax = max(ymax, __shfl_xor(ymax, o));
-        dX = max(dX, __shfl_xor(dX, o)); dY = max(dY, __shfl_xor(dY, o));
+    {  // combine the two endpoint lanes
+        xmin = min(xmin, __shfl_xor(xmin, 1)); xmax = max(xmax, __shfl_xor(xmax, 1));
+        ymin = min(ymin, __shfl_xor(ymin, 1)); ymax = max(ymax, __shfl_xor(ymax, 1));
+        dX = max(dX, __shfl_xor(dX, 1)); dY = max(dY, __shfl_xor(dY, 1));
     }
+    TPB_STAMP();
+    const bool rebin = rebin_word != 0;  // lists still valid otherwise (tp_set_margin)
     if (!rebin) return;
+    for (int v = blockIdx.x * 256 + tid; v < L.NP; v += gridDim.x * 256) L.points_binned[v] = L.points[v];
     if (q == 0) {
         int tx0 = 0, ty0 = 0, ntx = 1, cnt = 0;
         if (e < L.NE) {
@@ -153,13 +156,19 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
         s_excl[tid + 1] = inc;
         if (tid == 0) s_excl[0] = 0;
         if (tid == BIN_EDGES - 1) {
-            uint32_t base = 0;
-            if (inc) base = atomicAdd(&L.state->visit_total, (uint32_t)inc);
-            if (base + (uint32_t)inc > (uint32_t)L.visit_cap) atomicOr(&L.state->flags, TP_FLAG_VISIT_OVERFLOW);
+            // visit ids: every block owns a slice of the lower half of the record buffer (no global
+            // atomic on the common path); a block with long edges draws from the shared upper half
+            const uint32_t half = (uint32_t)L.visit_cap / 2, slice = half / gridDim.x;
+            uint32_t base = blockIdx.x * slice;
+            if ((uint32_t)inc > slice) {
+                base = half + atomicAdd(&L.state->visit_total, (uint32_t)inc);
+                if (base + (uint32_t)inc > (uint32_t)L.visit_cap) atomicOr(&L.state->flags, TP_FLAG_VISIT_OVERFLOW);
+            }
             s_base = base;
         }
     }
     __syncthreads();
+    TPB_STAMP();
     const int total = s_excl[BIN_EDGES];
     const uint32_t base = s_base;
     for (int p = tid; p < total; p += 256) {
@@ -201,7 +210,9 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
         } else
             atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
     }
+    TPB_STAMP();
     __syncthreads();
+    TPB_STAMP();
     if (q == 0 && e < L.NE) {
         const int cnt = s_rect[j][3];
         int first = (int)base + s_excl[j], n = cnt;
@@ -441,8 +452,19 @@ __global__ __launch_bounds__(256) void k_reduce(tp_launch L) {
     if (ev.y > 64) {
         for (int k = 0; k < ev.y; k++) acc += src[(size_t)k * per_edge];
     } else {
-        for (unsigned long long m = mask; m; m &= m - 1)  // only the tiles that carry records
-            acc += src[(size_t)(__ffsll((long long)m) - 1) * per_edge];
+        // only the tiles that carry records; up to eight loads in flight per trip
+        unsigned long long m = mask;
+        while (m) {
+            int64_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = m ? __ffsll((long long)m) - 1 : -1;
+                v[u] = k >= 0 ? src[(size_t)k * per_edge] : 0;
+                m &= m - 1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += v[u];
+        }
     }
     L.wline[gid] = acc;
 }
