@@ -248,18 +248,18 @@ __device__ __forceinline__ uint4 as_uint4(pix4 a) { return make_uint4(a.x, a.y, 
 // ------------------------------------------------------------------------------------------------
 // k_accumulate
 // ------------------------------------------------------------------------------------------------
-// Phase-1 lane mapping (waves 0..3 only): wave w owns tile rows 8w..8w+7; lane = seg*8 + rl walks the
-// 16 pixels [16 seg, 16 seg + 16) of row 8w + rl sequentially, and the eight segments of a row are
-// combined by a 3-step scan at lane distance 8.  Consecutive lanes belong to consecutive ROWS, whose
-// LDS rows are 2064 B = 16 B (mod 128) apart, so every ds_write_b128 lane group hits 8 distinct
-// 16-byte slots: the prefix table is written without bank conflicts.
-#define P1_WAVES 4
-#define P1_PX 16
+// Phase-1 lane mapping: wave w owns tile rows 4w..4w+3; lane = seg*4 + rl walks the 8 pixels
+// [8 seg, 8 seg + 8) of row 4w + rl sequentially, and the sixteen segments of a row are combined by a
+// 4-step scan at lane distance 4.  Consecutive lanes belong to consecutive ROWS, whose LDS rows are
+// 2064 B = 16 B (mod 128) apart, so a ds_write_b128 lane group (8 lanes = 4 rows x 2 segments, the
+// segments 128 B apart) hits every 16-byte slot at most twice.
+#define P1_WAVES 8
+#define P1_PX 8
 
-__device__ __forceinline__ uint32_t scan8_stride8(uint32_t v, int seg) {
+__device__ __forceinline__ uint32_t scan16_stride4(uint32_t v, int seg) {
 #pragma unroll
-    for (int d = 1; d < 8; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)v, 8 * d);
+    for (int d = 1; d < 16; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, 4 * d);
         v += seg >= d ? o : 0u;
     }
     return v;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
     const int tid = threadIdx.x;
     const int ntiles = L.tiles_x * L.tiles_y;
     const int lane = tid & 63, wave = tid >> 6;
-    const int rl = lane & 7, seg = lane >> 3, prow = wave * 8 + rl;  // phase-1 role (wave < P1_WAVES)
+    const int rl = lane & 3, seg = lane >> 2, prow = wave * 4 + rl;  // phase-1 role
     if (blockIdx.x == 0 && tid == 0) L.state->rebin_req = 0;  // consumed by the k_bin that ran before us
 
     // the block walks tiles blockIdx.x, +gridDim.x, ...; the pixels of the next tile are fetched into
@@ -311,9 +311,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
         const bool stale = L.margin_px >= 2;  // lists reused across iterations: positions come from vpos
         const int eu = stale ? e0->u : 0, ev = stale ? e0->v : 0;
         const int next = tile + gridDim.x;
-        // static-table rows for this tile's row boundaries -> LDS (waves 4..7 are idle in phase 1)
-        if (tid >= 256 && tid < 256 + T2_LDS_WORDS && nlist > 0) {
-            const int k = tid - 256, rr = k / TP_T2_WORDS, ww = k - rr * TP_T2_WORDS;
+        // static-table rows for this tile's row boundaries -> LDS
+        if (tid < T2_LDS_WORDS && nlist > 0) {
+            const int k = tid, rr = k / TP_T2_WORDS, ww = k - rr * TP_T2_WORDS;
             const int rabs = min(ty * TH + rr, L.vw.H);
             T2s[k] = L.t2[((size_t)rabs * (L.tiles_x + 1) + tx) * TP_T2_WORDS + ww];
         }
@@ -329,14 +329,14 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
                 run = run + pixel_moments(w);
             }
             pix4 ex;  // everything left of the segment
-            ex.x = scan8_stride8(run.x, seg) - run.x;
-            ex.y = scan8_stride8(run.y, seg) - run.y;
-            ex.z = scan8_stride8(run.z, seg) - run.z;
-            ex.w = scan8_stride8(run.w, seg) - run.w;
+            ex.x = scan16_stride4(run.x, seg) - run.x;
+            ex.y = scan16_stride4(run.y, seg) - run.y;
+            ex.z = scan16_stride4(run.z, seg) - run.z;
+            ex.w = scan16_stride4(run.w, seg) - run.w;
             uint4* row = P + prow * ROWLEN + seg * P1_PX;
 #pragma unroll
             for (int k = 0; k < P1_PX; k++) row[k] = as_uint4(ex + loc[k]);
-            if (seg == 7) row[P1_PX] = as_uint4(ex + run);
+            if (seg == 15) row[P1_PX] = as_uint4(ex + run);
         }
         if (next < ntiles && wave < P1_WAVES) fetch(next);  // in flight during phase 2
         TP_STAMP();
