@@ -540,23 +540,31 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
     if (int rc = validate_params(c, p, n_iters)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     const float dp = resolve_dp(c, p->flavour, p->dp);
-    double total_ms = 0.0;
+    if (c->lists_dp != dp || c->lists_ratio != c->ratio) {
+        HIP_TRY(c, force_rebin(c));
+        c->lists_dp = dp; c->lists_ratio = c->ratio;
+    }
+    // Eager launches enqueued back to back (no host sync in between); every accumulate dispatch
+    // carries its own begin/end timestamps in an event pair.  (Timed launches record nothing when
+    // captured into a hipGraph, so the fused path itself cannot be bracketed; the same kernel inside
+    // a graph replay runs ~1-2 us shorter -- see profiles/.)
+    std::vector<hipEvent_t> ev((size_t)2 * n_iters);
+    for (auto& e : ev) HIP_TRY(c, hipEventCreate(&e));
     for (int k = 0; k < n_iters; k++) {
         tp_launch L = make_launch(c, p->image_slot, dp);
-        if (k == 0 && (c->lists_dp != dp || c->lists_ratio != c->ratio)) {
-            HIP_TRY(c, force_rebin(c));
-            c->lists_dp = dp; c->lists_ratio = c->ratio;
-        }
         tp_launch_bin(L, c->stream);
-        tp_launch_accumulate_timed(L, c->stream, c->ev0, c->ev1);  // the dispatch's own begin/end stamps
+        tp_launch_accumulate_timed(L, c->stream, ev[2 * k], ev[2 * k + 1]);
         tp_launch_reduce(L, c->stream);
         tp_launch_update(L, p->flavour, p->rate, c->stream);
-        HIP_TRY(c, hipEventSynchronize(c->ev1));
-        float ms = 0.0f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        total_ms += ms;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double total_ms = 0.0;
+    for (int k = 0; k < n_iters; k++) {
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
+        total_ms += ms;
+    }
+    for (auto& e : ev) hipEventDestroy(e);
     *accumulate_us = n_iters ? total_ms * 1000.0 / n_iters : 0.0;
     c->accumulated = c->energized = false;
     return check_flags(c);
