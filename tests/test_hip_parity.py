@@ -215,3 +215,51 @@ def test_batch_config_properties():
     ctx.iterate(capi.default_params(0), 20)
     assert np.isfinite(ctx.retrieve(capi.BUF_POINTS)).all()
     ctx.close()
+
+
+def _check_moments(W, H, pts, tris, dp=None, seed=5):
+    img = synth.voronoi_raster(W, H, seed=seed, sites=7)
+    ratio = float(np.float32(W) / np.float32(H))
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts, tris)
+    if dp is not None:
+        ctx.set_dp(dp)
+    ctx.accumulate(0, capi.IMAGE_A)
+    ctx.energy(0)
+    d = O.dp(0, tris.shape[0]) if dp is None else dp
+    got = ctx.retrieve(capi.BUF_MOMENTS)
+    ctx.close()
+    assert np.array_equal(got, O.moments(img, pts, tris, d, ratio))
+    return got
+
+
+def test_edge_cases_small_and_degenerate():
+    """ragged / degenerate inputs: 1x1 and 1-pixel-wide rasters, exact tile multiples, a single
+    triangle, triangles entirely outside the domain, zero-area and repeated triangles"""
+    for W, H in [(1, 1), (1, 40), (300, 1), (128, 32), (256, 64), (129, 33)]:
+        ratio = float(np.float32(W) / np.float32(H))
+        pts, tris, _ = synth.two_triangle(ratio)
+        _check_moments(W, H, pts, tris)
+    W, H = 150, 90
+    ratio = float(np.float32(W) / np.float32(H))
+    one = (np.array([[-1.0, -0.5], [0.2, 0.9], [1.1, -0.7]], np.float32) * np.array([ratio / 1.7, 1], np.float32)).astype(np.float32)
+    _check_moments(W, H, one, np.array([[0, 1, 2, 0]], np.int32))
+    outside = (one + np.array([5.0 * ratio, 0.0], np.float32)).astype(np.float32)       # far right of the domain
+    m = _check_moments(W, H, outside, np.array([[0, 1, 2, 0]], np.int32))
+    assert int(m[:, 0].sum()) == 0
+    above = (one + np.array([0.0, 4.0], np.float32)).astype(np.float32)
+    assert int(_check_moments(W, H, above, np.array([[0, 1, 2, 0]], np.int32))[:, 0].sum()) == 0
+    pts = np.array([[-1, -1], [-1, 1], [1, -1], [1, 1], [0, 0], [0, 0], [0.5, 0.5]], np.float32)
+    pts[:, 0] *= np.float32(ratio)
+    tris = np.array([[0, 1, 2, 0], [0, 1, 2, 0], [4, 5, 6, 0], [4, 4, 4, 0], [2, 1, 3, 0], [3, 1, 2, 0]], np.int32)
+    _check_moments(W, H, pts, tris, dp=0.11)
+
+
+def test_wide_raster_many_tile_columns():
+    """4100 x 40: 33 tile columns (one partial), 2 tile rows -- exercises the static table widely"""
+    W, H = 4100, 40
+    ratio = float(np.float32(W) / np.float32(H))
+    pts, tris, _ = synth.grid_triangulation(15, 5, ratio=ratio)
+    _check_moments(W, H, pts, tris)
+    _check_moments(W, H, pts, tris, dp=0.6)
