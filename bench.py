@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flavour", type=int, default=0, help="0 triangulate (metric), 1 warp")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing only: every rank uses GPU 0 (with --backend gloo on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,7 +91,9 @@ def main():
     from tpose_amd import capi, dist_util, synth
     dist, device = None, None
     if world > 1:
-        dist, rank, world, device = dist_util.init("nccl")  # RCCL; one rank per GPU
+        dist, rank, world, device = dist_util.init(args.backend)  # RCCL; one rank per GPU
+    if args.share_gpu:
+        local_rank = 0
 
     # independent replica per rank: its own image (seeded by rank) and triangulation
     img, pts, tris, he, ratio = synth.workload(W, H, NT, seed=dist_util.replica_seed(rank))

@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--ta", required=True); ap.add_argument("--tb", required=True)
     ap.add_argument("--frames", type=int, default=400)
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use GPU 0 (with --backend gloo)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,7 +166,7 @@ def main():
     group = groups[rank // 2]
     A, B = load_ppm(args.ia), load_ppm(args.ib)
     hostlib.set_ratio(float(np.float32(A.shape[1]) / np.float32(A.shape[0])))
-    engine = HipEngine(local, A, B)
+    engine = HipEngine(0 if args.share_gpu else local, A, B)
     from . import capi
     forward = rank % 2 == 0  # even rank: T(A) against raster B
     levels = run_pair(dist, group, engine, args.ta if forward else args.tb,
