@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Time the fused grad-iter on the BASELINE.json configurations other than the headline one
+(profiles/README.md quotes the output).  Needs an MI355X."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from tpose_amd import capi, synth  # noqa: E402
+
+
+def run(name, W, H, NT, flavour, steps):
+    img, pts, tris, he, ratio = synth.workload(W, H, NT)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    colors = None
+    if flavour == capi.WARP:
+        ctx.set_image(capi.IMAGE_B, synth.displaced_raster(img))
+        colors = synth.mean_colors(img, pts, tris, ratio)
+    ctx.upload(pts, tris, colors)
+    p = capi.default_params(flavour)
+    ctx.iterate(p, 64)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.iterate(p, steps)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    acc = ctx.profile_iterate(p, 64)
+    bytes_iter = 4 * W * H + 16 * NT + 24 * 13 * NT + 24 * pts.shape[0]
+    out = dict(config=name, raster=[W, H], triangles=NT, flavour="warp" if flavour else "triangulate",
+               us_per_iter=dt / steps * 1e6, tri_iters_per_s=NT * steps / dt, accumulate_us=acc,
+               roofline_frac=bytes_iter / (acc * 1e-6) / 8e12)
+    ctx.close()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    run("headline 2048^2 / 3000", 2048, 2048, 3000, capi.TRIANGULATE, 2048)
+    run("warp flavour 2048^2 / 3000", 2048, 2048, 3000, capi.WARP, 2048)
+    run("batch element 4096^2 / 12000", 4096, 4096, 12000, capi.TRIANGULATE, 1024)
+    run("plumbing size 674x449 / 150", 674, 449, 150, capi.TRIANGULATE, 4096)
+    run("start state 2048^2 / 2", 2048, 2048, 2, capi.TRIANGULATE, 1024)

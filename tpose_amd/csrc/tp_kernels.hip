@@ -449,8 +449,16 @@ __global__ __launch_bounds__(256) void k_reduce(tp_launch L) {
     const unsigned long long mask = ev.y > 64 ? ~0ull : L.edge_mask[e];
     const int64_t* src = L.visits + (size_t)ev.x * per_edge + w;
     int64_t acc = 0;
-    if (ev.y > 64) {
-        for (int k = 0; k < ev.y; k++) acc += src[(size_t)k * per_edge];
+    if (ev.y > 64) {  // long edge, no mask: every tile of its rectangle carries a record
+        int k = 0;
+        for (; k + 16 <= ev.y; k += 16) {  // sixteen loads in flight per trip
+            int64_t v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = src[(size_t)(k + u) * per_edge];
+#pragma unroll
+            for (int u = 0; u < 16; u++) acc += v[u];
+        }
+        for (; k < ev.y; k++) acc += src[(size_t)k * per_edge];
     } else {
         // only the tiles that carry records; up to eight loads in flight per trip
         unsigned long long m = mask;
