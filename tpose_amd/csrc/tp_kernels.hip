@@ -171,44 +171,69 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
     TPB_STAMP();
     const int total = s_excl[BIN_EDGES];
     const uint32_t base = s_base;
-    for (int p = tid; p < total; p += 256) {
-        int lo = 0, hi = BIN_EDGES;  // largest jj with s_excl[jj] <= p
+    // ---- one thread per (edge, tile of its rectangle); the block groups its pairs by tile in an LDS
+    //      hash table so that each distinct tile costs ONE returning global atomic per block
+    __shared__ int h_key[256], h_cnt[256], h_base[256];
+    for (int pass0 = 0; pass0 < total; pass0 += 256) {
+        h_key[tid] = -1; h_cnt[tid] = 0;
+        __syncthreads();
+        const int p = pass0 + tid;
+        int tile = -1, lo = 0, hslot = 0, rank = 0;
+        if (p < total) {
+            int hi = BIN_EDGES;  // largest jj with s_excl[jj] <= p
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
-            const int mid = (lo + hi) >> 1;
-            if (s_excl[mid] <= p) lo = mid; else hi = mid;
+            for (int it = 0; it < 5; it++) {
+                const int mid = (lo + hi) >> 1;
+                if (s_excl[mid] <= p) lo = mid; else hi = mid;
+            }
+            const int k = p - s_excl[lo], ntx = s_rect[lo][2];
+            const int ky = k / ntx, kx = k - ky * ntx;
+            const int txx = s_rect[lo][0] + kx, tyy = s_rect[lo][1] + ky;
+            const bool dense = s_rect[lo][3] > 64;  // long edges: no culling, no mask
+            bool keep = true;
+            if (!dense) {
+                // Every sample (row, crossing column) of the nine lines lies within the base segment
+                // (+) box(dX, dY) (+) [0, 1 px) in x.  A tile strictly on one side of that band is never
+                // crossed.  Tiles of the first/last tile column also receive the clamped columns: kept.
+                const int64_t a = (int64_t)s_geom[lo][3] - s_geom[lo][1], b = -((int64_t)s_geom[lo][2] - s_geom[lo][0]);
+                const int64_t slack = (a < 0 ? -a : a) * ((int64_t)s_geom[lo][4] + 256) + (b < 0 ? -b : b) * (int64_t)s_geom[lo][5];
+                const int64_t x0 = 256LL * (txx * TW) + 128, x1 = 256LL * min(txx * TW + TW - 1, L.vw.W - 1) + 128;
+                const int64_t y0 = 256LL * (tyy * TH) + 128, y1 = 256LL * min(tyy * TH + TH - 1, L.vw.H - 1) + 128;
+                const int64_t ex0 = a * (x0 - s_geom[lo][0]), ex1 = a * (x1 - s_geom[lo][0]);
+                const int64_t ey0 = b * (y0 - s_geom[lo][1]), ey1 = b * (y1 - s_geom[lo][1]);
+                const int64_t emin = min(ex0, ex1) + min(ey0, ey1), emax = max(ex0, ex1) + max(ey0, ey1);
+                const bool edge_col = txx == 0 || txx == L.tiles_x - 1;
+                keep = edge_col || !(emin > slack || emax < -slack);
+                if (keep) atomicOr(&s_keep[lo], 1ull << k);
+            }
+            if (keep) {
+                tile = tyy * L.tiles_x + txx;
+                hslot = (tile * 40503) & 255;
+                while (true) {  // open addressing; at most 256 distinct keys for 256 slots
+                    const int old = atomicCAS(&h_key[hslot], -1, tile);
+                    if (old == -1 || old == tile) break;
+                    hslot = (hslot + 1) & 255;
+                }
+                rank = atomicAdd(&h_cnt[hslot], 1);
+            }
         }
-        const int k = p - s_excl[lo], ntx = s_rect[lo][2];
-        const int ky = k / ntx, kx = k - ky * ntx;
-        const int txx = s_rect[lo][0] + kx, tyy = s_rect[lo][1] + ky;
-        const bool dense = s_rect[lo][3] > 64;  // long edges: no culling, no mask
-        if (!dense) {
-            // Every sample (row, crossing column) of the nine lines lies within the base segment
-            // (+) box(dX, dY) (+) [0, 1 px) in x.  A tile strictly on one side of that band is never
-            // crossed.  Tiles of the first/last tile column also receive the clamped columns: kept.
-            const int64_t a = (int64_t)s_geom[lo][3] - s_geom[lo][1], b = -((int64_t)s_geom[lo][2] - s_geom[lo][0]);
-            const int64_t slack = (a < 0 ? -a : a) * ((int64_t)s_geom[lo][4] + 256) + (b < 0 ? -b : b) * (int64_t)s_geom[lo][5];
-            const int64_t x0 = 256LL * (txx * TW) + 128, x1 = 256LL * min(txx * TW + TW - 1, L.vw.W - 1) + 128;
-            const int64_t y0 = 256LL * (tyy * TH) + 128, y1 = 256LL * min(tyy * TH + TH - 1, L.vw.H - 1) + 128;
-            const int64_t ex0 = a * (x0 - s_geom[lo][0]), ex1 = a * (x1 - s_geom[lo][0]);
-            const int64_t ey0 = b * (y0 - s_geom[lo][1]), ey1 = b * (y1 - s_geom[lo][1]);
-            const int64_t emin = min(ex0, ex1) + min(ey0, ey1), emax = max(ex0, ex1) + max(ey0, ey1);
-            const bool edge_col = txx == 0 || txx == L.tiles_x - 1;
-            if (!edge_col && (emin > slack || emax < -slack)) continue;
-            atomicOr(&s_keep[lo], 1ull << k);
-        }
-        const int tile = tyy * L.tiles_x + txx;
-        const int slot = atomicAdd(&L.tilecount[tile], 1);
-        if (slot < L.list_cap) {
-            tp_list_entry en;
-            en.visit = (int)base + p;
-            en.edge = blockIdx.x * BIN_EDGES + lo;
-            en.u = s_uv[lo][0]; en.v = s_uv[lo][1];
+        __syncthreads();
+        if (h_key[tid] >= 0) h_base[tid] = atomicAdd(&L.tilecount[h_key[tid]], h_cnt[tid]);
+        __syncthreads();
+        if (tile >= 0) {
+            const int slot = h_base[hslot] + rank;
+            if (slot < L.list_cap) {
+                tp_list_entry en;
+                en.visit = (int)base + p;
+                en.edge = blockIdx.x * BIN_EDGES + lo;
+                en.u = s_uv[lo][0]; en.v = s_uv[lo][1];
 #pragma unroll
-            for (int m = 0; m < 5; m++) { en.a[m] = s_pos[lo][0][m]; en.b[m] = s_pos[lo][1][m]; }
-            L.tilelist[(size_t)tile * L.list_cap + slot] = en;
-        } else
-            atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
+                for (int m = 0; m < 5; m++) { en.a[m] = s_pos[lo][0][m]; en.b[m] = s_pos[lo][1][m]; }
+                L.tilelist[(size_t)tile * L.list_cap + slot] = en;
+            } else
+                atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
+        }
+        __syncthreads();
     }
     TPB_STAMP();
     __syncthreads();
