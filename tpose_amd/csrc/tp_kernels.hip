@@ -390,22 +390,39 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
             tp_edge_walk ew;
             const int pr = TH >> lsplit;  // rows per part
             tp_setup_edge(A.x, A.y, B.x, B.y, row0 + pr * part, min(row0 + pr * part + pr - 1, row1), ew);
-            // one row per trip, branch-free: rows whose crossing column falls into another tile
-            // column read the all-zero entry P[r][0] and are not counted
+            // eight rows per trip, fully unrolled and predicated so that the eight prefix reads are in
+            // flight together: rows outside the line's rows, or whose crossing column falls into another
+            // tile column, read the all-zero entry P[r][0] and are not counted
             uint64_t axy = 0, azw = 0;
             uint32_t sx = 0, nin = 0;
             int32_t first = INT32_MAX;
-            const ulonglong2* rowp = reinterpret_cast<const ulonglong2*>(P) + (ew.ra - row0) * ROWLEN;
-            for (int r = ew.ra; r <= ew.rb; ++r, rowp += ROWLEN) {
-                int32_t x = tp_walker_value(ew.w);
-                ew.w.x += ew.w.s;
-                x = min(max(x, 0), W);
-                const bool in = tile_col_of(x, L.tiles_x) == tx;
-                const ulonglong2 a = rowp[in ? x - col0 : 0];
-                axy += a.x; azw += a.y;
-                sx += in ? (uint32_t)x : 0u;
-                nin += in ? 1u : 0u;
-                first = min(first, in ? r : INT32_MAX);
+            const int rbase = row0 + pr * part;
+            const uint32_t nvalid = (uint32_t)max(ew.rb - ew.ra + 1, 0);
+            // columns of this tile column: [col0, col0 + TW), the last one also takes the clamp value W
+            const uint32_t lim = tx == L.tiles_x - 1 ? (uint32_t)(W - col0 + 1) : (uint32_t)TW;
+            int64_t xw = ew.w.x - (int64_t)(ew.ra - rbase) * ew.w.s;  // walker moved back to row rbase
+            const ulonglong2* rowp = reinterpret_cast<const ulonglong2*>(P) + (rbase - row0) * ROWLEN;
+            for (int c0 = 0; c0 < pr; c0 += 8, rowp += 8 * ROWLEN) {
+                const int koff = ew.ra - rbase - c0;  // chunk-relative index of the first valid row
+                if (!__any((int)nvalid + koff > 0 && koff < 8)) { xw += 8 * ew.w.s; continue; }
+                ulonglong2 ent[8];
+                uint32_t inmask = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int32_t x = min(max((int32_t)(xw >> 32), 0), W);
+                    xw += ew.w.s;
+                    const uint32_t xl = (uint32_t)(x - col0);
+                    const bool in = xl < lim && (uint32_t)(k - koff) < nvalid;
+                    ent[k] = rowp[k * ROWLEN + (in ? xl : 0u)];
+                    sx += in ? (uint32_t)x : 0u;
+                    inmask |= in ? (1u << k) : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) { axy += ent[k].x; azw += ent[k].y; }
+                if (inmask) {
+                    nin += (uint32_t)__builtin_popcount(inmask);
+                    first = min(first, rbase + c0 + (int)__builtin_ctz(inmask));
+                }
             }
             // combine the parts (adjacent lanes; a line's lanes are always active together)
             for (int o = 1; o < split; o <<= 1) {
