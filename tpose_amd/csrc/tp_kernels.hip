@@ -273,18 +273,21 @@ __device__ __forceinline__ uint4 as_uint4(pix4 a) { return make_uint4(a.x, a.y, 
 // ------------------------------------------------------------------------------------------------
 // k_accumulate
 // ------------------------------------------------------------------------------------------------
-// Phase-1 lane mapping: wave w owns tile rows 4w..4w+3; lane = seg*4 + rl walks the 8 pixels
-// [8 seg, 8 seg + 8) of row 4w + rl sequentially, and the sixteen segments of a row are combined by a
-// 4-step scan at lane distance 4.  Consecutive lanes belong to consecutive ROWS, whose LDS rows are
-// 2064 B = 16 B (mod 128) apart, so a ds_write_b128 lane group (8 lanes = 4 rows x 2 segments, the
-// segments 128 B apart) hits every 16-byte slot at most twice.
-#define P1_WAVES 8
-#define P1_PX 8
+// Phase-1 lane mapping: wave w owns tile rows P1_RL*w ..; lane = seg*P1_RL + rl walks the P1_PX pixels
+// [P1_PX seg, P1_PX (seg+1)) of row P1_RL*w + rl sequentially, and the segments of a row are combined
+// by a log2(P1_SEGS)-step scan at lane distance P1_RL.  Consecutive lanes belong to consecutive ROWS,
+// whose LDS rows are 2064 B = 16 B (mod 128) apart, so the eight lanes of a ds_write_b128 group hit
+// eight different 16-byte slots.
+#define P1_PX 8                    // pixels per lane
+#define P1_SEGS (TW / P1_PX)       // lanes per tile row
+#define P1_RL (64 / P1_SEGS)       // tile rows per wave
+#define P1_WAVES (TH / P1_RL)
+static_assert(P1_WAVES * 64 <= ACC_THREADS, "phase-1 roles");
 
-__device__ __forceinline__ uint32_t scan16_stride4(uint32_t v, int seg) {
+__device__ __forceinline__ uint32_t scan_segments(uint32_t v, int seg) {
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)v, 4 * d);
+    for (int d = 1; d < P1_SEGS; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, P1_RL * d);
         v += seg >= d ? o : 0u;
     }
     return v;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
     const int tid = threadIdx.x;
     const int ntiles = L.tiles_x * L.tiles_y;
     const int lane = tid & 63, wave = tid >> 6;
-    const int rl = lane & 3, seg = lane >> 2, prow = wave * 4 + rl;  // phase-1 role
+    const int rl = lane % P1_RL, seg = lane / P1_RL, prow = wave * P1_RL + rl;  // phase-1 role
     if (blockIdx.x == 0 && tid == 0) L.state->rebin_req = 0;  // consumed by the k_bin that ran before us
 
     // the block walks tiles blockIdx.x, +gridDim.x, ...; the pixels of the next tile are fetched into
@@ -319,10 +322,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
         const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
         int nlist = L.tilecount[tile];
         if (nlist > L.list_cap) nlist = L.list_cap;
-        // work unit = (edge, line, 1/split of the tile's rows): `split` adjacent lanes share a line; as
-        // many as fit the workgroup in one pass, so short lists finish sooner
+        // work unit = (edge, line, 1/split of the tile's rows): `split` adjacent lanes share a line.  The
+        // walk is VALU-bound and every part repeats the line's set-up, so lines are only split while
+        // all parts still fit two waves (short lists, e.g. the two-triangle start state)
         const int nlines = nlist * TP_NLINES;
-        const int lsplit = nlines * 4 <= ACC_THREADS ? 2 : nlines * 2 <= ACC_THREADS ? 1 : 0;  // log2(split)
+        const int lsplit = (L.debug & 4) ? 0 : (L.debug & 32) ? (nlines * 4 <= ACC_THREADS ? 2 : nlines * 2 <= ACC_THREADS ? 1 : 0) : nlines * 4 <= 128 ? 2 : nlines * 2 <= 128 ? 1 : 0;  // log2(split)
         const int split = 1 << lsplit;
         const int nitems = nlines << lsplit;
         const tp_list_entry* list = L.tilelist + (size_t)tile * L.list_cap;
@@ -354,14 +358,14 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
                 run = run + pixel_moments(w);
             }
             pix4 ex;  // everything left of the segment
-            ex.x = scan16_stride4(run.x, seg) - run.x;
-            ex.y = scan16_stride4(run.y, seg) - run.y;
-            ex.z = scan16_stride4(run.z, seg) - run.z;
-            ex.w = scan16_stride4(run.w, seg) - run.w;
+            ex.x = scan_segments(run.x, seg) - run.x;
+            ex.y = scan_segments(run.y, seg) - run.y;
+            ex.z = scan_segments(run.z, seg) - run.z;
+            ex.w = scan_segments(run.w, seg) - run.w;
             uint4* row = P + prow * ROWLEN + seg * P1_PX;
 #pragma unroll
             for (int k = 0; k < P1_PX; k++) row[k] = as_uint4(ex + loc[k]);
-            if (seg == 15) row[P1_PX] = as_uint4(ex + run);
+            if (seg == P1_SEGS - 1) row[P1_PX] = as_uint4(ex + run);
         }
         if (next < ntiles && wave < P1_WAVES) fetch(next);  // in flight during phase 2
         TP_STAMP();
