@@ -13,6 +13,7 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+#include <chrono>
 
 namespace {
 
@@ -629,6 +630,47 @@ int tp_debug_dump(tp_context* c, unsigned long long* out, int n) {
     if (!L.dbg) return TP_ERR_STATE;
     hipStreamSynchronize(c->stream);
     hipMemcpy(out, L.dbg, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
+    return TP_OK;
+}
+
+// debug: per-tile list lengths of the current work lists
+int tp_debug_tilecount(tp_context* c, int* out, int n) {
+    if (!c || !out) return TP_ERR_INVALID;
+    hipStreamSynchronize(c->stream);
+    tp_launch L = make_launch(c, 0, 0.0f);
+    hipMemcpy(out, L.tilecount, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost);
+    return TP_OK;
+}
+
+// launch-overhead probe: n back-to-back launches of an (almost) empty kernel in k_accumulate's shape
+int tp_debug_null_launch(tp_context* c, int mode, int blocks, int threads, int lds, int n, double* us) {
+    if (!c || !us || !c->uploaded) return TP_ERR_STATE;
+    HIP_TRY(c, hipSetDevice(c->device));
+    tp_launch L = make_launch(c, 0, 0.0f);
+    std::vector<hipEvent_t> ev((size_t)2 * n);
+    for (auto& e : ev) HIP_TRY(c, hipEventCreate(&e));
+    const int n16 = (int)((size_t)L.pitch * (size_t)(L.tiles_y * TP_TILE_H) / 16);
+    for (int k = 0; k < n; k++)
+        tp_launch_probe(L.img, L.visits, mode, n16, blocks, threads, (size_t)lds, c->stream, ev[2 * k], ev[2 * k + 1]);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double total = 0.0;
+    for (int k = 0; k < n; k++) { float ms = 0; HIP_TRY(c, hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1])); total += ms; }
+    for (auto& e : ev) hipEventDestroy(e);
+    *us = total * 1000.0 / n;
+    if (mode >= 16) {  // wall-clock cost per launch of 64 probes captured into a graph, replayed n times
+        hipGraph_t g; hipGraphExec_t ge;
+        HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < 64; k++) tp_launch_probe(L.img, L.visits, mode & 15, n16, blocks, threads, (size_t)lds, c->stream, nullptr, nullptr);
+        HIP_TRY(c, hipStreamEndCapture(c->stream, &g));
+        HIP_TRY(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        HIP_TRY(c, hipGraphLaunch(ge, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < n; k++) HIP_TRY(c, hipGraphLaunch(ge, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        *us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (64.0 * n);
+        hipGraphExecDestroy(ge); hipGraphDestroy(g);
+    }
     return TP_OK;
 }
 

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
             }
         }
         TP_STAMP();
-        if (next < ntiles) __syncthreads();  // the table is rebuilt for the next tile
+        if (next < ntiles || (L.debug & 8)) __syncthreads();  // the table is rebuilt for the next tile
         TP_STAMP();
     }
 }
@@ -728,4 +728,28 @@ __global__ void k_selftest_walker(const int64_t* N0, const int32_t* step, const 
 }
 void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s) {
     hipLaunchKernelGGL(k_selftest_walker, dim3((n + 255) / 256), dim3(256), 0, s, N0, step, d, n, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch-overhead probes (debug entry tp_debug_null_launch; not part of the product path)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ACC_THREADS) void k_probe(const uint4* src, uint4* dst, int mode, int n16) {
+    extern __shared__ __attribute__((aligned(16))) uint4 P[];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode == 1) {  // 8 MB of record-like stores
+        dst[gid] = make_uint4(gid, 1, 2, 3);
+        dst[gid + gridDim.x * blockDim.x] = make_uint4(gid, 4, 5, 6);
+    } else if (mode == 2) {  // read 16 MB, no compute
+        uint4 a = make_uint4(0, 0, 0, 0);
+        for (int k = gid; k < n16; k += gridDim.x * blockDim.x) { const uint4 v = src[k]; a.x ^= v.x; a.y ^= v.y; a.z ^= v.z; a.w ^= v.w; }
+        if ((a.x ^ a.y ^ a.z ^ a.w) == 0x12345678u) dst[gid] = a;
+    } else if (mode == 4) {
+        P[threadIdx.x] = make_uint4(gid, 0, 0, 0);
+        __syncthreads();
+        if (P[(threadIdx.x + 1) & (ACC_THREADS - 1)].x == 0xffffffffu) dst[gid] = P[0];
+    }
+}
+void tp_launch_probe(const void* src, void* dst, int mode, int n16, int blocks, int threads, size_t lds, hipStream_t s,
+                     hipEvent_t start, hipEvent_t stop) {
+    hipExtLaunchKernelGGL(k_probe, dim3(blocks), dim3(threads), lds, s, start, stop, 0, (const uint4*)src, (uint4*)dst, mode, n16);
 }
