@@ -37,9 +37,59 @@ def run(name, W, H, NT, flavour, steps):
     print(json.dumps(out), flush=True)
 
 
+def run_readback(W, H, NT, steps):
+    """the reference's frame: one grad-iter, then four blocking readbacks
+    (software/triangulate/main.cpp:196-204: terr, perr, cn, points)"""
+    img, pts, tris, he, ratio = synth.workload(W, H, NT)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts, tris, None)
+    p = capi.default_params(capi.TRIANGULATE)
+    for warm in range(2):
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ctx.iterate(p, 1)
+            ctx.retrieve(capi.BUF_TENERGY); ctx.retrieve(capi.BUF_PENERGY)
+            ctx.retrieve(capi.BUF_COLNUM); ctx.retrieve(capi.BUF_POINTS)
+        dt = time.perf_counter() - t0
+    ctx.close()
+    print(json.dumps(dict(config="readback every iter %dx%d / %d" % (W, H, NT), us_per_iter=dt / steps * 1e6,
+                          tri_iters_per_s=NT * steps / dt)), flush=True)
+
+
+def run_cold(W, H, NT, nctx, reps):
+    """cold-cache sweep: cycle through nctx contexts, each with its own plane, so that every
+    k_accumulate launch finds its raster neither in L2 nor in the 256 MB Infinity Cache"""
+    ctxs = []
+    for k in range(nctx):
+        img, pts, tris, he, ratio = synth.workload(W, H, NT, seed=1234 + k)
+        c = capi.Context(0, W, H)
+        c.set_image(capi.IMAGE_A, img)
+        c.upload(pts, tris, None)
+        ctxs.append(c)
+    p = capi.default_params(capi.TRIANGULATE)
+    for c in ctxs:
+        c.profile_iterate(p, 2)
+    tot, n = 0.0, 0
+    for r in range(reps):
+        for c in ctxs:
+            tot += c.profile_iterate(p, 1)
+            n += 1
+    warm = ctxs[0].profile_iterate(p, 64)
+    bytes_iter = 4 * W * H + 16 * NT + 24 * 13 * NT + 24 * ctxs[0].NP
+    print(json.dumps(dict(config="cold cache %dx%d / %d, %d planes = %.0f MB cycled" % (W, H, NT, nctx, nctx * 4 * W * H / 1e6),
+                          accumulate_us_cold=tot / n, accumulate_us_warm_same_process=warm,
+                          roofline_frac_cold=bytes_iter / (tot / n * 1e-6) / 8e12)), flush=True)
+    for c in ctxs:
+        c.close()
+
+
 if __name__ == "__main__":
     run("headline 2048^2 / 3000", 2048, 2048, 3000, capi.TRIANGULATE, 2048)
     run("warp flavour 2048^2 / 3000", 2048, 2048, 3000, capi.WARP, 2048)
     run("batch element 4096^2 / 12000", 4096, 4096, 12000, capi.TRIANGULATE, 1024)
     run("plumbing size 674x449 / 150", 674, 449, 150, capi.TRIANGULATE, 4096)
     run("start state 2048^2 / 2", 2048, 2048, 2, capi.TRIANGULATE, 1024)
+    run_readback(2048, 2048, 3000, 512)
+    run_cold(2048, 2048, 3000, 18, 4)
+    run_cold(4096, 4096, 12000, 5, 8)

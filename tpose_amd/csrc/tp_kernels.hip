@@ -489,6 +489,12 @@ void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t st
 __global__ __launch_bounds__(256) void k_reduce(tp_launch L) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int per_edge = TP_NLINES * TP_W_WORDS;  // 54 consecutive int64 per record
+    if (L.margin_px < 2) {
+        // work lists are rebuilt every iteration: k_accumulate has consumed them, re-arm them here
+        // (with a margin, k_update's vote decides)
+        for (int k = gid; k < L.tiles_x * L.tiles_y; k += gridDim.x * blockDim.x) L.tilecount[k] = 0;
+        if (gid == 0) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
+    }
     if (gid >= L.NE * per_edge) return;
     const int e = gid / per_edge, w = gid - e * per_edge;
     const int2 ev = L.edge_visit[e];  // k_bin keeps first + count inside the visit buffer
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float 
         v = s == 0 ? tri.x : s == 1 ? tri.y : tri.z;
         deg = L.vtx_off[v + 1] - L.vtx_off[v];
         p = L.points[v];
-        pb = L.points_binned[v];
+        if (L.margin_px >= 2) pb = L.points_binned[v];
     }
     int32_t e = 0;
     if (live) e = emit_variant(L, flavour, t, i, variant_moments(L, t, i), false);
@@ -655,7 +661,7 @@ __global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float 
     const uint32_t e1 = (uint32_t)__shfl_xor(e, 1);
     const uint32_t gx = (uint32_t)e - e1;                     // valid on even lanes of the quad
     const uint32_t gy = (uint32_t)__shfl_down((int)gx, 2);    // lane 4q+0 fetches lane 4q+2's value
-    int need = L.margin_px < 2;                                // margin off: rebuild every iteration
+    int need = 0;
     if (leader) {
         const float R = L.vw.ratio;
         const float lim = (float)(L.margin_px - 1);
@@ -687,6 +693,7 @@ __global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float 
             }
         }
     }
+    if (L.margin_px < 2) return;  // no margin: k_reduce re-arms the lists every iteration
     need = __syncthreads_or(need);
     if (threadIdx.x == 0) {
         const uint32_t old = atomicAdd(&L.state->arrive, 1u + (need ? 0x10000u : 0u));
