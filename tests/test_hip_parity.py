@@ -263,3 +263,42 @@ def test_wide_raster_many_tile_columns():
     pts, tris, _ = synth.grid_triangulation(15, 5, ratio=ratio)
     _check_moments(W, H, pts, tris)
     _check_moments(W, H, pts, tris, dp=0.6)
+
+
+@pytest.mark.parametrize("kind", ["nan", "inf", "huge", "allsame"])
+def test_pathological_points_never_fault(kind):
+    """NaN / infinite / far-away / coincident vertex positions blow the work-list capacities at the
+    metric size: the library must answer with TP_ERR_CAPACITY (or succeed), never read or write out
+    of bounds, and the context must stay usable after a fresh upload."""
+    W = H = 2048
+    img, pts, tris, he, ratio = synth.workload(W, H, 3000)
+    bad = pts.copy()
+    sel = (np.arange(bad.shape[0]) % 7 == 5)
+    if kind == "nan":
+        bad[sel] = np.nan
+    elif kind == "inf":
+        bad[sel] = np.inf
+    elif kind == "huge":
+        bad *= np.float32(1e6)
+    else:
+        bad[:] = 0
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(bad, tris, None)
+    p = capi.default_params(capi.TRIANGULATE)
+    try:
+        ctx.iterate(p, 3)
+        ctx.synchronize()
+    except capi.TposeError as e:
+        assert e.code == capi.TP_ERR_CAPACITY, e
+    # the same context, sane input again: results match a fresh context bit for bit
+    ctx.upload(pts, tris, None)
+    ctx.iterate(p, 2)
+    got = ctx.retrieve(capi.BUF_POINTS)
+    ref = capi.Context(0, W, H)
+    ref.set_image(capi.IMAGE_A, img)
+    ref.upload(pts, tris, None)
+    ref.iterate(p, 2)
+    want = ref.retrieve(capi.BUF_POINTS)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    ctx.close(); ref.close()

@@ -240,10 +240,10 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
     TPB_STAMP();
     if (q == 0 && e < L.NE) {
         const int cnt = s_rect[j][3];
-        int first = (int)base + s_excl[j], n = cnt;
-        if (first + n > L.visit_cap) n = max(0, L.visit_cap - first);  // overflow is flagged; stay in bounds
-        L.edge_visit[e] = make_int2(first, n);
-        L.edge_mask[e] = cnt > 64 ? ~0ull : s_keep[j];
+        const long long first = (long long)base + s_excl[j];
+        const bool fits = first + cnt <= (long long)L.visit_cap;  // overflow is flagged; k_reduce must stay in bounds
+        L.edge_visit[e] = make_int2(fits ? (int)first : 0, fits ? cnt : 0);
+        L.edge_mask[e] = !fits ? 0ull : cnt > 64 ? ~0ull : s_keep[j];
     }
 }
 
