@@ -80,6 +80,11 @@ struct tp_context {
     int last_flavour = 0;
     uint64_t generation = 1;
     std::vector<graph_entry> graphs;
+    // fused iterations enqueued since the last successful check of the device flags: when a work list
+    // overflowed, k_update stopped stepping; the host grows the lists and replays what is missing
+    struct segment { tp_params p; int n; };
+    std::vector<segment> pending;
+    uint32_t done_base = 0;  // tp_device_state::iters_done when pending[0] started
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -182,14 +187,77 @@ void enqueue_iter(tp_context* c, const tp_params& p, float dp) {
     tp_launch_update(L, p.flavour, p.rate, c->stream);  // finalize + gradient + shift; re-arms the lists
 }
 
-int check_flags(tp_context* c) {
-    tp_device_state st{};
-    HIP_TRY(c, hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
-    if (st.flags) {
-        return fail(c, TP_ERR_CAPACITY, "device work list overflow (flags=%u, list_cap=%d, visit_cap=%d)",
-                    st.flags, c->list_cap, c->visit_cap);
+int enqueue_iters(tp_context* c, const tp_params* p, int n_iters);
+
+// grow whichever work list overflowed (flags: TP_FLAG_*); false when nothing can grow any further
+bool grow_lists(tp_context* c, uint32_t flags, hipError_t* err) {
+    const int ntiles = c->tiles_x * c->tiles_y;
+    bool grown = false;
+    *err = hipSuccess;
+    if (flags & TP_FLAG_VISIT_OVERFLOW) {
+        const size_t limit = (size_t)1 << 24;  // 7.2 GB of records
+        if ((size_t)c->visit_cap < limit) {
+            size_t vcap = (size_t)c->visit_cap * 2;
+            if (vcap > limit) vcap = limit;
+            hipFree(c->visits); c->visits = nullptr;
+            if ((*err = dev_alloc(&c->visits, vcap * TP_NLINES * TP_W_WORDS)) != hipSuccess) return false;
+            c->visit_cap = (int)vcap;
+            grown = true;
+        }
     }
-    return TP_OK;
+    if (flags & TP_FLAG_LIST_OVERFLOW) {
+        if (c->list_cap < c->capE) {  // a tile never holds more than one entry per edge
+            size_t cap = (size_t)c->list_cap * 2;
+            if (cap > (size_t)c->capE) cap = (size_t)c->capE;
+            hipFree(c->tilelist); c->tilelist = nullptr;
+            if ((*err = dev_alloc(&c->tilelist, cap * ntiles)) != hipSuccess) return false;
+            c->tilelist_elems = cap * ntiles;
+            c->list_cap = (int)cap;
+            grown = true;
+        }
+    }
+    if (grown) { c->generation++; drop_graphs(c); }  // captured graphs bake addresses and capacities
+    return grown;
+}
+
+// Reads the device flags (the stream must be idle).  A work-list overflow is repaired here: k_update
+// does not step while a flag is up, so the triangulation is still the one of the last good
+// iteration; the lists are grown and the missing iterations replayed -- the caller never sees it,
+// unless the lists cannot grow any further (TP_ERR_CAPACITY).
+int check_flags(tp_context* c) {
+    for (int round = 0; round < 40; round++) {
+        tp_device_state st{};
+        HIP_TRY(c, hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
+        if (!st.flags) {
+            c->pending.clear();
+            c->done_base = st.iters_done;
+            return TP_OK;
+        }
+        hipError_t err = hipSuccess;
+        if (!grow_lists(c, st.flags, &err)) {
+            c->pending.clear();
+            c->done_base = st.iters_done;
+            if (err != hipSuccess) return fail(c, TP_ERR_HIP, "growing the work lists: %s", hipGetErrorString(err));
+            return fail(c, TP_ERR_CAPACITY, "device work list overflow (flags=%u, list_cap=%d, visit_cap=%d)",
+                        st.flags, c->list_cap, c->visit_cap);
+        }
+        uint32_t done = st.iters_done - c->done_base;
+        std::vector<tp_context::segment> todo;
+        for (auto& sg : c->pending) {
+            const uint32_t skip = done < (uint32_t)sg.n ? done : (uint32_t)sg.n;
+            done -= skip;
+            if ((uint32_t)sg.n > skip) todo.push_back({sg.p, sg.n - (int)skip});
+        }
+        c->pending.clear();
+        c->done_base = st.iters_done;
+        const uint32_t zero = 0;
+        HIP_TRY(c, hipMemcpy(&c->state->flags, &zero, sizeof zero, hipMemcpyHostToDevice));
+        c->lists_dp = -1.0f;  // rebuild the lists
+        for (auto& sg : todo)
+            if (int rc = enqueue_iters(c, &sg.p, sg.n)) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return fail(c, TP_ERR_CAPACITY, "device work lists keep overflowing");
 }
 
 }  // namespace
@@ -427,6 +495,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     HIP_TRY(c, hipMemset(c->state, 0, sizeof(tp_device_state)));
+    c->pending.clear(); c->done_base = 0;
     c->lists_dp = -1.0f;  // forces a rebuild of the work lists at the next use
     HIP_TRY(c, hipMemset(c->gacc, 0, sizeof(unsigned long long) * 2 * (size_t)c->capP));
     c->generation++;  // captured graphs bake NT, NP, dp and buffer addresses
@@ -440,13 +509,31 @@ int tp_accumulate(tp_context* c, int flavour, int slot) {
     if (!c->uploaded) return fail(c, TP_ERR_STATE, "accumulate before upload");
     if (int rc = check_slot(c, slot)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    tp_launch L = make_launch(c, slot, resolve_dp(c, flavour, c->dp_override));
-    HIP_TRY(c, force_rebin(c));  // the piecewise API rebuilds the work lists on every sweep
-    c->lists_dp = L.vw.dp; c->lists_ratio = c->ratio;
-    tp_launch_bin(L, c->stream);
-    tp_launch_accumulate(L, c->stream);
-    tp_launch_reduce(L, c->stream);
-    HIP_TRY(c, hipGetLastError());
+    // fused iterations still in flight settle first (and are replayed if a work list overflowed)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rc = check_flags(c)) return rc;
+    for (int round = 0;; round++) {
+        tp_launch L = make_launch(c, slot, resolve_dp(c, flavour, c->dp_override));
+        HIP_TRY(c, force_rebin(c));  // the piecewise API rebuilds the work lists on every sweep
+        c->lists_dp = L.vw.dp; c->lists_ratio = c->ratio;
+        tp_launch_bin(L, c->stream);
+        tp_launch_accumulate(L, c->stream);
+        tp_launch_reduce(L, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        // a sweep over overflowed work lists is incomplete: grow them and sweep again
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        uint32_t flags = 0;
+        HIP_TRY(c, hipMemcpy(&flags, &c->state->flags, sizeof flags, hipMemcpyDeviceToHost));
+        if (!flags) break;
+        hipError_t err = hipSuccess;
+        if (round >= 40 || !grow_lists(c, flags, &err)) {
+            if (err != hipSuccess) return fail(c, TP_ERR_HIP, "growing the work lists: %s", hipGetErrorString(err));
+            return fail(c, TP_ERR_CAPACITY, "device work list overflow (flags=%u, list_cap=%d, visit_cap=%d)",
+                        flags, c->list_cap, c->visit_cap);
+        }
+        const uint32_t zero = 0;
+        HIP_TRY(c, hipMemcpy(&c->state->flags, &zero, sizeof zero, hipMemcpyHostToDevice));
+    }
     c->acc_slot = slot; c->acc_flavour = flavour;
     c->accumulated = true; c->energized = false;
     return TP_OK;
@@ -492,11 +579,11 @@ static int validate_params(tp_context* c, const tp_params* p, int n_iters) {
     return check_slot(c, p->image_slot);
 }
 
-int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
-    if (!c) return TP_ERR_INVALID;
-    if (int rc = validate_params(c, p, n_iters)) return rc;
-    if (n_iters == 0) return TP_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
+}  // extern "C"
+
+namespace {
+// enqueue n fused grad-iters on the context stream and remember them until the flags were checked
+int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
     const float dp = resolve_dp(c, p->flavour, p->dp);
 
     if (c->lists_dp != dp || c->lists_ratio != c->ratio) {
@@ -533,7 +620,21 @@ int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
     HIP_TRY(c, hipGetLastError());
     c->acc_slot = p->image_slot; c->last_flavour = p->flavour;
     c->accumulated = c->energized = false;
+    if (!c->pending.empty() && memcmp(&c->pending.back().p, p, sizeof *p) == 0) c->pending.back().n += n_iters;
+    else c->pending.push_back({*p, n_iters});
     return TP_OK;
+}
+}  // namespace
+
+
+extern "C" {
+
+int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
+    if (!c) return TP_ERR_INVALID;
+    if (int rc = validate_params(c, p, n_iters)) return rc;
+    if (n_iters == 0) return TP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return enqueue_iters(c, p, n_iters);
 }
 
 int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* accumulate_us) {
@@ -558,6 +659,7 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
         tp_launch_reduce(L, c->stream);
         tp_launch_update(L, p->flavour, p->rate, c->stream);
     }
+    c->pending.push_back({*p, n_iters});
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     double total_ms = 0.0;
     for (int k = 0; k < n_iters; k++) {

@@ -20,7 +20,8 @@ struct tp_device_state {
     uint32_t rebin_req;    // 1: k_bin must rebuild the work lists (upload, or a vertex left its margin)
     uint32_t arrive;       // k_update: blocks arrived | (blocks voting for a rebuild) << 16
     uint32_t rebin_count;  // statistics: rebuilds so far
-    uint32_t pad[3];
+    uint32_t iters_done;   // fused iterations k_update completed (it does not step while a flag is up)
+    uint32_t pad[2];
 };
 
 // One (edge, tile) work item: which undirected edge (nine lanes walk its nine lines), where the

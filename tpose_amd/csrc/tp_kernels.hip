@@ -636,6 +636,10 @@ void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s) {
 __global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float rate) {
     __shared__ int s_last;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    // a work list overflowed in this or an earlier iteration: the line sums are incomplete.  Do not
+    // step -- the host grows the lists and replays from the last good iteration (check_flags)
+    if (L.state->flags) return;
+    if (gid == 0) L.state->iters_done++;
 
     // threads [0, 12 NT): quads (t, s, k); threads [12 NT, 13 NT): the base variants
     const int NT = L.NT;
