@@ -326,6 +326,22 @@ inline void retrieve_colors(triangulation* tr) {
     check(tp_retrieve(ctx, TP_BUF_COLACC, &tr->colors[0].x, (size_t)4 * tr->NT), "retrieve(colacc)");
 }
 
+// the `draw` lambda (mode 2 of triangle.fs; software/triangulate/main.cpp:157-174) without a window:
+// a flat-shaded RGBA8 picture of the current triangulation, average colours of the last sweep.
+// software/view draws the STORED colours at mix(points, originpoints, s) (view/shader/triangle.vs):
+// draw_stored(tr, s, ...) after upload(tr).
+inline void draw(uint8_t* rgba, size_t stride_bytes) {
+    check(tp_render(ctx, TP_RENDER_AVERAGE, nullptr, rgba, stride_bytes), "draw");
+}
+inline void draw_stored(triangulation* tr, float s, uint8_t* rgba, size_t stride_bytes) {
+    std::vector<vec2> mixed(tr->points.size());
+    for (size_t i = 0; i < mixed.size(); i++) {  // glsl mix(a, b, s) = a*(1-s) + b*s, per component
+        mixed[i].x = tr->points[i].x * (1.0f - s) + tr->originpoints[i].x * s;
+        mixed[i].y = tr->points[i].y * (1.0f - s) + tr->originpoints[i].y * s;
+    }
+    check(tp_render(ctx, TP_RENDER_STORED, &mixed[0].x, rgba, stride_bytes), "draw_stored");
+}
+
 // error bookkeeping (float32, ascending t -- the summation order is part of the contract)
 inline float toterr = 1.0f;
 inline float newerr;

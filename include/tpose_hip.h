@@ -136,6 +136,17 @@ int tp_get_stream(tp_context* ctx, void** hip_stream);
  * average accumulate-kernel duration in microseconds */
 int tp_profile_iterate(tp_context* ctx, const tp_params* p, int n_iters, double* accumulate_us);
 
+/* Flat-shaded picture of the triangulation: every raster pixel gets the colour of the base triangle
+ * that covers it (same coverage rule as the sweep, so every covered pixel is written exactly once),
+ * uncovered pixels are opaque black.  Replaces the display pass `mode == 2` of
+ * software/triangulate/shader/triangle.fs:45-50 (source TP_RENDER_AVERAGE: colacc/colnum of the last
+ * sweep, as the reference draws it) and of software/view/shader/triangle.fs (TP_RENDER_STORED: the
+ * colours given to tp_upload).  `points` (float[2*NP], host) overrides the vertex positions for this
+ * picture only -- software/view/shader/triangle.vs draws mix(points, originpoints, s) -- or NULL for
+ * the context's current positions.  dst: RGBA8, row 0 on top, `stride` bytes per row. */
+enum { TP_RENDER_AVERAGE = 0, TP_RENDER_STORED = 1 };
+int tp_render(tp_context* ctx, int source, const float* points, uint8_t* dst_rgba, size_t stride);
+
 /* introspection for tests/benchmarks: 0 = tiles_x, 1 = tiles_y, 2 = tile width, 3 = tile height,
  * 4 = (triangle,tile) pairs of the current work lists, 5 = device-side overflow flags,
  * 6 = number of work-list rebuilds requested by the device so far */

@@ -92,3 +92,39 @@ int tp_retrieve(tp_context* c, int what, void* dst, size_t count) {
     }
     return TP_OK;
 }
+
+/* display pass (triangle.fs mode 2 / software/view): per-pixel ownership by the oracle's coverage test */
+int tp_render(tp_context* c, int source, const float* points, uint8_t* dst, size_t stride) {
+    const float* pts = points ? points : c->points;
+    for (int y = 0; y < c->H; y++)
+        for (int x = 0; x < c->W; x++) {
+            uint8_t* p = dst + (size_t)y * stride + 4 * (size_t)x;
+            p[0] = p[1] = p[2] = 0; p[3] = 255;
+        }
+    for (int t = 0; t < c->NT; t++) {
+        int32_t xy[6];
+        tpo_variant_vertices(pts, c->tris, t, 0, 0.0f, c->ratio, c->W, c->H, xy);
+        uint8_t col[3];
+        const int32_t* a = c->ca + (size_t)4 * t;
+        if (source == TP_RENDER_AVERAGE) {
+            if (c->cn[t] == 0) continue;
+            for (int k = 0; k < 3; k++) {
+                float f = ((float)a[k] / (float)c->cn[t]) / 255.0f;
+                f = f < 0 ? 0 : f > 1 ? 1 : f;
+                col[k] = (uint8_t)(int)(f * 255.0f + 0.5f);
+            }
+        } else
+            for (int k = 0; k < 3; k++) col[k] = (uint8_t)(a[k] < 0 ? 0 : a[k] > 255 ? 255 : a[k]);
+        int ymin = xy[1], ymax = xy[1], xmin = xy[0], xmax = xy[0];
+        for (int k = 1; k < 3; k++) {
+            if (xy[2 * k] < xmin) xmin = xy[2 * k]; if (xy[2 * k] > xmax) xmax = xy[2 * k];
+            if (xy[2 * k + 1] < ymin) ymin = xy[2 * k + 1]; if (xy[2 * k + 1] > ymax) ymax = xy[2 * k + 1];
+        }
+        int r0 = (ymin >> 8) - 1, r1 = (ymax >> 8) + 1, c0 = (xmin >> 8) - 1, c1 = (xmax >> 8) + 1;
+        if (r0 < 0) r0 = 0; if (r1 > c->H - 1) r1 = c->H - 1; if (c0 < 0) c0 = 0; if (c1 > c->W - 1) c1 = c->W - 1;
+        for (int r = r0; r <= r1; r++)
+            for (int x = c0; x <= c1; x++)
+                if (tpo_covered(xy, x, r)) memcpy(dst + (size_t)r * stride + 4 * (size_t)x, col, 3);
+    }
+    return TP_OK;
+}

@@ -113,3 +113,18 @@ def test_warp_gpu_matches_cpu_backend_bytes(scene, schedule):
         c = open(str(scene / ("c_%s_%s.tri.warp" % (schedule, n))), "rb").read()
         g = open(str(scene / ("g_%s_%s.tri.warp" % (schedule, n))), "rb").read()
         assert c == g and len(c) > 0
+
+
+@pytest.mark.gpu
+def test_view_gpu_matches_cpu_backend_bytes(scene):
+    """headless software/view: the picture of a .tri level (stored colours, morphed by s) is the same
+    PPM from the HIP renderer and from the oracle's per-pixel coverage test"""
+    cpu_t = build_cpu("triangulate")
+    run(cpu_t, "-i", str(scene / "a.ppm"), "-o", str(scene / "v.tri"), "-maxframes", "1500", "-maxtris", "60", "-quiet")
+    cpu, gpu = build_cpu("view"), build_gpu("view")
+    for s in ("0", "0.37"):
+        o1 = run(cpu, "-t", str(scene / "v.tri"), "-s", s, "-height", "240", "-o", str(scene / "vc.ppm"))
+        o2 = run(gpu, "-t", str(scene / "v.tri"), "-s", s, "-height", "240", "-o", str(scene / "vg.ppm"))
+        assert o1.replace("vc.ppm", "") == o2.replace("vg.ppm", "")
+        a, b = open(str(scene / "vc.ppm"), "rb").read(), open(str(scene / "vg.ppm"), "rb").read()
+        assert len(a) > 240 * 240 * 3 and a == b

@@ -308,3 +308,52 @@ def test_work_lists_grow_instead_of_failing(kind):
     want = fresh.retrieve(capi.BUF_POINTS)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     ctx.close(); fresh.close()
+
+
+def _brute_picture(pts, tris, W, H, ratio, colours):
+    """every pixel takes the colour of the base triangle whose coverage mask holds it (tests/brute.py)"""
+    import brute
+    pic = np.zeros((H, W, 4), np.uint8)
+    pic[:, :, 3] = 255
+    owners = np.zeros((H, W), np.int32)
+    for t in range(tris.shape[0]):
+        m = brute.coverage_mask(brute.variant_xy(pts, tris[t], 0, 0.0, ratio, W, H), W, H)
+        owners += m
+        if colours[t] is not None:
+            pic[m, :3] = colours[t]
+    return pic, owners
+
+
+def test_render_flat_shaded_picture():
+    """tp_render (display pass, triangle.fs mode 2 / software/view): pixel ownership is the sweep's
+    coverage rule; colours are the averages of the last sweep or the uploaded ones"""
+    W, H = 300, 200
+    img, imgB, pts, tris, ratio, stored = case(W, H, (15, 5))
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts, tris, stored)
+    got_stored = ctx.render(capi.RENDER_STORED)
+    want, owners = _brute_picture(pts, tris, W, H, ratio, [c[:3] for c in stored])
+    assert owners.min() == 1 and owners.max() == 1  # a triangulation of the domain tiles the raster
+    assert np.array_equal(got_stored, want)
+    # averages of the sweep: reference display divides in float and the framebuffer rounds to nearest
+    ctx.upload(pts, tris, None)
+    ctx.accumulate(capi.TRIANGULATE, capi.IMAGE_A)
+    ctx.energy(capi.TRIANGULATE)
+    ca, cn = ctx.retrieve(capi.BUF_COLACC)[: tris.shape[0]], ctx.retrieve(capi.BUF_COLNUM)[: tris.shape[0]]
+    cols = []
+    for t in range(tris.shape[0]):
+        if cn[t] == 0:
+            cols.append(None)
+            continue
+        f = (ca[t, :3].astype(np.float32) / np.float32(cn[t])) / np.float32(255)
+        cols.append(np.floor(np.clip(f, 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint8))
+    want, _ = _brute_picture(pts, tris, W, H, ratio, cols)
+    assert np.array_equal(ctx.render(capi.RENDER_AVERAGE), want)
+    # a morphed mesh (software/view draws mix(points, originpoints, s)): positions for this picture only
+    moved = pts.copy()
+    moved[4:] += np.float32(0.01)
+    want, _ = _brute_picture(moved, tris, W, H, ratio, cols)
+    assert np.array_equal(ctx.render(capi.RENDER_AVERAGE, points=moved), want)
+    assert np.array_equal(ctx.retrieve(capi.BUF_POINTS), pts)
+    ctx.close()

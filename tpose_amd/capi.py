@@ -22,8 +22,11 @@ SYMBOLS = [
     "tp_abi_version", "tp_device_count", "tp_last_error", "tp_create", "tp_destroy", "tp_set_ratio",
     "tp_get_ratio", "tp_set_dp", "tp_set_margin", "tp_set_image", "tp_set_image_device", "tp_upload", "tp_accumulate",
     "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_synchronize",
-    "tp_get_stream", "tp_profile_iterate", "tp_get_info", "tp_selftest_walker",
+    "tp_get_stream", "tp_profile_iterate", "tp_get_info", "tp_selftest_walker", "tp_render",
 ]
+
+
+RENDER_AVERAGE, RENDER_STORED = 0, 1
 
 
 class Params(C.Structure):
@@ -71,6 +74,7 @@ def load():
         lib.tp_get_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         lib.tp_device_count.argtypes = [C.POINTER(C.c_int)]
         lib.tp_selftest_walker.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        lib.tp_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = lib
     return _lib
 
@@ -168,6 +172,18 @@ class Context:
 
     def synchronize(self):
         self._ck(self.lib.tp_synchronize(self.h))
+
+    def render(self, source=0, points=None):
+        """flat-shaded RGBA8 picture [H, W, 4] (tp_render); source 0: average colours of the last sweep,
+        1: the uploaded colours; `points` overrides the vertex positions for this picture"""
+        out = np.zeros((self.H, self.W, 4), np.uint8)
+        pp = None
+        if points is not None:
+            pp = np.ascontiguousarray(points, np.float32)
+            assert pp.shape == (self.NP, 2)
+        self._ck(self.lib.tp_render(self.h, source, pp.ctypes.data if pp is not None else None,
+                                    out.ctypes.data, out.strides[0]))
+        return out
 
     def retrieve(self, what, count=None):
         V = 13 * self.NT

@@ -74,7 +74,7 @@ struct tp_context {
     int64_t* moments = nullptr;
     unsigned long long* gacc = nullptr;
 
-    bool uploaded = false, accumulated = false, energized = false;
+    bool uploaded = false, accumulated = false, energized = false, have_colors = false;
     int acc_slot = 0, acc_flavour = 0;
     float dp_override = 0.0f;  // <= 0: reference law
     int last_flavour = 0;
@@ -487,6 +487,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
     HIP_TRY(c, hipMemcpy(c->vtx_off, off.data(), sizeof(int) * (size_t)(NP + 1), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->vtx_adj, adj.data(), sizeof(int) * 3 * (size_t)NT, hipMemcpyHostToDevice));
     c->NT = NT; c->NP = NP;
+    c->have_colors = colors != nullptr;
     if (colors) {
         HIP_TRY(c, hipMemcpy(c->colors, colors, sizeof(int32_t) * 4 * (size_t)NT, hipMemcpyHostToDevice));
         tp_launch L = make_launch(c, 0, 0.0f);
@@ -702,6 +703,34 @@ int tp_retrieve(tp_context* c, int what, void* dst, size_t count) {
     }
     if (count > avail) return fail(c, TP_ERR_INVALID, "retrieve: count %zu > %zu available", count, avail);
     HIP_TRY(c, hipMemcpy(dst, src, count * elem, hipMemcpyDeviceToHost));
+    return TP_OK;
+}
+
+int tp_render(tp_context* c, int source, const float* points, uint8_t* dst, size_t stride) {
+    if (!c) return TP_ERR_INVALID;
+    if (!dst) return fail(c, TP_ERR_INVALID, "render: dst is NULL");
+    if (source != TP_RENDER_AVERAGE && source != TP_RENDER_STORED) return fail(c, TP_ERR_INVALID, "render: bad source %d", source);
+    if (stride < (size_t)c->W * 4) return fail(c, TP_ERR_INVALID, "stride %zu < 4*width", stride);
+    if (!c->uploaded) return fail(c, TP_ERR_STATE, "render before upload");
+    if (source == TP_RENDER_STORED && !c->have_colors) return fail(c, TP_ERR_STATE, "render: no colours were uploaded");
+    if (int rc = tp_synchronize(c)) return rc;  // settles (and, after an overflow, replays) fused iterations
+    uint8_t* pic = nullptr;
+    float2* pts = nullptr;
+    HIP_TRY(c, dev_alloc(&pic, (size_t)c->W * c->H * 4));
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)pic, 0xff000000u, (size_t)c->W * c->H, c->stream);  // opaque black
+    if (e == hipSuccess && points) {
+        e = dev_alloc(&pts, (size_t)c->NP);
+        if (e == hipSuccess) e = hipMemcpy(pts, points, sizeof(float) * 2 * (size_t)c->NP, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) {
+        tp_launch L = make_launch(c, 0, 0.0f);
+        tp_launch_render(L, pts ? pts : c->points, source, pic, c->W, c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy2D(dst, stride, pic, (size_t)c->W * 4, (size_t)c->W * 4, c->H, hipMemcpyDeviceToHost);
+    hipFree(pic); hipFree(pts);
+    if (e != hipSuccess) return fail(c, TP_ERR_HIP, "render: %s", hipGetErrorString(e));
     return TP_OK;
 }
 

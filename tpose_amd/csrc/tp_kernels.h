@@ -85,5 +85,6 @@ void tp_launch_static_table(const uint8_t* img, int pitch, int W, int H, int til
 size_t tp_accumulate_lds_bytes();
 hipError_t tp_kernels_init();  // per-device function attributes (dynamic LDS > 64 KiB)
 void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s);
+void tp_launch_render(const tp_launch& L, const float2* pts, int source, void* out, int out_pitch_px, hipStream_t s);
 void tp_launch_probe(const void* src, void* dst, int mode, int n16, int blocks, int threads, size_t lds, hipStream_t s,
                      hipEvent_t start, hipEvent_t stop);

@@ -742,6 +742,52 @@ void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_render (tp_render): flat-shaded picture, one 64-thread block per triangle, one 32-row window per
+// thread; spans from the same exact walkers as the sweep, so pixels are owned exactly once
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_render(tp_launch L, const float2* pts, int source, uchar4* out, int out_pitch_px) {
+    const int t = blockIdx.x;
+    const int4 tri = L.tris[t];
+    const int vid[3] = {tri.x, tri.y, tri.z};
+    int32_t X[3], Y[3];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const float2 p = pts[vid[s]];
+        tp_vertex_stage(p.x, p.y, 0, s, L.vw, X[s], Y[s]);
+    }
+    uchar4 col = make_uchar4(0, 0, 0, 255);
+    if (source == 0) {  // triangle.fs:48  vec3(ca.rgb) / cn / 255 -> RGBA8 (round to nearest)
+        const int4 a = L.ca[t];
+        const int n = L.cn[t];
+        if (n == 0) return;
+        const float r = tp_fdiv(tp_fdiv((float)a.x, (float)n), 255.0f), g = tp_fdiv(tp_fdiv((float)a.y, (float)n), 255.0f),
+                    b = tp_fdiv(tp_fdiv((float)a.z, (float)n), 255.0f);
+        col.x = (unsigned char)floorf(fminf(fmaxf(r, 0.0f), 1.0f) * 255.0f + 0.5f);
+        col.y = (unsigned char)floorf(fminf(fmaxf(g, 0.0f), 1.0f) * 255.0f + 0.5f);
+        col.z = (unsigned char)floorf(fminf(fmaxf(b, 0.0f), 1.0f) * 255.0f + 0.5f);
+    } else {
+        const int4 a = L.colors[t];
+        col.x = (unsigned char)min(max(a.x, 0), 255); col.y = (unsigned char)min(max(a.y, 0), 255);
+        col.z = (unsigned char)min(max(a.z, 0), 255);
+    }
+    const int ymin = min(Y[0], min(Y[1], Y[2])), ymax = max(Y[0], max(Y[1], Y[2]));
+    const int rtop = max(tp_first_centre(ymin), 0), rbot = min(tp_last_centre(ymax), L.vw.H - 1);
+    for (int w0 = rtop + 32 * (int)threadIdx.x; w0 <= rbot; w0 += 32 * 64) {
+        tp_span sp;
+        tp_setup_span(X, Y, w0, min(w0 + 31, rbot), sp);
+        for (int r = sp.r0; r <= sp.r1; r++) {
+            int32_t lo, hi;
+            tp_span_row(sp, 0, L.vw.W, lo, hi);
+            uchar4* row = out + (size_t)r * out_pitch_px;
+            for (int c = lo; c < hi; c++) row[c] = col;
+        }
+    }
+}
+void tp_launch_render(const tp_launch& L, const float2* pts, int source, void* out, int out_pitch_px, hipStream_t s) {
+    hipLaunchKernelGGL(k_render, dim3(L.NT), dim3(64), 0, s, L, pts, source, (uchar4*)out, out_pitch_px);
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch-overhead probes (debug entry tp_debug_null_launch; not part of the product path)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ACC_THREADS) void k_probe(const uint4* src, uint4* dst, int mode, int n16) {
