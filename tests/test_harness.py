@@ -128,3 +128,26 @@ def test_view_gpu_matches_cpu_backend_bytes(scene):
         assert o1.replace("vc.ppm", "") == o2.replace("vg.ppm", "")
         a, b = open(str(scene / "vc.ppm"), "rb").read(), open(str(scene / "vg.ppm"), "rb").read()
         assert len(a) > 240 * 240 * 3 and a == b
+
+
+def test_fundamental_harness_on_cpu(scene):
+    """BASELINE config 5 plumbing, host only: hierarchy for two views -> warp -> correspondences from the
+    warped vertices -> F_Sampson / F_RANSAC; and the reference's own match file"""
+    cpu_t, cpu_w = build_cpu("triangulate"), build_cpu("warp")
+    for n in ("a", "b"):
+        run(cpu_t, "-i", str(scene / (n + ".ppm")), "-o", str(scene / ("f_%s.tri" % n)), "-maxframes", "1500", "-maxtris", "60", "-quiet")
+    ta, tb = str(scene / "f_a.tri"), str(scene / "f_b.tri")
+    run(cpu_w, "-ia", str(scene / "a.ppm"), "-ib", str(scene / "b.ppm"), "-ta", ta, "-tb", tb, "-levelframes", "100", "-quiet")
+    subprocess.check_call(["make", "-s", "-C", HOST, "fundamental"])
+    exe = os.path.join(HOST, "fundamental")
+    out = run(exe, ta, ta + ".warp", tb, tb + ".warp", "-points", str(scene / "pts.txt"))
+    na, nb = records(ta)[0][2], records(tb)[0][2]
+    ma = int(out.split("Found A Matches: ")[1].split()[0]); mb = int(out.split("Found B Matches: ")[1].split()[0])
+    assert na - 4 <= ma <= na and nb - 4 <= mb <= nb  # every vertex some triangle uses
+    vals = [float(l.split(":")[1]) for l in out.splitlines() if "mean squared Sampson distance" in l]
+    assert len(vals) == 3 and all(np.isfinite(v) for v in vals) and vals[0] < 1e-2
+    pts = np.loadtxt(str(scene / "pts.txt"))
+    assert pts.shape == (ma + mb, 3)
+    out = run(exe, "-matches", os.path.join(HERE, "golden", "sfm_matches.txt"), "-image", "960x540")
+    vals = [float(l.split(":")[1]) for l in out.splitlines() if "mean squared Sampson distance" in l]
+    assert len(vals) == 3 and all(np.isfinite(v) and v < 1e-3 for v in vals)

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "tpose/io.hpp"
+#include "tpose/multiview.hpp"
 #include "tpose/triangulation.hpp"
 
 using tpose::triangulation;
@@ -62,5 +63,54 @@ int tph_flip(void* h, int he, float minangle) { return static_cast<triangulation
 int tph_split(void* h, int t) { return static_cast<triangulation*>(h)->split(t); }
 int tph_collapse(void* h, int he) { return static_cast<triangulation*>(h)->collapse(he); }
 int tph_prune(void* h, int t) { return static_cast<triangulation*>(h)->prune(t); }
+
+
+// ---- two-view geometry (include/tpose/multiview.hpp); matches as float[2N] arrays, F as float[9] row-major
+static void to_vec(const float* p, int n, std::vector<tpose::vec2>& v) { v.resize(n); for (int i = 0; i < n; i++) v[i] = tpose::vec2(p[2 * i], p[2 * i + 1]); }
+static void put_F(const tpose::mview::Matrix3f& F, float* out) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out[3 * r + c] = F(r, c); }
+static tpose::mview::Matrix3f get_F(const float* in) { tpose::mview::Matrix3f F; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) F(r, c) = in[3 * r + c]; return F; }
+
+// method 0: F_8Point, 1: F_Sampson, 2: F_RANSAC (threshold 0.001), 3: F_LMEDS (the reference's alias, 0.0025)
+void tph_fundamental(int method, const float* a, const float* b, int n, float* F9) {
+    std::vector<tpose::vec2> A, B;
+    to_vec(a, n, A); to_vec(b, n, B);
+    using namespace tpose::mview;
+    put_F(method == 0 ? F_8Point(A, B) : method == 1 ? F_Sampson(A, B) : method == 2 ? F_RANSAC(A, B) : F_LMEDS(A, B), F9);
+}
+double tph_mean_sampson(const float* F9, const float* a, const float* b, int n) {
+    std::vector<tpose::vec2> A, B;
+    to_vec(a, n, A); to_vec(b, n, B);
+    return tpose::mview::mean_sampson(get_F(F9), A, B);
+}
+// optimal correction of every match, in place
+void tph_correct_matches(const float* F9, float* a, float* b, int n) {
+    const tpose::mview::Matrix3f F = get_F(F9);
+    for (int i = 0; i < n; i++) {
+        tpose::vec2 A(a[2 * i], a[2 * i + 1]), B(b[2 * i], b[2 * i + 1]);
+        tpose::mview::triangulate(F, A, B);
+        a[2 * i] = A.x; a[2 * i + 1] = A.y; b[2 * i] = B.x; b[2 * i + 1] = B.y;
+    }
+}
+// 3D points float[4N] for pose candidate `check`
+void tph_triangulate(const float* F9, const float* K9, const float* a, const float* b, int n, int check, float* X4) {
+    std::vector<tpose::vec2> A, B;
+    to_vec(a, n, A); to_vec(b, n, B);
+    tpose::mview::check = check;
+    const auto pts = tpose::mview::triangulate(get_F(F9), get_F(K9), A, B);
+    for (int i = 0; i < n; i++) { X4[4 * i] = pts[i].x; X4[4 * i + 1] = pts[i].y; X4[4 * i + 2] = pts[i].z; X4[4 * i + 3] = pts[i].w; }
+}
+int tph_realroots(const double* coeff, int ncoeff, double* out) {
+    const std::vector<double> r = tpose::mview::realroots(std::vector<double>(coeff, coeff + ncoeff));
+    for (size_t i = 0; i < r.size(); i++) out[i] = r[i];
+    return (int)r.size();
+}
+void tph_epole(const float* F9, int right, float* e2) { const tpose::vec2 e = tpose::mview::epole(get_F(F9), right != 0); e2[0] = e.x; e2[1] = e.y; }
+int tph_readmatches(const char* file, float* a, float* b, int cap) {
+    std::vector<tpose::vec2> A, B;
+    if (!tpose::io::readmatches(file, A, B)) return -1;
+    const int n = (int)A.size() < cap ? (int)A.size() : cap;
+    for (int i = 0; i < n; i++) { a[2 * i] = A[i].x; a[2 * i + 1] = A[i].y; b[2 * i] = B[i].x; b[2 * i + 1] = B[i].y; }
+    return (int)A.size();
+}
 
 }  // extern "C"

@@ -38,6 +38,14 @@ def load():
         lib.tph_flip.argtypes = [C.c_void_p, C.c_int, C.c_float]
         for f in ("tph_split", "tph_collapse", "tph_prune"):
             getattr(lib, f).argtypes = [C.c_void_p, C.c_int]
+        lib.tph_fundamental.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        lib.tph_mean_sampson.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        lib.tph_mean_sampson.restype = C.c_double
+        lib.tph_correct_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        lib.tph_triangulate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.tph_realroots.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.tph_epole.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.tph_readmatches.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]
         lib.tph_set_verbose(0)
         _lib = lib
     return _lib
@@ -144,3 +152,60 @@ class Triangulation:
 
     def collapse(self, h):
         return bool(self.lib.tph_collapse(self.h, h))
+
+
+# ---- two-view geometry (include/tpose/multiview.hpp) ------------------------------------------------
+F_8POINT, F_SAMPSON, F_RANSAC, F_LMEDS = 0, 1, 2, 3
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def fundamental(method, A, B):
+    """tpose::mview::F_8Point / F_Sampson / F_RANSAC / F_LMEDS on matches A, B: float[N, 2] -> F[3, 3]"""
+    A, B = _f32(A), _f32(B)
+    F = np.zeros((3, 3), np.float32)
+    load().tph_fundamental(method, A.ctypes.data, B.ctypes.data, A.shape[0], F.ctypes.data)
+    return F
+
+
+def mean_sampson(F, A, B):
+    F, A, B = _f32(F), _f32(A), _f32(B)
+    return float(load().tph_mean_sampson(F.ctypes.data, A.ctypes.data, B.ctypes.data, A.shape[0]))
+
+
+def correct_matches(F, A, B):
+    """optimal two-view correction (tpose::mview::triangulate(F, A, B)); returns the moved copies"""
+    F, A, B = _f32(F), _f32(A).copy(), _f32(B).copy()
+    load().tph_correct_matches(F.ctypes.data, A.ctypes.data, B.ctypes.data, A.shape[0])
+    return A, B
+
+
+def triangulate(F, K, A, B, check=3):
+    F, K, A, B = _f32(F), _f32(K), _f32(A), _f32(B)
+    X = np.zeros((A.shape[0], 4), np.float32)
+    load().tph_triangulate(F.ctypes.data, K.ctypes.data, A.ctypes.data, B.ctypes.data, A.shape[0], check, X.ctypes.data)
+    return X
+
+
+def realroots(coeff):
+    c = np.ascontiguousarray(coeff, np.float64)
+    out = np.zeros(c.size, np.float64)
+    n = load().tph_realroots(c.ctypes.data, c.size, out.ctypes.data)
+    return out[:n]
+
+
+def epole(F, right=True):
+    F = _f32(F)
+    e = np.zeros(2, np.float32)
+    load().tph_epole(F.ctypes.data, 1 if right else 0, e.ctypes.data)
+    return e
+
+
+def readmatches(path, cap=1 << 16):
+    a, b = np.zeros((cap, 2), np.float32), np.zeros((cap, 2), np.float32)
+    n = load().tph_readmatches(path.encode(), a.ctypes.data, b.ctypes.data, cap)
+    if n < 0:
+        raise IOError(path)
+    return a[:n].copy(), b[:n].copy()
