@@ -511,8 +511,10 @@ int tp_accumulate(tp_context* c, int flavour, int slot) {
     if (int rc = check_slot(c, slot)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     // fused iterations still in flight settle first (and are replayed if a work list overflowed)
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (int rc = check_flags(c)) return rc;
+    if (!c->pending.empty()) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (int rc = check_flags(c)) return rc;
+    }
     for (int round = 0;; round++) {
         tp_launch L = make_launch(c, slot, resolve_dp(c, flavour, c->dp_override));
         HIP_TRY(c, force_rebin(c));  // the piecewise API rebuilds the work lists on every sweep

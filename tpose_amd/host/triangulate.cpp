@@ -2,7 +2,8 @@
 // image triangulation with the reference's frame schedule (software/triangulate/main.cpp:190-353),
 // driven through the tpose:: host mirror (include/tpose/) on top of the HIP C ABI.
 //
-//   triangulate -i image.ppm [-o out.tri] [-window 1.5] [-maxframes N] [-maxtris N] [-device D] [-quiet]
+//   triangulate -i image.ppm [-o out.tri] [-window 1.5] [-maxframes N] [-maxtris N] [-levels 50,100,...]
+//               [-device D] [-quiet]
 //
 // One frame = doenergy, doshift, read back tenergy/penergy/colnum/points, then -- once the relative
 // energy change drops below 1e-4 -- export (on the 50,100,...,1000 ladder), energy-sorted flip set with
@@ -17,6 +18,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "tpose/io.hpp"
@@ -30,6 +32,7 @@ int main(int argc, char** argv) {
     float window = 1.0f;
     long maxframes = 1L << 40;
     int maxtris = 1 << 30, device = 0;
+    std::string levels;  // export list override (the reference hard-codes 50..1000; its showcase uses 3000)
     bool quiet = false;
     for (int a = 1; a < argc; a++) {
         const std::string k = argv[a];
@@ -39,6 +42,7 @@ int main(int argc, char** argv) {
         else if (k == "-window") window = (float)std::atof(val());
         else if (k == "-maxframes") maxframes = std::atol(val());
         else if (k == "-maxtris") maxtris = std::atoi(val());
+        else if (k == "-levels") levels = val();
         else if (k == "-device") device = std::atoi(val());
         else if (k == "-quiet") quiet = true;
         else { std::cerr << "unknown option " << k << "\n"; return 2; }
@@ -50,6 +54,18 @@ int main(int argc, char** argv) {
     io::verbose = !quiet;
 
     std::vector<int> exportlist = {1000, 900, 800, 700, 600, 500, 400, 300, 200, 100, 50};  // consumed from the back
+    if (!levels.empty()) {
+        exportlist.clear();
+        size_t pos = 0;
+        while (pos < levels.size()) {
+            const size_t comma = levels.find(',', pos);
+            exportlist.insert(exportlist.begin(), std::atoi(levels.substr(pos, comma - pos).c_str()));
+            if (comma == std::string::npos) break;
+            pos = comma + 1;
+        }
+    }
+    const int nlevels = (int)exportlist.size();
+    const auto t_start = std::chrono::steady_clock::now();
 
     RATIO = (float)img.w / (float)img.h;
     Raster raster = img;
@@ -142,7 +158,8 @@ int main(int argc, char** argv) {
         tpose::computecolors();  // the reference's render pipeline: colours at the new positions
     }
     std::cout << "frames " << frame << " triangles " << tr.NT << " points " << tr.NP << " levels written "
-              << (11 - (int)exportlist.size()) << std::endl;
+              << (nlevels - (int)exportlist.size()) << std::endl;
+    std::cerr << "seconds " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
     tpose::quit();
     return 0;
 }
