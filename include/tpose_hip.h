@@ -135,6 +135,13 @@ int tp_get_stream(tp_context* ctx, void** hip_stream);
 /* runs n_iters grad-iters eagerly with HIP events around every accumulate launch; returns the
  * average accumulate-kernel duration in microseconds */
 int tp_profile_iterate(tp_context* ctx, const tp_params* p, int n_iters, double* accumulate_us);
+/* average duration of the accumulate kernel as it runs inside the fused path: the work lists of the current
+ * state are built once (k_bin), then `launches` back-to-back launches of the kernel -- same lists, same raster,
+ * idempotent -- are captured into one hipGraph and a replay is bracketed by two HIP events on the context's
+ * stream; returns elapsed / launches in microseconds (includes the ~0.2 us between graph nodes).  The
+ * triangulation is not advanced.  (tp_profile_iterate's per-dispatch timestamps need eager launches, which
+ * run ~1 us longer than the same kernel inside a graph replay.) */
+int tp_profile_accumulate(tp_context* ctx, const tp_params* p, int launches, double* accumulate_us);
 
 /* Flat-shaded picture of the triangulation: every raster pixel gets the colour of the base triangle
  * that covers it (same coverage rule as the sweep, so every covered pixel is written exactly once),

@@ -22,7 +22,7 @@ SYMBOLS = [
     "tp_abi_version", "tp_device_count", "tp_last_error", "tp_create", "tp_destroy", "tp_set_ratio",
     "tp_get_ratio", "tp_set_dp", "tp_set_margin", "tp_set_image", "tp_set_image_device", "tp_upload", "tp_accumulate",
     "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_synchronize",
-    "tp_get_stream", "tp_profile_iterate", "tp_get_info", "tp_selftest_walker", "tp_render",
+    "tp_get_stream", "tp_profile_iterate", "tp_profile_accumulate", "tp_get_info", "tp_selftest_walker", "tp_render",
 ]
 
 
@@ -71,6 +71,7 @@ def load():
         lib.tp_synchronize.argtypes = [C.c_void_p]
         lib.tp_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         lib.tp_profile_iterate.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_double)]
+        lib.tp_profile_accumulate.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_double)]
         lib.tp_get_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         lib.tp_device_count.argtypes = [C.POINTER(C.c_int)]
         lib.tp_selftest_walker.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -168,6 +169,11 @@ class Context:
     def profile_iterate(self, params, n):
         us = C.c_double(0)
         self._ck(self.lib.tp_profile_iterate(self.h, C.byref(params), n, C.byref(us)))
+        return us.value
+
+    def profile_accumulate(self, params, launches=64):
+        us = C.c_double(0)
+        self._ck(self.lib.tp_profile_accumulate(self.h, C.byref(params), launches, C.byref(us)))
         return us.value
 
     def synchronize(self):

@@ -676,6 +676,41 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
     return check_flags(c);
 }
 
+int tp_profile_accumulate(tp_context* c, const tp_params* p, int launches, double* accumulate_us) {
+    if (!c || !accumulate_us) return TP_ERR_INVALID;
+    if (int rc = validate_params(c, p, launches)) return rc;
+    if (launches < 1) return fail(c, TP_ERR_INVALID, "launches < 1");
+    if (int rc = tp_synchronize(c)) return rc;
+    const float dp = resolve_dp(c, p->flavour, p->dp);
+    HIP_TRY(c, force_rebin(c));
+    c->lists_dp = dp; c->lists_ratio = c->ratio;
+    tp_launch L = make_launch(c, p->image_slot, dp);
+    tp_launch_bin(L, c->stream);  // work lists of the current state; every accumulate launch below consumes the same ones
+    HIP_TRY(c, hipGetLastError());
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    for (int k = 0; k < launches; k++) tp_launch_accumulate(L, c->stream);
+    HIP_TRY(c, hipStreamEndCapture(c->stream, &graph));
+    hipError_t err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (err != hipSuccess) return fail(c, TP_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(err));
+    if (!c->ev0) { HIP_TRY(c, hipEventCreate(&c->ev0)); HIP_TRY(c, hipEventCreate(&c->ev1)); }
+    float ms = 0.0f;
+    err = hipGraphLaunch(exec, c->stream);  // warm-up replay
+    if (err == hipSuccess) err = hipEventRecord(c->ev0, c->stream);
+    if (err == hipSuccess) err = hipGraphLaunch(exec, c->stream);
+    if (err == hipSuccess) err = hipEventRecord(c->ev1, c->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    hipGraphExecDestroy(exec);
+    if (err != hipSuccess) return fail(c, TP_ERR_HIP, "profile_accumulate: %s", hipGetErrorString(err));
+    *accumulate_us = (double)ms * 1000.0 / launches;
+    // the lists stay valid for the unchanged positions (k_accumulate consumed the rebuild request)
+    c->accumulated = c->energized = false;
+    return check_flags(c);
+}
+
 int tp_synchronize(tp_context* c) {
     if (!c) return TP_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
