@@ -313,10 +313,10 @@ inline void doenergy() { check(tp_energy(ctx, flavour), "doenergy"); }
 inline void doshift() { check(tp_shift(ctx, flavour == TP_WARP ? 0.00003f : 0.00005f), "doshift"); }
 // the four Buffer::retrieve calls of every frame
 inline void retrieve(triangulation* tr) {
-    check(tp_retrieve(ctx, TP_BUF_TENERGY, terr, (size_t)13 * tr->NT), "retrieve(tenergy)");
-    check(tp_retrieve(ctx, TP_BUF_PENERGY, perr, (size_t)13 * tr->NT), "retrieve(penergy)");
-    check(tp_retrieve(ctx, TP_BUF_COLNUM, cn, (size_t)13 * tr->NT), "retrieve(colnum)");
-    check(tp_retrieve(ctx, TP_BUF_POINTS, &tr->points[0].x, (size_t)2 * tr->NP), "retrieve(points)");
+    const int what[4] = {TP_BUF_TENERGY, TP_BUF_PENERGY, TP_BUF_COLNUM, TP_BUF_POINTS};
+    void* const dst[4] = {terr, perr, cn, &tr->points[0].x};
+    const size_t count[4] = {(size_t)13 * tr->NT, (size_t)13 * tr->NT, (size_t)13 * tr->NT, (size_t)2 * tr->NP};
+    check(tp_retrieve_many(ctx, 4, what, dst, count), "retrieve");  // one wait for the four buffers
 }
 inline void retrieve_energy(triangulation* tr) {
     check(tp_retrieve(ctx, TP_BUF_TENERGY, terr, (size_t)13 * tr->NT), "retrieve(tenergy)");

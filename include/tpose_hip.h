@@ -126,6 +126,10 @@ int tp_iterate(tp_context* ctx, const tp_params* p, int n_iters);
 /* Buffer::retrieve (triangulate/main.cpp:201-204, 221): copies `count` elements (int32 / float /
  * int64 units as listed in tp_buffer) into dst after waiting for enqueued work. */
 int tp_retrieve(tp_context* ctx, int what, void* dst, size_t count);
+/* the same for n buffers with ONE wait: what[k] -> dst[k], count[k] elements.  The reference reads four
+ * buffers back every frame (software/triangulate/main.cpp:201-204, warp/main.cpp:226-229); done one by one,
+ * each is a blocking round trip. */
+int tp_retrieve_many(tp_context* ctx, int n, const int* what, void* const* dst, const size_t* count);
 int tp_synchronize(tp_context* ctx);
 
 /* measurement hooks (bench.py): the HIP stream the kernels run on, and HIP-event timing of the

@@ -128,3 +128,11 @@ int tp_render(tp_context* c, int source, const float* points, uint8_t* dst, size
     }
     return TP_OK;
 }
+
+int tp_retrieve_many(tp_context* c, int n, const int* what, void* const* dst, const size_t* count) {
+    for (int k = 0; k < n; k++) {
+        int rc = tp_retrieve(c, what[k], dst[k], count[k]);
+        if (rc) return rc;
+    }
+    return TP_OK;
+}

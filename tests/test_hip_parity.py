@@ -357,3 +357,20 @@ def test_render_flat_shaded_picture():
     assert np.array_equal(ctx.render(capi.RENDER_AVERAGE, points=moved), want)
     assert np.array_equal(ctx.retrieve(capi.BUF_POINTS), pts)
     ctx.close()
+
+
+def test_batched_readback_equals_single_readbacks():
+    """tp_retrieve_many: the reference's four per-frame readbacks with one wait"""
+    W, H = 300, 200
+    img, imgB, pts, tris, ratio, colors = case(W, H, (15, 5))
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts, tris, None)
+    ctx.iterate(capi.default_params(capi.TRIANGULATE), 3)
+    whats = [capi.BUF_TENERGY, capi.BUF_PENERGY, capi.BUF_COLNUM, capi.BUF_POINTS, capi.BUF_COLACC, capi.BUF_GRADIENT]
+    many = ctx.retrieve_many(whats)
+    for w, a in zip(whats, many):
+        b = ctx.retrieve(w)
+        assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert not many[1].any()  # penergy is dead in the reference: always zero
+    ctx.close()

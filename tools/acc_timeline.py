@@ -79,3 +79,13 @@ print(json.dumps({"nlist": pct(cnt), "corr_walk0_nlist": float(np.corrcoef(w0.me
                   "walk0_by_nlist": {int(k): float(w0.mean(axis=0)[n0 == k].mean()) for k in np.unique(n0)},
                   "walk1_by_nlist": {int(k): float(w1.mean(axis=0)[n1 == k].mean()) for k in np.unique(n1)},
                   "blocktime_by_sum": {int(k): float(blk.mean(axis=0)[(n0 + n1) == k].mean()) for k in np.unique(n0 + n1)}}))
+
+# inside the walk (wave 0, its first work item): set-up done, rows done, static-table part done
+def seg(a, b):
+    d = (st[:, :, b] - st[:, :, a]) / 100.0
+    ok = (st[:, :, a] > 0) & (st[:, :, b] > 0) & (d >= 0) & (d < 50)
+    return float(d[ok].mean()) if ok.any() else None
+print(json.dumps({"walk0: barrier -> setup done": seg(2, 9), "walk0: setup -> rows done": seg(9, 10), "walk0: rows -> table part done": seg(10, 11),
+                  "walk0: table part -> walk_done stamp": seg(11, 3),
+                  "walk1: barrier -> setup done": seg(6, 12), "walk1: setup -> rows done": seg(12, 13), "walk1: rows -> table part done": seg(13, 14),
+                  "walk1: table part -> walk_done stamp": seg(14, 7)}))

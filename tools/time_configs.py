@@ -52,9 +52,15 @@ def run_readback(W, H, NT, steps):
             ctx.retrieve(capi.BUF_TENERGY); ctx.retrieve(capi.BUF_PENERGY)
             ctx.retrieve(capi.BUF_COLNUM); ctx.retrieve(capi.BUF_POINTS)
         dt = time.perf_counter() - t0
+    for warm in range(2):
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ctx.iterate(p, 1)
+            ctx.retrieve_many([capi.BUF_TENERGY, capi.BUF_PENERGY, capi.BUF_COLNUM, capi.BUF_POINTS])
+        dt2 = time.perf_counter() - t0
     ctx.close()
-    print(json.dumps(dict(config="readback every iter %dx%d / %d" % (W, H, NT), us_per_iter=dt / steps * 1e6,
-                          tri_iters_per_s=NT * steps / dt)), flush=True)
+    print(json.dumps(dict(config="readback every iter %dx%d / %d" % (W, H, NT), us_per_iter_four_calls=dt / steps * 1e6,
+                          us_per_iter_one_batched_call=dt2 / steps * 1e6, tri_iters_per_s=NT * steps / dt2)), flush=True)
 
 
 def run_cold(W, H, NT, nctx, reps):

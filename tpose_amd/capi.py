@@ -21,7 +21,7 @@ BUF_TENERGY, BUF_COLNUM, BUF_COLACC, BUF_POINTS, BUF_GRADIENT, BUF_PENERGY, BUF_
 SYMBOLS = [
     "tp_abi_version", "tp_device_count", "tp_last_error", "tp_create", "tp_destroy", "tp_set_ratio",
     "tp_get_ratio", "tp_set_dp", "tp_set_margin", "tp_set_image", "tp_set_image_device", "tp_upload", "tp_accumulate",
-    "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_synchronize",
+    "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_retrieve_many", "tp_synchronize",
     "tp_get_stream", "tp_profile_iterate", "tp_profile_accumulate", "tp_get_info", "tp_selftest_walker", "tp_render",
 ]
 
@@ -68,6 +68,7 @@ def load():
         lib.tp_default_params.restype = None
         lib.tp_iterate.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int]
         lib.tp_retrieve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        lib.tp_retrieve_many.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.tp_synchronize.argtypes = [C.c_void_p]
         lib.tp_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         lib.tp_profile_iterate.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_double)]
@@ -202,6 +203,20 @@ class Context:
         n = out.size if count is None else count
         self._ck(self.lib.tp_retrieve(self.h, what, out.ctypes.data, n))
         return out
+
+    def retrieve_many(self, whats):
+        """several buffers with one wait (tp_retrieve_many); returns a list of arrays"""
+        V = 13 * self.NT
+        spec = {BUF_TENERGY: ((V,), np.int32), BUF_COLNUM: ((V,), np.int32), BUF_COLACC: ((V, 4), np.int32),
+                BUF_POINTS: ((self.NP, 2), np.float32), BUF_GRADIENT: ((self.NP, 2), np.int32),
+                BUF_PENERGY: ((V,), np.int32), BUF_MOMENTS: ((V, 6), np.int64)}
+        outs = [np.zeros(*spec[w]) for w in whats]
+        n = len(whats)
+        wa = (C.c_int * n)(*whats)
+        da = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        ca = (C.c_size_t * n)(*[o.size for o in outs])
+        self._ck(self.lib.tp_retrieve_many(self.h, n, wa, da, ca))
+        return outs
 
     def info(self, what):
         v = C.c_int64(0)

@@ -86,6 +86,8 @@ struct tp_context {
     std::vector<segment> pending;
     uint32_t done_base = 0;  // tp_device_state::iters_done when pending[0] started
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint8_t* pinned = nullptr;   // host-pinned staging for readbacks (one synchronisation per batch)
+    size_t pinned_bytes = 0;
 };
 
 namespace {
@@ -317,6 +319,7 @@ int tp_destroy(tp_context* c) {
     free_triangulation(c);
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->tilecount); hipFree(c->state);
     hipFree(c->t2[0]); hipFree(c->t2[1]); hipFree(c->seg_scratch);
+    if (c->pinned) hipHostFree(c->pinned);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -523,10 +526,18 @@ int tp_accumulate(tp_context* c, int flavour, int slot) {
         tp_launch_accumulate(L, c->stream);
         tp_launch_reduce(L, c->stream);
         HIP_TRY(c, hipGetLastError());
-        // a sweep over overflowed work lists is incomplete: grow them and sweep again
+        // a sweep over overflowed work lists is incomplete: grow them and sweep again (the flag word rides the
+        // stream into pinned memory: one wait)
+        if (c->pinned_bytes < 256) {
+            if (c->pinned) hipHostFree(c->pinned);
+            c->pinned = nullptr; c->pinned_bytes = 0;
+            HIP_TRY(c, hipHostMalloc((void**)&c->pinned, 1 << 20, hipHostMallocDefault));
+            c->pinned_bytes = 1 << 20;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->pinned, &c->state->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         uint32_t flags = 0;
-        HIP_TRY(c, hipMemcpy(&flags, &c->state->flags, sizeof flags, hipMemcpyDeviceToHost));
+        memcpy(&flags, c->pinned, sizeof flags);
         if (!flags) break;
         hipError_t err = hipSuccess;
         if (round >= 40 || !grow_lists(c, flags, &err)) {
@@ -715,31 +726,68 @@ int tp_synchronize(tp_context* c) {
     if (!c) return TP_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return check_flags(c);
+    // only fused iterations can leave an overflow flag behind (tp_accumulate settles its own)
+    return c->pending.empty() ? TP_OK : check_flags(c);
 }
 
-int tp_retrieve(tp_context* c, int what, void* dst, size_t count) {
-    if (!c) return TP_ERR_INVALID;
-    if (!dst && count) return fail(c, TP_ERR_INVALID, "retrieve: dst is NULL");
-    if (!c->uploaded) return fail(c, TP_ERR_STATE, "retrieve before upload");
-    if (int rc = tp_synchronize(c)) return rc;
+namespace {
+// device source of a tp_buffer; bytes = 0 for the all-zero penergy
+int buffer_source(tp_context* c, int what, size_t count, const void** src, size_t* bytes) {
     const size_t V = (size_t)13 * c->NT;
-    const void* src = nullptr;
     size_t elem = 4, avail = 0;
+    *src = nullptr;
     switch (what) {
-        case TP_BUF_TENERGY: src = c->ten; avail = V; break;
-        case TP_BUF_COLNUM: src = c->cn; avail = V; break;
-        case TP_BUF_COLACC: src = c->ca; avail = 4 * V; break;
-        case TP_BUF_POINTS: src = c->points; avail = 2 * (size_t)c->NP; break;
-        case TP_BUF_GRADIENT: src = c->gr; avail = 2 * (size_t)c->NP; break;
-        case TP_BUF_PENERGY: memset(dst, 0, count * 4); return TP_OK;
+        case TP_BUF_TENERGY: *src = c->ten; avail = V; break;
+        case TP_BUF_COLNUM: *src = c->cn; avail = V; break;
+        case TP_BUF_COLACC: *src = c->ca; avail = 4 * V; break;
+        case TP_BUF_POINTS: *src = c->points; avail = 2 * (size_t)c->NP; break;
+        case TP_BUF_GRADIENT: *src = c->gr; avail = 2 * (size_t)c->NP; break;
+        case TP_BUF_PENERGY: *bytes = 0; return TP_OK;
         case TP_BUF_MOMENTS:
             if (!c->energized) return fail(c, TP_ERR_STATE, "moments are only kept by tp_energy (piecewise API)");
-            src = c->moments; avail = 6 * V; elem = 8; break;
+            *src = c->moments; avail = 6 * V; elem = 8; break;
         default: return fail(c, TP_ERR_INVALID, "retrieve: unknown buffer %d", what);
     }
     if (count > avail) return fail(c, TP_ERR_INVALID, "retrieve: count %zu > %zu available", count, avail);
-    HIP_TRY(c, hipMemcpy(dst, src, count * elem, hipMemcpyDeviceToHost));
+    *bytes = count * elem;
+    return TP_OK;
+}
+}  // namespace
+
+int tp_retrieve(tp_context* c, int what, void* dst, size_t count) {
+    return tp_retrieve_many(c, 1, &what, &dst, &count);
+}
+
+int tp_retrieve_many(tp_context* c, int n, const int* what, void* const* dst, const size_t* count) {
+    if (!c) return TP_ERR_INVALID;
+    if (n < 0 || (n && (!what || !dst || !count))) return fail(c, TP_ERR_INVALID, "retrieve: bad arguments");
+    if (!c->uploaded) return fail(c, TP_ERR_STATE, "retrieve before upload");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->pending.empty())  // fused iterations outstanding: settle them (and replay after an overflow) first
+        if (int rc = tp_synchronize(c)) return rc;
+    std::vector<const void*> src(n);
+    std::vector<size_t> bytes(n), off(n);
+    size_t total = 0;
+    for (int k = 0; k < n; k++) {
+        if (!dst[k] && count[k]) return fail(c, TP_ERR_INVALID, "retrieve: dst is NULL");
+        if (int rc = buffer_source(c, what[k], count[k], &src[k], &bytes[k])) return rc;
+        off[k] = total;
+        total += (bytes[k] + 255) & ~(size_t)255;
+    }
+    if (total > c->pinned_bytes) {
+        if (c->pinned) hipHostFree(c->pinned);
+        c->pinned = nullptr; c->pinned_bytes = 0;
+        HIP_TRY(c, hipHostMalloc((void**)&c->pinned, total + total / 2, hipHostMallocDefault));
+        c->pinned_bytes = total + total / 2;
+    }
+    // all copies ride the context's stream behind the enqueued work: ONE wait for the whole batch
+    for (int k = 0; k < n; k++)
+        if (bytes[k]) HIP_TRY(c, hipMemcpyAsync(c->pinned + off[k], src[k], bytes[k], hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < n; k++) {
+        if (bytes[k]) memcpy(dst[k], c->pinned + off[k], bytes[k]);
+        else if (what[k] == TP_BUF_PENERGY) memset(dst[k], 0, count[k] * 4);
+    }
     return TP_OK;
 }
 

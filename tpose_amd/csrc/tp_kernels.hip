@@ -394,6 +394,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
             tp_edge_walk ew;
             const int pr = TH >> lsplit;  // rows per part
             tp_setup_edge(A.x, A.y, B.x, B.y, row0 + pr * part, min(row0 + pr * part + pr - 1, row1), ew);
+#define TP_STAMP_AT(slot) do { if ((L.debug & 8) && tid == 0 && item == tid) L.dbg[blockIdx.x * 16 + (slot) + (tile == (int)blockIdx.x ? 0 : 3)] = wall_clock64(); } while (0)
+            TP_STAMP_AT(9);
             // eight rows per trip, fully unrolled and predicated so that the eight prefix reads are in
             // flight together: rows outside the line's rows, or whose crossing column falls into another
             // tile column, read the all-zero entry P[r][0] and are not counted
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
                     first = min(first, rbase + c0 + (int)__builtin_ctz(inmask));
                 }
             }
+            TP_STAMP_AT(10);
             // combine the parts (adjacent lanes; a line's lanes are always active together)
             for (int o = 1; o < split; o <<= 1) {
                 sx += (uint32_t)__shfl_xor((int)sx, o);
@@ -446,6 +449,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
 #pragma unroll
                 for (int k = 0; k < TP_T2_WORDS; k++) st[k] = t1[k] - t0[k];
             }
+            TP_STAMP_AT(11);
             if (visit < L.visit_cap) {
                 int64_t* out = L.visits + ((size_t)visit * TP_NLINES + ver) * TP_W_WORDS;
                 out[0] = (int64_t)sx;
