@@ -174,10 +174,9 @@ int check_slot(tp_context* c, int slot) {
 hipError_t force_rebin(tp_context* c) {
     hipError_t e = hipMemsetAsync(c->tilecount, 0, sizeof(int) * (size_t)c->tiles_x * c->tiles_y, c->stream);
     if (e != hipSuccess) return e;
-    static const uint32_t zero_one[3] = {0u, 0u, 1u};
-    e = hipMemcpyAsync(&c->state->visit_total, &zero_one[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    e = hipMemsetAsync(&c->state->visit_total, 0, sizeof(uint32_t), c->stream);
     if (e != hipSuccess) return e;
-    return hipMemcpyAsync(&c->state->rebin_req, &zero_one[2], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    return hipMemsetD32Async((hipDeviceptr_t)&c->state->rebin_req, 1, 1, c->stream);
 }
 
 // enqueue one grad-iter on the context stream (no sync)
