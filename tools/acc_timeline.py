@@ -14,6 +14,7 @@ import numpy as np  # noqa: E402
 from tpose_amd import capi, synth  # noqa: E402
 
 W = H = 2048
+NB = 768  # resident workgroups of k_accumulate (accumulate_grid)
 NT = 3000
 img, pts, tris, he, ratio = synth.workload(W, H, NT)
 ctx = capi.Context(0, W, H)
@@ -29,16 +30,16 @@ acc = []
 for rep in range(32):
     ctx.iterate(p, 1)
     ctx.synchronize()
-    buf = np.zeros(512 * 16, np.uint64)
+    buf = np.zeros(NB * 16, np.uint64)
     rc = lib.tp_debug_dump(ctx.h, buf.ctypes.data, buf.size)
     assert rc == 0, rc
-    st = buf.reshape(512, 16).astype(np.int64)
+    st = buf.reshape(NB, 16).astype(np.int64)
     acc.append(st)
 st = np.stack(acc)  # [rep, block, stamp]
 t0 = st[:, :, 0].min(axis=1, keepdims=True)
 names = ["start", "t0_prefix_done", "t0_barrier", "t0_walk_done", "t0_barrier2", "t1_prefix_done", "t1_barrier",
          "t1_walk_done", "end"]
-out = {"units": "us after the first workgroup's first stamp; 32 launches x 512 workgroups", "stamps": {}}
+out = {"units": "us after the first workgroup's first stamp; 32 launches x %d workgroups" % NB, "stamps": {}}
 for k, n in enumerate(names):
     v = (st[:, :, k] - t0) / 100.0
     out["stamps"][n] = {"min": float(v.min(axis=1).mean()), "median": float(np.median(v, axis=1).mean()),

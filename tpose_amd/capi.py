@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtpose_hip.so")
+LIB_PATH = os.environ.get("TPOSE_HIP_LIB") or os.path.join(_HERE, "libtpose_hip.so")  # override: A/B builds
 
 TP_OK, TP_ERR_INVALID, TP_ERR_NO_DEVICE, TP_ERR_HIP, TP_ERR_CAPACITY, TP_ERR_STATE = range(6)
 TRIANGULATE, WARP = 0, 1

@@ -155,7 +155,7 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     static const int dbg = getenv("TPOSE_DEBUG_ACC") ? atoi(getenv("TPOSE_DEBUG_ACC")) : 0;
     L.debug = dbg;
     static unsigned long long* dbgbuf = nullptr;
-    if ((dbg & 24) && !dbgbuf) { hipMalloc((void**)&dbgbuf, 512 * 16 * sizeof(unsigned long long)); hipMemset(dbgbuf, 0, 512 * 16 * 8); }
+    if ((dbg & 24) && !dbgbuf) { hipMalloc((void**)&dbgbuf, 1024 * 16 * sizeof(unsigned long long)); hipMemset(dbgbuf, 0, 1024 * 16 * 8); }
     L.dbg = dbgbuf;
     return L;
 }

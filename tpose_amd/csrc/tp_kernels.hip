@@ -31,7 +31,10 @@ static_assert(TH == 32 && TH <= TP_WALK_MAXROWS, "tile height");
 
 // LDS: the prefix table + the static-table rows bounding the tile's 32 rows (33 x 5 int64)
 #define T2_LDS_WORDS ((TH + 1) * TP_T2_WORDS)
-size_t tp_accumulate_lds_bytes() { return (size_t)TH * ROWLEN * sizeof(uint4) + T2_LDS_WORDS * sizeof(int64_t); }
+#define ACC_GRID 768
+#define WALK_ROWS 4   // rows per unrolled trip of the line walk
+#define ENTRY_WORDS 3  // 12-byte prefix entries: three workgroups per CU (3 x 50.9 KB of the 160 KB)
+size_t tp_accumulate_lds_bytes() { return (size_t)TH * ROWLEN * ENTRY_WORDS * sizeof(uint32_t) + T2_LDS_WORDS * sizeof(int64_t); }
 
 __device__ __forceinline__ int tile_col_of(int x, int tiles_x) { return min(x / TW, tiles_x - 1); }
 
@@ -251,24 +254,23 @@ void tp_launch_bin(const tp_launch& L, hipStream_t s) {
     hipLaunchKernelGGL(k_bin, dim3((L.NE + BIN_EDGES - 1) / BIN_EDGES), dim3(256), 0, s, L);
 }
 
-// LDS prefix entry (uint4), per row exclusive prefix over the tile's 128 columns:
-//   x = sum r,  y = sum g,  z = sum b | n_odd << 20,  w = (sum r^2+g^2+b^2) << 2
-// Read as two u64 {x,y} and {z,w}: sums of entries over up to 32 rows never carry between the
-// fields that matter -- sum b < 2^20 (4096*255), n_odd <= 4096 spills at most into bit 32, which
-// the << 2 on q keeps free -- so a lane accumulates whole entries with 64-bit adds and unpacks once.
-struct pix4 { uint32_t x, y, z, w; };
+// LDS prefix entry (12 bytes), per row exclusive prefix over the tile's 128 columns, 16-bit fields packed in pairs:
+//   x = sum r | sum g << 16,   y = sum b | n_odd << 16,   z = sum r^2+g^2+b^2
+// (128 pixels: sum of a channel <= 32640 < 2^16, n_odd <= 128, q < 2^25: nothing carries between fields, so the
+// prefix build adds and scans whole words).  The walk adds the 16-bit halves into 32-bit accumulators (SDWA
+// word selects, one instruction per field per row).
+struct pix3 { uint32_t x, y, z; };
 
-__device__ __forceinline__ pix4 pixel_moments(uint32_t rgba) {
+__device__ __forceinline__ pix3 pixel_moments(uint32_t rgba) {
     const uint32_t m = rgba & 0x00ffffffu;
-    const uint32_t r = m & 0xffu, g = (m >> 8) & 0xffu, b = m >> 16;
-    pix4 o;
-    o.x = r; o.y = g;
-    o.z = b | (((r + g + b) & 1u) << 20);
-    o.w = (r * r + g * g + b * b) << 2;
+    const uint32_t s = __builtin_amdgcn_udot4(m, 0x00010101u, 0u, false);  // r + g + b
+    pix3 o;
+    o.x = __builtin_amdgcn_perm(0u, m, 0x0c010c00u);                        // r | g << 16
+    o.y = (m >> 16) | ((s & 1u) << 16);                                     // b | odd << 16
+    o.z = __builtin_amdgcn_udot4(m, m, 0u, false);                          // r^2 + g^2 + b^2
     return o;
 }
-__device__ __forceinline__ pix4 operator+(pix4 a, pix4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
-__device__ __forceinline__ uint4 as_uint4(pix4 a) { return make_uint4(a.x, a.y, a.z, a.w); }
+__device__ __forceinline__ pix3 operator+(pix3 a, pix3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 
 // ------------------------------------------------------------------------------------------------
 // k_accumulate
@@ -276,8 +278,7 @@ __device__ __forceinline__ uint4 as_uint4(pix4 a) { return make_uint4(a.x, a.y, 
 // Phase-1 lane mapping: wave w owns tile rows P1_RL*w ..; lane = seg*P1_RL + rl walks the P1_PX pixels
 // [P1_PX seg, P1_PX (seg+1)) of row P1_RL*w + rl sequentially, and the segments of a row are combined
 // by a log2(P1_SEGS)-step scan at lane distance P1_RL.  Consecutive lanes belong to consecutive ROWS,
-// whose LDS rows are 2064 B = 16 B (mod 128) apart, so the eight lanes of a ds_write_b128 group hit
-// eight different 16-byte slots.
+// whose LDS rows are 1548 B = 12 B (mod 128) apart, so the lanes of a 12-byte store group hit different banks.
 #define P1_PX 8                    // pixels per lane
 #define P1_SEGS (TW / P1_PX)       // lanes per tile row
 #define P1_RL (64 / P1_SEGS)       // tile rows per wave
@@ -293,9 +294,9 @@ __device__ __forceinline__ uint32_t scan_segments(uint32_t v, int seg) {
     return v;
 }
 
-__global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
-    extern __shared__ __attribute__((aligned(16))) uint4 P[];  // [TH][ROWLEN], then int64 T2s[TH+1][5]
-    int64_t* T2s = reinterpret_cast<int64_t*>(P + TH * ROWLEN);
+__global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  // 6 waves per SIMD: 3 workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) uint32_t P[];  // [TH][ROWLEN][3], then int64 T2s[TH+1][5]
+    int64_t* T2s = reinterpret_cast<int64_t*>(P + TH * ROWLEN * ENTRY_WORDS);
 
     const int tid = threadIdx.x;
     const int ntiles = L.tiles_x * L.tiles_y;
@@ -338,7 +339,6 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
         int visit = e0->visit;
         int2 A = e0->a[(ver0 >= 1 && ver0 <= 4) ? ver0 : 0], B = e0->b[ver0 >= 5 ? ver0 - 4 : 0];
         const bool stale = L.margin_px >= 2;  // lists reused across iterations: positions come from vpos
-        const int eu = stale ? e0->u : 0, ev = stale ? e0->v : 0;
         const int next = tile + gridDim.x;
         // static-table rows for this tile's row boundaries -> LDS
         if (tid < T2_LDS_WORDS && nlist > 0) {
@@ -349,23 +349,28 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
 
         // ---- phase 1: pixels -> row prefix sums in LDS --------------------------------------
         if (wave < P1_WAVES && nlist > 0 && !(L.debug & 1)) {
-            pix4 loc[P1_PX];  // exclusive prefix inside the lane's 16-pixel segment
-            pix4 run = {0, 0, 0, 0};
+            pix3 loc[P1_PX];  // exclusive prefix inside the lane's segment
+            pix3 run = {0, 0, 0};
 #pragma unroll
             for (int k = 0; k < P1_PX; k++) {
                 const uint32_t w = k % 4 == 0 ? px[k / 4].x : k % 4 == 1 ? px[k / 4].y : k % 4 == 2 ? px[k / 4].z : px[k / 4].w;
                 loc[k] = run;
                 run = run + pixel_moments(w);
             }
-            pix4 ex;  // everything left of the segment
+            pix3 ex;  // everything left of the segment
             ex.x = scan_segments(run.x, seg) - run.x;
             ex.y = scan_segments(run.y, seg) - run.y;
             ex.z = scan_segments(run.z, seg) - run.z;
-            ex.w = scan_segments(run.w, seg) - run.w;
-            uint4* row = P + prow * ROWLEN + seg * P1_PX;
+            uint32_t* row = P + (prow * ROWLEN + seg * P1_PX) * ENTRY_WORDS;
 #pragma unroll
-            for (int k = 0; k < P1_PX; k++) row[k] = as_uint4(ex + loc[k]);
-            if (seg == P1_SEGS - 1) row[P1_PX] = as_uint4(ex + run);
+            for (int k = 0; k < P1_PX; k++) {
+                const pix3 e = ex + loc[k];
+                row[3 * k] = e.x; row[3 * k + 1] = e.y; row[3 * k + 2] = e.z;
+            }
+            if (seg == P1_SEGS - 1) {
+                const pix3 e = ex + run;
+                row[3 * P1_PX] = e.x; row[3 * P1_PX + 1] = e.y; row[3 * P1_PX + 2] = e.z;
+            }
         }
         if (next < ntiles && wave < P1_WAVES) fetch(next);  // in flight during phase 2
         TP_STAMP();
@@ -389,7 +394,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
                 A = stale ? L.vpos[(size_t)ee->u * 5 + mu] : ee->a[mu];
                 B = stale ? L.vpos[(size_t)ee->v * 5 + mv] : ee->b[mv];
             } else if (stale) {
-                A = L.vpos[(size_t)eu * 5 + mu]; B = L.vpos[(size_t)ev * 5 + mv];
+                const tp_list_entry* ee = list + en;
+                A = L.vpos[(size_t)ee->u * 5 + mu]; B = L.vpos[(size_t)ee->v * 5 + mv];
             }
             tp_edge_walk ew;
             const int pr = TH >> lsplit;  // rows per part
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
             // eight rows per trip, fully unrolled and predicated so that the eight prefix reads are in
             // flight together: rows outside the line's rows, or whose crossing column falls into another
             // tile column, read the all-zero entry P[r][0] and are not counted
-            uint64_t axy = 0, azw = 0;
+            uint32_t ar = 0, ag = 0, ab = 0, ao = 0, aq = 0;  // 32 rows: channel sums < 2^20, q < 2^30
             uint32_t sx = 0, nin = 0;
             int32_t first = INT32_MAX;
             const int rbase = row0 + pr * part;
@@ -407,24 +413,29 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
             // columns of this tile column: [col0, col0 + TW), the last one also takes the clamp value W
             const uint32_t lim = tx == L.tiles_x - 1 ? (uint32_t)(W - col0 + 1) : (uint32_t)TW;
             int64_t xw = ew.w.x - (int64_t)(ew.ra - rbase) * ew.w.s;  // walker moved back to row rbase
-            const ulonglong2* rowp = reinterpret_cast<const ulonglong2*>(P) + (rbase - row0) * ROWLEN;
-            for (int c0 = 0; c0 < pr; c0 += 8, rowp += 8 * ROWLEN) {
+            int rowi = (rbase - row0) * ROWLEN * ENTRY_WORDS;  // 32-bit LDS word index of the trip's first row
+            for (int c0 = 0; c0 < pr; c0 += WALK_ROWS, rowi += WALK_ROWS * ROWLEN * ENTRY_WORDS) {
                 const int koff = ew.ra - rbase - c0;  // chunk-relative index of the first valid row
-                if (!__any((int)nvalid + koff > 0 && koff < 8)) { xw += 8 * ew.w.s; continue; }
-                ulonglong2 ent[8];
+                if (!__any((int)nvalid + koff > 0 && koff < WALK_ROWS)) { xw += WALK_ROWS * ew.w.s; continue; }
+                pix3 ent[WALK_ROWS];
                 uint32_t inmask = 0;
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < WALK_ROWS; k++) {
                     const int32_t x = min(max((int32_t)(xw >> 32), 0), W);
                     xw += ew.w.s;
                     const uint32_t xl = (uint32_t)(x - col0);
                     const bool in = xl < lim && (uint32_t)(k - koff) < nvalid;
-                    ent[k] = rowp[k * ROWLEN + (in ? xl : 0u)];
+                    const int ei = rowi + k * ROWLEN * ENTRY_WORDS + (in ? (int)(xl * ENTRY_WORDS) : 0);
+                    ent[k].x = P[ei]; ent[k].y = P[ei + 1]; ent[k].z = P[ei + 2];
                     sx += in ? (uint32_t)x : 0u;
                     inmask |= in ? (1u << k) : 0u;
                 }
 #pragma unroll
-                for (int k = 0; k < 8; k++) { axy += ent[k].x; azw += ent[k].y; }
+                for (int k = 0; k < WALK_ROWS; k++) {
+                    ar += ent[k].x & 0xffffu; ag += ent[k].x >> 16;
+                    ab += ent[k].y & 0xffffu; ao += ent[k].y >> 16;
+                    aq += ent[k].z;
+                }
                 if (inmask) {
                     nin += (uint32_t)__builtin_popcount(inmask);
                     first = min(first, rbase + c0 + (int)__builtin_ctz(inmask));
@@ -436,8 +447,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
                 sx += (uint32_t)__shfl_xor((int)sx, o);
                 nin += (uint32_t)__shfl_xor((int)nin, o);
                 first = min(first, __shfl_xor(first, o));
-                axy += ((uint64_t)(uint32_t)__shfl_xor((int)(axy >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)axy, o);
-                azw += ((uint64_t)(uint32_t)__shfl_xor((int)(azw >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)azw, o);
+                ar += (uint32_t)__shfl_xor((int)ar, o); ag += (uint32_t)__shfl_xor((int)ag, o);
+                ab += (uint32_t)__shfl_xor((int)ab, o); ao += (uint32_t)__shfl_xor((int)ao, o);
+                aq += (uint32_t)__shfl_xor((int)aq, o);
             }
             if (part != 0) continue;
             // rows that count are contiguous (the line is monotone): add everything left of this tile
@@ -453,11 +465,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
             if (visit < L.visit_cap) {
                 int64_t* out = L.visits + ((size_t)visit * TP_NLINES + ver) * TP_W_WORDS;
                 out[0] = (int64_t)sx;
-                out[1] = (int64_t)((azw >> 20) & 0x3fffu) + st[0];
-                out[2] = (int64_t)(uint32_t)axy + st[1];
-                out[3] = (int64_t)(axy >> 32) + st[2];
-                out[4] = (int64_t)(azw & 0xfffffu) + st[3];
-                out[5] = (int64_t)(azw >> 34) + st[4];
+                out[1] = (int64_t)ao + st[0];
+                out[2] = (int64_t)ar + st[1];
+                out[3] = (int64_t)ag + st[2];
+                out[4] = (int64_t)ab + st[3];
+                out[5] = (int64_t)aq + st[4];
             }
         }
         TP_STAMP();
@@ -467,9 +479,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate(tp_launch L) {
 }
 
 static int accumulate_grid(const tp_launch& L) {
-    // every workgroup resident at once (2 per CU by LDS); each walks its tiles with prefetch
+    // every workgroup resident at once (3 per CU by LDS and registers); each walks its tiles with prefetch
     const int ntiles = L.tiles_x * L.tiles_y;
-    return ntiles < 512 ? ntiles : 512;
+    return ntiles < ACC_GRID ? ntiles : ACC_GRID;
 }
 
 hipError_t tp_kernels_init() {
@@ -795,7 +807,7 @@ void tp_launch_render(const tp_launch& L, const float2* pts, int source, void* o
 // launch-overhead probes (debug entry tp_debug_null_launch; not part of the product path)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ACC_THREADS) void k_probe(const uint4* src, uint4* dst, int mode, int n16) {
-    extern __shared__ __attribute__((aligned(16))) uint4 P[];
+    extern __shared__ __attribute__((aligned(16))) uint4 PP[];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (mode == 1) {  // 8 MB of record-like stores
         dst[gid] = make_uint4(gid, 1, 2, 3);
@@ -805,9 +817,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_probe(const uint4* src, uint4* 
         for (int k = gid; k < n16; k += gridDim.x * blockDim.x) { const uint4 v = src[k]; a.x ^= v.x; a.y ^= v.y; a.z ^= v.z; a.w ^= v.w; }
         if ((a.x ^ a.y ^ a.z ^ a.w) == 0x12345678u) dst[gid] = a;
     } else if (mode == 4) {
-        P[threadIdx.x] = make_uint4(gid, 0, 0, 0);
+        PP[threadIdx.x] = make_uint4(gid, 0, 0, 0);
         __syncthreads();
-        if (P[(threadIdx.x + 1) & (ACC_THREADS - 1)].x == 0xffffffffu) dst[gid] = P[0];
+        if (PP[(threadIdx.x + 1) & (ACC_THREADS - 1)].x == 0xffffffffu) dst[gid] = PP[0];
     }
 }
 void tp_launch_probe(const void* src, void* dst, int mode, int n16, int blocks, int threads, size_t lds, hipStream_t s,
