@@ -59,7 +59,7 @@ struct tp_context {
     int* he_edge = nullptr;
     int2* vpos = nullptr;
     int2* edge_visit = nullptr;
-    int64_t* visits = nullptr;
+    uint32_t* visits = nullptr;
     int visit_cap = 0;
     int64_t* wline = nullptr;
     unsigned long long* edge_mask = nullptr;
@@ -196,12 +196,12 @@ bool grow_lists(tp_context* c, uint32_t flags, hipError_t* err) {
     bool grown = false;
     *err = hipSuccess;
     if (flags & TP_FLAG_VISIT_OVERFLOW) {
-        const size_t limit = (size_t)1 << 24;  // 7.2 GB of records
+        const size_t limit = (size_t)1 << 24;  // 4.8 GB of records
         if ((size_t)c->visit_cap < limit) {
             size_t vcap = (size_t)c->visit_cap * 2;
             if (vcap > limit) vcap = limit;
             hipFree(c->visits); c->visits = nullptr;
-            if ((*err = dev_alloc(&c->visits, vcap * TP_NLINES * TP_W_WORDS)) != hipSuccess) return false;
+            if ((*err = dev_alloc(&c->visits, vcap * TP_NLINES * TP_REC_DWORDS)) != hipSuccess) return false;
             c->visit_cap = (int)vcap;
             grown = true;
         }
@@ -453,7 +453,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         // (edge, tile) visits: typical edges cross a handful of tiles, a few long ones many
         size_t vcap = (size_t)capE * 24 + (size_t)ntiles * 8;
         if (vcap > ((size_t)1 << 24)) vcap = (size_t)1 << 24;
-        HIP_TRY(c, dev_alloc(&c->visits, vcap * TP_NLINES * TP_W_WORDS));
+        HIP_TRY(c, dev_alloc(&c->visits, vcap * TP_NLINES * TP_REC_DWORDS));
         c->visit_cap = (int)vcap;
         c->capE = capE;
         c->tilelist_elems = 0;

@@ -8,6 +8,8 @@
 #define TP_TILE_H 32
 #define TP_NLINES 9        /* lines per undirected edge: base + 4 moves of either endpoint */
 #define TP_W_WORDS 6       /* int64 per line sum: sum x, n_odd, sum r, sum g, sum b, q */
+#define TP_REC_DWORDS 8    /* per-tile record of a line, 32 bytes: u32 sum x, n_odd, sum r, sum g, sum b, 0, u64 q
+                              (<= 32 rows of <= 16384 columns: every 32-bit field < 2^28) */
 #define TP_T2_WORDS 5      /* int64 per static-table entry: n_odd, sum r, sum g, sum b, q */
 
 // device-side flag bits (tp_device_state::flags)
@@ -56,7 +58,7 @@ struct tp_launch {
     int list_cap;
     int2* edge_visit;         // [NE] (first visit, #tiles of its rectangle)
     unsigned long long* edge_mask;  // [NE] which tiles of the rectangle carry records (<= 64 tiles)
-    int64_t* visits;          // [visit_cap][TP_NLINES][TP_W_WORDS] per-tile line sums
+    uint32_t* visits;         // [visit_cap][TP_NLINES][TP_REC_DWORDS] per-tile line records
     int visit_cap;
     int64_t* wline;           // [NE][TP_NLINES][TP_W_WORDS] line sums over the whole raster
     tp_device_state* state;

@@ -462,14 +462,11 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
                 for (int k = 0; k < TP_T2_WORDS; k++) st[k] = t1[k] - t0[k];
             }
             TP_STAMP_AT(11);
-            if (visit < L.visit_cap) {
-                int64_t* out = L.visits + ((size_t)visit * TP_NLINES + ver) * TP_W_WORDS;
-                out[0] = (int64_t)sx;
-                out[1] = (int64_t)ao + st[0];
-                out[2] = (int64_t)ar + st[1];
-                out[3] = (int64_t)ag + st[2];
-                out[4] = (int64_t)ab + st[3];
-                out[5] = (int64_t)aq + st[4];
+            if (visit < L.visit_cap) {  // 32-byte record: two 16-byte stores
+                uint4* out = reinterpret_cast<uint4*>(L.visits + ((size_t)visit * TP_NLINES + ver) * TP_REC_DWORDS);
+                const uint64_t q = (uint64_t)((int64_t)aq + st[4]);
+                out[0] = make_uint4(sx, (uint32_t)((int64_t)ao + st[0]), (uint32_t)((int64_t)ar + st[1]), (uint32_t)((int64_t)ag + st[2]));
+                out[1] = make_uint4((uint32_t)((int64_t)ab + st[3]), 0u, (uint32_t)q, (uint32_t)(q >> 32));
             }
         }
         TP_STAMP();
@@ -504,45 +501,51 @@ void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t st
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reduce(tp_launch L) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int per_edge = TP_NLINES * TP_W_WORDS;  // 54 consecutive int64 per record
     if (L.margin_px < 2) {
         // work lists are rebuilt every iteration: k_accumulate has consumed them, re-arm them here
         // (with a margin, k_update's vote decides)
         for (int k = gid; k < L.tiles_x * L.tiles_y; k += gridDim.x * blockDim.x) L.tilecount[k] = 0;
         if (gid == 0) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
     }
+    const int per_edge = TP_NLINES * TP_W_WORDS;  // 54 consecutive int64 per edge in wline
     if (gid >= L.NE * per_edge) return;
-    const int e = gid / per_edge, w = gid - e * per_edge;
-    const int2 ev = L.edge_visit[e];  // k_bin keeps first + count inside the visit buffer
+    const int e = gid / per_edge, lw = gid - e * per_edge, line = lw / TP_W_WORDS, w = lw - line * TP_W_WORDS;
+    const int2 ev = L.edge_visit[e];  // k_bin keeps first + count inside the record buffer
     const unsigned long long mask = ev.y > 64 ? ~0ull : L.edge_mask[e];
-    const int64_t* src = L.visits + (size_t)ev.x * per_edge + w;
-    int64_t acc = 0;
+    // records are 8 dwords per line: fields 0..4 are u32, the q field a u64 at dwords 6..7 (its low half is
+    // loaded like a u32 field, the high half by a second load that only the q threads issue)
+    const int stride = TP_NLINES * TP_REC_DWORDS;
+    const uint32_t* src = L.visits + ((size_t)ev.x * TP_NLINES + line) * TP_REC_DWORDS + (w < 5 ? w : 6);
+    const bool wide = w == 5;
+    uint64_t acc = 0;
+    uint32_t acch = 0;
     if (ev.y > 64) {  // long edge, no mask: every tile of its rectangle carries a record
         int k = 0;
         for (; k + 16 <= ev.y; k += 16) {  // sixteen loads in flight per trip
-            int64_t v[16];
+            uint32_t v[16], h[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = src[(size_t)(k + u) * per_edge];
+            for (int u = 0; u < 16; u++) { v[u] = src[(size_t)(k + u) * stride]; h[u] = wide ? src[(size_t)(k + u) * stride + 1] : 0u; }
 #pragma unroll
-            for (int u = 0; u < 16; u++) acc += v[u];
+            for (int u = 0; u < 16; u++) { acc += v[u]; acch += h[u]; }
         }
-        for (; k < ev.y; k++) acc += src[(size_t)k * per_edge];
+        for (; k < ev.y; k++) { acc += src[(size_t)k * stride]; acch += wide ? src[(size_t)k * stride + 1] : 0u; }
     } else {
         // only the tiles that carry records; up to eight loads in flight per trip
         unsigned long long m = mask;
         while (m) {
-            int64_t v[8];
+            uint32_t v[8], h[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int k = m ? __ffsll((long long)m) - 1 : -1;
-                v[u] = k >= 0 ? src[(size_t)k * per_edge] : 0;
+                v[u] = k >= 0 ? src[(size_t)k * stride] : 0u;
+                h[u] = (k >= 0 && wide) ? src[(size_t)k * stride + 1] : 0u;
                 m &= m - 1;
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) acc += v[u];
+            for (int u = 0; u < 8; u++) { acc += v[u]; acch += h[u]; }
         }
     }
-    L.wline[gid] = acc;
+    L.wline[gid] = (int64_t)(acc + ((uint64_t)acch << 32));
 }
 void tp_launch_reduce(const tp_launch& L, hipStream_t s) {
     const int n = L.NE * TP_NLINES * TP_W_WORDS;
