@@ -87,9 +87,11 @@ void tp_launch_static_table(const uint8_t* img, int pitch, int W, int H, int til
 // ------------------------------------------------------------------------------------------------
 // k_bin: 64 edges per 256-thread block, 4 lanes per edge (lanes 0/1 transform the two endpoints)
 // ------------------------------------------------------------------------------------------------
-#define BIN_EDGES 32  // edges per 256-thread block, 8 lanes each (lanes 0/1 transform the endpoints)
+#define BIN_EDGES 32   // edges per workgroup, 8 lanes each (lanes 0/1 transform the endpoints)
+#define BIN_LOG 5      // log2(BIN_EDGES)
+#define BIN_THREADS (BIN_EDGES * 8)
 
-__global__ __launch_bounds__(256) void k_bin(tp_launch L) {
+__global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
     __shared__ int s_excl[BIN_EDGES + 1];  // exclusive scan of rectangle sizes
     __shared__ int s_rect[BIN_EDGES][4];   // tx0, ty0, ntx, #tiles
     __shared__ int s_geom[BIN_EDGES][6];   // base endpoints (Xa, Ya, Xb, Yb) and the moves' reach (dX, dY), 1/256 px
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
     TPB_STAMP();
     const bool rebin = rebin_word != 0;  // lists still valid otherwise (tp_set_margin)
     if (!rebin) return;
-    for (int v = blockIdx.x * 256 + tid; v < L.NP; v += gridDim.x * 256) L.points_binned[v] = L.points[v];
+    for (int v = blockIdx.x * BIN_THREADS + tid; v < L.NP; v += gridDim.x * BIN_THREADS) L.points_binned[v] = L.points[v];
     if (q == 0) {
         int tx0 = 0, ty0 = 0, ntx = 1, cnt = 0;
         if (e < L.NE) {
@@ -176,8 +178,8 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
     const uint32_t base = s_base;
     // ---- one thread per (edge, tile of its rectangle); the block groups its pairs by tile in an LDS
     //      hash table so that each distinct tile costs ONE returning global atomic per block
-    __shared__ int h_key[256], h_cnt[256], h_base[256];
-    for (int pass0 = 0; pass0 < total; pass0 += 256) {
+    __shared__ int h_key[BIN_THREADS], h_cnt[BIN_THREADS], h_base[BIN_THREADS];
+    for (int pass0 = 0; pass0 < total; pass0 += BIN_THREADS) {
         h_key[tid] = -1; h_cnt[tid] = 0;
         __syncthreads();
         const int p = pass0 + tid;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
         if (p < total) {
             int hi = BIN_EDGES;  // largest jj with s_excl[jj] <= p
 #pragma unroll
-            for (int it = 0; it < 5; it++) {
+            for (int it = 0; it < BIN_LOG; it++) {
                 const int mid = (lo + hi) >> 1;
                 if (s_excl[mid] <= p) lo = mid; else hi = mid;
             }
@@ -211,11 +213,11 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
             }
             if (keep) {
                 tile = tyy * L.tiles_x + txx;
-                hslot = (tile * 40503) & 255;
-                while (true) {  // open addressing; at most 256 distinct keys for 256 slots
+                hslot = (tile * 40503) & (BIN_THREADS - 1);
+                while (true) {  // open addressing; at most BIN_THREADS distinct keys for as many slots
                     const int old = atomicCAS(&h_key[hslot], -1, tile);
                     if (old == -1 || old == tile) break;
-                    hslot = (hslot + 1) & 255;
+                    hslot = (hslot + 1) & (BIN_THREADS - 1);
                 }
                 rank = atomicAdd(&h_cnt[hslot], 1);
             }
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void k_bin(tp_launch L) {
 }
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s) {
-    hipLaunchKernelGGL(k_bin, dim3((L.NE + BIN_EDGES - 1) / BIN_EDGES), dim3(256), 0, s, L);
+    hipLaunchKernelGGL(k_bin, dim3((L.NE + BIN_EDGES - 1) / BIN_EDGES), dim3(BIN_THREADS), 0, s, L);
 }
 
 // LDS prefix entry (12 bytes), per row exclusive prefix over the tile's 128 columns, 16-bit fields packed in pairs:
@@ -652,7 +654,8 @@ void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s) {
 // does not depend on arrival order.  The last block to finish knows whether any vertex left its
 // work-list margin and re-arms the lists for the next k_bin.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float rate) {
+#define UPD_THREADS 64  // small workgroups: 13 NT threads are only ~600 waves, spread them over all CUs
+__global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour, float rate) {
     __shared__ int s_last;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     // a work list overflowed in this or an earlier iteration: the line sums are incomplete.  Do not
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(256) void k_update(tp_launch L, int flavour, float 
 }
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s) {
     const int n = 13 * L.NT;
-    hipLaunchKernelGGL(k_update, dim3((n + 255) / 256), dim3(256), 0, s, L, flavour, rate);
+    hipLaunchKernelGGL(k_update, dim3((n + UPD_THREADS - 1) / UPD_THREADS), dim3(UPD_THREADS), 0, s, L, flavour, rate);
 }
 
 // tpose::upload colour replication (source/triangulation.hpp:633-641): col[i*NT + k] = colors[k]
