@@ -311,6 +311,14 @@ inline void computecolors() { check(tp_accumulate(ctx, flavour, swept_slot()), "
 inline void doreset() { computecolors(); }
 inline void doenergy() { check(tp_energy(ctx, flavour), "doenergy"); }
 inline void doshift() { check(tp_shift(ctx, flavour == TP_WARP ? 0.00003f : 0.00005f), "doshift"); }
+// computecolors + doenergy + doshift as ONE fused launch sequence without host round trips (tp_iterate): the
+// same buffers afterwards -- tenergy / colnum / colacc of the sweep at the positions BEFORE the step, points after
+inline void doframe() {
+    tp_params p;
+    tp_default_params(flavour, &p);
+    p.image_slot = swept_slot();
+    check(tp_iterate(ctx, &p, 1), "doframe");
+}
 // the four Buffer::retrieve calls of every frame
 inline void retrieve(triangulation* tr) {
     const int what[4] = {TP_BUF_TENERGY, TP_BUF_PENERGY, TP_BUF_COLNUM, TP_BUF_POINTS};

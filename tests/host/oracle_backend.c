@@ -136,3 +136,20 @@ int tp_retrieve_many(tp_context* c, int n, const int* what, void* const* dst, co
     }
     return TP_OK;
 }
+
+void tp_default_params(int flavour, tp_params* p) {
+    p->flavour = flavour;
+    p->image_slot = flavour == TP_WARP ? TP_IMAGE_B : TP_IMAGE_A;
+    p->rate = flavour == TP_WARP ? 0.00003f : 0.00005f;
+    p->dp = 0.0f;
+}
+
+/* fused grad-iters = the three piecewise steps in the reference's order */
+int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
+    for (int k = 0; k < n_iters; k++) {
+        tp_accumulate(c, p->flavour, p->image_slot);
+        tp_energy(c, p->flavour);
+        tp_shift(c, p->rate);
+    }
+    return TP_OK;
+}

@@ -79,13 +79,18 @@ int main(int argc, char** argv) {
     tpose::upload(&tr, false);
     if (!quiet) std::cout << "Number of Triangles: " << tr.NT << std::endl;
     tpose::computecolors();
+    // The reference's frame is doenergy, doshift, four readbacks, topology work, computecolors (its render pipeline).
+    // The trailing computecolors only feeds the next frame's doenergy, so a frame that follows one without topology
+    // work runs computecolors + doenergy + doshift as one fused device sequence (tpose::doframe) -- same buffers.
+    bool fresh = true;  // colacc / colnum belong to the current triangulation and positions
 
     long frame = 0;
     bool done = false;
     while (!done && frame < maxframes) {
         frame++;
-        tpose::doenergy();
-        tpose::doshift();
+        if (fresh) { tpose::doenergy(); tpose::doshift(); }
+        else tpose::doframe();
+        fresh = false;
         tpose::retrieve(&tr);
 
         bool updated = false;
@@ -154,8 +159,9 @@ int main(int argc, char** argv) {
             const float e = tpose::gettoterr(&tr);
             if (!quiet) std::cout << tr.NT << " " << std::setprecision(16) << e << std::endl;
             tpose::upload(&tr, false);
+            tpose::computecolors();  // a new topology: the sweep cannot ride the next frame's fused sequence
+            fresh = true;            // (upload drops the device lists; keep the reference's order of calls)
         }
-        tpose::computecolors();  // the reference's render pipeline: colours at the new positions
     }
     std::cout << "frames " << frame << " triangles " << tr.NT << " points " << tr.NP << " levels written "
               << (nlevels - (int)exportlist.size()) << std::endl;

@@ -67,9 +67,7 @@ int main(int argc, char** argv) {
     long frame = 0, inlevel = 0;
     while (frame < maxframes) {
         frame++; inlevel++;
-        tpose::doreset();
-        tpose::doenergy();
-        tpose::doshift();
+        tpose::doframe();  // doreset + doenergy + doshift of the reference's frame, fused on the device
         tpose::retrieve(tr);
         if (tpose::geterr(tr) < 1E-6 || inlevel >= levelframes) {
             inlevel = 0;
