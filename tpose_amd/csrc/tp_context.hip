@@ -88,6 +88,12 @@ struct tp_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t* pinned = nullptr;   // host-pinned staging for readbacks (one synchronisation per batch)
     size_t pinned_bytes = 0;
+    uint8_t* up_pinned = nullptr;  // host-pinned staging for tp_upload (copies ride the stream, no wait at the end)
+    size_t up_pinned_bytes = 0;
+    std::vector<uint64_t> hkeys;   // open-addressing table of tp_upload: undirected edge key -> id
+    std::vector<int> hvals;
+    std::vector<uint32_t> hstamp;
+    uint32_t hgen = 0;
 };
 
 namespace {
@@ -319,6 +325,7 @@ int tp_destroy(tp_context* c) {
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->tilecount); hipFree(c->state);
     hipFree(c->t2[0]); hipFree(c->t2[1]); hipFree(c->seg_scratch);
     if (c->pinned) hipHostFree(c->pinned);
+    if (c->up_pinned) hipHostFree(c->up_pinned);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -422,23 +429,30 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         c->capT = capT; c->capP = capP;
         c->tilelist_elems = 0;
     }
-    // undirected edges: every half-edge (o -> d) maps to the edge {min, max} and a direction bit
+    // undirected edges: every half-edge (o -> d) maps to the edge {min, max} and a direction bit.  Flat
+    // open-addressing table kept in the context (uploads follow every topology update of the schedule).
     std::vector<int> he_edge((size_t)3 * NT);
     std::vector<int> edge_uv;  // 2 ints per edge
+    edge_uv.reserve((size_t)6 * NT);
     {
-        std::unordered_map<uint64_t, int> ids;
-        ids.reserve((size_t)3 * NT);
+        size_t cap = 1024;
+        while (cap < (size_t)8 * NT) cap <<= 1;
+        if (c->hkeys.size() != cap) { c->hkeys.assign(cap, 0); c->hvals.assign(cap, 0); c->hstamp.assign(cap, 0); c->hgen = 0; }
+        if (++c->hgen == 0) { std::fill(c->hstamp.begin(), c->hstamp.end(), 0u); c->hgen = 1; }
+        const uint32_t gen = c->hgen;
+        const size_t hmask = cap - 1;
         for (int t = 0; t < NT; t++)
             for (int k = 0; k < 3; k++) {
                 const int o = tris[4 * t + k], d = tris[4 * t + (k + 1) % 3];
                 const int u = o < d ? o : d, v = o < d ? d : o;
                 const uint64_t key = ((uint64_t)(uint32_t)u << 32) | (uint32_t)v;
-                auto it = ids.find(key);
-                if (it == ids.end()) {
-                    it = ids.emplace(key, (int)(edge_uv.size() / 2)).first;
+                size_t slot = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & hmask;
+                while (c->hstamp[slot] == gen && c->hkeys[slot] != key) slot = (slot + 1) & hmask;
+                if (c->hstamp[slot] != gen) {
+                    c->hstamp[slot] = gen; c->hkeys[slot] = key; c->hvals[slot] = (int)(edge_uv.size() / 2);
                     edge_uv.push_back(u); edge_uv.push_back(v);
                 }
-                he_edge[(size_t)3 * t + k] = it->second * 2 + (o != u ? 1 : 0);
+                he_edge[(size_t)3 * t + k] = c->hvals[slot] * 2 + (o != u ? 1 : 0);
             }
     }
     const int NE = (int)(edge_uv.size() / 2);
@@ -473,8 +487,6 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         c->list_cap = (int)(c->tilelist_elems / ntiles);
         if (c->list_cap > c->capE) c->list_cap = c->capE;
     }
-    HIP_TRY(c, hipMemcpy(c->edge_uv, edge_uv.data(), sizeof(int) * 2 * (size_t)NE, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->he_edge, he_edge.data(), sizeof(int) * 3 * (size_t)NT, hipMemcpyHostToDevice));
 
     // vertex -> outgoing half-edge ids (3t+s), the gather form of gradient.cs' scatter
     std::vector<int> off(NP + 1, 0), adj((size_t)3 * NT);
@@ -484,23 +496,46 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         std::vector<int> cur(off.begin(), off.end() - 1);
         for (int t = 0; t < NT; t++) for (int s = 0; s < 3; s++) adj[cur[tris[4 * t + s]]++] = 3 * t + s;
     }
-    HIP_TRY(c, hipMemcpy(c->points, points, sizeof(float) * 2 * (size_t)NP, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->tris, tris, sizeof(int32_t) * 4 * (size_t)NT, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->vtx_off, off.data(), sizeof(int) * (size_t)(NP + 1), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->vtx_adj, adj.data(), sizeof(int) * 3 * (size_t)NT, hipMemcpyHostToDevice));
+    // everything goes through one pinned staging buffer and rides the stream: no wait at the end (the next
+    // upload waits for the stream before it touches the staging buffer again)
+    {
+        struct part { void* dst; const void* src; size_t bytes; };
+        const part parts[] = {
+            {c->edge_uv, edge_uv.data(), sizeof(int) * 2 * (size_t)NE},
+            {c->he_edge, he_edge.data(), sizeof(int) * 3 * (size_t)NT},
+            {c->points, points, sizeof(float) * 2 * (size_t)NP},
+            {c->tris, tris, sizeof(int32_t) * 4 * (size_t)NT},
+            {c->vtx_off, off.data(), sizeof(int) * (size_t)(NP + 1)},
+            {c->vtx_adj, adj.data(), sizeof(int) * 3 * (size_t)NT},
+            {c->colors, colors, colors ? sizeof(int32_t) * 4 * (size_t)NT : 0},
+        };
+        size_t total = 0;
+        for (auto& pt : parts) total += (pt.bytes + 255) & ~(size_t)255;
+        if (total > c->up_pinned_bytes) {
+            if (c->up_pinned) hipHostFree(c->up_pinned);
+            c->up_pinned = nullptr; c->up_pinned_bytes = 0;
+            HIP_TRY(c, hipHostMalloc((void**)&c->up_pinned, total * 2, hipHostMallocDefault));
+            c->up_pinned_bytes = total * 2;
+        }
+        size_t o = 0;
+        for (auto& pt : parts) {
+            if (!pt.bytes) continue;
+            memcpy(c->up_pinned + o, pt.src, pt.bytes);
+            HIP_TRY(c, hipMemcpyAsync(pt.dst, c->up_pinned + o, pt.bytes, hipMemcpyHostToDevice, c->stream));
+            o += (pt.bytes + 255) & ~(size_t)255;
+        }
+    }
     c->NT = NT; c->NP = NP;
     c->have_colors = colors != nullptr;
     if (colors) {
-        HIP_TRY(c, hipMemcpy(c->colors, colors, sizeof(int32_t) * 4 * (size_t)NT, hipMemcpyHostToDevice));
         tp_launch L = make_launch(c, 0, 0.0f);
         tp_launch_replicate_colors(L, c->stream);
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    HIP_TRY(c, hipMemset(c->state, 0, sizeof(tp_device_state)));
+    HIP_TRY(c, hipMemsetAsync(c->state, 0, sizeof(tp_device_state), c->stream));
     c->pending.clear(); c->done_base = 0;
     c->lists_dp = -1.0f;  // forces a rebuild of the work lists at the next use
-    HIP_TRY(c, hipMemset(c->gacc, 0, sizeof(unsigned long long) * 2 * (size_t)c->capP));
+    HIP_TRY(c, hipMemsetAsync(c->gacc, 0, sizeof(unsigned long long) * 2 * (size_t)c->capP, c->stream));
     c->generation++;  // captured graphs bake NT, NP, dp and buffer addresses
     c->uploaded = true; c->accumulated = c->energized = false;
     return TP_OK;
