@@ -18,6 +18,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <algorithm>
 #include <chrono>
 #include <vector>
 
@@ -86,12 +87,18 @@ int main(int argc, char** argv) {
 
     long frame = 0;
     bool done = false;
+    double t_device = 0, t_converged = 0, t_loops = 0;  // where the wall time goes (stderr, with "seconds")
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     while (!done && frame < maxframes) {
         frame++;
+        const auto t0 = now();
         if (fresh) { tpose::doenergy(); tpose::doshift(); }
         else tpose::doframe();
         fresh = false;
         tpose::retrieve(&tr);
+        const auto t1 = now();
+        t_device += secs(t0, t1);
 
         bool updated = false;
         if (tpose::geterr(&tr) < 1E-4) {
@@ -105,26 +112,28 @@ int main(int argc, char** argv) {
                 exportlist.pop_back();
             }
 
-            // half-edges ordered by the energy of their triangle pair (ties are dropped, like the
-            // reference's std::set keyed on energy alone)
-            struct by_energy {
-                bool operator()(const std::pair<int, float>& l, const std::pair<int, float>& r) const { return l.second > r.second; }
-            };
-            std::set<std::pair<int, float>, by_energy> ranked;
+            // half-edges ordered by the energy of their triangle pair, highest first; of several with EQUAL energy
+            // only the first one inserted survives -- the reference keeps them in a std::set keyed on the energy
+            // alone.  Same order and same survivors from a stable sort + unique (a set of 3 NT nodes per
+            // convergence step is the costliest host work of the schedule).
+            std::vector<std::pair<int, float>> ranked;
+            ranked.reserve(tr.triangles.size() * 3);
             for (int t = 0; t < (int)tr.triangles.size(); t++)
                 for (int k = 0; k < 3; k++) {
                     const int w = tr.halfedges[3 * t + k];
-                    if (w >= 0) ranked.emplace(3 * t + k, tpose::terr[t] + tpose::terr[w / 3]);
+                    if (w >= 0) ranked.emplace_back(3 * t + k, tpose::terr[t] + tpose::terr[w / 3]);
                 }
-            std::set<int> locked;            // half-edges whose triangle already takes part in a flip
-            std::map<int, float> chosen;     // half-edge -> pair energy before the flip
+            std::stable_sort(ranked.begin(), ranked.end(), [](const std::pair<int, float>& l, const std::pair<int, float>& r) { return l.second > r.second; });
+            ranked.erase(std::unique(ranked.begin(), ranked.end(), [](const std::pair<int, float>& l, const std::pair<int, float>& r) { return l.second == r.second; }), ranked.end());
+            std::vector<char> locked(tr.halfedges.size(), 0);  // half-edges whose triangle already takes part in a flip
+            std::map<int, float> chosen;                        // half-edge -> pair energy before the flip
             for (auto& h : ranked) {
-                if (locked.count(h.first)) continue;
+                if (locked[h.first]) continue;
                 const int w = tr.halfedges[h.first];
                 if (w < 0) continue;
-                if (locked.count(w)) continue;
+                if (locked[w]) continue;
                 chosen[h.first] = h.second;
-                for (int k = 0; k < 3; k++) { locked.insert(3 * (h.first / 3) + k); locked.insert(3 * (w / 3) + k); }
+                for (int k = 0; k < 3; k++) { locked[3 * (h.first / 3) + k] = 1; locked[3 * (w / 3) + k] = 1; }
             }
             for (auto& h : chosen) tr.flip(h.first, 0.0f);
             tpose::upload(&tr, false);
@@ -141,6 +150,8 @@ int main(int argc, char** argv) {
             const int worst = tpose::maxerrid(&tr);
             if (worst >= 0 && tr.split(worst)) updated = true;
         }
+        const auto t2 = now();
+        t_converged += secs(t1, t2);
 
         for (size_t t = 0; t < (size_t)tr.NT; t++)
             if (tr.boundary((int)t) == 3)
@@ -162,9 +173,12 @@ int main(int argc, char** argv) {
             tpose::computecolors();  // a new topology: the sweep cannot ride the next frame's fused sequence
             fresh = true;            // (upload drops the device lists; keep the reference's order of calls)
         }
+        t_loops += secs(t2, now());
     }
     std::cout << "frames " << frame << " triangles " << tr.NT << " points " << tr.NP << " levels written "
               << (nlevels - (int)exportlist.size()) << std::endl;
+    std::cerr << "frame device calls + readbacks " << t_device << " s, convergence steps (flip set, split) " << t_converged
+              << " s, per-frame host loops (prune, angle, collapse) + re-upload " << t_loops << " s" << std::endl;
     std::cerr << "seconds " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
     tpose::quit();
     return 0;
