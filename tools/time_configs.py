@@ -90,6 +90,34 @@ def run_cold(W, H, NT, nctx, reps):
         c.close()
 
 
+def run_concurrent(W, H, NT, nctx, steps):
+    """nctx independent problems on ONE GPU, each in its own context and stream (the batch configuration has more
+    pairs than GPUs to spare): the single-problem path is latency-bound, so they overlap"""
+    ctxs = []
+    for k in range(nctx):
+        img, pts, tris, he, ratio = synth.workload(W, H, NT, seed=1234 + k)
+        c = capi.Context(0, W, H)
+        c.set_image(capi.IMAGE_A, img)
+        c.upload(pts, tris, None)
+        ctxs.append(c)
+    p = capi.default_params(capi.TRIANGULATE)
+    for c in ctxs:
+        c.iterate(p, 64)
+    for c in ctxs:
+        c.synchronize()
+    t0 = time.perf_counter()
+    for start in range(0, steps, 256):  # interleave the enqueues so that no stream runs dry
+        for c in ctxs:
+            c.iterate(p, 256)
+    for c in ctxs:
+        c.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps(dict(config="%d concurrent contexts on one GPU, %dx%d / %d each" % (nctx, W, H, NT),
+                          aggregate_tri_iters_per_s=nctx * NT * steps / dt, us_per_iter_per_context=dt / steps * 1e6)), flush=True)
+    for c in ctxs:
+        c.close()
+
+
 if __name__ == "__main__":
     run("headline 2048^2 / 3000", 2048, 2048, 3000, capi.TRIANGULATE, 2048)
     run("warp flavour 2048^2 / 3000", 2048, 2048, 3000, capi.WARP, 2048)
@@ -99,3 +127,5 @@ if __name__ == "__main__":
     run_readback(2048, 2048, 3000, 512)
     run_cold(2048, 2048, 3000, 18, 4)
     run_cold(4096, 4096, 12000, 5, 8)
+    run_concurrent(2048, 2048, 3000, 2, 2048)
+    run_concurrent(2048, 2048, 3000, 4, 2048)
