@@ -4,6 +4,8 @@ Integer buffers (`colnum`, `colacc`, `tenergy`, `gradient`, moments) must be ide
 positions are float32 produced by the same sequence of IEEE operations (shift.cs:45) and must be
 BIT-identical too (tolerance 0 ulp, stated here; see DESIGN.md "Numerics").
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -374,3 +376,35 @@ def test_batched_readback_equals_single_readbacks():
         assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
     assert not many[1].any()  # penergy is dead in the reference: always zero
     ctx.close()
+
+
+def test_fused_path_clamps_vertices_no_triangle_uses():
+    """shift.cs runs for every vertex i >= 4: a vertex outside the domain that no triangle references is still
+    clamped to the domain edge (found by tools/soak.py)"""
+    W, H = 233, 101
+    img = synth.voronoi_raster(W, H, seed=11, sites=9)
+    ratio = float(np.float32(W) / np.float32(H))
+    pts = np.array([[-ratio, -1], [-ratio, 1], [ratio, -1], [ratio, 1], [0.1, 0.2], [0.5, -0.3], [-0.4, 0.1],
+                    [3.0, 0.5], [-0.2, -7.0], [0.3, 0.3]], np.float32)   # 7, 8 outside and unused; 9 inside and unused
+    tris = np.array([[4, 5, 6, 0], [0, 4, 6, 0]], np.int32)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    for flavour in (0, 1):
+        colors = np.array([[10, 20, 30, 1], [200, 100, 50, 1]], np.int32) if flavour else None
+        ctx.upload(pts, tris, colors)
+        p = capi.default_params(flavour, image_slot=capi.IMAGE_A)
+        ctx.iterate(p, 3)
+        ref = O.iterate(img, pts, tris, flavour, ratio, RATE[flavour], 3, colors=colors, literal=False)
+        got = ctx.retrieve(capi.BUF_POINTS)
+        assert np.array_equal(got.view(np.uint32), ref["points"].view(np.uint32))
+        assert got[7, 0] == np.float32(ratio) and got[8, 1] == np.float32(-1.0) and np.array_equal(got[9], pts[9])
+    ctx.close()
+
+
+def test_randomised_soak_sample():
+    """a slice of tools/soak.py (random sizes, soups, grids, flavours, dp, margins) as a regular test"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "36", "99"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -719,6 +719,15 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
             }
         }
     }
+    // vertices no triangle uses get no arrival, but shift.cs still clamps them to the domain (shift.cs:25-43
+    // runs for every i in [4, NPoints); their gradient is never touched)
+    if (gid >= 4 && gid < L.NP && L.vtx_off[gid + 1] == L.vtx_off[gid]) {
+        float2 q = L.points[gid];
+        const float R = L.vw.ratio;
+        q.x = q.x <= -R ? -R : (q.x >= R ? R : q.x);
+        q.y = q.y <= -1.0f ? -1.0f : (q.y >= 1.0f ? 1.0f : q.y);
+        L.points[gid] = q;
+    }
     if (L.margin_px < 2) return;  // no margin: k_reduce re-arms the lists every iteration
     need = __syncthreads_or(need);
     if (threadIdx.x == 0) {
@@ -737,7 +746,7 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
     }
 }
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s) {
-    const int n = 13 * L.NT;
+    const int n = 13 * L.NT > L.NP ? 13 * L.NT : L.NP;  // one thread per variant, and at least one per vertex
     hipLaunchKernelGGL(k_update, dim3((n + UPD_THREADS - 1) / UPD_THREADS), dim3(UPD_THREADS), 0, s, L, flavour, rate);
 }
 
