@@ -18,7 +18,11 @@ for case in range(cases):
     W, H = int(rng.integers(17, 700)), int(rng.integers(9, 420))
     if case % 9 == 0:
         W, H = int(rng.integers(1000, 2300)), int(rng.integers(600, 1300))
+    if case % 11 == 5:
+        W, H = int(rng.integers(1, 17)), int(rng.integers(1, 40))  # smaller than one tile
     ratio = float(np.float32(W) / np.float32(H))
+    if case % 7 == 3:
+        ratio = float(np.float32(rng.choice([0.5, 1.0, 1.7777])))  # tpose::RATIO need not be the raster's aspect
     img = synth.voronoi_raster(W, H, seed=int(rng.integers(1 << 30)), sites=int(rng.integers(3, 40)))
     kind = case % 3
     if kind == 0:  # soup
@@ -35,6 +39,7 @@ for case in range(cases):
     flavour = int(rng.integers(0, 2))
     dp = float(rng.choice([0.0, 0.05, 0.011, 0.2]))  # 0: the reference law
     ctx = capi.Context(0, W, H)
+    ctx.set_ratio(ratio)
     ctx.set_image(capi.IMAGE_A, img)
     imgB = synth.displaced_raster(img, amp=5.0) if flavour else None
     colors = None
@@ -58,11 +63,22 @@ for case in range(cases):
     ctx.set_margin(margin)
     params = capi.default_params(flavour)
     params.dp = dp
+    rate = float(np.float32(rng.choice([params.rate, 1e-5, 2e-4])))
+    params.rate = rate
     ctx.iterate(params, iters)
-    ref = O.iterate(sweep, pts, tris, flavour, ratio, 0.00003 if flavour else 0.00005, iters, colors=colors, dp_=dpe, literal=False)
+    ref = O.iterate(sweep, pts, tris, flavour, ratio, rate, iters, colors=colors, dp_=dpe, literal=False)
     ok &= np.array_equal(ctx.retrieve(capi.BUF_TENERGY), ref["ten"]) and np.array_equal(ctx.retrieve(capi.BUF_COLNUM), ref["cn"])
     ok &= np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
     ok &= np.array_equal(ctx.retrieve(capi.BUF_GRADIENT), ref["gr"].reshape(-1, 2))
+    # the piecewise calls in the reference's order give the same state
+    ctx.upload(pts, tris, colors)
+    ctx.set_margin(0)
+    for k in range(iters):
+        ctx.accumulate(flavour, capi.IMAGE_B if flavour else capi.IMAGE_A)
+        ctx.energy(flavour)
+        ctx.shift(rate)
+    ok &= np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
+    ok &= np.array_equal(ctx.retrieve(capi.BUF_TENERGY), ref["ten"]) and np.array_equal(ctx.retrieve(capi.BUF_GRADIENT), ref["gr"].reshape(-1, 2))
     ctx.close()
     if not ok:
         bad += 1
