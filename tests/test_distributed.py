@@ -72,3 +72,49 @@ def test_two_way_warp_world_size_2_gloo(tmp_path):
     t = hostlib.Triangulation()
     assert t.read(str(tmp_path / "A.tri.warp")) and t.read(str(tmp_path / "A.tri.warp"))
     assert t.NT == 48 and not np.array_equal(t.points, t.originpoints)
+
+
+import pytest  # noqa: E402
+
+ROOT = os.path.dirname(HERE)
+
+
+def _torchrun(args, nproc, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port())] + args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """the driver's launch line for N > 1 (one rank per GPU over RCCL), here with both ranks on the one GPU of the
+    test box and gloo for the two collectives: one JSON line from rank 0, whole-job aggregate, weak scaling"""
+    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "256", "--warmup", "32", "--backend", "gloo", "--share-gpu"], 2)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 256 and line["warmup"] == 32
+    assert line["value"] > 0 and abs(line["value"] - 3000 * 256 * 2 / (line["ms_per_step"] * 256e-3)) < 1e-6 * line["value"]
+    assert "cpu_baseline" not in line and line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_two_way_warp_two_ranks_hip_engine(tmp_path):
+    """tpose_amd.warp_dist end to end with the HIP engine: one direction per rank, per-level exchange"""
+    W, H = 160, 120
+    ratio = float(np.float32(W) / np.float32(H))
+    A = synth.voronoi_raster(W, H, seed=5, sites=6, noise=2)
+    B = synth.displaced_raster(A, amp=3.0)
+    for name, img in (("A", A), ("B", B)):
+        with open(str(tmp_path / (name + ".ppm")), "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (W, H))
+            f.write(np.ascontiguousarray(img[:, :, :3]).tobytes())
+        write_stack(str(tmp_path / (name + ".tri")), img, ratio, [(3, 2), (6, 4)])
+    r = _torchrun(["-m", "tpose_amd.warp_dist", "--ia", str(tmp_path / "A.ppm"), "--ib", str(tmp_path / "B.ppm"), "--ta", str(tmp_path / "A.tri"),
+                   "--tb", str(tmp_path / "B.tri"), "--frames", "64", "--backend", "gloo", "--share-gpu"], 2)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "levels: 2" in r.stdout
+    for name in ("A.tri", "B.tri"):
+        assert os.path.getsize(str(tmp_path / (name + ".warp"))) == os.path.getsize(str(tmp_path / name))
