@@ -62,7 +62,6 @@ struct tp_context {
     uint32_t* visits = nullptr;
     int visit_cap = 0;
     int64_t* wline = nullptr;
-    unsigned long long* edge_mask = nullptr;
     int64_t* t2[2] = {nullptr, nullptr};   // static per-image tables
     uint32_t* seg_scratch = nullptr;
     tp_device_state* state = nullptr;
@@ -130,11 +129,11 @@ void drop_graphs(tp_context* c) {
 void free_triangulation(tp_context* c) {
     hipFree(c->points); hipFree(c->points_binned); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
     hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->edge_visit); hipFree(c->visits);
-    hipFree(c->wline); hipFree(c->edge_mask); hipFree(c->tilelist);
+    hipFree(c->wline); hipFree(c->tilelist);
     hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
     c->points = nullptr; c->points_binned = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
     c->edge_uv = nullptr; c->he_edge = nullptr; c->vpos = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
-    c->wline = nullptr; c->edge_mask = nullptr; c->tilelist = nullptr; c->capE = 0;
+    c->wline = nullptr; c->tilelist = nullptr; c->capE = 0;
     c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
     c->capT = c->capP = 0;
 }
@@ -153,7 +152,7 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.vtx_off = c->vtx_off; L.vtx_adj = c->vtx_adj;
     L.tilecount = c->tilecount; L.tilelist = c->tilelist; L.list_cap = c->list_cap;
     L.edge_uv = c->edge_uv; L.he_edge = c->he_edge; L.vpos = c->vpos; L.NE = c->NE;
-    L.edge_visit = c->edge_visit; L.edge_mask = c->edge_mask; L.visits = c->visits; L.visit_cap = c->visit_cap; L.wline = c->wline;
+    L.edge_visit = c->edge_visit; L.visits = c->visits; L.visit_cap = c->visit_cap; L.wline = c->wline;
     L.t2 = c->t2[slot];
     L.state = c->state;
     L.ten = c->ten; L.cn = c->cn; L.ca = c->ca; L.gr = c->gr; L.moments = c->moments;
@@ -457,12 +456,11 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
     }
     const int NE = (int)(edge_uv.size() / 2);
     if (NE > c->capE) {
-        hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->wline); hipFree(c->edge_mask);
-        c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr; c->wline = nullptr; c->edge_mask = nullptr;
+        hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->wline);
+        c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr; c->wline = nullptr;
         const int capE = NE + NE / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->edge_uv, capE));
         HIP_TRY(c, dev_alloc(&c->edge_visit, capE));
-        HIP_TRY(c, dev_alloc(&c->edge_mask, capE));
         HIP_TRY(c, dev_alloc(&c->wline, (size_t)capE * TP_NLINES * TP_W_WORDS));
         // (edge, tile) visits: typical edges cross a handful of tiles, a few long ones many
         size_t vcap = (size_t)capE * 24 + (size_t)ntiles * 8;

@@ -56,8 +56,7 @@ struct tp_launch {
     int* tilecount;           // [tiles]
     tp_list_entry* tilelist;  // [tiles * list_cap]
     int list_cap;
-    int2* edge_visit;         // [NE] (first visit, #tiles of its rectangle)
-    unsigned long long* edge_mask;  // [NE] which tiles of the rectangle carry records (<= 64 tiles)
+    int2* edge_visit;         // [NE] (first record, #records = tiles a line of the edge can cross)
     uint32_t* visits;         // [visit_cap][TP_NLINES][TP_REC_DWORDS] per-tile line records
     int visit_cap;
     int64_t* wline;           // [NE][TP_NLINES][TP_W_WORDS] line sums over the whole raster

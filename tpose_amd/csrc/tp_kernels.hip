@@ -97,7 +97,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
     __shared__ int s_geom[BIN_EDGES][6];   // base endpoints (Xa, Ya, Xb, Yb) and the moves' reach (dX, dY), 1/256 px
     __shared__ int s_uv[BIN_EDGES][2];
     __shared__ int2 s_pos[BIN_EDGES][2][5];
-    __shared__ unsigned long long s_keep[BIN_EDGES];  // tiles of the rectangle some line can cross
+    __shared__ int s_kept[BIN_EDGES], s_rank[BIN_EDGES], s_first[BIN_EDGES + 1];  // tiles some line can cross: count, arrivals, scan
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x;
     const uint32_t rebin_word = L.state->rebin_req;  // consumed late: the loads below do not wait for it
@@ -148,7 +148,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
         }
         s_rect[j][0] = tx0; s_rect[j][1] = ty0; s_rect[j][2] = ntx; s_rect[j][3] = cnt;
         s_geom[j][4] = dX + 256 * L.margin_px; s_geom[j][5] = dY + 256 * L.margin_px;
-        s_keep[j] = 0ull;
     }
     __syncthreads();
     if (tid < BIN_EDGES) {  // wave 0: inclusive scan of the rectangle sizes by shuffles
@@ -160,8 +159,62 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
         }
         s_excl[tid + 1] = inc;
         if (tid == 0) s_excl[0] = 0;
+        s_kept[tid] = 0; s_rank[tid] = 0;
+    }
+    __syncthreads();
+    TPB_STAMP();
+    const int total = s_excl[BIN_EDGES];
+
+    // (edge, tile of its rectangle) -> which edge, which tile, and whether any of the nine lines can cross it.
+    // Every sample (row, crossing column) of the nine lines lies within the base segment (+) box(dX, dY) (+)
+    // [0, 1 px) in x: a tile strictly on one side of that band is never crossed.  Tiles of the first / last
+    // tile column also receive the clamped columns: kept.
+    auto pair_of = [&](int p, int& lo, int& tile) -> bool {
+        int hi = BIN_EDGES;  // largest jj with s_excl[jj] <= p
+        lo = 0;
+#pragma unroll
+        for (int it = 0; it < BIN_LOG; it++) {
+            const int mid = (lo + hi) >> 1;
+            if (s_excl[mid] <= p) lo = mid; else hi = mid;
+        }
+        const int k = p - s_excl[lo], ntx = s_rect[lo][2];
+        const int ky = k / ntx, kx = k - ky * ntx;
+        const int txx = s_rect[lo][0] + kx, tyy = s_rect[lo][1] + ky;
+        tile = tyy * L.tiles_x + txx;
+        const int64_t a = (int64_t)s_geom[lo][3] - s_geom[lo][1], b = -((int64_t)s_geom[lo][2] - s_geom[lo][0]);
+        const int64_t slack = (a < 0 ? -a : a) * ((int64_t)s_geom[lo][4] + 256) + (b < 0 ? -b : b) * (int64_t)s_geom[lo][5];
+        const int64_t x0 = 256LL * (txx * TW) + 128, x1 = 256LL * min(txx * TW + TW - 1, L.vw.W - 1) + 128;
+        const int64_t y0 = 256LL * (tyy * TH) + 128, y1 = 256LL * min(tyy * TH + TH - 1, L.vw.H - 1) + 128;
+        const int64_t ex0 = a * (x0 - s_geom[lo][0]), ex1 = a * (x1 - s_geom[lo][0]);
+        const int64_t ey0 = b * (y0 - s_geom[lo][1]), ey1 = b * (y1 - s_geom[lo][1]);
+        const int64_t emin = min(ex0, ex1) + min(ey0, ey1), emax = max(ex0, ex1) + max(ey0, ey1);
+        const bool edge_col = txx == 0 || txx == L.tiles_x - 1;
+        return edge_col || !(emin > slack || emax < -slack);
+    };
+
+    // ---- pass A: how many tiles every edge keeps (records are allocated for those only, contiguously per edge)
+    const bool one_pass = total <= BIN_THREADS;  // the common case: the pair stays in registers for pass B
+    int lo1 = 0, tile1 = -1;
+    bool keep1 = false;
+    for (int pass0 = 0; pass0 < total; pass0 += BIN_THREADS) {
+        const int p = pass0 + tid;
+        if (p < total) {
+            keep1 = pair_of(p, lo1, tile1);
+            if (keep1) atomicAdd(&s_kept[lo1], 1);
+        }
+    }
+    __syncthreads();
+    if (tid < BIN_EDGES) {
+        int inc = s_kept[tid];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(inc, o);
+            if (tid >= o) inc += v;
+        }
+        s_first[tid + 1] = inc;
+        if (tid == 0) s_first[0] = 0;
         if (tid == BIN_EDGES - 1) {
-            // visit ids: every block owns a slice of the lower half of the record buffer (no global
+            // record ids: every block owns a slice of the lower half of the record buffer (no global
             // atomic on the common path); a block with long edges draws from the shared upper half
             const uint32_t half = (uint32_t)L.visit_cap / 2, slice = half / gridDim.x;
             uint32_t base = blockIdx.x * slice;
@@ -173,46 +226,22 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
         }
     }
     __syncthreads();
-    TPB_STAMP();
-    const int total = s_excl[BIN_EDGES];
     const uint32_t base = s_base;
-    // ---- one thread per (edge, tile of its rectangle); the block groups its pairs by tile in an LDS
-    //      hash table so that each distinct tile costs ONE returning global atomic per block
+
+    // ---- pass B: the block groups its kept pairs by tile in an LDS hash table so that each distinct tile
+    //      costs ONE returning global atomic per block; record slot = the edge's first + its arrival rank
     __shared__ int h_key[BIN_THREADS], h_cnt[BIN_THREADS], h_base[BIN_THREADS];
     for (int pass0 = 0; pass0 < total; pass0 += BIN_THREADS) {
         h_key[tid] = -1; h_cnt[tid] = 0;
         __syncthreads();
         const int p = pass0 + tid;
-        int tile = -1, lo = 0, hslot = 0, rank = 0;
+        int tile = -1, lo = 0, hslot = 0, rank = 0, visit = 0;
         if (p < total) {
-            int hi = BIN_EDGES;  // largest jj with s_excl[jj] <= p
-#pragma unroll
-            for (int it = 0; it < BIN_LOG; it++) {
-                const int mid = (lo + hi) >> 1;
-                if (s_excl[mid] <= p) lo = mid; else hi = mid;
-            }
-            const int k = p - s_excl[lo], ntx = s_rect[lo][2];
-            const int ky = k / ntx, kx = k - ky * ntx;
-            const int txx = s_rect[lo][0] + kx, tyy = s_rect[lo][1] + ky;
-            const bool dense = s_rect[lo][3] > 64;  // long edges: no culling, no mask
-            bool keep = true;
-            if (!dense) {
-                // Every sample (row, crossing column) of the nine lines lies within the base segment
-                // (+) box(dX, dY) (+) [0, 1 px) in x.  A tile strictly on one side of that band is never
-                // crossed.  Tiles of the first/last tile column also receive the clamped columns: kept.
-                const int64_t a = (int64_t)s_geom[lo][3] - s_geom[lo][1], b = -((int64_t)s_geom[lo][2] - s_geom[lo][0]);
-                const int64_t slack = (a < 0 ? -a : a) * ((int64_t)s_geom[lo][4] + 256) + (b < 0 ? -b : b) * (int64_t)s_geom[lo][5];
-                const int64_t x0 = 256LL * (txx * TW) + 128, x1 = 256LL * min(txx * TW + TW - 1, L.vw.W - 1) + 128;
-                const int64_t y0 = 256LL * (tyy * TH) + 128, y1 = 256LL * min(tyy * TH + TH - 1, L.vw.H - 1) + 128;
-                const int64_t ex0 = a * (x0 - s_geom[lo][0]), ex1 = a * (x1 - s_geom[lo][0]);
-                const int64_t ey0 = b * (y0 - s_geom[lo][1]), ey1 = b * (y1 - s_geom[lo][1]);
-                const int64_t emin = min(ex0, ex1) + min(ey0, ey1), emax = max(ex0, ex1) + max(ey0, ey1);
-                const bool edge_col = txx == 0 || txx == L.tiles_x - 1;
-                keep = edge_col || !(emin > slack || emax < -slack);
-                if (keep) atomicOr(&s_keep[lo], 1ull << k);
-            }
+            bool keep;
+            if (one_pass) { keep = keep1; lo = lo1; tile = tile1; }
+            else keep = pair_of(p, lo, tile);
             if (keep) {
-                tile = tyy * L.tiles_x + txx;
+                visit = (int)base + s_first[lo] + atomicAdd(&s_rank[lo], 1);
                 hslot = (tile * 40503) & (BIN_THREADS - 1);
                 while (true) {  // open addressing; at most BIN_THREADS distinct keys for as many slots
                     const int old = atomicCAS(&h_key[hslot], -1, tile);
@@ -220,7 +249,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
                     hslot = (hslot + 1) & (BIN_THREADS - 1);
                 }
                 rank = atomicAdd(&h_cnt[hslot], 1);
-            }
+            } else
+                tile = -1;
         }
         __syncthreads();
         if (h_key[tid] >= 0) h_base[tid] = atomicAdd(&L.tilecount[h_key[tid]], h_cnt[tid]);
@@ -229,7 +259,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
             const int slot = h_base[hslot] + rank;
             if (slot < L.list_cap) {
                 tp_list_entry en;
-                en.visit = (int)base + p;
+                en.visit = visit;
                 en.edge = blockIdx.x * BIN_EDGES + lo;
                 en.u = s_uv[lo][0]; en.v = s_uv[lo][1];
 #pragma unroll
@@ -241,14 +271,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
         __syncthreads();
     }
     TPB_STAMP();
-    __syncthreads();
     TPB_STAMP();
     if (q == 0 && e < L.NE) {
-        const int cnt = s_rect[j][3];
-        const long long first = (long long)base + s_excl[j];
-        const bool fits = first + cnt <= (long long)L.visit_cap;  // overflow is flagged; k_reduce must stay in bounds
-        L.edge_visit[e] = make_int2(fits ? (int)first : 0, fits ? cnt : 0);
-        L.edge_mask[e] = !fits ? 0ull : cnt > 64 ? ~0ull : s_keep[j];
+        const long long first = (long long)base + s_first[j];
+        const bool fits = first + s_kept[j] <= (long long)L.visit_cap;  // overflow is flagged; k_reduce must stay in bounds
+        L.edge_visit[e] = make_int2(fits ? (int)first : 0, fits ? s_kept[j] : 0);
     }
 }
 
@@ -512,8 +539,7 @@ __global__ __launch_bounds__(256) void k_reduce(tp_launch L) {
     const int per_edge = TP_NLINES * TP_W_WORDS;  // 54 consecutive int64 per edge in wline
     if (gid >= L.NE * per_edge) return;
     const int e = gid / per_edge, lw = gid - e * per_edge, line = lw / TP_W_WORDS, w = lw - line * TP_W_WORDS;
-    const int2 ev = L.edge_visit[e];  // k_bin keeps first + count inside the record buffer
-    const unsigned long long mask = ev.y > 64 ? ~0ull : L.edge_mask[e];
+    const int2 ev = L.edge_visit[e];  // first record and number of records (tiles a line of this edge can cross)
     // records are 8 dwords per line: fields 0..4 are u32, the q field a u64 at dwords 6..7 (its low half is
     // loaded like a u32 field, the high half by a second load that only the q threads issue)
     const int stride = TP_NLINES * TP_REC_DWORDS;
@@ -521,31 +547,25 @@ __global__ __launch_bounds__(256) void k_reduce(tp_launch L) {
     const bool wide = w == 5;
     uint64_t acc = 0;
     uint32_t acch = 0;
-    if (ev.y > 64) {  // long edge, no mask: every tile of its rectangle carries a record
-        int k = 0;
-        for (; k + 16 <= ev.y; k += 16) {  // sixteen loads in flight per trip
-            uint32_t v[16], h[16];
+    int k = 0;
+    for (; k + 16 <= ev.y; k += 16) {  // long edges: sixteen loads in flight per trip
+        uint32_t v[16], h[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) { v[u] = src[(size_t)(k + u) * stride]; h[u] = wide ? src[(size_t)(k + u) * stride + 1] : 0u; }
+        for (int u = 0; u < 16; u++) { v[u] = src[(size_t)(k + u) * stride]; h[u] = wide ? src[(size_t)(k + u) * stride + 1] : 0u; }
 #pragma unroll
-            for (int u = 0; u < 16; u++) { acc += v[u]; acch += h[u]; }
+        for (int u = 0; u < 16; u++) { acc += v[u]; acch += h[u]; }
+    }
+    while (k < ev.y) {  // the usual few records: up to eight loads in flight
+        uint32_t v[8], h[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool on = k + u < ev.y;
+            v[u] = on ? src[(size_t)(k + u) * stride] : 0u;
+            h[u] = (on && wide) ? src[(size_t)(k + u) * stride + 1] : 0u;
         }
-        for (; k < ev.y; k++) { acc += src[(size_t)k * stride]; acch += wide ? src[(size_t)k * stride + 1] : 0u; }
-    } else {
-        // only the tiles that carry records; up to eight loads in flight per trip
-        unsigned long long m = mask;
-        while (m) {
-            uint32_t v[8], h[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int k = m ? __ffsll((long long)m) - 1 : -1;
-                v[u] = k >= 0 ? src[(size_t)k * stride] : 0u;
-                h[u] = (k >= 0 && wide) ? src[(size_t)k * stride + 1] : 0u;
-                m &= m - 1;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) { acc += v[u]; acch += h[u]; }
-        }
+        for (int u = 0; u < 8; u++) { acc += v[u]; acch += h[u]; }
+        k += 8;
     }
     L.wline[gid] = (int64_t)(acc + ((uint64_t)acch << 32));
 }
