@@ -890,6 +890,13 @@ int tp_debug_tilecount(tp_context* c, int* out, int n) {
     return TP_OK;
 }
 
+// debug: raw bytes from the start of the record buffer (the probes write there)
+int tp_debug_read_visits(tp_context* c, void* out, size_t bytes) {
+    if (!c || !out) return TP_ERR_INVALID;
+    hipStreamSynchronize(c->stream);
+    return hipMemcpy(out, c->visits, bytes, hipMemcpyDeviceToHost) == hipSuccess ? TP_OK : TP_ERR_HIP;
+}
+
 // launch-overhead probe: n back-to-back launches of an (almost) empty kernel in k_accumulate's shape
 int tp_debug_null_launch(tp_context* c, int mode, int blocks, int threads, int lds, int n, double* us) {
     if (!c || !us || !c->uploaded) return TP_ERR_STATE;

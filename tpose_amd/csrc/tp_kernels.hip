@@ -851,6 +851,13 @@ __global__ __launch_bounds__(ACC_THREADS) void k_probe(const uint4* src, uint4* 
         uint4 a = make_uint4(0, 0, 0, 0);
         for (int k = gid; k < n16; k += gridDim.x * blockDim.x) { const uint4 v = src[k]; a.x ^= v.x; a.y ^= v.y; a.z ^= v.z; a.w ^= v.w; }
         if ((a.x ^ a.y ^ a.z ^ a.w) == 0x12345678u) dst[gid] = a;
+    } else if (mode == 5) {  // where do the waves of a workgroup land?  HW_ID: wave, SIMD, CU, SH, SE (+ XCC_ID)
+        if ((threadIdx.x & 63) == 0) {
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID, all 32 bits
+            const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
+            reinterpret_cast<uint2*>(dst)[blockIdx.x * 16 + (threadIdx.x >> 6)] = make_uint2(hw, xcc);
+        }
+        __builtin_amdgcn_s_sleep(100);
     } else if (mode == 4) {
         PP[threadIdx.x] = make_uint4(gid, 0, 0, 0);
         __syncthreads();
