@@ -5,9 +5,9 @@ export TMPDIR=/tmp
 O=gpurun_out/final
 rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python bench.py --no-cpu-baseline > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python bench.py --no-cpu-baseline --no-pmc > $O/kt.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- python bench.py --steps 64 --warmup 16 --no-cpu-baseline > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- python bench.py --steps 64 --warmup 16 --no-cpu-baseline --no-pmc > $O/pmc_$c.log 2>&1
 done
 python tools/time_configs.py > $O/configs.jsonl 2> $O/configs.err
 python tools/acc_timeline.py > $O/acc_timeline.json 2> $O/acc_timeline.err
