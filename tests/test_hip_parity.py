@@ -408,3 +408,20 @@ def test_randomised_soak_sample():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "36", "99"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_cached_graphs_follow_ratio_and_dp():
+    """captured graphs bake RATIO and dp: changing tpose::RATIO, or the dp of the params, between two tp_iterate
+    calls must not replay a stale graph"""
+    W, H = 300, 200
+    img, imgB, pts, tris, ratio, colors = case(W, H, (15, 5))
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    for r, dp in ((ratio, 0.0), (1.2, 0.0), (1.2, 0.013), (ratio, 0.013)):
+        ctx.set_ratio(r)
+        ctx.upload(pts, tris, None)
+        p = capi.default_params(capi.TRIANGULATE, dp=dp)
+        ctx.iterate(p, 32)  # two graph replays
+        ref = O.iterate(img, pts, tris, 0, r, RATE[0], 32, dp_=dp if dp > 0 else None, literal=False)
+        assert np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32)), (r, dp)
+    ctx.close()

@@ -341,7 +341,7 @@ int tp_set_ratio(tp_context* c, float ratio) {
 
 int tp_set_dp(tp_context* c, float dp) {
     if (!c) return TP_ERR_INVALID;
-    c->dp_override = dp;
+    c->dp_override = dp;  // piecewise calls only; tp_iterate takes dp from its params (part of the graph key)
     c->accumulated = c->energized = false;
     return TP_OK;
 }
