@@ -8,12 +8,14 @@
 // 13 variants of all triangles share 9 lines per undirected edge.
 //
 //   k_bin         per edge: snapped endpoint positions for the five vertex moves (-> vpos), bounding
-//                 box of its nine lines -> the tiles it may cross -> per-tile work lists
-//   k_accumulate  THE hot kernel: workgroups walk 128x32-pixel tiles; a tile's RGBA8 pixels are read
-//                 once (16 B per lane, prefetched during the previous tile's walk), turned into
-//                 per-row prefix sums of the pixel moments in LDS without bank conflicts, and every
-//                 (edge line, tile) pair is walked by ONE lane: per row one exact crossing column
-//                 from a 32.32 edge walker and ONE LDS lookup.  No atomics, no per-fragment work.
+//                 box of its nine lines -> the tiles the band of lines can cross -> per-tile work lists
+//                 and a contiguous run of 32-byte records per edge
+//   k_accumulate  THE hot kernel: three resident workgroups per CU walk 128x32-pixel tiles; a tile's RGBA8
+//                 pixels are read once (32 B per lane, prefetched during the previous tile's walk), turned
+//                 into per-row prefix sums of the pixel moments in LDS (12-byte packed entries, no bank
+//                 conflicts), and every (edge line, tile) pair is walked by ONE lane: per row one exact
+//                 crossing column from a 32.32 edge walker and ONE LDS entry.  No atomics, no per-fragment
+//                 work.
 //   k_reduce      per line: sum its per-tile records -> W(e)
 //   k_update      per variant: signed sum of three W(e) -> exact moments -> `colnum`, `colacc`,
 //                 `tenergy` (reference layout); central differences; per-vertex arrival atomics;
@@ -85,7 +87,7 @@ void tp_launch_static_table(const uint8_t* img, int pitch, int W, int H, int til
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_bin: 64 edges per 256-thread block, 4 lanes per edge (lanes 0/1 transform the two endpoints)
+// k_bin: BIN_EDGES edges per workgroup, 8 lanes per edge (lanes 0/1 transform the two endpoints)
 // ------------------------------------------------------------------------------------------------
 #define BIN_EDGES 32   // edges per workgroup, 8 lanes each (lanes 0/1 transform the endpoints)
 #define BIN_LOG 5      // log2(BIN_EDGES)
