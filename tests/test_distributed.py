@@ -118,3 +118,18 @@ def test_two_way_warp_two_ranks_hip_engine(tmp_path):
     assert "levels: 2" in r.stdout
     for name in ("A.tri", "B.tri"):
         assert os.path.getsize(str(tmp_path / (name + ".warp"))) == os.path.getsize(str(tmp_path / name))
+
+
+@pytest.mark.gpu
+def test_batch_runner_two_ranks(tmp_path):
+    """tools/run_batch.py (BASELINE config 4 in the small): pairs sharded over ranks, two directions of a pair
+    concurrently in two contexts, per-pair metrics gathered at the end"""
+    r = _torchrun([os.path.join("tools", "run_batch.py"), "--pairs", "3", "--iters", "48", "--size", "512", "--triangles", "150",
+                   "--backend", "gloo", "--share-gpu"], 2)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and [p["pair"] for p in line["pairs"]] == [0, 1, 2]
+    assert sorted(p["rank"] for p in line["pairs"]) == [0, 0, 1]
+    for p in line["pairs"]:
+        assert all(a < b for a, b in zip(p["energy_after"], p["energy_before"]))  # the descent lowers the warp energy
+    assert line["triangles_iters_per_s"] > 0

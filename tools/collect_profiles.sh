@@ -15,6 +15,7 @@ python tools/time_coarse.py > $O/coarse.jsonl 2>&1
 python tools/probe_launch.py > $O/launch_probe.txt 2>&1
 python tools/run_config2.py 600 > $O/config2.txt 2>&1
 python tools/run_config3.py > $O/config3.txt 2>&1
+python tools/run_batch.py --pairs 8 --iters 512 > $O/config4.json 2> $O/config4.err
 # keep the merged directory small: only the per-kernel summaries of the traces
 find $O -name "*kernel_trace.csv" -size +30M -delete
 ls -la $O $O/kt/* | head -40

@@ -54,7 +54,8 @@ if pmc:
                     "units KB; gfx950 correction: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated")
     json.dump(pmc, open(os.path.join(dst, tag + "_pmc_hbm.json"), "w"), indent=1)
 for name, to in (("configs.jsonl", "_configs.jsonl"), ("acc_timeline.json", "_accumulate_timeline.json"), ("coarse.jsonl", "_coarse_meshes.jsonl"),
-                 ("launch_probe.txt", "_launch_probe.txt"), ("config2.txt", "_config2_schedule.txt"), ("config3.txt", "_config3_warp.txt")):
+                 ("launch_probe.txt", "_launch_probe.txt"), ("config2.txt", "_config2_schedule.txt"), ("config3.txt", "_config3_warp.txt"),
+                 ("config4.json", "_config4_batch.json")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, tag + to))
