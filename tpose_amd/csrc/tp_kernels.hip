@@ -93,7 +93,7 @@ void tp_launch_static_table(const uint8_t* img, int pitch, int W, int H, int til
 #define BIN_LOG 5      // log2(BIN_EDGES)
 #define BIN_THREADS (BIN_EDGES * 8)
 
-__global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
+__global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L, int epb) {  // epb <= BIN_EDGES edges per workgroup
     __shared__ int s_excl[BIN_EDGES + 1];  // exclusive scan of rectangle sizes
     __shared__ int s_rect[BIN_EDGES][4];   // tx0, ty0, ntx, #tiles
     __shared__ int s_geom[BIN_EDGES][6];   // base endpoints (Xa, Ya, Xb, Yb) and the moves' reach (dX, dY), 1/256 px
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
     TPB_STAMP();
 
     const int j = tid >> 3, q = tid & 7;
-    const int e = blockIdx.x * BIN_EDGES + j;
+    const int e = j < epb ? blockIdx.x * epb + j : L.NE;  // lanes beyond epb edges idle (small meshes: more workgroups)
     int32_t xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN, dX = 0, dY = 0;
     if (e < L.NE && q < 2) {
         const int2 uv = L.edge_uv[e];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
             if (slot < L.list_cap) {
                 tp_list_entry en;
                 en.visit = visit;
-                en.edge = blockIdx.x * BIN_EDGES + lo;
+                en.edge = blockIdx.x * epb + lo;
                 en.u = s_uv[lo][0]; en.v = s_uv[lo][1];
 #pragma unroll
                 for (int m = 0; m < 5; m++) { en.a[m] = s_pos[lo][0][m]; en.b[m] = s_pos[lo][1][m]; }
@@ -282,7 +282,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
 }
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s) {
-    hipLaunchKernelGGL(k_bin, dim3((L.NE + BIN_EDGES - 1) / BIN_EDGES), dim3(BIN_THREADS), 0, s, L);
+    // few edges (coarse meshes on large rasters: long edges, thousands of tiles each): fewer edges per workgroup
+    int epb = L.NE / 128;
+    epb = epb < 1 ? 1 : epb > BIN_EDGES ? BIN_EDGES : epb;
+    hipLaunchKernelGGL(k_bin, dim3((L.NE + epb - 1) / epb), dim3(BIN_THREADS), 0, s, L, epb);
 }
 
 // LDS prefix entry (12 bytes), per row exclusive prefix over the tile's 128 columns, 16-bit fields packed in pairs:
@@ -530,13 +533,15 @@ void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t st
 // ------------------------------------------------------------------------------------------------
 // k_reduce: W(line) = sum of its per-tile records; one thread per (edge, line, word)
 // ------------------------------------------------------------------------------------------------
+template <int P>  // P adjacent lanes share one sum (coarse meshes: hundreds of records per line)
 __global__ __launch_bounds__(256) void k_reduce(tp_launch L) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tidg = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = tidg / P, part = tidg % P;
     if (L.margin_px < 2) {
         // work lists are rebuilt every iteration: k_accumulate has consumed them, re-arm them here
         // (with a margin, k_update's vote decides)
-        for (int k = gid; k < L.tiles_x * L.tiles_y; k += gridDim.x * blockDim.x) L.tilecount[k] = 0;
-        if (gid == 0) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
+        for (int k = tidg; k < L.tiles_x * L.tiles_y; k += gridDim.x * blockDim.x) L.tilecount[k] = 0;
+        if (tidg == 0) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
     }
     const int per_edge = TP_NLINES * TP_W_WORDS;  // 54 consecutive int64 per edge in wline
     if (gid >= L.NE * per_edge) return;
@@ -549,11 +554,11 @@ __global__ __launch_bounds__(256) void k_reduce(tp_launch L) {
     const bool wide = w == 5;
     uint64_t acc = 0;
     uint32_t acch = 0;
-    int k = 0;
-    for (; k + 16 <= ev.y; k += 16) {  // long edges: sixteen loads in flight per trip
+    int k = part;  // lane `part` of the P sharing this sum takes records part, part + P, ...
+    for (; k + 15 * P < ev.y; k += 16 * P) {  // long edges: sixteen loads in flight per trip
         uint32_t v[16], h[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) { v[u] = src[(size_t)(k + u) * stride]; h[u] = wide ? src[(size_t)(k + u) * stride + 1] : 0u; }
+        for (int u = 0; u < 16; u++) { v[u] = src[(size_t)(k + u * P) * stride]; h[u] = wide ? src[(size_t)(k + u * P) * stride + 1] : 0u; }
 #pragma unroll
         for (int u = 0; u < 16; u++) { acc += v[u]; acch += h[u]; }
     }
@@ -561,19 +566,26 @@ __global__ __launch_bounds__(256) void k_reduce(tp_launch L) {
         uint32_t v[8], h[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const bool on = k + u < ev.y;
-            v[u] = on ? src[(size_t)(k + u) * stride] : 0u;
-            h[u] = (on && wide) ? src[(size_t)(k + u) * stride + 1] : 0u;
+            const bool on = k + u * P < ev.y;
+            v[u] = on ? src[(size_t)(k + u * P) * stride] : 0u;
+            h[u] = (on && wide) ? src[(size_t)(k + u * P) * stride + 1] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) { acc += v[u]; acch += h[u]; }
-        k += 8;
+        k += 8 * P;
     }
-    L.wline[gid] = (int64_t)(acc + ((uint64_t)acch << 32));
+    acc += (uint64_t)acch << 32;
+#pragma unroll
+    for (int o = 1; o < P; o <<= 1)  // the P lanes are adjacent and always active together
+        acc += ((uint64_t)(uint32_t)__shfl_xor((int)(acc >> 32), o) << 32 | (uint32_t)__shfl_xor((int)(uint32_t)acc, o)) ;
+    if (part != 0) return;
+    L.wline[gid] = (int64_t)acc;
 }
 void tp_launch_reduce(const tp_launch& L, hipStream_t s) {
     const int n = L.NE * TP_NLINES * TP_W_WORDS;
-    hipLaunchKernelGGL(k_reduce, dim3((n + 255) / 256), dim3(256), 0, s, L);
+    if (L.NE >= 1024) hipLaunchKernelGGL(k_reduce<1>, dim3((n + 255) / 256), dim3(256), 0, s, L);
+    else if (L.NE >= 128) hipLaunchKernelGGL(k_reduce<4>, dim3((n * 4 + 255) / 256), dim3(256), 0, s, L);
+    else hipLaunchKernelGGL(k_reduce<16>, dim3((n * 16 + 255) / 256), dim3(256), 0, s, L);
 }
 
 // ------------------------------------------------------------------------------------------------
