@@ -26,7 +26,7 @@ if trace:  # split the graph-replayed and the eager (event-bracketed) population
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     out = {}
     for name in ("k_accumulate", "k_bin", "k_reduce", "k_update"):
-        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if r["Kernel_Name"].startswith(name)]
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if name + "(" in r["Kernel_Name"] or name + "<" in r["Kernel_Name"]]
         eager, graph = d[-256:], d[:-256]
         out[name] = {"graph_replay_avg_us": sum(graph) / max(len(graph), 1) / 1e3, "graph_replay_launches": len(graph),
                      "eager_avg_us": sum(eager) / max(len(eager), 1) / 1e3, "eager_launches": len(eager)}
@@ -40,7 +40,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f)):
         if r.get("Counter_Name") != c:
             continue
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "")
         s = acc.setdefault(k, [0.0, 0])
         s[0] += float(r["Counter_Value"]); s[1] += 1
     for k, (tot, n) in acc.items():

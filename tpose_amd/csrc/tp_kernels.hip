@@ -282,10 +282,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L, int epb) {  //
 }
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s) {
-    // few edges (coarse meshes on large rasters: long edges, thousands of tiles each): fewer edges per workgroup
-    int epb = L.NE / 128;
+    // coarse meshes on large rasters (long edges, up to thousands of tiles each): fewer edges per workgroup
+    const long long tiles = (long long)L.tiles_x * L.tiles_y;
+    long long epb = 8LL * L.NE / (tiles > 0 ? tiles : 1);
     epb = epb < 1 ? 1 : epb > BIN_EDGES ? BIN_EDGES : epb;
-    hipLaunchKernelGGL(k_bin, dim3((L.NE + epb - 1) / epb), dim3(BIN_THREADS), 0, s, L, epb);
+    hipLaunchKernelGGL(k_bin, dim3((unsigned)((L.NE + epb - 1) / epb)), dim3(BIN_THREADS), 0, s, L, (int)epb);
 }
 
 // LDS prefix entry (12 bytes), per row exclusive prefix over the tile's 128 columns, 16-bit fields packed in pairs:
@@ -583,8 +584,10 @@ __global__ __launch_bounds__(256) void k_reduce(tp_launch L) {
 }
 void tp_launch_reduce(const tp_launch& L, hipStream_t s) {
     const int n = L.NE * TP_NLINES * TP_W_WORDS;
-    if (L.NE >= 1024) hipLaunchKernelGGL(k_reduce<1>, dim3((n + 255) / 256), dim3(256), 0, s, L);
-    else if (L.NE >= 128) hipLaunchKernelGGL(k_reduce<4>, dim3((n * 4 + 255) / 256), dim3(256), 0, s, L);
+    // records per line grow with tiles per edge: several lanes per sum when there are more tiles than edges
+    const long long tiles = (long long)L.tiles_x * L.tiles_y;
+    if (tiles < L.NE) hipLaunchKernelGGL(k_reduce<1>, dim3((n + 255) / 256), dim3(256), 0, s, L);
+    else if (tiles < 8LL * L.NE) hipLaunchKernelGGL(k_reduce<4>, dim3((n * 4 + 255) / 256), dim3(256), 0, s, L);
     else hipLaunchKernelGGL(k_reduce<16>, dim3((n * 16 + 255) / 256), dim3(256), 0, s, L);
 }
 
