@@ -24,7 +24,11 @@ class OracleEngine:
         state, done = [np.float32(1.0)], 0
         while done < frames:
             n = min(check, frames - done)
-            out = O.iterate(self.img[sweep_slot], pts, tris, O.WARP, ratio, warp_dist.RATE_WARP, n, colors=colors, literal=False)
+            if n > 1:
+                out = O.iterate(self.img[sweep_slot], pts, tris, O.WARP, ratio, warp_dist.RATE_WARP, n - 1, colors=colors, literal=False)
+                pts = out["points"]
+                warp_dist.geterr32(out["ten"][: tri.NT], state)
+            out = O.iterate(self.img[sweep_slot], pts, tris, O.WARP, ratio, warp_dist.RATE_WARP, 1, colors=colors, literal=False)
             pts = out["points"]
             done += n
             if warp_dist.geterr32(out["ten"][: tri.NT], state) < tol:

@@ -45,7 +45,9 @@ class HipEngine:
         self.ctx.set_image(capi.IMAGE_B, imgB)
 
     def optimise(self, tri, sweep_slot, frames, check=8, tol=1e-6):
-        """descend `tri` (stored colours) against raster `sweep_slot`; returns frames spent"""
+        """descend `tri` (stored colours) against raster `sweep_slot`; returns frames spent.  The reference tests
+        the relative energy change between CONSECUTIVE frames every frame (software/warp/main.cpp:231); here the
+        same test is sampled on the last two frames of every `check` fused iterations (two small readbacks)."""
         capi = self.capi
         self.ctx.set_ratio(hostlib.get_ratio())
         self.ctx.upload(tri.points, tri.triangles, tri.colors)
@@ -53,7 +55,10 @@ class HipEngine:
         state, done = [np.float32(1.0)], 0
         while done < frames:
             n = min(check, frames - done)
-            self.ctx.iterate(params, n)
+            if n > 1:
+                self.ctx.iterate(params, n - 1)
+                geterr32(self.ctx.retrieve(capi.BUF_TENERGY)[: tri.NT], state)
+            self.ctx.iterate(params, 1)
             done += n
             if geterr32(self.ctx.retrieve(capi.BUF_TENERGY)[: tri.NT], state) < tol:
                 break
