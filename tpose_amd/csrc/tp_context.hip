@@ -455,6 +455,15 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
             }
     }
     const int NE = (int)(edge_uv.size() / 2);
+    // bit 30 of an endpoint id: this edge is the one that publishes the vertex's snapped positions (vpos) -- the
+    // first edge that mentions the vertex; the others would only repeat the same stores
+    {
+        std::vector<char> owned((size_t)NP, 0);
+        for (size_t k = 0; k < edge_uv.size(); k++) {
+            const int v = edge_uv[k];
+            if (!owned[v]) { owned[v] = 1; edge_uv[k] = v | (1 << 30); }
+        }
+    }
     if (NE > c->capE) {
         hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->wline);
         c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr; c->wline = nullptr;

@@ -49,7 +49,7 @@ struct tp_launch {
     int NT, NP, NE;
     const int* vtx_off;     // CSR by origin vertex: half-edge ids 3t+s
     const int* vtx_adj;
-    const int2* edge_uv;    // [NE] endpoints of every undirected edge, u <= v
+    const int2* edge_uv;    // [NE] endpoints of every undirected edge, u <= v; bit 30: this edge publishes the vertex (vpos)
     const int* he_edge;     // [3 NT] edge id * 2 + (half-edge runs v -> u)
     int2* vpos;             // [NP][5] snapped 24.8 position of every vertex: unmoved, +dx, -dx, +dy, -dy
     // work lists

@@ -112,14 +112,16 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L, int epb) {  //
     int32_t xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN, dX = 0, dY = 0;
     if (e < L.NE && q < 2) {
         const int2 uv = L.edge_uv[e];
-        const int v = q == 0 ? uv.x : uv.y;
+        const int vraw = q == 0 ? uv.x : uv.y;
+        const int v = vraw & 0x3fffffff;
+        const bool publish = (vraw >> 30) & 1;  // one edge per vertex writes vpos (k_update reads it)
         const float2 p = L.points[v];
         int32_t bx = 0, by = 0;
 #pragma unroll
         for (int m = 0; m < 5; m++) {  // vertex stage for the five moves (several edges write the same values)
             int32_t X, Y;
             tp_vertex_stage(p.x, p.y, m, 0, L.vw, X, Y);
-            L.vpos[(size_t)v * 5 + m] = make_int2(X, Y);
+            if (publish) L.vpos[(size_t)v * 5 + m] = make_int2(X, Y);
             s_pos[j][q][m] = make_int2(X, Y);
             if (m == 0) { bx = X; by = Y; s_geom[j][2 * q] = X; s_geom[j][2 * q + 1] = Y; s_uv[j][q] = v; }
             xmin = min(xmin, X); xmax = max(xmax, X); ymin = min(ymin, Y); ymax = max(ymax, Y);
@@ -134,7 +136,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L, int epb) {  //
     TPB_STAMP();
     const bool rebin = rebin_word != 0;  // lists still valid otherwise (tp_set_margin)
     if (!rebin) return;
-    for (int v = blockIdx.x * BIN_THREADS + tid; v < L.NP; v += gridDim.x * BIN_THREADS) L.points_binned[v] = L.points[v];
+    if (L.margin_px >= 2)  // only the margin vote of k_update reads it
+        for (int v = blockIdx.x * BIN_THREADS + tid; v < L.NP; v += gridDim.x * BIN_THREADS) L.points_binned[v] = L.points[v];
     if (q == 0) {
         int tx0 = 0, ty0 = 0, ntx = 1, cnt = 0;
         if (e < L.NE) {
