@@ -425,3 +425,50 @@ def test_cached_graphs_follow_ratio_and_dp():
         ref = O.iterate(img, pts, tris, 0, r, RATE[0], 32, dp_=dp if dp > 0 else None, literal=False)
         assert np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32)), (r, dp)
     ctx.close()
+
+
+def test_device_resident_raster_with_padded_stride():
+    """tp_set_image_device: the raster already lives in HBM (here a torch tensor whose rows are padded)"""
+    import torch
+    W, H = 301, 97
+    img, imgB, pts, tris, ratio, colors = case(W, H, (9, 4))
+    dev = torch.zeros((H, W + 13, 4), dtype=torch.uint8, device="cuda:0")
+    dev[:, :W] = torch.from_numpy(img).cuda()
+    torch.cuda.synchronize()
+    ctx = capi.Context(0, W, H)
+    ctx.set_image_device(capi.IMAGE_A, dev.data_ptr(), dev.stride(0))
+    ctx.upload(pts, tris, None)
+    ctx.iterate(capi.default_params(capi.TRIANGULATE), 5)
+    ref = O.iterate(img, pts, tris, 0, ratio, RATE[0], 5, literal=False)
+    assert np.array_equal(ctx.retrieve(capi.BUF_TENERGY), ref["ten"])
+    assert np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
+    ctx.close()
+
+
+def test_two_host_threads_two_contexts():
+    """contexts are independent: two host threads drive one each on the same GPU at the same time"""
+    import threading
+    W, H = 640, 360
+    results = {}
+
+    def work(k):
+        img, imgB, pts, tris, ratio, colors = case(W, H, (20 + 3 * k, 11), seed=50 + k)
+        ctx = capi.Context(0, W, H)
+        ctx.set_image(capi.IMAGE_A, img)
+        ctx.upload(pts, tris, None)
+        p = capi.default_params(capi.TRIANGULATE)
+        for rep in range(20):
+            ctx.iterate(p, 17)
+        got = (ctx.retrieve(capi.BUF_TENERGY), ctx.retrieve(capi.BUF_POINTS))
+        ctx.close()
+        results[k] = (got, (img, pts, tris, ratio))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(2):
+        (ten, points), (img, pts, tris, ratio) = results[k]
+        ref = O.iterate(img, pts, tris, 0, ratio, RATE[0], 340, literal=False)
+        assert np.array_equal(ten, ref["ten"]) and np.array_equal(points.view(np.uint32), ref["points"].view(np.uint32))
