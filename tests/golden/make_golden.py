@@ -30,12 +30,23 @@ CASES = {
     "tri_33x17_2": (33, 17, None, 0, (1, 10)),
     "warp_64x48_48": (64, 48, (6, 4), 1, (1, 10, 50)),
     "warp_97x61_48": (97, 61, (6, 4), 1, (1, 10)),
+    # the start state after split(0); split(1) (state iv: NT 6 / NP 6), built with the host mirror
+    "tri_64x48_split6": (64, 48, "split", 0, (1, 10, 50)),
 }
 
 
 def main():
     for name, (W, H, grid, fl, iters) in CASES.items():
-        img, imgB, pts, tris, ratio, colors = case(W, H, grid)
+        if grid == "split":
+            from tpose_amd import hostlib, synth
+            img, imgB, _, _, ratio, _ = case(W, H, None)
+            hostlib.set_ratio(ratio)
+            t = hostlib.Triangulation()
+            assert t.split(0) and t.split(1) and t.NT == 6 and t.NP == 6
+            pts, tris = t.points.copy(), t.triangles.copy()
+            colors = synth.mean_colors(img, pts, tris, ratio)
+        else:
+            img, imgB, pts, tris, ratio, colors = case(W, H, grid)
         sweep = imgB if fl else img
         col = colors if fl else None
         # first iteration: every buffer, cross-checked by the brute force
