@@ -428,21 +428,28 @@ def test_cached_graphs_follow_ratio_and_dp():
 
 
 def test_device_resident_raster_with_padded_stride():
-    """tp_set_image_device: the raster already lives in HBM (here a torch tensor whose rows are padded)"""
-    import torch
+    """tp_set_image_device: the raster already lives in HBM, rows padded (allocated through the HIP runtime the
+    library itself uses -- PyTorch-ROCm bundles its own runtime and must be imported first when both are used)"""
+    import ctypes
     W, H = 301, 97
     img, imgB, pts, tris, ratio, colors = case(W, H, (9, 4))
-    dev = torch.zeros((H, W + 13, 4), dtype=torch.uint8, device="cuda:0")
-    dev[:, :W] = torch.from_numpy(img).cuda()
-    torch.cuda.synchronize()
     ctx = capi.Context(0, W, H)
-    ctx.set_image_device(capi.IMAGE_A, dev.data_ptr(), dev.stride(0))
+    hip = ctypes.CDLL("libamdhip64.so.7" if "torch" not in __import__("sys").modules else "libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy2D.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    stride = (W + 13) * 4
+    dev = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dev), stride * H) == 0
+    assert hip.hipMemcpy2D(dev, stride, img.ctypes.data, W * 4, W * 4, H, 1) == 0  # hipMemcpyHostToDevice
+    ctx.set_image_device(capi.IMAGE_A, dev.value, stride)
     ctx.upload(pts, tris, None)
     ctx.iterate(capi.default_params(capi.TRIANGULATE), 5)
     ref = O.iterate(img, pts, tris, 0, ratio, RATE[0], 5, literal=False)
     assert np.array_equal(ctx.retrieve(capi.BUF_TENERGY), ref["ten"])
     assert np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
     ctx.close()
+    hip.hipFree(dev)
 
 
 def test_two_host_threads_two_contexts():
