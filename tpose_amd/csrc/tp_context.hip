@@ -14,6 +14,23 @@
 #include <unordered_map>
 #include <vector>
 #include <chrono>
+#include <mutex>
+#include <shared_mutex>
+
+// Stream capture is process-wide state in the HIP runtime: while one host thread captures a graph, allocations, frees and
+// synchronous copies issued by OTHER threads (other contexts) invalidate the capture, whatever the capture mode.  Every
+// entry point therefore holds a shared lock, and a capture upgrades to the exclusive one: captures are rare (once per
+// upload / parameter set), so contexts driven from different threads still run concurrently.
+static std::shared_mutex g_api_mutex;
+static thread_local int g_api_depth = 0;
+struct api_guard {  // outermost entry point of this thread takes the shared lock (entry points call each other)
+    api_guard() { if (g_api_depth++ == 0) g_api_mutex.lock_shared(); }
+    ~api_guard() { if (--g_api_depth == 0) g_api_mutex.unlock_shared(); }
+};
+struct capture_guard {  // inside an entry point: trade the shared lock for the exclusive one
+    capture_guard() { g_api_mutex.unlock_shared(); g_api_mutex.lock(); }
+    ~capture_guard() { g_api_mutex.unlock(); g_api_mutex.lock_shared(); }
+};
 
 namespace {
 
@@ -273,6 +290,7 @@ extern "C" {
 int tp_abi_version(void) { return TP_ABI_VERSION; }
 
 int tp_device_count(int* count) {
+    api_guard api_lock;
     if (!count) return TP_ERR_INVALID;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -284,6 +302,7 @@ int tp_device_count(int* count) {
 const char* tp_last_error(const tp_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
 int tp_create(int device, int width, int height, tp_context** out) {
+    api_guard api_lock;
     if (!out) return fail(nullptr, TP_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (width < 1 || height < 1 || width > TP_MAX_RASTER || height > TP_MAX_RASTER)
@@ -316,6 +335,7 @@ int tp_create(int device, int width, int height, tp_context** out) {
 }
 
 int tp_destroy(tp_context* c) {
+    api_guard api_lock;
     if (!c) return TP_OK;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
@@ -383,14 +403,17 @@ static int set_image_common(tp_context* c, int slot, const void* src, size_t str
 }
 
 int tp_set_image(tp_context* c, int slot, const uint8_t* rgba, size_t stride) {
+    api_guard api_lock;
     return set_image_common(c, slot, rgba, stride, hipMemcpyHostToDevice);
 }
 
 int tp_set_image_device(tp_context* c, int slot, const void* dev, size_t stride) {
+    api_guard api_lock;
     return set_image_common(c, slot, dev, stride, hipMemcpyDeviceToDevice);
 }
 
 int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, int NT, const int32_t* colors) {
+    api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     if (!points || !tris || NP < 1 || NT < 1) return fail(c, TP_ERR_INVALID, "upload: bad arguments (NP=%d NT=%d)", NP, NT);
     if ((size_t)13 * NT > (size_t)TP_MAXT) return fail(c, TP_ERR_CAPACITY, "13*NT = %d exceeds MAXT = %d", 13 * NT, TP_MAXT);
@@ -549,6 +572,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
 }
 
 int tp_accumulate(tp_context* c, int flavour, int slot) {
+    api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     if (flavour != TP_TRIANGULATE && flavour != TP_WARP) return fail(c, TP_ERR_INVALID, "bad flavour %d", flavour);
     if (!c->uploaded) return fail(c, TP_ERR_STATE, "accumulate before upload");
@@ -595,6 +619,7 @@ int tp_accumulate(tp_context* c, int flavour, int slot) {
 }
 
 int tp_energy(tp_context* c, int flavour) {
+    api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     if (flavour != TP_TRIANGULATE && flavour != TP_WARP) return fail(c, TP_ERR_INVALID, "bad flavour %d", flavour);
     if (!c->accumulated) return fail(c, TP_ERR_STATE, "energy before accumulate");
@@ -608,6 +633,7 @@ int tp_energy(tp_context* c, int flavour) {
 }
 
 int tp_shift(tp_context* c, float rate) {
+    api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     if (!c->energized) return fail(c, TP_ERR_STATE, "shift before energy");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -654,7 +680,8 @@ int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
             if (e.generation == c->generation && e.iters == CHUNK && memcmp(&e.params, p, sizeof *p) == 0) g = &e;
         if (!g) {
             hipGraph_t graph = nullptr;
-            HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            capture_guard capture_lock;
+            HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
             for (int k = 0; k < CHUNK; k++) enqueue_iter(c, *p, dp);
             HIP_TRY(c, hipStreamEndCapture(c->stream, &graph));
             graph_entry e;
@@ -685,6 +712,7 @@ int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
 extern "C" {
 
 int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
+    api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     if (int rc = validate_params(c, p, n_iters)) return rc;
     if (n_iters == 0) return TP_OK;
@@ -693,6 +721,7 @@ int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
 }
 
 int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* accumulate_us) {
+    api_guard api_lock;
     if (!c || !accumulate_us) return TP_ERR_INVALID;
     if (int rc = validate_params(c, p, n_iters)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -729,6 +758,7 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
 }
 
 int tp_profile_accumulate(tp_context* c, const tp_params* p, int launches, double* accumulate_us) {
+    api_guard api_lock;
     if (!c || !accumulate_us) return TP_ERR_INVALID;
     if (int rc = validate_params(c, p, launches)) return rc;
     if (launches < 1) return fail(c, TP_ERR_INVALID, "launches < 1");
@@ -741,11 +771,15 @@ int tp_profile_accumulate(tp_context* c, const tp_params* p, int launches, doubl
     HIP_TRY(c, hipGetLastError());
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    for (int k = 0; k < launches; k++) tp_launch_accumulate(L, c->stream);
-    HIP_TRY(c, hipStreamEndCapture(c->stream, &graph));
-    hipError_t err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
+    hipError_t err;
+    {
+        capture_guard capture_lock;
+        HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+        for (int k = 0; k < launches; k++) tp_launch_accumulate(L, c->stream);
+        HIP_TRY(c, hipStreamEndCapture(c->stream, &graph));
+        err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+    }
     if (err != hipSuccess) return fail(c, TP_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(err));
     if (!c->ev0) { HIP_TRY(c, hipEventCreate(&c->ev0)); HIP_TRY(c, hipEventCreate(&c->ev1)); }
     float ms = 0.0f;
@@ -764,6 +798,7 @@ int tp_profile_accumulate(tp_context* c, const tp_params* p, int launches, doubl
 }
 
 int tp_synchronize(tp_context* c) {
+    api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -796,10 +831,12 @@ int buffer_source(tp_context* c, int what, size_t count, const void** src, size_
 }  // namespace
 
 int tp_retrieve(tp_context* c, int what, void* dst, size_t count) {
+    api_guard api_lock;
     return tp_retrieve_many(c, 1, &what, &dst, &count);
 }
 
 int tp_retrieve_many(tp_context* c, int n, const int* what, void* const* dst, const size_t* count) {
+    api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     if (n < 0 || (n && (!what || !dst || !count))) return fail(c, TP_ERR_INVALID, "retrieve: bad arguments");
     if (!c->uploaded) return fail(c, TP_ERR_STATE, "retrieve before upload");
@@ -833,6 +870,7 @@ int tp_retrieve_many(tp_context* c, int n, const int* what, void* const* dst, co
 }
 
 int tp_render(tp_context* c, int source, const float* points, uint8_t* dst, size_t stride) {
+    api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     if (!dst) return fail(c, TP_ERR_INVALID, "render: dst is NULL");
     if (source != TP_RENDER_AVERAGE && source != TP_RENDER_STORED) return fail(c, TP_ERR_INVALID, "render: bad source %d", source);
@@ -867,6 +905,7 @@ int tp_get_stream(tp_context* c, void** s) {
 }
 
 int tp_selftest_walker(tp_context* c, const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out) {
+    api_guard api_lock;
     if (!c || !N0 || !step || !d || !out || n < 0) return TP_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     int64_t* dN = nullptr; int32_t *ds = nullptr, *dd = nullptr, *dout = nullptr;
@@ -883,6 +922,7 @@ int tp_selftest_walker(tp_context* c, const int64_t* N0, const int32_t* step, co
 }
 
 int tp_debug_dump(tp_context* c, unsigned long long* out, int n) {
+    api_guard api_lock;
     tp_launch L = make_launch(c, 0, 0.0f);
     if (!L.dbg) return TP_ERR_STATE;
     hipStreamSynchronize(c->stream);
@@ -892,6 +932,7 @@ int tp_debug_dump(tp_context* c, unsigned long long* out, int n) {
 
 // debug: per-tile list lengths of the current work lists
 int tp_debug_tilecount(tp_context* c, int* out, int n) {
+    api_guard api_lock;
     if (!c || !out) return TP_ERR_INVALID;
     hipStreamSynchronize(c->stream);
     tp_launch L = make_launch(c, 0, 0.0f);
@@ -901,6 +942,7 @@ int tp_debug_tilecount(tp_context* c, int* out, int n) {
 
 // debug: raw bytes from the start of the record buffer (the probes write there)
 int tp_debug_read_visits(tp_context* c, void* out, size_t bytes) {
+    api_guard api_lock;
     if (!c || !out) return TP_ERR_INVALID;
     hipStreamSynchronize(c->stream);
     return hipMemcpy(out, c->visits, bytes, hipMemcpyDeviceToHost) == hipSuccess ? TP_OK : TP_ERR_HIP;
@@ -908,6 +950,7 @@ int tp_debug_read_visits(tp_context* c, void* out, size_t bytes) {
 
 // launch-overhead probe: n back-to-back launches of an (almost) empty kernel in k_accumulate's shape
 int tp_debug_null_launch(tp_context* c, int mode, int blocks, int threads, int lds, int n, double* us) {
+    api_guard api_lock;
     if (!c || !us || !c->uploaded) return TP_ERR_STATE;
     HIP_TRY(c, hipSetDevice(c->device));
     tp_launch L = make_launch(c, 0, 0.0f);
@@ -923,7 +966,8 @@ int tp_debug_null_launch(tp_context* c, int mode, int blocks, int threads, int l
     *us = total * 1000.0 / n;
     if (mode >= 16) {  // wall-clock cost per launch of 64 probes captured into a graph, replayed n times
         hipGraph_t g; hipGraphExec_t ge;
-        HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        capture_guard capture_lock;
+        HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
         for (int k = 0; k < 64; k++) tp_launch_probe(L.img, L.visits, mode & 15, n16, blocks, threads, (size_t)lds, c->stream, nullptr, nullptr);
         HIP_TRY(c, hipStreamEndCapture(c->stream, &g));
         HIP_TRY(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
@@ -939,6 +983,7 @@ int tp_debug_null_launch(tp_context* c, int mode, int blocks, int threads, int l
 }
 
 int tp_get_info(tp_context* c, int what, int64_t* value) {
+    api_guard api_lock;
     if (!c || !value) return TP_ERR_INVALID;
     switch (what) {
         case 0: *value = c->tiles_x; return TP_OK;
