@@ -122,6 +122,10 @@ void tp_default_params(int flavour, tp_params* p);
  * round trip (the reference reads back four buffers every frame, triangulate/main.cpp:201-204).
  * Asynchronous: returns after enqueueing; tp_retrieve / tp_synchronize wait. */
 int tp_iterate(tp_context* ctx, const tp_params* p, int n_iters);
+/* Optional: build the launch graph tp_iterate replays for these parameters now (it is otherwise built by the
+ * first tp_iterate of >= 16 iterations after an upload), so that no later call pays for it.  Runs nothing.
+ * The reference has no counterpart -- its frame loop issues GL calls one by one (triangulate/main.cpp:190-204). */
+int tp_prepare(tp_context* ctx, const tp_params* p);
 
 /* Buffer::retrieve (triangulate/main.cpp:201-204, 221): copies `count` elements (int32 / float /
  * int64 units as listed in tp_buffer) into dst after waiting for enqueued work. */
@@ -159,7 +163,7 @@ enum { TP_RENDER_AVERAGE = 0, TP_RENDER_STORED = 1 };
 int tp_render(tp_context* ctx, int source, const float* points, uint8_t* dst_rgba, size_t stride);
 
 /* introspection for tests/benchmarks: 0 = tiles_x, 1 = tiles_y, 2 = tile width, 3 = tile height,
- * 4 = (triangle,tile) pairs of the current work lists, 5 = device-side overflow flags,
+ * 4 = (edge,tile) record slots drawn from the shared part of the record buffer, 5 = device-side overflow flags,
  * 6 = number of work-list rebuilds requested by the device so far */
 int tp_get_info(tp_context* ctx, int what, int64_t* value);
 
@@ -167,6 +171,13 @@ int tp_get_info(tp_context* ctx, int what, int64_t* value);
  * floor((N0 + r*step)/d), r = 0..31, as the accumulate kernel derives them.  out = int32[32*n]. */
 int tp_selftest_walker(tp_context* ctx, const int64_t* N0, const int32_t* step, const int32_t* d,
                        int n, int32_t* out);
+
+
+/* device self-test of the whole-line walker the sweep uses since round 2 (tp_raster.h, tp_setup_line): for line k
+ * through the snapped points (ends[4k], ends[4k+1]) - (ends[4k+2], ends[4k+3]) (1/256 pixel) on a raster of
+ * H[k] rows, out[(rows+2)k] = first row, out[(rows+2)k+1] = last row (first > last: no row), and then the crossing
+ * column of `rows` consecutive rows from the first, derived tile by tile exactly as the accumulate kernel does. */
+int tp_selftest_line(tp_context* ctx, const int32_t* ends, const int32_t* H, int n, int rows, int32_t* out);
 
 #ifdef __cplusplus
 }

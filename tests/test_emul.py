@@ -150,3 +150,88 @@ def test_edge_centric_form_on_triangle_soup(em):
         tris[:, :3] = rng.integers(0, NP, (40, 3))
         dp = [0.05, 0.0078125, 0.3][trial % 3]
         assert np.array_equal(emul_moments_edges(em, img, pts, tris, dp, ratio), O.moments(img, pts, tris, dp, ratio)), trial
+
+
+# ---- round 2: whole-line 24.40 walkers, per-tile-row band enumeration ------------------------------------------
+def emul_moments_lines(em, img, pts, tris, dp, ratio, tile_w=128, tile_h=16, margin=0):
+    NT, NP = tris.shape[0], pts.shape[0]
+    H, W = img.shape[:2]
+    mom = np.zeros((13 * NT, 6), np.int64)
+    nv = C.c_int64(0)
+    em.emul_moments_lines(img.ctypes.data_as(C.c_void_p), C.c_size_t(img.strides[0]), W, H,
+                          pts.ctypes.data_as(C.c_void_p), tris.ctypes.data_as(C.c_void_p), NT, NP,
+                          C.c_float(dp), C.c_float(ratio), tile_w, tile_h, margin, mom.ctypes.data_as(C.c_void_p),
+                          C.byref(nv))
+    return mom, nv.value
+
+
+@pytest.mark.parametrize("W,H,grid", [(97, 61, (6, 4)), (300, 200, (15, 5)), (257, 131, (6, 4)), (200, 150, None),
+                                      (640, 480, (50, 30))])
+@pytest.mark.parametrize("dp", [None, 0.2])
+@pytest.mark.parametrize("tile", [(128, 16), (128, 32), (32, 8)])
+def test_line_walkers_and_band_match_oracle(em, W, H, grid, dp, tile):
+    img, _, pts, tris, ratio, _ = case(W, H, grid)
+    d = O.dp(0, tris.shape[0]) if dp is None else dp
+    ref = O.moments(img, pts, tris, d, ratio)
+    mom, nv = emul_moments_lines(em, img, pts, tris, d, ratio, tile[0], tile[1])
+    assert np.array_equal(mom, ref)
+    mom2, nv2 = emul_moments_lines(em, img, pts, tris, d, ratio, tile[0], tile[1], margin=5)
+    assert np.array_equal(mom2, ref) and nv2 >= nv
+
+
+def test_line_walkers_on_triangle_soup(em):
+    W, H = 200, 150
+    img = synth.voronoi_raster(W, H, seed=3, sites=10)
+    ratio = float(np.float32(W) / np.float32(H))
+    rng = np.random.default_rng(4)
+    for trial in range(40):
+        NP = 30
+        pts = (rng.random((NP, 2)).astype(np.float32) * 2 - 1) * np.float32(1.3)
+        pts[:, 0] *= np.float32(ratio)
+        if trial % 3 == 0:
+            pts = (np.round(pts * 8) / 8).astype(np.float32)
+        if trial % 5 == 0:
+            pts[:5] = pts[5:10]
+        if trial % 7 == 0:
+            pts[10:14] *= np.float32(1e6)   # far outside: coordinates clamp
+        if trial % 11 == 0:
+            pts[3, 0] = np.float32("nan")
+        tris = np.zeros((40, 4), np.int32)
+        tris[:, :3] = rng.integers(0, NP, (40, 3))
+        dp = [0.05, 0.0078125, 0.3][trial % 3]
+        tile = [(128, 16), (64, 16), (16, 4)][trial % 3]
+        mom, _ = emul_moments_lines(em, img, pts, tris, dp, ratio, tile[0], tile[1])
+        assert np.array_equal(mom, O.moments(img, pts, tris, dp, ratio)), trial
+
+
+def test_whole_line_walker_is_exact(em):
+    """every row of a line, evaluated tile by tile from ONE 24.40 set-up, equals exact integer arithmetic --
+    up to the largest raster (16384 rows), the largest coordinates, knife-edge and lattice-aligned lines"""
+    rng = np.random.default_rng(9)
+    em.emul_line_check.argtypes = [C.c_int32] * 6 + [C.c_void_p]
+    bad = C.c_int32(0)
+    lo, hi = -(1 << 22), 1 << 23
+    n = 0
+    for trial in range(3000):
+        kind = trial % 6
+        H = [16384, 2048, 4096, 600, 16384, 97][kind]
+        if kind == 0:    # anything in the coordinate range, tallest raster
+            Xa, Ya, Xb, Yb = (int(rng.integers(lo, hi + 1)) for _ in range(4))
+        elif kind == 1:  # raster-sized
+            Xa, Xb = (int(rng.integers(-100 * 256, 2148 * 256)) for _ in range(2))
+            Ya, Yb = (int(rng.integers(-100 * 256, 2148 * 256)) for _ in range(2))
+        elif kind == 2:  # lattice aligned: exact ties everywhere
+            Xa, Ya, Xb, Yb = (256 * int(rng.integers(-50, 4200)) + 128 for _ in range(4))
+        elif kind == 3:  # nearly horizontal / nearly vertical
+            Xa, Ya = int(rng.integers(0, 600 * 256)), int(rng.integers(0, 600 * 256))
+            Xb, Yb = (Xa + int(rng.integers(-5, 6)), int(rng.integers(0, 600 * 256))) if trial % 2 else \
+                     (int(rng.integers(lo, hi)), Ya + int(rng.integers(1, 700)))
+        elif kind == 4:  # extremes
+            Xa, Ya, Xb, Yb = int(rng.choice([lo, hi])), lo, int(rng.choice([lo, hi])), hi
+        else:
+            Xa, Ya, Xb, Yb = (int(rng.integers(-30 * 256, 130 * 256)) for _ in range(4))
+        for th in (16, 32):
+            r = em.emul_line_check(Xa, Ya, Xb, Yb, H, th, C.byref(bad))
+            assert r == 0, (Xa, Ya, Xb, Yb, H, th, bad.value)
+            n += 1
+    assert n == 6000

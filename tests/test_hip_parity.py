@@ -154,6 +154,45 @@ def test_device_walker_floor_is_exact():
     ctx.close()
 
 
+def test_device_whole_line_walker_is_exact():
+    """The whole-line 24.40 walker of round 2 (one set-up per line and iteration; tiles derive their 32.32 walker
+    from it) on the GPU against exact integer arithmetic: up to 300 rows of every line, rasters up to 16384 rows,
+    the full coordinate range, lattice-aligned and nearly horizontal / vertical lines."""
+    rng = np.random.default_rng(21)
+    n, rows = 60000, 300
+    lo, hi = -(1 << 22), 1 << 23
+    ends = rng.integers(lo, hi + 1, (n, 4)).astype(np.int64)
+    H = rng.choice([16384, 4096, 2048, 600, 97], n).astype(np.int64)
+    k = n // 4
+    ends[:k] = rng.integers(-100 * 256, 2148 * 256, (k, 4))                       # raster-sized
+    ends[k:2 * k] = 256 * rng.integers(-50, 4200, (k, 4)) + 128                     # pixel centres: ties everywhere
+    ends[2 * k:2 * k + k // 2, 2] = ends[2 * k:2 * k + k // 2, 0] + rng.integers(-5, 6, k // 2)   # nearly vertical
+    ends[2 * k + k // 2:3 * k, 3] = ends[2 * k + k // 2:3 * k, 1] + rng.integers(1, 700, k // 2)  # nearly horizontal
+    ends = np.clip(ends, lo, hi)
+    ctx = capi.Context(0, 64, 64)
+    got = ctx.selftest_line(ends, H, rows).astype(np.int64)
+    ctx.close()
+    Xa, Ya, Xb, Yb = ends.T
+    swap = Ya > Yb
+    Xt, Yt = np.where(swap, Xb, Xa), np.where(swap, Yb, Ya)
+    Xq, Yq = np.where(swap, Xa, Xb), np.where(swap, Ya, Yb)
+    dy, dx = Yq - Yt, Xq - Xt
+    ra = np.maximum((Yt - 128 + 255) >> 8, 0)
+    rb = np.minimum(((Yq - 128 + 255) >> 8) - 1, H - 1)
+    live = (dy > 0) & (ra <= rb)
+    assert np.array_equal(got[~live, 0] > got[~live, 1], np.ones((~live).sum(), bool))
+    assert np.array_equal(got[live, 0], ra[live]) and np.array_equal(got[live, 1], rb[live])
+    # first column c with (256 c + 128 - Xt) dy >= dx (256 r + 128 - Yt); python ints: no overflow
+    idx = np.nonzero(live)[0]
+    r = ra[idx, None] + np.arange(rows)[None, :]
+    ok = r <= rb[idx, None]
+    num = dx[idx, None].astype(object) * (256 * r + 128 - Yt[idx, None]).astype(object) - \
+        (128 - Xt[idx, None]).astype(object) * dy[idx, None].astype(object)
+    den = (256 * dy[idx, None]).astype(object)
+    exact = -((-num) // den)   # ceil
+    assert np.array_equal(got[idx, 2:][ok], exact[ok].astype(np.int64))
+
+
 @pytest.mark.parametrize("margin", [0, 2, 6, 40])
 def test_work_list_reuse_never_changes_results(margin):
     """The fused iteration reuses its per-tile work lists while vertices stay inside a margin; any

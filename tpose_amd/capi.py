@@ -23,6 +23,7 @@ SYMBOLS = [
     "tp_get_ratio", "tp_set_dp", "tp_set_margin", "tp_set_image", "tp_set_image_device", "tp_upload", "tp_accumulate",
     "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_retrieve_many", "tp_synchronize",
     "tp_get_stream", "tp_profile_iterate", "tp_profile_accumulate", "tp_get_info", "tp_selftest_walker", "tp_render",
+    "tp_prepare", "tp_selftest_line",
 ]
 
 
@@ -77,6 +78,8 @@ def load():
         lib.tp_device_count.argtypes = [C.POINTER(C.c_int)]
         lib.tp_selftest_walker.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.tp_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.tp_prepare.argtypes = [C.c_void_p, C.POINTER(Params)]
+        lib.tp_selftest_line.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -166,6 +169,19 @@ class Context:
 
     def iterate(self, params, n):
         self._ck(self.lib.tp_iterate(self.h, C.byref(params), n))
+
+    def prepare(self, params):
+        """build the launch graph of the fused iteration now (tp_prepare)"""
+        self._ck(self.lib.tp_prepare(self.h, C.byref(params)))
+
+    def selftest_line(self, ends, H, rows):
+        """ends int32[n,4] (Xa,Ya,Xb,Yb in 1/256 px), H int32[n] -> int32[n, rows+2]: ra, rb, crossing columns"""
+        ends = np.ascontiguousarray(ends, np.int32)
+        H = np.ascontiguousarray(H, np.int32)
+        out = np.zeros((ends.shape[0], rows + 2), np.int32)
+        self._ck(self.lib.tp_selftest_line(self.h, ends.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p),
+                                           ends.shape[0], rows, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def profile_iterate(self, params, n):
         us = C.c_double(0)

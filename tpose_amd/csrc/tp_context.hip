@@ -68,7 +68,7 @@ struct tp_context {
     // work lists
     int tiles_x = 0, tiles_y = 0;
     int* tilecount = nullptr;
-    tp_list_entry* tilelist = nullptr;
+    int2* tilelist = nullptr;
     size_t tilelist_elems = 0;
     int list_cap = 0;
     int NE = 0, capE = 0;
@@ -78,7 +78,8 @@ struct tp_context {
     int2* edge_visit = nullptr;
     uint32_t* visits = nullptr;
     int visit_cap = 0;
-    int64_t* wline = nullptr;
+    longlong2* line_xs = nullptr;  // per-iteration line table: nine whole-line walkers per edge
+    int2* line_rows = nullptr;
     int64_t* t2[2] = {nullptr, nullptr};   // static per-image tables
     uint32_t* seg_scratch = nullptr;
     tp_device_state* state = nullptr;
@@ -104,6 +105,9 @@ struct tp_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t* pinned = nullptr;   // host-pinned staging for readbacks (one synchronisation per batch)
     size_t pinned_bytes = 0;
+    uint8_t* render_pic = nullptr;   // tp_render scratch (kept: the viewer renders every frame)
+    float2* render_pts = nullptr;
+    size_t render_pts_cap = 0;
     uint8_t* up_pinned = nullptr;  // host-pinned staging for tp_upload (copies ride the stream, no wait at the end)
     size_t up_pinned_bytes = 0;
     std::vector<uint64_t> hkeys;   // open-addressing table of tp_upload: undirected edge key -> id
@@ -146,11 +150,11 @@ void drop_graphs(tp_context* c) {
 void free_triangulation(tp_context* c) {
     hipFree(c->points); hipFree(c->points_binned); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
     hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->edge_visit); hipFree(c->visits);
-    hipFree(c->wline); hipFree(c->tilelist);
+    hipFree(c->line_xs); hipFree(c->line_rows); hipFree(c->tilelist);
     hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
     c->points = nullptr; c->points_binned = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
     c->edge_uv = nullptr; c->he_edge = nullptr; c->vpos = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
-    c->wline = nullptr; c->tilelist = nullptr; c->capE = 0;
+    c->line_xs = nullptr; c->line_rows = nullptr; c->tilelist = nullptr; c->capE = 0;
     c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
     c->capT = c->capP = 0;
 }
@@ -169,16 +173,17 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.vtx_off = c->vtx_off; L.vtx_adj = c->vtx_adj;
     L.tilecount = c->tilecount; L.tilelist = c->tilelist; L.list_cap = c->list_cap;
     L.edge_uv = c->edge_uv; L.he_edge = c->he_edge; L.vpos = c->vpos; L.NE = c->NE;
-    L.edge_visit = c->edge_visit; L.visits = c->visits; L.visit_cap = c->visit_cap; L.wline = c->wline;
+    L.edge_visit = c->edge_visit; L.visits = c->visits; L.visit_cap = c->visit_cap;
+    L.line_xs = c->line_xs; L.line_rows = c->line_rows;
     L.t2 = c->t2[slot];
     L.state = c->state;
     L.ten = c->ten; L.cn = c->cn; L.ca = c->ca; L.gr = c->gr; L.moments = c->moments;
     L.gacc = c->gacc;
-    static const int dbg = getenv("TPOSE_DEBUG_ACC") ? atoi(getenv("TPOSE_DEBUG_ACC")) : 0;
-    L.debug = dbg;
+#ifdef TPOSE_DEBUG  // debug flavour of the library (tools/acc_timeline.py): per-block phase timestamps
     static unsigned long long* dbgbuf = nullptr;
-    if ((dbg & 24) && !dbgbuf) { hipMalloc((void**)&dbgbuf, 1024 * 16 * sizeof(unsigned long long)); hipMemset(dbgbuf, 0, 1024 * 16 * 8); }
+    if (!dbgbuf) { hipMalloc((void**)&dbgbuf, 4096 * 8 * sizeof(unsigned long long)); hipMemset(dbgbuf, 0, 4096 * 8 * 8); }
     L.dbg = dbgbuf;
+#endif
     return L;
 }
 
@@ -204,15 +209,16 @@ hipError_t force_rebin(tp_context* c) {
 // enqueue one grad-iter on the context stream (no sync)
 void enqueue_iter(tp_context* c, const tp_params& p, float dp) {
     tp_launch L = make_launch(c, p.image_slot, dp);
-    tp_launch_bin(L, c->stream);  // vertex stage; rebuilds the work lists when requested
+    tp_launch_bin(L, c->stream);  // vertex stage + line table; rebuilds the work lists when requested
     tp_launch_accumulate(L, c->stream);
-    tp_launch_reduce(L, c->stream);
-    tp_launch_update(L, p.flavour, p.rate, c->stream);  // finalize + gradient + shift; re-arms the lists
+    tp_launch_update(L, p.flavour, p.rate, c->stream);  // line sums + finalize + gradient + shift; re-arms the lists
 }
 
 int enqueue_iters(tp_context* c, const tp_params* p, int n_iters);
 
-// grow whichever work list overflowed (flags: TP_FLAG_*); false when nothing can grow any further
+// grow whichever work list overflowed (flags: TP_FLAG_*); false when nothing can grow any further.  The new
+// buffer is allocated BEFORE the old one is released: when the allocation fails the context keeps its old lists
+// and capacities (and stays usable); graphs are dropped whenever an address changed.
 bool grow_lists(tp_context* c, uint32_t flags, hipError_t* err) {
     const int ntiles = c->tiles_x * c->tiles_y;
     bool grown = false;
@@ -222,25 +228,31 @@ bool grow_lists(tp_context* c, uint32_t flags, hipError_t* err) {
         if ((size_t)c->visit_cap < limit) {
             size_t vcap = (size_t)c->visit_cap * 2;
             if (vcap > limit) vcap = limit;
-            hipFree(c->visits); c->visits = nullptr;
-            if ((*err = dev_alloc(&c->visits, vcap * TP_NLINES * TP_REC_DWORDS)) != hipSuccess) return false;
-            c->visit_cap = (int)vcap;
-            grown = true;
+            uint32_t* fresh = nullptr;
+            if ((*err = dev_alloc(&fresh, vcap * TP_NLINES * TP_REC_DWORDS)) == hipSuccess) {
+                hipFree(c->visits);
+                c->visits = fresh;
+                c->visit_cap = (int)vcap;
+                grown = true;
+            }
         }
     }
-    if (flags & TP_FLAG_LIST_OVERFLOW) {
+    if (*err == hipSuccess && (flags & TP_FLAG_LIST_OVERFLOW)) {
         if (c->list_cap < c->capE) {  // a tile never holds more than one entry per edge
             size_t cap = (size_t)c->list_cap * 2;
             if (cap > (size_t)c->capE) cap = (size_t)c->capE;
-            hipFree(c->tilelist); c->tilelist = nullptr;
-            if ((*err = dev_alloc(&c->tilelist, cap * ntiles)) != hipSuccess) return false;
-            c->tilelist_elems = cap * ntiles;
-            c->list_cap = (int)cap;
-            grown = true;
+            int2* fresh = nullptr;
+            if ((*err = dev_alloc(&fresh, cap * ntiles)) == hipSuccess) {
+                hipFree(c->tilelist);
+                c->tilelist = fresh;
+                c->tilelist_elems = cap * ntiles;
+                c->list_cap = (int)cap;
+                grown = true;
+            }
         }
     }
     if (grown) { c->generation++; drop_graphs(c); }  // captured graphs bake addresses and capacities
-    return grown;
+    return grown && *err == hipSuccess;
 }
 
 // Reads the device flags (the stream must be idle).  A work-list overflow is repaired here: k_update
@@ -343,6 +355,7 @@ int tp_destroy(tp_context* c) {
     free_triangulation(c);
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->tilecount); hipFree(c->state);
     hipFree(c->t2[0]); hipFree(c->t2[1]); hipFree(c->seg_scratch);
+    hipFree(c->render_pic); hipFree(c->render_pts);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->up_pinned) hipHostFree(c->up_pinned);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -353,6 +366,7 @@ int tp_destroy(tp_context* c) {
 }
 
 int tp_set_ratio(tp_context* c, float ratio) {
+    api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     if (!(ratio > 0.0f)) return fail(c, TP_ERR_INVALID, "RATIO must be positive");
     if (ratio != c->ratio) { c->ratio = ratio; c->generation++; c->accumulated = c->energized = false; }
@@ -360,6 +374,7 @@ int tp_set_ratio(tp_context* c, float ratio) {
 }
 
 int tp_set_dp(tp_context* c, float dp) {
+    api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     c->dp_override = dp;  // piecewise calls only; tp_iterate takes dp from its params (part of the graph key)
     c->accumulated = c->energized = false;
@@ -367,6 +382,7 @@ int tp_set_dp(tp_context* c, float dp) {
 }
 
 int tp_set_margin(tp_context* c, int margin_px) {
+    api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     if (margin_px < 0 || margin_px > 1024) return fail(c, TP_ERR_INVALID, "margin %d outside 0..1024", margin_px);
     if (margin_px != c->margin_px) { c->margin_px = margin_px; c->lists_dp = -1.0f; c->generation++; }
@@ -488,12 +504,13 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         }
     }
     if (NE > c->capE) {
-        hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->wline);
-        c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr; c->wline = nullptr;
+        hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->line_xs); hipFree(c->line_rows);
+        c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr; c->line_xs = nullptr; c->line_rows = nullptr;
         const int capE = NE + NE / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->edge_uv, capE));
         HIP_TRY(c, dev_alloc(&c->edge_visit, capE));
-        HIP_TRY(c, dev_alloc(&c->wline, (size_t)capE * TP_NLINES * TP_W_WORDS));
+        HIP_TRY(c, dev_alloc(&c->line_xs, (size_t)capE * TP_NLINES));
+        HIP_TRY(c, dev_alloc(&c->line_rows, (size_t)capE * TP_NLINES));
         // (edge, tile) visits: typical edges cross a handful of tiles, a few long ones many
         size_t vcap = (size_t)capE * 24 + (size_t)ntiles * 8;
         if (vcap > ((size_t)1 << 24)) vcap = (size_t)1 << 24;
@@ -589,7 +606,6 @@ int tp_accumulate(tp_context* c, int flavour, int slot) {
         c->lists_dp = L.vw.dp; c->lists_ratio = c->ratio;
         tp_launch_bin(L, c->stream);
         tp_launch_accumulate(L, c->stream);
-        tp_launch_reduce(L, c->stream);
         HIP_TRY(c, hipGetLastError());
         // a sweep over overflowed work lists is incomplete: grow them and sweep again (the flag word rides the
         // stream into pinned memory: one wait)
@@ -641,6 +657,7 @@ int tp_shift(tp_context* c, float rate) {
     tp_launch_shift(L, rate, c->stream);
     HIP_TRY(c, hipGetLastError());
     c->accumulated = c->energized = false;  // geometry moved
+    c->lists_dp = -1.0f;  // ... without the margin vote of the fused update: the next fused iteration rebuilds the work lists
     return TP_OK;
 }
 
@@ -663,6 +680,43 @@ static int validate_params(tp_context* c, const tp_params* p, int n_iters) {
 }  // extern "C"
 
 namespace {
+const int CHUNK = 16;  // fused iterations per graph: hides the ~10 us replay floor; a remainder runs eagerly
+
+// Capture whatever `body` enqueues on the context stream into an executable graph.  On any failure the
+// capture is ended and the partial graph destroyed, so the stream never stays in capture mode.
+template <class F>
+int capture_graph(tp_context* c, F&& body, hipGraphExec_t* exec) {
+    capture_guard capture_lock;
+    hipGraph_t graph = nullptr;
+    *exec = nullptr;
+    hipError_t err = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
+    if (err != hipSuccess) return fail(c, TP_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(err));
+    body();
+    hipError_t launch_err = hipGetLastError();  // launch errors raised while capturing
+    err = hipStreamEndCapture(c->stream, &graph);
+    if (err == hipSuccess && launch_err != hipSuccess) err = launch_err;
+    if (err == hipSuccess) err = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+    if (graph) hipGraphDestroy(graph);
+    if (err != hipSuccess) {
+        if (*exec) { hipGraphExecDestroy(*exec); *exec = nullptr; }
+        return fail(c, TP_ERR_HIP, "graph capture: %s", hipGetErrorString(err));
+    }
+    return TP_OK;
+}
+
+// the graph of CHUNK fused grad-iters for these parameters (captured once per upload / parameter set)
+int chunk_graph(tp_context* c, const tp_params* p, float dp, graph_entry** out) {
+    for (auto& e : c->graphs)
+        if (e.generation == c->generation && e.iters == CHUNK && memcmp(&e.params, p, sizeof *p) == 0) { *out = &e; return TP_OK; }
+    graph_entry e;
+    if (int rc = capture_graph(c, [&] { for (int k = 0; k < CHUNK; k++) enqueue_iter(c, *p, dp); }, &e.exec)) return rc;
+    e.params = *p; e.iters = CHUNK; e.generation = c->generation;
+    if (c->graphs.size() > 8) drop_graphs(c);
+    c->graphs.push_back(e);
+    *out = &c->graphs.back();
+    return TP_OK;
+}
+
 // enqueue n fused grad-iters on the context stream and remember them until the flags were checked
 int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
     const float dp = resolve_dp(c, p->flavour, p->dp);
@@ -671,28 +725,10 @@ int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
         HIP_TRY(c, force_rebin(c));
         c->lists_dp = dp; c->lists_ratio = c->ratio;
     }
-    // graphs of CHUNK fused iterations hide the ~10 us replay floor; the remainder runs eagerly
-    const int CHUNK = 16;
     int left = n_iters;
     if (left >= CHUNK) {
         graph_entry* g = nullptr;
-        for (auto& e : c->graphs)
-            if (e.generation == c->generation && e.iters == CHUNK && memcmp(&e.params, p, sizeof *p) == 0) g = &e;
-        if (!g) {
-            hipGraph_t graph = nullptr;
-            capture_guard capture_lock;
-            HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-            for (int k = 0; k < CHUNK; k++) enqueue_iter(c, *p, dp);
-            HIP_TRY(c, hipStreamEndCapture(c->stream, &graph));
-            graph_entry e;
-            hipError_t err = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
-            hipGraphDestroy(graph);
-            if (err != hipSuccess) return fail(c, TP_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(err));
-            e.params = *p; e.iters = CHUNK; e.generation = c->generation;
-            if (c->graphs.size() > 8) drop_graphs(c);
-            c->graphs.push_back(e);
-            g = &c->graphs.back();
-        }
+        if (int rc = chunk_graph(c, p, dp, &g)) return rc;
         while (left >= CHUNK) {
             HIP_TRY(c, hipGraphLaunch(g->exec, c->stream));
             left -= CHUNK;
@@ -720,6 +756,15 @@ int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
     return enqueue_iters(c, p, n_iters);
 }
 
+int tp_prepare(tp_context* c, const tp_params* p) {
+    api_guard api_lock;
+    if (!c) return TP_ERR_INVALID;
+    if (int rc = validate_params(c, p, 0)) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    graph_entry* g = nullptr;
+    return chunk_graph(c, p, resolve_dp(c, p->flavour, p->dp), &g);
+}
+
 int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* accumulate_us) {
     api_guard api_lock;
     if (!c || !accumulate_us) return TP_ERR_INVALID;
@@ -740,7 +785,6 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
         tp_launch L = make_launch(c, p->image_slot, dp);
         tp_launch_bin(L, c->stream);
         tp_launch_accumulate_timed(L, c->stream, ev[2 * k], ev[2 * k + 1]);
-        tp_launch_reduce(L, c->stream);
         tp_launch_update(L, p->flavour, p->rate, c->stream);
     }
     c->pending.push_back({*p, n_iters});
@@ -769,18 +813,9 @@ int tp_profile_accumulate(tp_context* c, const tp_params* p, int launches, doubl
     tp_launch L = make_launch(c, p->image_slot, dp);
     tp_launch_bin(L, c->stream);  // work lists of the current state; every accumulate launch below consumes the same ones
     HIP_TRY(c, hipGetLastError());
-    hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipError_t err;
-    {
-        capture_guard capture_lock;
-        HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-        for (int k = 0; k < launches; k++) tp_launch_accumulate(L, c->stream);
-        HIP_TRY(c, hipStreamEndCapture(c->stream, &graph));
-        err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
-    }
-    if (err != hipSuccess) return fail(c, TP_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(err));
+    if (int rc = capture_graph(c, [&] { for (int k = 0; k < launches; k++) tp_launch_accumulate(L, c->stream); }, &exec)) return rc;
     if (!c->ev0) { HIP_TRY(c, hipEventCreate(&c->ev0)); HIP_TRY(c, hipEventCreate(&c->ev1)); }
     float ms = 0.0f;
     err = hipGraphLaunch(exec, c->stream);  // warm-up replay
@@ -878,13 +913,18 @@ int tp_render(tp_context* c, int source, const float* points, uint8_t* dst, size
     if (!c->uploaded) return fail(c, TP_ERR_STATE, "render before upload");
     if (source == TP_RENDER_STORED && !c->have_colors) return fail(c, TP_ERR_STATE, "render: no colours were uploaded");
     if (int rc = tp_synchronize(c)) return rc;  // settles (and, after an overflow, replays) fused iterations
-    uint8_t* pic = nullptr;
+    if (!c->render_pic) HIP_TRY(c, dev_alloc(&c->render_pic, (size_t)c->W * c->H * 4));
+    uint8_t* pic = c->render_pic;
     float2* pts = nullptr;
-    HIP_TRY(c, dev_alloc(&pic, (size_t)c->W * c->H * 4));
     hipError_t e = hipMemsetD32Async((hipDeviceptr_t)pic, 0xff000000u, (size_t)c->W * c->H, c->stream);  // opaque black
     if (e == hipSuccess && points) {
-        e = dev_alloc(&pts, (size_t)c->NP);
-        if (e == hipSuccess) e = hipMemcpy(pts, points, sizeof(float) * 2 * (size_t)c->NP, hipMemcpyHostToDevice);
+        if (c->render_pts_cap < (size_t)c->NP) {
+            hipFree(c->render_pts); c->render_pts = nullptr; c->render_pts_cap = 0;
+            e = dev_alloc(&c->render_pts, (size_t)c->capP);
+            if (e == hipSuccess) c->render_pts_cap = (size_t)c->capP;
+        }
+        pts = c->render_pts;
+        if (e == hipSuccess) e = hipMemcpyAsync(pts, points, sizeof(float) * 2 * (size_t)c->NP, hipMemcpyHostToDevice, c->stream);
     }
     if (e == hipSuccess) {
         tp_launch L = make_launch(c, 0, 0.0f);
@@ -893,7 +933,6 @@ int tp_render(tp_context* c, int source, const float* points, uint8_t* dst, size
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy2D(dst, stride, pic, (size_t)c->W * 4, (size_t)c->W * 4, c->H, hipMemcpyDeviceToHost);
-    hipFree(pic); hipFree(pts);
     if (e != hipSuccess) return fail(c, TP_ERR_HIP, "render: %s", hipGetErrorString(e));
     return TP_OK;
 }
@@ -921,6 +960,28 @@ int tp_selftest_walker(tp_context* c, const int64_t* N0, const int32_t* step, co
     return TP_OK;
 }
 
+int tp_selftest_line(tp_context* c, const int32_t* ends, const int32_t* H, int n, int rows, int32_t* out) {
+    api_guard api_lock;
+    if (!c || !ends || !H || !out || n < 0 || rows < 1) return TP_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int4* de = nullptr; int* dh = nullptr; int32_t* dout = nullptr;
+    hipError_t e = dev_alloc(&de, n);
+    if (e == hipSuccess) e = dev_alloc(&dh, n);
+    if (e == hipSuccess) e = dev_alloc(&dout, (size_t)n * (rows + 2));
+    if (e == hipSuccess) e = hipMemcpy(de, ends, sizeof(int4) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dh, H, sizeof(int) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        tp_launch_selftest_line(de, dh, n, rows, dout, c->stream);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(int32_t) * (size_t)n * (rows + 2), hipMemcpyDeviceToHost);
+    hipFree(de); hipFree(dh); hipFree(dout);
+    if (e != hipSuccess) return fail(c, TP_ERR_HIP, "selftest_line: %s", hipGetErrorString(e));
+    return TP_OK;
+}
+
+#ifdef TPOSE_DEBUG
+// debug flavour only (libtpose_hip_debug.so, tools/acc_timeline.py): the per-block phase timestamps
 int tp_debug_dump(tp_context* c, unsigned long long* out, int n) {
     api_guard api_lock;
     tp_launch L = make_launch(c, 0, 0.0f);
@@ -929,58 +990,7 @@ int tp_debug_dump(tp_context* c, unsigned long long* out, int n) {
     hipMemcpy(out, L.dbg, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
     return TP_OK;
 }
-
-// debug: per-tile list lengths of the current work lists
-int tp_debug_tilecount(tp_context* c, int* out, int n) {
-    api_guard api_lock;
-    if (!c || !out) return TP_ERR_INVALID;
-    hipStreamSynchronize(c->stream);
-    tp_launch L = make_launch(c, 0, 0.0f);
-    hipMemcpy(out, L.tilecount, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost);
-    return TP_OK;
-}
-
-// debug: raw bytes from the start of the record buffer (the probes write there)
-int tp_debug_read_visits(tp_context* c, void* out, size_t bytes) {
-    api_guard api_lock;
-    if (!c || !out) return TP_ERR_INVALID;
-    hipStreamSynchronize(c->stream);
-    return hipMemcpy(out, c->visits, bytes, hipMemcpyDeviceToHost) == hipSuccess ? TP_OK : TP_ERR_HIP;
-}
-
-// launch-overhead probe: n back-to-back launches of an (almost) empty kernel in k_accumulate's shape
-int tp_debug_null_launch(tp_context* c, int mode, int blocks, int threads, int lds, int n, double* us) {
-    api_guard api_lock;
-    if (!c || !us || !c->uploaded) return TP_ERR_STATE;
-    HIP_TRY(c, hipSetDevice(c->device));
-    tp_launch L = make_launch(c, 0, 0.0f);
-    std::vector<hipEvent_t> ev((size_t)2 * n);
-    for (auto& e : ev) HIP_TRY(c, hipEventCreate(&e));
-    const int n16 = (int)((size_t)L.pitch * (size_t)(L.tiles_y * TP_TILE_H) / 16);
-    for (int k = 0; k < n; k++)
-        tp_launch_probe(L.img, L.visits, mode, n16, blocks, threads, (size_t)lds, c->stream, ev[2 * k], ev[2 * k + 1]);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    double total = 0.0;
-    for (int k = 0; k < n; k++) { float ms = 0; HIP_TRY(c, hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1])); total += ms; }
-    for (auto& e : ev) hipEventDestroy(e);
-    *us = total * 1000.0 / n;
-    if (mode >= 16) {  // wall-clock cost per launch of 64 probes captured into a graph, replayed n times
-        hipGraph_t g; hipGraphExec_t ge;
-        capture_guard capture_lock;
-        HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-        for (int k = 0; k < 64; k++) tp_launch_probe(L.img, L.visits, mode & 15, n16, blocks, threads, (size_t)lds, c->stream, nullptr, nullptr);
-        HIP_TRY(c, hipStreamEndCapture(c->stream, &g));
-        HIP_TRY(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        HIP_TRY(c, hipGraphLaunch(ge, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int k = 0; k < n; k++) HIP_TRY(c, hipGraphLaunch(ge, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        *us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (64.0 * n);
-        hipGraphExecDestroy(ge); hipGraphDestroy(g);
-    }
-    return TP_OK;
-}
+#endif
 
 int tp_get_info(tp_context* c, int what, int64_t* value) {
     api_guard api_lock;

@@ -5,9 +5,9 @@
 #include "tp_raster.h"
 
 #define TP_TILE_W 128
-#define TP_TILE_H 32
+#define TP_TILE_H 16
 #define TP_NLINES 9        /* lines per undirected edge: base + 4 moves of either endpoint */
-#define TP_W_WORDS 6       /* int64 per line sum: sum x, n_odd, sum r, sum g, sum b, q */
+#define TP_W_WORDS 6       /* values per line sum: sum x, n_odd, sum r, sum g, sum b, q */
 #define TP_REC_DWORDS 8    /* per-tile record of a line, 32 bytes: u32 sum x, n_odd, sum r, sum g, sum b, 0, u64 q
                               (<= 32 rows of <= 16384 columns: every 32-bit field < 2^28) */
 #define TP_T2_WORDS 5      /* int64 per static-table entry: n_odd, sum r, sum g, sum b, q */
@@ -17,20 +17,13 @@
 #define TP_FLAG_VISIT_OVERFLOW 2u
 
 struct tp_device_state {
-    uint32_t visit_total;  // (edge, tile) visits of the current work lists
+    uint32_t visit_total;  // (edge, tile) visits drawn from the shared half of the record buffer
     uint32_t flags;        // sticky overflow flags
     uint32_t rebin_req;    // 1: k_bin must rebuild the work lists (upload, or a vertex left its margin)
     uint32_t arrive;       // k_update: blocks arrived | (blocks voting for a rebuild) << 16
     uint32_t rebin_count;  // statistics: rebuilds so far
     uint32_t iters_done;   // fused iterations k_update completed (it does not step while a flag is up)
     uint32_t pad[2];
-};
-
-// One (edge, tile) work item: which undirected edge (nine lanes walk its nine lines), where the
-// nine records go, and the edge's endpoints so that the walk needs no dependent index load.
-struct __attribute__((aligned(16))) tp_list_entry {
-    int visit, edge, u, v;
-    int2 a[5], b[5];  // snapped positions of endpoint u / v for the five moves (valid for this iteration)
 };
 
 struct tp_launch {
@@ -52,14 +45,16 @@ struct tp_launch {
     const int2* edge_uv;    // [NE] endpoints of every undirected edge, u <= v; bit 30: this edge publishes the vertex (vpos)
     const int* he_edge;     // [3 NT] edge id * 2 + (half-edge runs v -> u)
     int2* vpos;             // [NP][5] snapped 24.8 position of every vertex: unmoved, +dx, -dx, +dy, -dy
+    // per-iteration line table: the nine lines of every edge, set up once (tp_setup_line)
+    longlong2* line_xs;     // [NE][TP_NLINES] (x, s) 24.40 walker at row ra and its step
+    int2* line_rows;        // [NE][TP_NLINES] (ra, rb) rows of the line inside the raster
     // work lists
     int* tilecount;           // [tiles]
-    tp_list_entry* tilelist;  // [tiles * list_cap]
+    int2* tilelist;           // [tiles * list_cap] (edge, record slot of this (edge, tile) visit)
     int list_cap;
-    int2* edge_visit;         // [NE] (first record, #records = tiles a line of the edge can cross)
+    int2* edge_visit;         // [NE] (first record slot, #slots = tiles the band of the edge's lines can touch)
     uint32_t* visits;         // [visit_cap][TP_NLINES][TP_REC_DWORDS] per-tile line records
     int visit_cap;
-    int64_t* wline;           // [NE][TP_NLINES][TP_W_WORDS] line sums over the whole raster
     tp_device_state* state;
     // outputs (reference layout)
     int32_t* ten;
@@ -68,14 +63,14 @@ struct tp_launch {
     int2* gr;
     int64_t* moments;          // optional int64[13NT][6]
     unsigned long long* gacc;  // [NP][2] fused-update accumulators: (gradient component << 32) | arrivals
-    int debug;                 // ablation knobs (TPOSE_DEBUG_ACC), 0 in production
-    unsigned long long* dbg;   // per-block phase timestamps when (debug & 8)
+#ifdef TPOSE_DEBUG
+    unsigned long long* dbg;   // per-block phase timestamps (debug flavour of the library only)
+#endif
 };
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s);
 void tp_launch_accumulate(const tp_launch& L, hipStream_t s);
 void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t start, hipEvent_t stop);
-void tp_launch_reduce(const tp_launch& L, hipStream_t s);
 void tp_launch_finalize(const tp_launch& L, int flavour, bool write_moments, hipStream_t s);
 void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s);
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s);
@@ -84,8 +79,7 @@ void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s);
 void tp_launch_static_table(const uint8_t* img, int pitch, int W, int H, int tiles_x, uint32_t* seg_scratch,
                             int64_t* t2, hipStream_t s);
 size_t tp_accumulate_lds_bytes();
-hipError_t tp_kernels_init();  // per-device function attributes (dynamic LDS > 64 KiB)
+hipError_t tp_kernels_init();  // per-device function attributes
 void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s);
+void tp_launch_selftest_line(const int4* ends, const int* H, int n, int rows, int32_t* out, hipStream_t s);
 void tp_launch_render(const tp_launch& L, const float2* pts, int source, void* out, int out_pitch_px, hipStream_t s);
-void tp_launch_probe(const void* src, void* dst, int mode, int n16, int blocks, int threads, size_t lds, hipStream_t s,
-                     hipEvent_t start, hipEvent_t stop);

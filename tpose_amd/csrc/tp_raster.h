@@ -345,3 +345,114 @@ TP_HD int tp_edge_version(int variant, int k, int flipped) {
     if (s == (k == 2 ? 0 : k + 1)) return flipped ? m : 4 + m;   // destination displaced
     return 0;
 }
+
+// =============================================================================================
+// Whole-line walkers (round 2).  A line is set up ONCE per iteration -- not once per (line, tile) --
+// as x(r) = x(ra) + (r - ra) * s in 24.40 fixed point, valid for every row of the line inside the
+// raster (up to TP_MAX_RASTER rows), and a tile derives its own 32.32 walker from it with two shifts.
+//
+// Error budget, in units of 2^-40 with u = 2^40 / d the spacing of the attainable fractions of N_r / d
+// (d = dy < 2^23.6 because snapped coordinates lie in [-2^22, 2^23]):  t = N_0 / d and ts = dx / d carry a
+// relative error <= 2^-50 (|t| <= 2^15 + 2: the crossing column of a row BETWEEN the line's endpoints;
+// |ts| < 2^16 whenever the line has two rows, i.e. d > 256), each truncation loses < 1 unit, so after R <=
+// 16383 steps   x_r - BIAS  lies in  (N_r/d - (R + 2) - 2^-8 u,  N_r/d + 2^-8 u].  The tile's walker
+// X(j) = (x(row0) >> 8) + j * (s >> 8), j < 32, in units of 2^-32, is below x(row0 + j) / 256 by less
+// than j + 1 units of 2^-32 = 256 (j + 1) units of 2^-40.  With BIAS = u / 2 the value therefore stays
+// strictly inside [N_r/d, N_r/d + u) as long as  R + 2 + 8448 + 2^-7 u < u / 2,  which holds for every
+// d < 2^23.6 (u > 86 000 > 2 * (16385 + 8448) / (1 - 2^-6)).  Hence floor(X(j)) == floor(N_r / d): EXACT.
+// Single-row lines store s = 0 (the slope of a nearly horizontal line does not fit the format and is
+// never used); empty lines have ra > rb.
+// =============================================================================================
+#define TP_LINE_FRAC 40
+
+struct tp_line {
+    int64_t x, s;    // 24.40: crossing column of row ra (+ bias), step per row
+    int32_t ra, rb;  // absolute rows (inclusive) inside the raster; empty when ra > rb
+};
+
+// floor(t) * 2^40 + trunc(frac(t) * 2^40) for |t| < 2^22
+TP_HD int64_t tp_fix40(double t) {
+    const double q = floor(t);
+    const double f = (t - q) * 1099511627776.0;  // exact subtraction; [0, 2^40)
+    const double fh = floor(f * (1.0 / 4294967296.0));
+    const double fl = f - fh * 4294967296.0;     // exact: [0, 2^32)
+    const int32_t qi = (int32_t)q;
+    const uint32_t hi = (uint32_t)fh > 255u ? 255u : (uint32_t)fh;
+    const uint32_t lo = fl >= 4294967295.0 ? 4294967295u : (uint32_t)fl;
+    return (int64_t)((uint64_t)(int64_t)qi << 40) + (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+TP_HD void tp_setup_line(int32_t Xa, int32_t Ya, int32_t Xb, int32_t Yb, int32_t H, tp_line& ln) {
+    const bool swap = Ya > Yb;
+    const int32_t Xt = swap ? Xb : Xa, Yt = swap ? Yb : Ya, Xq = swap ? Xa : Xb, Yq = swap ? Ya : Yb;
+    const int32_t dy = Yq - Yt, dx = Xq - Xt;
+    const int32_t ra = tp_max(0, tp_first_centre(Yt));          // Yt <= 256 r + 128
+    const int32_t rb = tp_min(H - 1, tp_first_centre(Yq) - 1);  // 256 r + 128 < Yq
+    const bool live = dy > 0 && ra <= rb;
+    const int32_t d = dy > 0 ? dy : 1;
+    const int64_t N1 = (int64_t)dx * (256LL * ra + 128 - Yt) + (int64_t)(Xt - 128) * dy;
+    const int64_t Nc = -((-N1) >> 8);  // ceil(N1 / 256)
+    const double inv = tp_rcp_exact((double)d);
+    double t = (double)(Nc + d - 1) * inv;   // floor((Nc + d - 1) / d) = ceil(Nc / d): the first column on or right of the line
+    t = fmin(fmax(t, -4194304.0), 4194304.0);  // never reached for a live line (|t| <= 2^15 + 2)
+    const int64_t bias = (int64_t)(549755813888.0 * inv);  // 2^39 / d = u / 2
+    ln.x = live ? tp_fix40(t) + bias : 0;
+    ln.s = (live && rb > ra) ? tp_fix40((double)dx * inv) : 0;
+    ln.ra = live ? ra : 1;
+    ln.rb = live ? rb : 0;
+}
+
+// the tile's 32.32 walker for rows row0, row0 + 1, ... (row0 within 32767 rows of ra)
+TP_HD tp_walker tp_line_at(const tp_line& ln, int32_t row0) {
+    tp_walker w;
+    w.x = (ln.x + (int64_t)(row0 - ln.ra) * ln.s) >> (TP_LINE_FRAC - 32);
+    w.s = ln.s >> (TP_LINE_FRAC - 32);
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Which tiles can the nine lines of an edge touch?  Every sample (row centre y, line abscissa x) of a
+// line whose endpoints are the base endpoints displaced by at most (dX, dY) lies in
+// base segment (+) box(dX, dY); the crossing COLUMN c of the sample satisfies 256 c in [x - 128, x + 128).
+// Per tile row this gives a conservative column interval (float arithmetic + one pixel of slack).
+// Columns are clamped like the walk clamps them: left of the raster contributes nothing (prefix 0),
+// right of it the full row (entry W of the last tile column).
+// ---------------------------------------------------------------------------------------------
+struct tp_band {
+    int32_t Xa, Ya, Xb, Yb;  // base endpoints (1/256 px)
+    int32_t dX, dY;          // reach of the endpoint moves (+ margin), 1/256 px
+};
+
+// pixel rows [r0, r1] any of the lines can have (empty when r0 > r1)
+TP_HD void tp_band_rows(const tp_band& b, int32_t H, int32_t& r0, int32_t& r1) {
+    const int32_t ymin = tp_min(b.Ya, b.Yb) - b.dY, ymax = tp_max(b.Ya, b.Yb) + b.dY;
+    r0 = tp_max(tp_first_centre(ymin), 0);
+    r1 = tp_min(tp_first_centre(ymax) - 1, H - 1);
+}
+
+// tile columns [tx0, tx1] of the tile row covering pixel rows [pr0, pr1]; false: none
+TP_HD bool tp_band_cols(const tp_band& b, int32_t pr0, int32_t pr1, int32_t W, int32_t tile_w, int32_t tiles_x,
+                        int32_t& tx0, int32_t& tx1) {
+    const int32_t Ymin = tp_min(b.Ya, b.Yb), Ymax = tp_max(b.Ya, b.Yb);
+    // base points that can reach these rows: y within dY of a row centre
+    const int32_t y0 = tp_max(256 * pr0 + 128 - b.dY, Ymin), y1 = tp_min(256 * pr1 + 128 + b.dY, Ymax);
+    if (y0 > y1) return false;
+    float xlo, xhi;
+    if (b.Ya == b.Yb) {
+        xlo = (float)tp_min(b.Xa, b.Xb); xhi = (float)tp_max(b.Xa, b.Xb);
+    } else {
+        const float slope = tp_fdiv((float)(b.Xb - b.Xa), (float)(b.Yb - b.Ya));
+        const float xa = tp_fadd((float)b.Xa, tp_fmul((float)(y0 - b.Ya), slope));
+        const float xb = tp_fadd((float)b.Xa, tp_fmul((float)(y1 - b.Ya), slope));
+        xlo = fminf(xa, xb); xhi = fmaxf(xa, xb);
+    }
+    const float reach = (float)(b.dX + 128 + 256);  // endpoint moves, column rounding, float slack
+    const float flo = floorf(tp_fmul(tp_fsub(xlo, reach), 1.0f / 256.0f));
+    const float fhi = floorf(tp_fmul(tp_fadd(xhi, reach), 1.0f / 256.0f));
+    if (fhi < 0.0f) return false;  // every crossing column clamps to 0: prefix 0, nothing to add
+    const int32_t c0 = flo < 0.0f ? 0 : (flo > (float)W ? W : (int32_t)flo);
+    const int32_t c1 = fhi > (float)W ? W : (int32_t)fhi;
+    tx0 = tp_min(c0 / tile_w, tiles_x - 1);
+    tx1 = tp_min(c1 / tile_w, tiles_x - 1);
+    return true;
+}
