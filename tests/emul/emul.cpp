@@ -207,6 +207,14 @@ extern "C" int emul_moments_lines(const uint8_t* img, size_t stride, int W, int 
         }
     std::vector<int64_t> Wt(edges.size() * 9 * 6, 0);
     int64_t visits = 0;
+    // cumulative static table like the device's t2: T2[r][tc] = moments of rows < r, columns < tc * tile_w
+    std::vector<int64_t> T2((size_t)(H + 1) * (tiles_x + 1) * 5, 0);
+    for (int r = 0; r < H; r++)
+        for (int tc = 0; tc <= tiles_x; tc++) {
+            const int c = tp_min(tc * tile_w, W);
+            for (int k = 0; k < 5; k++)
+                T2[((size_t)(r + 1) * (tiles_x + 1) + tc) * 5 + k] = T2[((size_t)r * (tiles_x + 1) + tc) * 5 + k] + P[((size_t)r * (W + 1) + c) * 5 + k];
+        }
     for (size_t e = 0; e < edges.size(); e++) {
         const int u = edges[e].first, v = edges[e].second;
         tp_line ln[9];
@@ -221,6 +229,12 @@ extern "C" int emul_moments_lines(const uint8_t* img, size_t stride, int W, int 
         for (int ver = 0; ver < 9; ver++) {
             const int mu = ver >= 1 && ver <= 4 ? ver : 0, mv = ver >= 5 ? ver - 4 : 0;
             tp_setup_line(vx[u * 5 + mu], vy[u * 5 + mu], vx[v * 5 + mv], vy[v * 5 + mv], H, ln[ver]);
+            // static part: per run of rows inside one tile column, a difference of the cumulative table
+            int64_t* acc = &Wt[(e * 9 + ver) * 6];
+            tp_line_column_runs(ln[ver], W, tile_w, tiles_x, [&](int32_t tc, int32_t ra, int32_t rb) {
+                for (int k = 0; k < 5; k++)
+                    acc[1 + k] += T2[((size_t)(rb + 1) * (tiles_x + 1) + tc) * 5 + k] - T2[((size_t)ra * (tiles_x + 1) + tc) * 5 + k];
+            });
         }
         int32_t r0, r1;
         tp_band_rows(b, H, r0, r1);
@@ -232,8 +246,9 @@ extern "C" int emul_moments_lines(const uint8_t* img, size_t stride, int W, int 
             for (int tx = tx0; tx <= tx1; tx++) {
                 visits++;
                 const int col0 = tx * tile_w;
-                const uint32_t lim = tx == tiles_x - 1 ? (uint32_t)(W - col0 + 1) : (uint32_t)tile_w;
+                const int lim = tx == tiles_x - 1 ? W - col0 + 1 : tile_w;
                 for (int ver = 0; ver < 9; ver++) {
+                    if (!tp_line_live(ln[ver], row0, row1, col0, lim, W)) continue;  // k_bin lists live lines only
                     tp_walker w = tp_line_at(ln[ver], row0);
                     const int koff = ln[ver].ra - row0;
                     const uint32_t nvalid = (uint32_t)tp_max(ln[ver].rb - ln[ver].ra + 1, 0);
@@ -243,10 +258,12 @@ extern "C" int emul_moments_lines(const uint8_t* img, size_t stride, int W, int 
                         w.x += w.s;
                         x = x < 0 ? 0 : (x > W ? W : x);
                         const uint32_t xl = (uint32_t)(x - col0);
-                        const bool in = xl < lim && (uint32_t)(j - koff) < nvalid;
+                        const bool in = xl < (uint32_t)lim && (uint32_t)(j - koff) < nvalid;
                         if (!in) continue;
                         acc[0] += x;
-                        for (int k = 0; k < 5; k++) acc[1 + k] += P[((size_t)(row0 + j) * (W + 1) + x) * 5 + k];
+                        // tile-local prefix = full-row prefix minus everything left of the tile column
+                        for (int k = 0; k < 5; k++)
+                            acc[1 + k] += P[((size_t)(row0 + j) * (W + 1) + x) * 5 + k] - P[((size_t)(row0 + j) * (W + 1) + col0) * 5 + k];
                     }
                 }
             }

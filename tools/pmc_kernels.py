@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Per-kernel hardware counters of the headline workload: runs `rocprofv3 --pmc <counters>` (counters only, no trace
+domains; one pass per group) over tools/time_acc.py and prints the per-launch average of every counter for every
+kernel.  Needs an MI355X.   python tools/pmc_kernels.py [out.json]"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GROUPS = [
+    ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"],
+    ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"],
+    ["GRBM_GUI_ACTIVE", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_VMEM", "SQ_THREAD_CYCLES_VALU", "SQ_INST_CYCLES_SALU", "SQ_WAIT_INST_ANY"],
+    ["FETCH_SIZE"], ["WRITE_SIZE"],
+]
+exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+out = {}
+for grp in GROUPS:
+    d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
+    env = dict(os.environ, TPOSE_TIME_ACC_SHORT="1")
+    cmd = [exe, "--pmc"] + grp + ["--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "tools", "time_acc.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=d, env=env, timeout=600)
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if r.returncode != 0 or not files:
+        print("group failed:", grp, r.returncode, r.stderr[-400:], file=sys.stderr)
+        continue
+    acc = {}
+    for row in csv.DictReader(open(files[0])):
+        k = row["Kernel_Name"].split("(")[0]
+        key = (k, row["Counter_Name"])
+        a = acc.setdefault(key, [0.0, 0])
+        a[0] += float(row["Counter_Value"]); a[1] += 1
+    for (k, c), (tot, n) in acc.items():
+        out.setdefault(k, {})[c] = round(tot / n, 1)
+        out[k]["launches"] = n
+    shutil.rmtree(d, ignore_errors=True)
+txt = json.dumps(out, indent=1, sort_keys=True)
+print(txt)
+if len(sys.argv) > 1:
+    open(sys.argv[1], "w").write(txt)

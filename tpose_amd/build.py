@@ -32,14 +32,15 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not stale():
+def build(force=False, verbose=False, extra=(), out=None):
+    """out: build a variant (debug flavour, timing experiments) next to the product library instead of it"""
+    if out is None and not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + list(extra) + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    cmd = [hipcc()] + FLAGS + list(extra) + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", out or LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -80,6 +80,9 @@ struct tp_context {
     int visit_cap = 0;
     longlong2* line_xs = nullptr;  // per-iteration line table: nine whole-line walkers per edge
     int2* line_rows = nullptr;
+    int64_t* line_static = nullptr;
+    uint16_t* vmask = nullptr;     // per (edge, tile) visit: which of the nine lines are live there
+    uint32_t* segex[2] = {nullptr, nullptr};  // static per-image packed segment prefixes
     int64_t* t2[2] = {nullptr, nullptr};   // static per-image tables
     uint32_t* seg_scratch = nullptr;
     tp_device_state* state = nullptr;
@@ -150,11 +153,11 @@ void drop_graphs(tp_context* c) {
 void free_triangulation(tp_context* c) {
     hipFree(c->points); hipFree(c->points_binned); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
     hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->edge_visit); hipFree(c->visits);
-    hipFree(c->line_xs); hipFree(c->line_rows); hipFree(c->tilelist);
+    hipFree(c->line_xs); hipFree(c->line_rows); hipFree(c->line_static); hipFree(c->vmask); hipFree(c->tilelist);
     hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
     c->points = nullptr; c->points_binned = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
     c->edge_uv = nullptr; c->he_edge = nullptr; c->vpos = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
-    c->line_xs = nullptr; c->line_rows = nullptr; c->tilelist = nullptr; c->capE = 0;
+    c->line_xs = nullptr; c->line_rows = nullptr; c->line_static = nullptr; c->vmask = nullptr; c->tilelist = nullptr; c->capE = 0;
     c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
     c->capT = c->capP = 0;
 }
@@ -174,7 +177,8 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.tilecount = c->tilecount; L.tilelist = c->tilelist; L.list_cap = c->list_cap;
     L.edge_uv = c->edge_uv; L.he_edge = c->he_edge; L.vpos = c->vpos; L.NE = c->NE;
     L.edge_visit = c->edge_visit; L.visits = c->visits; L.visit_cap = c->visit_cap;
-    L.line_xs = c->line_xs; L.line_rows = c->line_rows;
+    L.line_xs = c->line_xs; L.line_rows = c->line_rows; L.line_static = c->line_static; L.vmask = c->vmask;
+    L.segex = c->segex[slot];
     L.t2 = c->t2[slot];
     L.state = c->state;
     L.ten = c->ten; L.cn = c->cn; L.ca = c->ca; L.gr = c->gr; L.moments = c->moments;
@@ -229,18 +233,21 @@ bool grow_lists(tp_context* c, uint32_t flags, hipError_t* err) {
             size_t vcap = (size_t)c->visit_cap * 2;
             if (vcap > limit) vcap = limit;
             uint32_t* fresh = nullptr;
-            if ((*err = dev_alloc(&fresh, vcap * TP_NLINES * TP_REC_DWORDS)) == hipSuccess) {
-                hipFree(c->visits);
-                c->visits = fresh;
+            uint16_t* fresh_mask = nullptr;
+            if ((*err = dev_alloc(&fresh, vcap * TP_NLINES * TP_REC_DWORDS)) == hipSuccess &&
+                (*err = dev_alloc(&fresh_mask, vcap)) == hipSuccess) {
+                hipFree(c->visits); hipFree(c->vmask);
+                c->visits = fresh; c->vmask = fresh_mask;
                 c->visit_cap = (int)vcap;
                 grown = true;
-            }
+            } else
+                hipFree(fresh);
         }
     }
     if (*err == hipSuccess && (flags & TP_FLAG_LIST_OVERFLOW)) {
-        if (c->list_cap < c->capE) {  // a tile never holds more than one entry per edge
+        if (c->list_cap < c->capE * TP_NLINES) {  // a tile never holds more than one entry per line
             size_t cap = (size_t)c->list_cap * 2;
-            if (cap > (size_t)c->capE) cap = (size_t)c->capE;
+            if (cap > (size_t)c->capE * TP_NLINES) cap = (size_t)c->capE * TP_NLINES;
             int2* fresh = nullptr;
             if ((*err = dev_alloc(&fresh, cap * ntiles)) == hipSuccess) {
                 hipFree(c->tilelist);
@@ -354,7 +361,7 @@ int tp_destroy(tp_context* c) {
     drop_graphs(c);
     free_triangulation(c);
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->tilecount); hipFree(c->state);
-    hipFree(c->t2[0]); hipFree(c->t2[1]); hipFree(c->seg_scratch);
+    hipFree(c->t2[0]); hipFree(c->t2[1]); hipFree(c->seg_scratch); hipFree(c->segex[0]); hipFree(c->segex[1]);
     hipFree(c->render_pic); hipFree(c->render_pts);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->up_pinned) hipHostFree(c->up_pinned);
@@ -410,7 +417,9 @@ static int set_image_common(tp_context* c, int slot, const void* src, size_t str
     // static table of this image: moments of everything above a row and left of a tile column
     if (!c->t2[slot]) HIP_TRY(c, dev_alloc(&c->t2[slot], (size_t)(c->H + 1) * (c->tiles_x + 1) * TP_T2_WORDS));
     if (!c->seg_scratch) HIP_TRY(c, dev_alloc(&c->seg_scratch, (size_t)c->H * c->tiles_x * 5));
-    tp_launch_static_table(c->img[slot], c->Wp * 4, c->W, c->H, c->tiles_x, c->seg_scratch, c->t2[slot], c->stream);
+    if (!c->segex[slot]) HIP_TRY(c, dev_alloc(&c->segex[slot], (size_t)c->Hp * c->tiles_x * TP_SEG_ENTRIES * 3));
+    // (the alpha bytes of the context's copy are replaced by the pixel parity: the sweep, like the reference, never reads alpha)
+    tp_launch_static_table(c->img[slot], c->Wp * 4, c->W, c->H, c->Hp, c->tiles_x, c->seg_scratch, c->t2[slot], c->segex[slot], c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_img[slot] = true;
@@ -505,34 +514,39 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
     }
     if (NE > c->capE) {
         hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->line_xs); hipFree(c->line_rows);
+        hipFree(c->line_static); hipFree(c->vmask);
         c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr; c->line_xs = nullptr; c->line_rows = nullptr;
+        c->line_static = nullptr; c->vmask = nullptr;
         const int capE = NE + NE / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->edge_uv, capE));
         HIP_TRY(c, dev_alloc(&c->edge_visit, capE));
         HIP_TRY(c, dev_alloc(&c->line_xs, (size_t)capE * TP_NLINES));
         HIP_TRY(c, dev_alloc(&c->line_rows, (size_t)capE * TP_NLINES));
+        HIP_TRY(c, dev_alloc(&c->line_static, (size_t)capE * TP_NLINES * TP_T2_WORDS));
         // (edge, tile) visits: typical edges cross a handful of tiles, a few long ones many
         size_t vcap = (size_t)capE * 24 + (size_t)ntiles * 8;
         if (vcap > ((size_t)1 << 24)) vcap = (size_t)1 << 24;
         HIP_TRY(c, dev_alloc(&c->visits, vcap * TP_NLINES * TP_REC_DWORDS));
+        HIP_TRY(c, dev_alloc(&c->vmask, vcap));
         c->visit_cap = (int)vcap;
         c->capE = capE;
         c->tilelist_elems = 0;
     }
     c->NE = NE;
-    // per-tile list capacity: never more than NE entries; generous multiple of the mean otherwise
+    // per-tile list capacity in (live line) entries: never more than 9 NE; a generous multiple of the mean otherwise
+    // (about 40 live lines per edge over all tiles at 16-row tiles); grows on demand (grow_lists)
     {
-        size_t mean = ((size_t)c->capE * 6) / (size_t)ntiles + 8;
-        size_t cap = mean * 16;
-        if (cap < 256) cap = 256;
-        if (cap > (size_t)c->capE) cap = (size_t)c->capE;
+        size_t mean = ((size_t)c->capE * 40) / (size_t)ntiles + 64;
+        size_t cap = mean * 4;
+        if (cap < 512) cap = 512;
+        if (cap > (size_t)c->capE * TP_NLINES) cap = (size_t)c->capE * TP_NLINES;
         if (cap * ntiles > c->tilelist_elems) {
             hipFree(c->tilelist); c->tilelist = nullptr;
             HIP_TRY(c, dev_alloc(&c->tilelist, cap * ntiles));
             c->tilelist_elems = cap * ntiles;
         }
         c->list_cap = (int)(c->tilelist_elems / ntiles);
-        if (c->list_cap > c->capE) c->list_cap = c->capE;
+        if ((size_t)c->list_cap > (size_t)c->capE * TP_NLINES) c->list_cap = c->capE * TP_NLINES;
     }
 
     // vertex -> outgoing half-edge ids (3t+s), the gather form of gradient.cs' scatter

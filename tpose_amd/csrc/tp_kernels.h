@@ -8,8 +8,9 @@
 #define TP_TILE_H 16
 #define TP_NLINES 9        /* lines per undirected edge: base + 4 moves of either endpoint */
 #define TP_W_WORDS 6       /* values per line sum: sum x, n_odd, sum r, sum g, sum b, q */
-#define TP_REC_DWORDS 8    /* per-tile record of a line, 32 bytes: u32 sum x, n_odd, sum r, sum g, sum b, 0, u64 q
-                              (<= 32 rows of <= 16384 columns: every 32-bit field < 2^28) */
+#define TP_REC_DWORDS 6    /* per-tile record of a line, 24 bytes: u32 sum x (absolute columns), then the TILE-LOCAL sums
+                              n_odd, r, g, b, q + n_odd over its counted rows (<= 16 rows x 128 columns: < 2^29) */
+#define TP_SEG_ENTRIES 17  /* static packed prefixes per (row, tile column): at the start of each 8-pixel segment + the row total */
 #define TP_T2_WORDS 5      /* int64 per static-table entry: n_odd, sum r, sum g, sum b, q */
 
 // device-side flag bits (tp_device_state::flags)
@@ -28,9 +29,10 @@ struct tp_device_state {
 
 struct tp_launch {
     // raster
-    const uint8_t* img;  // padded RGBA8 plane
+    const uint8_t* img;  // padded RGBA8 plane; the alpha byte holds (r + g + b) & 1 (tp_set_image rewrites it)
     int pitch;           // bytes per padded row
     const int64_t* t2;   // static table of the swept image: [H+1][tiles_x+1][TP_T2_WORDS]
+    const uint32_t* segex;  // static: [Hp][tiles_x][TP_SEG_ENTRIES][3] packed tile-local prefix at every 8th column
     tp_view vw;
     int tiles_x, tiles_y;
     // triangulation
@@ -48,12 +50,15 @@ struct tp_launch {
     // per-iteration line table: the nine lines of every edge, set up once (tp_setup_line)
     longlong2* line_xs;     // [NE][TP_NLINES] (x, s) 24.40 walker at row ra and its step
     int2* line_rows;        // [NE][TP_NLINES] (ra, rb) rows of the line inside the raster
+    int64_t* line_static;   // [NE][TP_NLINES][TP_T2_WORDS] static part of the line sums: everything left of the tile
+                            // column in each of the line's rows (differences of t2 per column run)
     // work lists
     int* tilecount;           // [tiles]
-    int2* tilelist;           // [tiles * list_cap] (edge, record slot of this (edge, tile) visit)
+    int2* tilelist;           // [tiles * list_cap] (line = edge * 9 + version, record = visit * 9 + version): LIVE lines only
     int list_cap;
-    int2* edge_visit;         // [NE] (first record slot, #slots = tiles the band of the edge's lines can touch)
-    uint32_t* visits;         // [visit_cap][TP_NLINES][TP_REC_DWORDS] per-tile line records
+    int2* edge_visit;         // [NE] (first visit, #visits = tiles the band of the edge's lines can touch)
+    uint16_t* vmask;          // [visit_cap] which of the nine lines of the visit's edge are live in that tile
+    uint32_t* visits;         // [visit_cap][TP_NLINES][TP_REC_DWORDS] per-tile line records (live lines only are written)
     int visit_cap;
     tp_device_state* state;
     // outputs (reference layout)
@@ -76,8 +81,9 @@ void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s);
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s);
 void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s);
 // static per-image table: t2[r][tc] = moments of all pixels in rows < r and columns < tc * TP_TILE_W
-void tp_launch_static_table(const uint8_t* img, int pitch, int W, int H, int tiles_x, uint32_t* seg_scratch,
-                            int64_t* t2, hipStream_t s);
+// also rewrites the alpha bytes of the padded plane and fills the packed segment prefixes `segex`
+void tp_launch_static_table(uint8_t* img, int pitch, int W, int H, int Hp, int tiles_x, uint32_t* seg_scratch,
+                            int64_t* t2, uint32_t* segex, hipStream_t s);
 size_t tp_accumulate_lds_bytes();
 hipError_t tp_kernels_init();  // per-device function attributes
 void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s);

@@ -7,19 +7,21 @@
 // sums W(e) = sum over the line's rows of the row-prefix sum at the line's crossing column, and the
 // 13 variants of all triangles share 9 lines per undirected edge.  Three kernels per grad-iter:
 //
-//   k_bin         per edge (16 lanes): vertex stage of both endpoints for the five moves, the nine lines set
-//                 up ONCE as whole-line 24.40 walkers (line table), then the tiles the band of lines can touch,
-//                 enumerated tile row by tile row -> per-tile work lists of (edge, record slot)
+//   k_bin         per edge (16 lanes, nine of them one line each): vertex stage of both endpoints for the five
+//                 moves, the nine lines set up ONCE as whole-line 24.40 walkers (line table) with the static part
+//                 of their sums (everything left of the tile column, from the per-image table), then the tiles the
+//                 band of lines can touch, tile row by tile row, with an exact per-line liveness test -> per-tile
+//                 work lists of the LIVE (line, record) pairs
 //   k_accumulate  THE hot kernel: one 256-thread workgroup per 128x16-pixel tile (six resident per CU, the
 //                 dispatcher balances the rest); the tile's RGBA8 pixels are read once (32 B per lane), turned
-//                 into per-row prefix sums of the pixel moments in LDS (12-byte packed entries, DPP row scan,
-//                 conflict-free padded layout), and every (edge line, tile) pair is walked by one to four lanes:
-//                 per row one exact crossing column from the line's walker and ONE LDS entry.  No atomics, no
-//                 per-fragment work.
-//   k_update      per variant: signed sum of the records of its three lines -> exact moments -> `colnum`,
-//                 `colacc`, `tenergy` (reference layout); central differences; per-vertex arrival atomics;
-//                 shift.cs step; re-arms the work lists.  (k_finalize + k_shift: the same as two launches,
-//                 piecewise API.)
+//                 into per-row prefix sums of the pixel moments in LDS (12-byte packed entries; running sums seeded
+//                 from a static per-image table, so no scan), and every live (line, tile) pair is walked by one to
+//                 four lanes: per row one exact crossing column from the line's walker and ONE LDS entry.  No
+//                 atomics, no per-fragment work.
+//   k_update      per variant: signed sum of its three lines (static part + tile records) -> exact moments ->
+//                 `colnum`, `colacc`, `tenergy` (reference layout); central differences; per-vertex arrival
+//                 atomics; shift.cs step; re-arms the work lists.  (k_finalize + k_shift: the same as two
+//                 launches, piecewise API.)
 #include "tp_kernels.h"
 #include <hip/hip_ext.h>
 
@@ -29,13 +31,6 @@
 
 static_assert(TW == 128, "prefix build: 16 lanes x 8 pixels per row, 16-bit channel sums");
 static_assert(TH % 4 == 0 && TH <= TP_WALK_MAXROWS && ACC_THREADS % 64 == 0, "tile height");
-
-// LDS prefix table: entry x of a row (x = 0..128, exclusive prefix over the tile's columns) lives at word
-// 3 x + (x >> 3): one pad word after every eight entries, so that the sixteen lanes of a row -- each storing
-// eight consecutive entries -- start 25 words apart and a 12-byte store group (8 lanes) touches 24 distinct banks.
-#define ROW_WORDS 404  // 3 * 129 + 16, rounded up to a multiple of 4
-#define T2_LDS_WORDS ((TH + 1) * TP_T2_WORDS)
-size_t tp_accumulate_lds_bytes() { return (size_t)TH * ROW_WORDS * sizeof(uint32_t) + T2_LDS_WORDS * sizeof(int64_t); }
 
 // DPP moves inside a row of 16 lanes; lanes without a source read 0
 template <int CTRL>
@@ -53,11 +48,38 @@ __device__ __forceinline__ int row_max16(int v) {  // maximum over the 16 lanes 
 }
 
 // ------------------------------------------------------------------------------------------------
-// static per-image table (built once per tp_set_image)
+// static per-image data (built once per tp_set_image)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void px_moments5(uint32_t rgba, uint32_t m[5]) {
     const uint32_t r = rgba & 0xffu, g = (rgba >> 8) & 0xffu, b = (rgba >> 16) & 0xffu;
     m[0] += (r + g + b) & 1u; m[1] += r; m[2] += g; m[3] += b; m[4] += r * r + g * g + b * b;
+}
+
+// The sweep never looks at alpha (neither does the reference: triangle.fs uses .rgb only), so the context's own
+// padded copy of the raster keeps (r + g + b) & 1 there: the parity every pixel contributes to n_odd.
+__global__ void k_static_alpha(uint8_t* img, int pitch, int Wp, int Hp) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= Wp * Hp) return;
+    uint32_t* p = reinterpret_cast<uint32_t*>(img + (size_t)(gid / Wp) * pitch) + gid % Wp;
+    const uint32_t w = *p & 0x00ffffffu;
+    *p = w | ((((w & 0xffu) + ((w >> 8) & 0xffu) + (w >> 16)) & 1u) << 24);
+}
+
+// packed tile-local prefix (the LDS entry format of k_accumulate) at the start of every 8-pixel segment of
+// every (row, tile column), and the row total: the sweep seeds its running sums with them
+__global__ void k_static_segex(const uint8_t* img, int pitch, int Hp, int tiles_x, uint32_t* segex) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= Hp * tiles_x) return;
+    const int r = gid / tiles_x, tc = gid - r * tiles_x;
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(img + (size_t)r * pitch) + tc * TP_TILE_W;
+    uint32_t* out = segex + (size_t)gid * TP_SEG_ENTRIES * 3;
+    uint32_t x = 0, y = 0, z = 0;
+    for (int c = 0; c <= TP_TILE_W; c++) {
+        if ((c & 7) == 0) { out[(c >> 3) * 3] = x; out[(c >> 3) * 3 + 1] = y; out[(c >> 3) * 3 + 2] = z; }
+        if (c == TP_TILE_W) break;
+        const uint32_t w = row[c], rr = w & 0xffu, gg = (w >> 8) & 0xffu, bb = (w >> 16) & 0xffu, f = w >> 24;
+        x += rr | (gg << 16); y += bb | (f << 16); z += rr * rr + gg * gg + bb * bb + f;
+    }
 }
 
 // seg[r][tc][5]: moments of row r inside tile column tc
@@ -72,14 +94,15 @@ __global__ void k_static_seg(const uint8_t* img, int pitch, int W, int H, int ti
     for (int k = 0; k < 5; k++) seg[(size_t)gid * 5 + k] = m[k];
 }
 // column prefix over rows, stored shifted by one tile column: t2[r][tc+1] = sum_{r' < r} seg[r'][tc]
+// (one thread per (tile column, word); the rows are a serial chain of H steps)
 __global__ void k_static_cols(const uint32_t* seg, int H, int tiles_x, int64_t* t2) {
-    const int tc = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tc >= tiles_x) return;
-    int64_t acc[5] = {0, 0, 0, 0, 0};
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= tiles_x * 5) return;
+    const int tc = gid / 5, k = gid - tc * 5;
+    int64_t acc = 0;
     for (int r = 0; r <= H; r++) {
-        int64_t* o = t2 + ((size_t)r * (tiles_x + 1) + tc + 1) * TP_T2_WORDS;
-        for (int k = 0; k < 5; k++) o[k] = acc[k];
-        if (r < H) for (int k = 0; k < 5; k++) acc[k] += seg[((size_t)r * tiles_x + tc) * 5 + k];
+        t2[((size_t)r * (tiles_x + 1) + tc + 1) * TP_T2_WORDS + k] = acc;
+        if (r < H) acc += seg[((size_t)r * tiles_x + tc) * 5 + k];
     }
 }
 // prefix over tile columns in place: t2[r][tc] = moments of rows < r, columns < tc*TW
@@ -92,27 +115,40 @@ __global__ void k_static_rows(int H, int tiles_x, int64_t* t2) {
     for (int tc = 1; tc <= tiles_x; tc++)
         for (int k = 0; k < 5; k++) { run[k] += row[tc * TP_T2_WORDS + k]; row[tc * TP_T2_WORDS + k] = run[k]; }
 }
-void tp_launch_static_table(const uint8_t* img, int pitch, int W, int H, int tiles_x, uint32_t* seg, int64_t* t2, hipStream_t s) {
+void tp_launch_static_table(uint8_t* img, int pitch, int W, int H, int Hp, int tiles_x, uint32_t* seg, int64_t* t2,
+                            uint32_t* segex, hipStream_t s) {
+    const int Wp = tiles_x * TW;
+    hipLaunchKernelGGL(k_static_alpha, dim3((unsigned)(((size_t)Wp * Hp + 255) / 256)), dim3(256), 0, s, img, pitch, Wp, Hp);
+    hipLaunchKernelGGL(k_static_segex, dim3((Hp * tiles_x + 63) / 64), dim3(64), 0, s, img, pitch, Hp, tiles_x, segex);
     hipLaunchKernelGGL(k_static_seg, dim3((H * tiles_x + 255) / 256), dim3(256), 0, s, img, pitch, W, H, tiles_x, seg);
-    hipLaunchKernelGGL(k_static_cols, dim3((tiles_x + 63) / 64), dim3(64), 0, s, seg, H, tiles_x, t2);
+    hipLaunchKernelGGL(k_static_cols, dim3((tiles_x * 5 + 63) / 64), dim3(64), 0, s, seg, H, tiles_x, t2);
     hipLaunchKernelGGL(k_static_rows, dim3((H + 1 + 255) / 256), dim3(256), 0, s, H, tiles_x, t2);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_bin: BIN_EDGES edges per workgroup, 16 lanes per edge
+// k_bin: per edge, one or several "rows" of 16 lanes; lane q < 9 of a row owns line q of the edge.
+//   phase 0  vertex stage, the nine whole-line walkers (line table) and their static sums
+//   pass A   the tiles the band of the nine lines can touch, counted tile row by tile row -> visit ids
+//   pass B   per (edge, tile) visit an EXACT liveness test per line; one returning atomic per visit reserves
+//            list slots for the live lines only, which are entered as (line, record)
+// SLOTS rows share an edge (tile rows ty0 + slot, + SLOTS, ...): 1 for ordinary meshes (16 edges per workgroup),
+// 16 for coarse meshes on large rasters whose edges touch hundreds of tiles (one edge per workgroup).
 // ------------------------------------------------------------------------------------------------
-#define BIN_EDGES 16
-#define BIN_THREADS (BIN_EDGES * 16)
+#define BIN_THREADS 256
 
-__global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L, int epb) {  // epb <= BIN_EDGES edges per workgroup
-    __shared__ int s_cnt[BIN_EDGES];     // tiles kept per edge
-    __shared__ int s_first[BIN_EDGES];   // exclusive scan
+template <int SLOTS>
+__global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
+    constexpr int EPB = 16 / SLOTS;     // edges per workgroup
+    __shared__ int s_cnt[16];           // visits per 16-lane row
+    __shared__ int s_first[16];         // exclusive scan over the rows of the workgroup
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x;
     const uint32_t rebin_word = L.state->rebin_req;  // consumed late: the loads below do not wait for it
-    const int j = tid >> 4, q = tid & 15;
-    const int e = j < epb ? blockIdx.x * epb + j : L.NE;  // lanes beyond epb edges idle (coarse meshes: more workgroups)
+    const int row16 = tid >> 4, q = tid & 15;
+    const int j = row16 / SLOTS, slot = row16 % SLOTS;
+    const int e = blockIdx.x * EPB + j;
     tp_band band = {0, 0, 0, 0, 0, 0};
+    tp_line ln; ln.x = 0; ln.s = 0; ln.ra = 1; ln.rb = 0;
     int dX = 0, dY = 0;
     if (e < L.NE) {
         const int2 uv = L.edge_uv[e];
@@ -120,20 +156,36 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L, int epb) {  //
         const float2 pu = L.points[u], pv = L.points[v];
         tp_vertex_stage(pu.x, pu.y, 0, 0, L.vw, band.Xa, band.Ya);
         tp_vertex_stage(pv.x, pv.y, 0, 0, L.vw, band.Xb, band.Yb);
-        if (q < TP_NLINES) {  // lane q sets up line q: endpoint u displaced by move mu, endpoint v by move mv
+        if (q < TP_NLINES) {  // line q: endpoint u displaced by move mu, endpoint v by move mv
             const int mu = (q >= 1 && q <= 4) ? q : 0, mv = q >= 5 ? q - 4 : 0;
             int32_t Xa, Ya, Xb, Yb;
             tp_vertex_stage(pu.x, pu.y, mu, 0, L.vw, Xa, Ya);
             tp_vertex_stage(pv.x, pv.y, mv, 0, L.vw, Xb, Yb);
-            // one edge per vertex publishes its snapped positions (k_update reads them)
-            if (mv == 0 && ((uv.x >> 30) & 1)) L.vpos[(size_t)u * 5 + mu] = make_int2(Xa, Ya);
-            if (mu == 0 && ((uv.y >> 30) & 1)) L.vpos[(size_t)v * 5 + mv] = make_int2(Xb, Yb);
-            tp_line ln;
             tp_setup_line(Xa, Ya, Xb, Yb, L.vw.H, ln);
-            L.line_xs[(size_t)e * TP_NLINES + q] = make_longlong2(ln.x, ln.s);
-            L.line_rows[(size_t)e * TP_NLINES + q] = make_int2(ln.ra, ln.rb);
             dX = max(abs(Xa - band.Xa), abs(Xb - band.Xb));
             dY = max(abs(Ya - band.Ya), abs(Yb - band.Yb));
+            if (slot == 0) {
+                // one edge per vertex publishes its snapped positions (k_update reads them)
+                if (mv == 0 && ((uv.x >> 30) & 1)) L.vpos[(size_t)u * 5 + mu] = make_int2(Xa, Ya);
+                if (mu == 0 && ((uv.y >> 30) & 1)) L.vpos[(size_t)v * 5 + mv] = make_int2(Xb, Yb);
+                const size_t li = (size_t)e * TP_NLINES + q;
+                L.line_xs[li] = make_longlong2(ln.x, ln.s);
+                L.line_rows[li] = make_int2(ln.ra, ln.rb);
+                // static part of the line sums: per run of rows inside one tile column, everything left of that
+                // column = a difference of the cumulative static table
+                int64_t st[TP_T2_WORDS] = {0, 0, 0, 0, 0};
+                const int64_t* t2 = L.t2;
+                const int tx1 = L.tiles_x + 1;
+                tp_line_column_runs(ln, L.vw.W, TW, L.tiles_x, [&](int32_t tc, int32_t ra, int32_t rb) {
+                    if (tc == 0) return;  // nothing is left of the first tile column
+                    const int64_t* a = t2 + ((size_t)ra * tx1 + tc) * TP_T2_WORDS;
+                    const int64_t* b = t2 + ((size_t)(rb + 1) * tx1 + tc) * TP_T2_WORDS;
+#pragma unroll
+                    for (int k = 0; k < TP_T2_WORDS; k++) st[k] += b[k] - a[k];
+                });
+#pragma unroll
+                for (int k = 0; k < TP_T2_WORDS; k++) L.line_static[li * TP_T2_WORDS + k] = st[k];
+            }
         }
     }
     if (rebin_word == 0) return;  // lists still valid (tp_set_margin)
@@ -142,7 +194,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L, int epb) {  //
     band.dX = row_max16(dX) + 256 * L.margin_px;
     band.dY = row_max16(dY) + 256 * L.margin_px;
 
-    // ---- pass A: tiles per edge, tile row by tile row (lane q takes tile rows ty0 + q, + 16, ...)
+    // ---- pass A: visits (tiles of the band) of this row's tile rows
     int ty0 = 0, ty1 = -1;
     if (e < L.NE) {
         int32_t r0, r1;
@@ -150,20 +202,19 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L, int epb) {  //
         if (r0 <= r1) { ty0 = r0 / TH; ty1 = r1 / TH; }
     }
     int cnt = 0;
-    for (int ty = ty0 + q; ty <= ty1; ty += 16) {
+    for (int ty = ty0 + slot; ty <= ty1; ty += SLOTS) {
         int32_t tx0, tx1;
         const int row0 = ty * TH;
         if (tp_band_cols(band, row0, min(row0 + TH - 1, L.vw.H - 1), L.vw.W, TW, L.tiles_x, tx0, tx1)) cnt += tx1 - tx0 + 1;
     }
-    const int inc = (int)row_scan16((uint32_t)cnt);
-    if (q == 15) s_cnt[j] = inc;
+    if (q == 0) s_cnt[row16] = cnt;
     __syncthreads();
-    if (tid < 64) {  // wave 0: scan of the per-edge counts, record slots for the block
-        int v = tid < BIN_EDGES ? s_cnt[tid] : 0;
-        const int incl = (int)row_scan16((uint32_t)v);  // BIN_EDGES == 16: one row
-        if (tid < BIN_EDGES) s_first[tid] = incl - v;
-        if (tid == BIN_EDGES - 1) {
-            // record slots: every block owns a slice of the lower half of the record buffer (no global
+    if (tid < 64) {  // wave 0: scan over the 16 rows, record slots for the block
+        const int v = tid < 16 ? s_cnt[tid] : 0;
+        const int incl = (int)row_scan16((uint32_t)v);
+        if (tid < 16) s_first[tid] = incl - v;
+        if (tid == 15) {
+            // visit ids: every block owns a slice of the lower half of the record buffer (no global
             // atomic on the common path); a block with long edges draws from the shared upper half
             const uint32_t half = (uint32_t)L.visit_cap / 2, slice = half / gridDim.x;
             uint32_t base = blockIdx.x * slice;
@@ -175,56 +226,72 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L, int epb) {  //
         }
     }
     __syncthreads();
-    // ---- pass B: one returning atomic per (edge, tile) -> list slot; the entry names the edge and its record slot
-    const long long first = (long long)s_base + s_first[j];
-    int visit = (int)first + (inc - cnt);
-    for (int ty = ty0 + q; ty <= ty1; ty += 16) {
+    // ---- pass B
+    const long long efirst = (long long)s_base + s_first[j * SLOTS];
+    int ecount = 0;
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++) ecount += s_cnt[j * SLOTS + k];
+    const bool fits = efirst + ecount <= (long long)L.visit_cap;  // overflow is flagged; everyone must stay in bounds
+    if (slot == 0 && q == 0 && e < L.NE) L.edge_visit[e] = make_int2(fits ? (int)efirst : 0, fits ? ecount : 0);
+    if (!fits) return;
+    int visit = (int)s_base + s_first[row16];
+    const int rowshift = tid & 48;  // position of this row's 16 lanes in the wave's ballot
+    for (int ty = ty0 + slot; ty <= ty1; ty += SLOTS) {
         int32_t tx0, tx1;
-        const int row0 = ty * TH;
-        if (!tp_band_cols(band, row0, min(row0 + TH - 1, L.vw.H - 1), L.vw.W, TW, L.tiles_x, tx0, tx1)) continue;
+        const int row0 = ty * TH, row1 = min(row0 + TH - 1, L.vw.H - 1);
+        if (!tp_band_cols(band, row0, row1, L.vw.W, TW, L.tiles_x, tx0, tx1)) continue;
         for (int tx = tx0; tx <= tx1; tx++, visit++) {
+            const int col0 = tx * TW;
+            const int lim = tx == L.tiles_x - 1 ? L.vw.W - col0 + 1 : TW;
+            // (lists kept across iterations -- tp_set_margin -- must hold every line of the band: a line can become live
+            // in a tile, or non-empty at all, while the vertices move inside the margin)
+            const bool live = q < TP_NLINES && (L.margin_px >= 2 || tp_line_live(ln, row0, row1, col0, lim, L.vw.W));
+            const uint32_t mask = (uint32_t)(__ballot(live) >> rowshift) & 0xffffu;  // the row's lanes are active together
+            if (q == 0) L.vmask[visit] = (uint16_t)mask;
+            if (mask == 0) continue;
             const int tile = ty * L.tiles_x + tx;
-            const int slot = atomicAdd(&L.tilecount[tile], 1);
-            if (slot < L.list_cap) L.tilelist[(size_t)tile * L.list_cap + slot] = make_int2(e, visit);
-            else atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
+            int slot0 = 0;
+            if (q == 0) slot0 = atomicAdd(&L.tilecount[tile], (int)__builtin_popcount(mask));
+            slot0 = __shfl(slot0, (tid & 63) & 48);
+            if (live) {
+                const int pos = slot0 + (int)__builtin_popcount(mask & ((1u << q) - 1u));
+                if (pos < L.list_cap) L.tilelist[(size_t)tile * L.list_cap + pos] = make_int2(e * TP_NLINES + q, visit * TP_NLINES + q);
+                else atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
+            }
         }
-    }
-    if (q == 15 && e < L.NE) {
-        const bool fits = first + inc <= (long long)L.visit_cap;  // overflow is flagged; readers must stay in bounds
-        L.edge_visit[e] = make_int2(fits ? (int)first : 0, fits ? inc : 0);
     }
 }
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s) {
-    // coarse meshes on large rasters (long edges, hundreds of tiles each): fewer edges per workgroup
+    // coarse meshes on large rasters (long edges, hundreds of tiles each): sixteen rows of lanes per edge
     const long long tiles = (long long)L.tiles_x * L.tiles_y;
-    long long epb = 16LL * L.NE / (tiles > 0 ? tiles : 1);
-    epb = epb < 1 ? 1 : epb > BIN_EDGES ? BIN_EDGES : epb;
-    hipLaunchKernelGGL(k_bin, dim3((unsigned)((L.NE + epb - 1) / epb)), dim3(BIN_THREADS), 0, s, L, (int)epb);
+    if (4LL * L.NE >= tiles) hipLaunchKernelGGL(k_bin<1>, dim3((unsigned)((L.NE + 15) / 16)), dim3(BIN_THREADS), 0, s, L);
+    else hipLaunchKernelGGL(k_bin<16>, dim3((unsigned)L.NE), dim3(BIN_THREADS), 0, s, L);
 }
 
 // LDS prefix entry (12 bytes), per row exclusive prefix over the tile's 128 columns, 16-bit fields packed in pairs:
-//   x = sum r | sum g << 16,   y = sum b | n_odd << 16,   z = sum r^2+g^2+b^2
-// (128 pixels: sum of a channel <= 32640 < 2^16, n_odd <= 128, q < 2^25: nothing carries between fields, so the
-// prefix build adds and scans whole words).
+//   x = sum r | sum g << 16,   y = sum b | n_odd << 16,   z = sum (r^2+g^2+b^2) + n_odd
+// (128 pixels: sum of a channel <= 32640 < 2^16, n_odd <= 128, z < 2^25: nothing carries between fields, so whole
+// words are added).  The alpha byte of the context's raster copy holds the pixel's parity f = (r+g+b) & 1, which
+// makes a pixel's three words ONE instruction each: two byte permutes and dot4(w, w) = r^2+g^2+b^2 + f.
 struct pix3 { uint32_t x, y, z; };
 
-__device__ __forceinline__ pix3 pixel_moments(uint32_t rgba) {
-    const uint32_t m = rgba & 0x00ffffffu;
-    const uint32_t s = __builtin_amdgcn_udot4(rgba, 0x00010101u, 0u, false);  // r + g + b
+__device__ __forceinline__ pix3 pixel_moments(uint32_t w) {
     pix3 o;
-    o.x = __builtin_amdgcn_perm(0u, rgba, 0x0c010c00u);          // r | g << 16
-    o.y = __builtin_amdgcn_perm(s & 1u, rgba, 0x0c040c02u);      // b | odd << 16
-    o.z = __builtin_amdgcn_udot4(rgba, m, 0u, false);            // r^2 + g^2 + b^2
+    o.x = __builtin_amdgcn_perm(0u, w, 0x0c010c00u);       // r | g << 16
+    o.y = __builtin_amdgcn_perm(0u, w, 0x0c030c02u);       // b | f << 16
+    o.z = __builtin_amdgcn_udot4(w, w, 0u, false);         // r^2 + g^2 + b^2 + f
     return o;
 }
 __device__ __forceinline__ pix3 operator+(pix3 a, pix3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 
 // ------------------------------------------------------------------------------------------------
 // k_accumulate: one workgroup per tile.  Lane = (tile row, 8-pixel segment) for the prefix build, then
-// lane = (edge line of the tile's work list, 1/split of the tile's rows) for the walk.
+// lane = (live edge line of the tile's work list, 1/split of the tile's rows) for the walk.
 // ------------------------------------------------------------------------------------------------
-#define WALK_ROWS 4  // rows per unrolled trip of the line walk
+#define WALK_ROWS 4   // rows per unrolled trip of the line walk
+#define ROW_WORDS 387 // 3 * 129; 387 = 3 (mod 32): lanes of consecutive ROWS store to distinct banks
+size_t tp_accumulate_lds_bytes() { return (size_t)(TH * ROW_WORDS + 1) * sizeof(uint32_t); }
 
 #ifdef TPOSE_DEBUG
 #define TP_STAMP(k) do { if (tid == 0 && blockIdx.x < 4096) L.dbg[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
@@ -232,9 +299,8 @@ __device__ __forceinline__ pix3 operator+(pix3 a, pix3 b) { return {a.x + b.x, a
 #define TP_STAMP(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  // 6 workgroups per CU (LDS: 6 x 26.5 KB)
-    extern __shared__ __attribute__((aligned(16))) uint32_t P[];  // [TH][ROW_WORDS], then int64 T2s[TH+1][5]
-    int64_t* T2s = reinterpret_cast<int64_t*>(P + TH * ROW_WORDS);
+__global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  // 6 workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) uint32_t P[];  // [TH][ROW_WORDS]
 
     const int tid = threadIdx.x;
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD one contiguous band of tile rows so
@@ -247,66 +313,53 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
     const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
     TP_STAMP(0);
 
-    // the tile's pixels: lane = (row, segment of 8 pixels), 32 bytes per lane
-    const int prow = tid >> 4, seg = tid & 15;
+    // the tile's pixels: lane = (row, segment of 8 pixels), 32 bytes per lane, + the packed prefix at the segment's
+    // start from the static table.  Consecutive lanes take consecutive rows (conflict-free LDS stores); a wave
+    // covers 16 rows x 4 segments = 128 contiguous bytes per row
+    const int prow = tid & 15, seg = tid >> 4;
     uint4 px[2];
+    pix3 run;
     {
         const uint4* src = reinterpret_cast<const uint4*>(L.img + (size_t)(ty * TH + prow) * L.pitch + (size_t)(tx * TW + seg * 8) * 4);
         px[0] = src[0]; px[1] = src[1];
+        const uint32_t* se = L.segex + (((size_t)(ty * TH + prow) * L.tiles_x + tx) * TP_SEG_ENTRIES + seg) * 3;
+        run.x = se[0]; run.y = se[1]; run.z = se[2];
     }
     int nlist = L.tilecount[tile];
     if (nlist > L.list_cap) nlist = L.list_cap;
     const int2* list = L.tilelist + (size_t)tile * L.list_cap;
-    // work unit = (edge, line, 1/split of the tile's rows): `split` adjacent lanes share a line while all parts fit
-    // the workgroup (the set-up of a part is a handful of instructions)
-    const int nlines = nlist * TP_NLINES;
-    const int lsplit = nlines * 4 <= ACC_THREADS ? 2 : nlines * 2 <= ACC_THREADS ? 1 : 0;  // log2(split)
+    // work unit = (live line, 1/split of the tile's rows): `split` adjacent lanes share a line while all parts fit
+    // the workgroup
+    const int lsplit = nlist * 4 <= ACC_THREADS ? 2 : nlist * 2 <= ACC_THREADS ? 1 : 0;  // log2(split)
     const int split = 1 << lsplit;
-    const int nitems = nlines << lsplit;
+    const int nitems = nlist << lsplit;
     // this lane's first work item is requested now: nothing after the barrier waits on global memory twice
     int item = tid;
     int2 ent = make_int2(0, 0);
     longlong2 lxs = make_longlong2(0, 0);
     int2 lrows = make_int2(1, 0);
     if (item < nitems) {
-        const int line = item >> lsplit, en = line / TP_NLINES, ver = line - en * TP_NLINES;
-        ent = list[en];
-        lxs = L.line_xs[(size_t)ent.x * TP_NLINES + ver];
-        lrows = L.line_rows[(size_t)ent.x * TP_NLINES + ver];
+        ent = list[item >> lsplit];
+        lxs = L.line_xs[ent.x];
+        lrows = L.line_rows[ent.x];
     }
     if (nlist == 0) return;  // nothing crosses this tile (uniform)
-    // static-table rows for this tile's row boundaries -> LDS
-    if (tid < T2_LDS_WORDS) {
-        const int rr = tid / TP_T2_WORDS, ww = tid - rr * TP_T2_WORDS;
-        const int rabs = min(ty * TH + rr, L.vw.H);
-        T2s[tid] = L.t2[((size_t)rabs * (L.tiles_x + 1) + tx) * TP_T2_WORDS + ww];
-    }
 
-    // ---- phase 1: pixels -> row prefix sums in LDS ----------------------------------------------
+    // ---- phase 1: pixels -> row prefix sums in LDS (running sums seeded by the static table: no scan) -------
+#if defined(TPOSE_ABLATE) && (TPOSE_ABLATE & 1)  // timing experiments only (tools/build_variants.py): no prefix build
+    if ((px[0].x ^ px[1].w ^ run.x) == 0x12345u) P[tid] = 1;
+#else
     {
-        pix3 loc[8];  // exclusive prefix inside the lane's segment
-        pix3 run = {0, 0, 0};
+        uint32_t* row = P + prow * ROW_WORDS + seg * 24;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t w = k % 4 == 0 ? px[k / 4].x : k % 4 == 1 ? px[k / 4].y : k % 4 == 2 ? px[k / 4].z : px[k / 4].w;
-            loc[k] = run;
+            row[3 * k] = run.x; row[3 * k + 1] = run.y; row[3 * k + 2] = run.z;
             run = run + pixel_moments(w);
         }
-        pix3 ex;  // everything left of the segment: the 16 lanes of a DPP row are the 16 segments of a tile row
-        ex.x = row_scan16(run.x) - run.x;
-        ex.y = row_scan16(run.y) - run.y;
-        ex.z = row_scan16(run.z) - run.z;
-        uint32_t* row = P + prow * ROW_WORDS + seg * 25;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const pix3 e = ex + loc[k];
-            row[3 * k] = e.x; row[3 * k + 1] = e.y; row[3 * k + 2] = e.z;
-        }
-        if (seg == 15) {  // entry 128: the whole row
-            const pix3 e = ex + run;
-            row[25] = e.x; row[26] = e.y; row[27] = e.z;
-        }
+        if (seg == 15) { row[24] = run.x; row[25] = run.y; row[26] = run.z; }  // entry 128: the whole row
     }
+#endif
     TP_STAMP(1);
     __syncthreads();
     TP_STAMP(2);
@@ -319,21 +372,24 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
     const uint32_t lim = tx == L.tiles_x - 1 ? (uint32_t)(W - col0 + 1) : (uint32_t)TW;
     const int pr = TH >> lsplit;  // rows per part
 
+#if defined(TPOSE_ABLATE) && (TPOSE_ABLATE & 2)  // timing experiments only: no walk
+    if ((lxs.x ^ lrows.x) == 0x1234567 && ent.y < L.visit_cap * TP_NLINES) L.visits[(size_t)ent.y * TP_REC_DWORDS] = 1;
+    if (false)
+#endif
     for (; item < nitems; item += ACC_THREADS) {
-        const int part = item & (split - 1), line = item >> lsplit;
-        const int en = line / TP_NLINES, ver = line - en * TP_NLINES;
+        const int part = item & (split - 1);
         if (item != tid) {  // rare: more items than lanes
-            ent = list[en];
-            lxs = L.line_xs[(size_t)ent.x * TP_NLINES + ver];
-            lrows = L.line_rows[(size_t)ent.x * TP_NLINES + ver];
+            ent = list[item >> lsplit];
+            lxs = L.line_xs[ent.x];
+            lrows = L.line_rows[ent.x];
         }
         const int j0 = part * pr;                       // first tile row of this part
         const int koff = lrows.x - row0 - j0;           // part-relative index of the line's first row
         const uint32_t nvalid = (uint32_t)max(lrows.y - lrows.x + 1, 0);
         tp_line ln; ln.x = lxs.x; ln.s = lxs.y; ln.ra = lrows.x; ln.rb = lrows.y;
         tp_walker wk = tp_line_at(ln, row0 + j0);       // exact 32.32 walker for this tile's rows
-        uint32_t ar = 0, ag = 0, ab = 0, ao = 0, aq = 0;  // <= 16 rows: channel sums < 2^20, q < 2^29
-        uint32_t sx = 0, inmask = 0;
+        // packed sums of two rows never carry (2 x 32640 < 2^16); unpacked into 32-bit sums per pair of rows
+        uint32_t ar = 0, ag = 0, ab = 0, ao = 0, aq = 0, sx = 0;
         const uint32_t* Pp = P + j0 * ROW_WORDS;
         for (int c0 = 0; c0 < pr; c0 += WALK_ROWS, Pp += WALK_ROWS * ROW_WORDS) {
             // rows outside the line's rows, or whose crossing column falls into another tile column, read the
@@ -346,46 +402,29 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
                 wk.x += wk.s;
                 const uint32_t xl = (uint32_t)(x - col0);
                 const bool in = xl < lim && (uint32_t)(c0 + k - koff) < nvalid;
-                const uint32_t xs = in ? xl : 0u;
-                const uint32_t* ep = Pp + k * ROW_WORDS + xs * 3 + (xs >> 3);
+                const uint32_t* ep = Pp + k * ROW_WORDS + (in ? __umul24(xl, 3u) : 0u);
                 entv[k].x = ep[0]; entv[k].y = ep[1]; entv[k].z = ep[2];
-                sx += xs;
-                inmask |= in ? (1u << (c0 + k)) : 0u;
+                sx += in ? (uint32_t)x : 0u;
             }
 #pragma unroll
-            for (int k = 0; k < WALK_ROWS; k++) {
-                ar += entv[k].x & 0xffffu; ag += entv[k].x >> 16;
-                ab += entv[k].y & 0xffffu; ao += entv[k].y >> 16;
-                aq += entv[k].z;
+            for (int k = 0; k < WALK_ROWS; k += 2) {
+                const uint32_t px2 = entv[k].x + entv[k + 1].x, py2 = entv[k].y + entv[k + 1].y;
+                ar += px2 & 0xffffu; ag += px2 >> 16;
+                ab += py2 & 0xffffu; ao += py2 >> 16;
+                aq += entv[k].z + entv[k + 1].z;
             }
         }
-        uint32_t nin = (uint32_t)__builtin_popcount(inmask);
-        int32_t first = inmask ? row0 + j0 + (int)__builtin_ctz(inmask) : INT32_MAX;
         // combine the parts (adjacent lanes; a line's lanes are always active together)
         for (int o = 1; o < split; o <<= 1) {
             sx += (uint32_t)__shfl_xor((int)sx, o);
-            nin += (uint32_t)__shfl_xor((int)nin, o);
-            first = min(first, __shfl_xor(first, o));
             ar += (uint32_t)__shfl_xor((int)ar, o); ag += (uint32_t)__shfl_xor((int)ag, o);
             ab += (uint32_t)__shfl_xor((int)ab, o); ao += (uint32_t)__shfl_xor((int)ao, o);
             aq += (uint32_t)__shfl_xor((int)aq, o);
         }
         if (part != 0) continue;
-        // rows that count are contiguous (the line is monotone): add everything left of this tile
-        // column for them from the static table
-        int64_t st[TP_T2_WORDS] = {0, 0, 0, 0, 0};
-        if (nin) {
-            const int64_t* t0 = T2s + (first - row0) * TP_T2_WORDS;
-            const int64_t* t1 = T2s + (first - row0 + (int)nin) * TP_T2_WORDS;
-#pragma unroll
-            for (int k = 0; k < TP_T2_WORDS; k++) st[k] = t1[k] - t0[k];
-        }
-        if (ent.y < L.visit_cap) {  // 32-byte record: two 16-byte stores
-            uint4* out = reinterpret_cast<uint4*>(L.visits + ((size_t)ent.y * TP_NLINES + ver) * TP_REC_DWORDS);
-            const uint64_t q = (uint64_t)((int64_t)aq + st[4]);
-            out[0] = make_uint4(sx + nin * (uint32_t)col0, (uint32_t)((int64_t)ao + st[0]), (uint32_t)((int64_t)ar + st[1]),
-                                (uint32_t)((int64_t)ag + st[2]));
-            out[1] = make_uint4((uint32_t)((int64_t)ab + st[3]), 0u, (uint32_t)q, (uint32_t)(q >> 32));
+        if (ent.y < L.visit_cap * TP_NLINES) {  // 24-byte record
+            uint2* out = reinterpret_cast<uint2*>(L.visits + (size_t)ent.y * TP_REC_DWORDS);
+            out[0] = make_uint2(sx, ao); out[1] = make_uint2(ar, ag); out[2] = make_uint2(ab, aq);
         }
     }
     TP_STAMP(3);
@@ -412,9 +451,10 @@ void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t st
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-variant moments = signed sum of three line sums; a line sum = sum of the line's per-tile records.
-// G adjacent lanes share a variant (coarse meshes: hundreds of records per line): lane `part` takes records
-// part, part + G, ... and the partial moments are combined with shuffles -- every lane returns the full moments.
+// per-variant moments = signed sum of three line sums; a line sum = its static part (k_bin) + the tile-local
+// records of the tiles it is live in (k_accumulate).  G adjacent lanes share a variant (coarse meshes: hundreds
+// of visits per edge): lane `part` takes visits part, part + G, ... and the partial moments are combined with
+// shuffles -- every lane returns the full moments.
 // ------------------------------------------------------------------------------------------------
 template <int G>
 __device__ __forceinline__ tp_moments variant_moments(const tp_launch& L, int t, int i, int part) {
@@ -423,43 +463,59 @@ __device__ __forceinline__ tp_moments variant_moments(const tp_launch& L, int t,
     const int ms = i > 0 ? (i - 1) >> 2 : 3, mm = i > 0 ? ((i - 1) & 3) + 1 : 0;
     int32_t X[3], Y[3], c[3];
     int2 ev[3];
-    const uint4* rec[3];
+    int ver[3], line[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {  // the records do not depend on the coefficients: request everything first
         const int he = L.he_edge[3 * t + k];
-        ev[k] = L.edge_visit[he >> 1];  // first record slot, number of slots
-        rec[k] = reinterpret_cast<const uint4*>(L.visits) + ((size_t)ev[k].x * TP_NLINES + tp_edge_version(i, k, he & 1)) * 2;
+        ver[k] = tp_edge_version(i, k, he & 1);
+        line[k] = (he >> 1) * TP_NLINES + ver[k];
+        ev[k] = L.edge_visit[he >> 1];  // first visit, number of visits
     }
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         const int2 q = L.vpos[(size_t)vid[s] * 5 + (s == ms ? mm : 0)];
         X[s] = q.x; Y[s] = q.y;
     }
+    int64_t st[3][TP_T2_WORDS];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int q = 0; q < TP_T2_WORDS; q++) st[k][q] = part == 0 ? L.line_static[(size_t)line[k] * TP_T2_WORDS + q] : 0;
+    // the visits of the three edges side by side: masks and records of a trip are in flight together
+    uint64_t a[3][TP_W_WORDS] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+    const int nmax = max(ev[0].y, max(ev[1].y, ev[2].y));
+    for (int j = part; j < nmax; j += 2 * G) {
+        uint2 r[2][3][3];
+        uint32_t live[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int jj = j + u * G;
+                const bool on = jj < ev[k].y;
+                const size_t visit = (size_t)ev[k].x + (on ? jj : 0);
+                live[u][k] = on ? (L.vmask[visit] >> ver[k]) & 1u : 0u;
+                const uint2* rec = reinterpret_cast<const uint2*>(L.visits + (visit * TP_NLINES + ver[k]) * TP_REC_DWORDS);
+                r[u][k][0] = rec[0]; r[u][k][1] = rec[1]; r[u][k][2] = rec[2];  // garbage unless live: selected below
+            }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const bool lv = live[u][k] != 0;
+                a[k][0] += lv ? r[u][k][0].x : 0u; a[k][1] += lv ? r[u][k][0].y : 0u;
+                a[k][2] += lv ? r[u][k][1].x : 0u; a[k][3] += lv ? r[u][k][1].y : 0u;
+                a[k][4] += lv ? r[u][k][2].x : 0u;
+                a[k][5] += lv ? r[u][k][2].y - r[u][k][0].y : 0u;  // q: the record holds q + n_odd
+            }
+    }
     tp_variant_coeffs(X, Y, c);
     int64_t m[TP_W_WORDS] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        uint64_t a[TP_W_WORDS] = {0, 0, 0, 0, 0, 0};
-        const uint4* r = rec[k];
-        const int n = ev[k].y;
-        int j = part;
-        for (; j + 3 * G < n; j += 4 * G) {  // four records (eight 16-byte loads) in flight
-            uint4 lo[4], hi[4];
+        m[0] += (int64_t)c[k] * (int64_t)a[k][0];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { lo[u] = r[(size_t)(j + u * G) * (TP_NLINES * 2)]; hi[u] = r[(size_t)(j + u * G) * (TP_NLINES * 2) + 1]; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                a[0] += lo[u].x; a[1] += lo[u].y; a[2] += lo[u].z; a[3] += lo[u].w; a[4] += hi[u].x;
-                a[5] += (uint64_t)hi[u].z | ((uint64_t)hi[u].w << 32);
-            }
-        }
-        for (; j < n; j += G) {
-            const uint4 lo = r[(size_t)j * (TP_NLINES * 2)], hi = r[(size_t)j * (TP_NLINES * 2) + 1];
-            a[0] += lo.x; a[1] += lo.y; a[2] += lo.z; a[3] += lo.w; a[4] += hi.x;
-            a[5] += (uint64_t)hi.z | ((uint64_t)hi.w << 32);
-        }
-#pragma unroll
-        for (int q = 0; q < TP_W_WORDS; q++) m[q] += (int64_t)c[k] * (int64_t)a[q];
+        for (int q = 1; q < TP_W_WORDS; q++) m[q] += (int64_t)c[k] * ((int64_t)a[k][q] + st[k][q - 1]);
     }
 #pragma unroll
     for (int o = 1; o < G; o <<= 1)  // the G lanes are adjacent and always active together
@@ -468,8 +524,8 @@ __device__ __forceinline__ tp_moments variant_moments(const tp_launch& L, int t,
             const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)m[q], o), hi = (uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)m[q] >> 32), o);
             m[q] += (int64_t)(((uint64_t)hi << 32) | lo);
         }
-    tp_moments r = {m[0], m[1], m[2], m[3], m[4], m[5]};
-    return r;
+    tp_moments res = {m[0], m[1], m[2], m[3], m[4], m[5]};
+    return res;
 }
 
 __device__ __forceinline__ int32_t emit_variant(const tp_launch& L, int flavour, int t, int i, const tp_moments& m,

@@ -456,3 +456,44 @@ TP_HD bool tp_band_cols(const tp_band& b, int32_t pr0, int32_t pr1, int32_t W, i
     tx1 = tp_min(c1 / tile_w, tiles_x - 1);
     return true;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Exact per-line helpers on top of the whole-line walker (k_bin uses them once per line and iteration).
+// ---------------------------------------------------------------------------------------------
+// exact crossing column of row r (ra <= r <= rb), clamped to [0, W] like the walk clamps it
+TP_HD int32_t tp_line_col(const tp_line& ln, int32_t r, int32_t W) {
+    const int32_t x = (int32_t)((ln.x + (int64_t)(r - ln.ra) * ln.s) >> TP_LINE_FRAC);
+    return x < 0 ? 0 : (x > W ? W : x);
+}
+
+// Can the line have a counted row in the tile (rows [row0, row1], columns [col0, col0 + lim))?  The crossing
+// column is monotone in the row, so every row of the overlap lies between the two end rows: never false
+// for a tile the line really crosses (it may be true for a line that jumps over the tile column in one row).
+TP_HD bool tp_line_live(const tp_line& ln, int32_t row0, int32_t row1, int32_t col0, int32_t lim, int32_t W) {
+    const int32_t rlo = tp_max(ln.ra, row0), rhi = tp_min(ln.rb, row1);
+    if (rlo > rhi) return false;
+    const int32_t xa = tp_line_col(ln, rlo, W), xb = tp_line_col(ln, rhi, W);
+    return tp_max(xa, xb) >= col0 && tp_min(xa, xb) < col0 + lim;
+}
+
+// The runs of consecutive rows a line spends in one tile column: f(tile column, first row, last row), in row
+// order.  The static part of the line's sums -- everything LEFT of the tile column in each of its rows -- is a
+// difference of the cumulative static table per run, so the walk itself only needs tile-local sums.
+template <class F>
+TP_HD void tp_line_column_runs(const tp_line& ln, int32_t W, int32_t tile_w, int32_t tiles_x, F&& f) {
+    if (ln.ra > ln.rb) return;
+    int32_t cur = ln.ra;
+    int32_t tc = tp_min(tp_line_col(ln, cur, W) / tile_w, tiles_x - 1);
+    const int32_t tcb = tp_min(tp_line_col(ln, ln.rb, W) / tile_w, tiles_x - 1);
+    while (tc != tcb) {
+        int32_t lo = cur, hi = ln.rb;  // tile column of lo is tc, of hi is not: bisect for the first row that left it
+        while (hi - lo > 1) {
+            const int32_t mid = lo + ((hi - lo) >> 1);
+            if (tp_min(tp_line_col(ln, mid, W) / tile_w, tiles_x - 1) == tc) lo = mid; else hi = mid;
+        }
+        f(tc, cur, hi - 1);
+        cur = hi;
+        tc = tp_min(tp_line_col(ln, hi, W) / tile_w, tiles_x - 1);
+    }
+    f(tc, cur, ln.rb);
+}
