@@ -81,6 +81,7 @@ struct tp_context {
     longlong2* line_xs = nullptr;  // per-iteration line table: nine whole-line walkers per edge
     int2* line_rows = nullptr;
     int64_t* line_static = nullptr;
+    int64_t* wline = nullptr;      // whole line sums, coarse meshes only (allocated on first use)
     uint16_t* vmask = nullptr;     // per (edge, tile) visit: which of the nine lines are live there
     uint32_t* segex[2] = {nullptr, nullptr};  // static per-image packed segment prefixes
     int64_t* t2[2] = {nullptr, nullptr};   // static per-image tables
@@ -153,11 +154,12 @@ void drop_graphs(tp_context* c) {
 void free_triangulation(tp_context* c) {
     hipFree(c->points); hipFree(c->points_binned); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
     hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->edge_visit); hipFree(c->visits);
-    hipFree(c->line_xs); hipFree(c->line_rows); hipFree(c->line_static); hipFree(c->vmask); hipFree(c->tilelist);
+    hipFree(c->line_xs); hipFree(c->line_rows); hipFree(c->line_static); hipFree(c->vmask); hipFree(c->tilelist); hipFree(c->wline);
     hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
     c->points = nullptr; c->points_binned = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
     c->edge_uv = nullptr; c->he_edge = nullptr; c->vpos = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
     c->line_xs = nullptr; c->line_rows = nullptr; c->line_static = nullptr; c->vmask = nullptr; c->tilelist = nullptr; c->capE = 0;
+    c->wline = nullptr;
     c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
     c->capT = c->capP = 0;
 }
@@ -179,13 +181,15 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.edge_visit = c->edge_visit; L.visits = c->visits; L.visit_cap = c->visit_cap;
     L.line_xs = c->line_xs; L.line_rows = c->line_rows; L.line_static = c->line_static; L.vmask = c->vmask;
     L.segex = c->segex[slot];
+    L.wline = nullptr;
+    if (tp_coarse_mesh(L)) L.wline = c->wline;  // hundreds of tiles per edge: k_linesum sums the records of a line once
     L.t2 = c->t2[slot];
     L.state = c->state;
     L.ten = c->ten; L.cn = c->cn; L.ca = c->ca; L.gr = c->gr; L.moments = c->moments;
     L.gacc = c->gacc;
 #ifdef TPOSE_DEBUG  // debug flavour of the library (tools/acc_timeline.py): per-block phase timestamps
     static unsigned long long* dbgbuf = nullptr;
-    if (!dbgbuf) { hipMalloc((void**)&dbgbuf, 4096 * 8 * sizeof(unsigned long long)); hipMemset(dbgbuf, 0, 4096 * 8 * 8); }
+    if (!dbgbuf) { hipMalloc((void**)&dbgbuf, 3 * 4096 * 8 * sizeof(unsigned long long)); hipMemset(dbgbuf, 0, 3 * 4096 * 8 * 8); }
     L.dbg = dbgbuf;
 #endif
     return L;
@@ -215,6 +219,7 @@ void enqueue_iter(tp_context* c, const tp_params& p, float dp) {
     tp_launch L = make_launch(c, p.image_slot, dp);
     tp_launch_bin(L, c->stream);  // vertex stage + line table; rebuilds the work lists when requested
     tp_launch_accumulate(L, c->stream);
+    if (L.wline) tp_launch_linesum(L, c->stream);
     tp_launch_update(L, p.flavour, p.rate, c->stream);  // line sums + finalize + gradient + shift; re-arms the lists
 }
 
@@ -514,7 +519,8 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
     }
     if (NE > c->capE) {
         hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->line_xs); hipFree(c->line_rows);
-        hipFree(c->line_static); hipFree(c->vmask);
+        hipFree(c->line_static); hipFree(c->vmask); hipFree(c->wline);
+        c->wline = nullptr;
         c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr; c->line_xs = nullptr; c->line_rows = nullptr;
         c->line_static = nullptr; c->vmask = nullptr;
         const int capE = NE + NE / 2 + 64;
@@ -533,6 +539,8 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         c->tilelist_elems = 0;
     }
     c->NE = NE;
+    if ((long long)ntiles > 4LL * NE && !c->wline)  // coarse mesh (tp_coarse_mesh): whole line sums by k_linesum
+        HIP_TRY(c, dev_alloc(&c->wline, (size_t)c->capE * TP_NLINES * TP_W_WORDS));
     // per-tile list capacity in (live line) entries: never more than 9 NE; a generous multiple of the mean otherwise
     // (about 40 live lines per edge over all tiles at 16-row tiles); grows on demand (grow_lists)
     {
@@ -620,6 +628,7 @@ int tp_accumulate(tp_context* c, int flavour, int slot) {
         c->lists_dp = L.vw.dp; c->lists_ratio = c->ratio;
         tp_launch_bin(L, c->stream);
         tp_launch_accumulate(L, c->stream);
+        if (L.wline) tp_launch_linesum(L, c->stream);
         HIP_TRY(c, hipGetLastError());
         // a sweep over overflowed work lists is incomplete: grow them and sweep again (the flag word rides the
         // stream into pinned memory: one wait)
@@ -799,6 +808,7 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
         tp_launch L = make_launch(c, p->image_slot, dp);
         tp_launch_bin(L, c->stream);
         tp_launch_accumulate_timed(L, c->stream, ev[2 * k], ev[2 * k + 1]);
+        if (L.wline) tp_launch_linesum(L, c->stream);
         tp_launch_update(L, p->flavour, p->rate, c->stream);
     }
     c->pending.push_back({*p, n_iters});

@@ -21,10 +21,10 @@ struct tp_device_state {
     uint32_t visit_total;  // (edge, tile) visits drawn from the shared half of the record buffer
     uint32_t flags;        // sticky overflow flags
     uint32_t rebin_req;    // 1: k_bin must rebuild the work lists (upload, or a vertex left its margin)
-    uint32_t arrive;       // k_update: blocks arrived | (blocks voting for a rebuild) << 16
     uint32_t rebin_count;  // statistics: rebuilds so far
     uint32_t iters_done;   // fused iterations k_update completed (it does not step while a flag is up)
-    uint32_t pad[2];
+    uint32_t pad;
+    unsigned long long arrive;  // k_update: blocks arrived | (blocks voting for a rebuild) << 32
 };
 
 struct tp_launch {
@@ -60,6 +60,7 @@ struct tp_launch {
     uint16_t* vmask;          // [visit_cap] which of the nine lines of the visit's edge are live in that tile
     uint32_t* visits;         // [visit_cap][TP_NLINES][TP_REC_DWORDS] per-tile line records (live lines only are written)
     int visit_cap;
+    int64_t* wline;           // [NE][TP_NLINES][TP_W_WORDS] whole line sums -- only for coarse meshes (k_linesum), else null
     tp_device_state* state;
     // outputs (reference layout)
     int32_t* ten;
@@ -76,6 +77,8 @@ struct tp_launch {
 void tp_launch_bin(const tp_launch& L, hipStream_t s);
 void tp_launch_accumulate(const tp_launch& L, hipStream_t s);
 void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t start, hipEvent_t stop);
+bool tp_coarse_mesh(const tp_launch& L);   // hundreds of tiles per edge: line sums by k_linesum (needs L.wline)
+void tp_launch_linesum(const tp_launch& L, hipStream_t s);
 void tp_launch_finalize(const tp_launch& L, int flavour, bool write_moments, hipStream_t s);
 void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s);
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s);

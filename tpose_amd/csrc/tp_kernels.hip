@@ -32,6 +32,14 @@
 static_assert(TW == 128, "prefix build: 16 lanes x 8 pixels per row, 16-bit channel sums");
 static_assert(TH % 4 == 0 && TH <= TP_WALK_MAXROWS && ACC_THREADS % 64 == 0, "tile height");
 
+// debug flavour of the library only (tools/kernel_timeline.py): thread 0 of the first 4096 workgroups of a kernel
+// stamps the 100 MHz wall clock at its phase boundaries; region 0 k_bin, 1 k_accumulate, 2 k_update
+#ifdef TPOSE_DEBUG
+#define TP_STAMP(region, k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) L.dbg[((region) * 4096 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TP_STAMP(region, k) do { } while (0)
+#endif
+
 // DPP moves inside a row of 16 lanes; lanes without a source read 0
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
@@ -126,51 +134,56 @@ void tp_launch_static_table(uint8_t* img, int pitch, int W, int H, int Hp, int t
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_bin: per edge, one or several "rows" of 16 lanes; lane q < 9 of a row owns line q of the edge.
-//   phase 0  vertex stage, the nine whole-line walkers (line table) and their static sums
-//   pass A   the tiles the band of the nine lines can touch, counted tile row by tile row -> visit ids
-//   pass B   per (edge, tile) visit an EXACT liveness test per line; one returning atomic per visit reserves
-//            list slots for the live lines only, which are entered as (line, record)
-// SLOTS rows share an edge (tile rows ty0 + slot, + SLOTS, ...): 1 for ordinary meshes (16 edges per workgroup),
-// 16 for coarse meshes on large rasters whose edges touch hundreds of tiles (one edge per workgroup).
+// k_bin: sixteen edges per workgroup, a row of 16 lanes each.
+//   phase 0  lane q < 9 of a row owns line q of the edge: vertex stage, the whole-line walker (line table) and
+//            the static part of its sums
+//   pass A   the tiles the band of the nine lines can touch, tile row by tile row (lane q takes tile rows
+//            ty0 + q, + 16, ...): counted, scanned -> consecutive visit ids per edge, then entered in an LDS table
+//   pass B   ONE LANE PER VISIT: an exact liveness test for each of the nine lines, one returning atomic that
+//            reserves list slots for the live ones (every visit's atomic is in flight at once), the entries.
 // ------------------------------------------------------------------------------------------------
 #define BIN_THREADS 256
+#define BIN_EDGES 16
+#define BIN_VISITS 1024  // visits per pass of the LDS table (more: further passes)
 
-template <int SLOTS>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
-    constexpr int EPB = 16 / SLOTS;     // edges per workgroup
-    __shared__ int s_cnt[16];           // visits per 16-lane row
-    __shared__ int s_first[16];         // exclusive scan over the rows of the workgroup
+    __shared__ int s_cnt[BIN_EDGES];     // visits per edge
+    __shared__ int s_first[BIN_EDGES];   // exclusive scan
+    __shared__ int s_total;
     __shared__ uint32_t s_base;
+    __shared__ int64_t s_lx[BIN_EDGES][TP_NLINES][2];
+    __shared__ int s_lr[BIN_EDGES][TP_NLINES][2];
+    __shared__ int s_vis[BIN_VISITS];    // (edge of the block << 27) | tile
     const int tid = threadIdx.x;
     const uint32_t rebin_word = L.state->rebin_req;  // consumed late: the loads below do not wait for it
-    const int row16 = tid >> 4, q = tid & 15;
-    const int j = row16 / SLOTS, slot = row16 % SLOTS;
-    const int e = blockIdx.x * EPB + j;
+    const int j = tid >> 4, q = tid & 15;
+    const int e = blockIdx.x * BIN_EDGES + j;
     tp_band band = {0, 0, 0, 0, 0, 0};
-    tp_line ln; ln.x = 0; ln.s = 0; ln.ra = 1; ln.rb = 0;
-    int dX = 0, dY = 0;
-    if (e < L.NE) {
-        const int2 uv = L.edge_uv[e];
-        const int u = uv.x & 0x3fffffff, v = uv.y & 0x3fffffff;
-        const float2 pu = L.points[u], pv = L.points[v];
-        tp_vertex_stage(pu.x, pu.y, 0, 0, L.vw, band.Xa, band.Ya);
-        tp_vertex_stage(pv.x, pv.y, 0, 0, L.vw, band.Xb, band.Yb);
-        if (q < TP_NLINES) {  // line q: endpoint u displaced by move mu, endpoint v by move mv
-            const int mu = (q >= 1 && q <= 4) ? q : 0, mv = q >= 5 ? q - 4 : 0;
-            int32_t Xa, Ya, Xb, Yb;
-            tp_vertex_stage(pu.x, pu.y, mu, 0, L.vw, Xa, Ya);
-            tp_vertex_stage(pv.x, pv.y, mv, 0, L.vw, Xb, Yb);
-            tp_setup_line(Xa, Ya, Xb, Yb, L.vw.H, ln);
-            dX = max(abs(Xa - band.Xa), abs(Xb - band.Xb));
-            dY = max(abs(Ya - band.Ya), abs(Yb - band.Yb));
-            if (slot == 0) {
+    TP_STAMP(0, 0);
+    {   // phase 0
+        tp_line ln; ln.x = 0; ln.s = 0; ln.ra = 1; ln.rb = 0;
+        int dX = 0, dY = 0;
+        if (e < L.NE) {
+            const int2 uv = L.edge_uv[e];
+            const int u = uv.x & 0x3fffffff, v = uv.y & 0x3fffffff;
+            const float2 pu = L.points[u], pv = L.points[v];
+            tp_vertex_stage(pu.x, pu.y, 0, 0, L.vw, band.Xa, band.Ya);
+            tp_vertex_stage(pv.x, pv.y, 0, 0, L.vw, band.Xb, band.Yb);
+            if (q < TP_NLINES) {  // line q: endpoint u displaced by move mu, endpoint v by move mv
+                const int mu = (q >= 1 && q <= 4) ? q : 0, mv = q >= 5 ? q - 4 : 0;
+                int32_t Xa, Ya, Xb, Yb;
+                tp_vertex_stage(pu.x, pu.y, mu, 0, L.vw, Xa, Ya);
+                tp_vertex_stage(pv.x, pv.y, mv, 0, L.vw, Xb, Yb);
+                tp_setup_line(Xa, Ya, Xb, Yb, L.vw.H, ln);
+                dX = max(abs(Xa - band.Xa), abs(Xb - band.Xb));
+                dY = max(abs(Ya - band.Ya), abs(Yb - band.Yb));
                 // one edge per vertex publishes its snapped positions (k_update reads them)
                 if (mv == 0 && ((uv.x >> 30) & 1)) L.vpos[(size_t)u * 5 + mu] = make_int2(Xa, Ya);
                 if (mu == 0 && ((uv.y >> 30) & 1)) L.vpos[(size_t)v * 5 + mv] = make_int2(Xb, Yb);
                 const size_t li = (size_t)e * TP_NLINES + q;
                 L.line_xs[li] = make_longlong2(ln.x, ln.s);
                 L.line_rows[li] = make_int2(ln.ra, ln.rb);
+                s_lx[j][q][0] = ln.x; s_lx[j][q][1] = ln.s; s_lr[j][q][0] = ln.ra; s_lr[j][q][1] = ln.rb;
                 // static part of the line sums: per run of rows inside one tile column, everything left of that
                 // column = a difference of the cumulative static table
                 int64_t st[TP_T2_WORDS] = {0, 0, 0, 0, 0};
@@ -187,14 +200,15 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
                 for (int k = 0; k < TP_T2_WORDS; k++) L.line_static[li * TP_T2_WORDS + k] = st[k];
             }
         }
+        band.dX = row_max16(dX) + 256 * L.margin_px;
+        band.dY = row_max16(dY) + 256 * L.margin_px;
     }
-    if (rebin_word == 0) return;  // lists still valid (tp_set_margin)
+    TP_STAMP(0, 1);
+    if (rebin_word == 0) return;  // lists still valid (tp_set_margin); uniform
     if (L.margin_px >= 2)  // only the margin vote of k_update reads it
         for (int v = blockIdx.x * BIN_THREADS + tid; v < L.NP; v += gridDim.x * BIN_THREADS) L.points_binned[v] = L.points[v];
-    band.dX = row_max16(dX) + 256 * L.margin_px;
-    band.dY = row_max16(dY) + 256 * L.margin_px;
 
-    // ---- pass A: visits (tiles of the band) of this row's tile rows
+    // ---- pass A: visits (tiles of the band), lane q takes the tile rows ty0 + q, + 16, ...
     int ty0 = 0, ty1 = -1;
     if (e < L.NE) {
         int32_t r0, r1;
@@ -202,18 +216,19 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
         if (r0 <= r1) { ty0 = r0 / TH; ty1 = r1 / TH; }
     }
     int cnt = 0;
-    for (int ty = ty0 + slot; ty <= ty1; ty += SLOTS) {
+    for (int ty = ty0 + q; ty <= ty1; ty += 16) {
         int32_t tx0, tx1;
         const int row0 = ty * TH;
         if (tp_band_cols(band, row0, min(row0 + TH - 1, L.vw.H - 1), L.vw.W, TW, L.tiles_x, tx0, tx1)) cnt += tx1 - tx0 + 1;
     }
-    if (q == 0) s_cnt[row16] = cnt;
-    __syncthreads();
-    if (tid < 64) {  // wave 0: scan over the 16 rows, record slots for the block
-        const int v = tid < 16 ? s_cnt[tid] : 0;
+    const int inc = (int)row_scan16((uint32_t)cnt);
+    if (q == 15) s_cnt[j] = inc;
+    __syncthreads();  // (also publishes the lines of phase 0)
+    if (tid < 64) {  // wave 0: scan of the per-edge counts, visit ids for the block
+        const int v = tid < BIN_EDGES ? s_cnt[tid] : 0;
         const int incl = (int)row_scan16((uint32_t)v);
-        if (tid < 16) s_first[tid] = incl - v;
-        if (tid == 15) {
+        if (tid < BIN_EDGES) s_first[tid] = incl - v;
+        if (tid == BIN_EDGES - 1) {
             // visit ids: every block owns a slice of the lower half of the record buffer (no global
             // atomic on the common path); a block with long edges draws from the shared upper half
             const uint32_t half = (uint32_t)L.visit_cap / 2, slice = half / gridDim.x;
@@ -223,50 +238,70 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
                 if (base + (uint32_t)incl > (uint32_t)L.visit_cap) atomicOr(&L.state->flags, TP_FLAG_VISIT_OVERFLOW);
             }
             s_base = base;
+            s_total = incl;
         }
     }
     __syncthreads();
-    // ---- pass B
-    const long long efirst = (long long)s_base + s_first[j * SLOTS];
-    int ecount = 0;
-#pragma unroll
-    for (int k = 0; k < SLOTS; k++) ecount += s_cnt[j * SLOTS + k];
-    const bool fits = efirst + ecount <= (long long)L.visit_cap;  // overflow is flagged; everyone must stay in bounds
-    if (slot == 0 && q == 0 && e < L.NE) L.edge_visit[e] = make_int2(fits ? (int)efirst : 0, fits ? ecount : 0);
-    if (!fits) return;
-    int visit = (int)s_base + s_first[row16];
-    const int rowshift = tid & 48;  // position of this row's 16 lanes in the wave's ballot
-    for (int ty = ty0 + slot; ty <= ty1; ty += SLOTS) {
-        int32_t tx0, tx1;
-        const int row0 = ty * TH, row1 = min(row0 + TH - 1, L.vw.H - 1);
-        if (!tp_band_cols(band, row0, row1, L.vw.W, TW, L.tiles_x, tx0, tx1)) continue;
-        for (int tx = tx0; tx <= tx1; tx++, visit++) {
+    TP_STAMP(0, 2);
+    const int total = s_total;
+    const uint32_t base = s_base;
+    const bool fits = (long long)base + total <= (long long)L.visit_cap;  // overflow is flagged; everyone stays in bounds
+    if (q == 15 && e < L.NE) L.edge_visit[e] = make_int2(fits ? (int)base + s_first[j] : 0, fits ? inc : 0);
+    if (!fits) return;  // uniform
+
+    for (int v0 = 0; v0 < total; v0 += BIN_VISITS) {
+        // the visits [v0, v0 + BIN_VISITS) of the block -> LDS table, in the order they were counted
+        int k = s_first[j] + (inc - cnt) - v0;
+        for (int ty = ty0 + q; ty <= ty1; ty += 16) {
+            int32_t tx0, tx1;
+            const int row0 = ty * TH;
+            if (!tp_band_cols(band, row0, min(row0 + TH - 1, L.vw.H - 1), L.vw.W, TW, L.tiles_x, tx0, tx1)) continue;
+            for (int tx = tx0; tx <= tx1; tx++, k++)
+                if (k >= 0 && k < BIN_VISITS) s_vis[k] = (j << 27) | (ty * L.tiles_x + tx);
+        }
+        __syncthreads();
+        TP_STAMP(0, 3);
+        // ---- pass B: a lane per visit
+        const int nv = min(total - v0, BIN_VISITS);
+        for (int t = tid; t < nv; t += BIN_THREADS) {
+            const int w = s_vis[t], jj = w >> 27, tile = w & 0x7ffffff;
+            const int visit = (int)base + v0 + t;
+            const int ty = tile / L.tiles_x, tx = tile - ty * L.tiles_x;
+            const int row0 = ty * TH, row1 = min(row0 + TH - 1, L.vw.H - 1);
             const int col0 = tx * TW;
             const int lim = tx == L.tiles_x - 1 ? L.vw.W - col0 + 1 : TW;
-            // (lists kept across iterations -- tp_set_margin -- must hold every line of the band: a line can become live
-            // in a tile, or non-empty at all, while the vertices move inside the margin)
-            const bool live = q < TP_NLINES && (L.margin_px >= 2 || tp_line_live(ln, row0, row1, col0, lim, L.vw.W));
-            const uint32_t mask = (uint32_t)(__ballot(live) >> rowshift) & 0xffffu;  // the row's lanes are active together
-            if (q == 0) L.vmask[visit] = (uint16_t)mask;
-            if (mask == 0) continue;
-            const int tile = ty * L.tiles_x + tx;
-            int slot0 = 0;
-            if (q == 0) slot0 = atomicAdd(&L.tilecount[tile], (int)__builtin_popcount(mask));
-            slot0 = __shfl(slot0, (tid & 63) & 48);
-            if (live) {
-                const int pos = slot0 + (int)__builtin_popcount(mask & ((1u << q) - 1u));
-                if (pos < L.list_cap) L.tilelist[(size_t)tile * L.list_cap + pos] = make_int2(e * TP_NLINES + q, visit * TP_NLINES + q);
-                else atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
+            uint32_t mask = 0;
+            if (L.margin_px >= 2) {
+                // lists kept across iterations (tp_set_margin) must hold every line of the band: a line can become
+                // live in a tile, or non-empty at all, while the vertices move inside the margin
+                mask = (1u << TP_NLINES) - 1u;
+            } else {
+#pragma unroll
+                for (int l = 0; l < TP_NLINES; l++) {
+                    tp_line ln; ln.x = s_lx[jj][l][0]; ln.s = s_lx[jj][l][1]; ln.ra = s_lr[jj][l][0]; ln.rb = s_lr[jj][l][1];
+                    mask |= tp_line_live(ln, row0, row1, col0, lim, L.vw.W) ? 1u << l : 0u;
+                }
             }
+            L.vmask[visit] = (uint16_t)mask;
+            if (mask == 0) continue;
+            const int ee = blockIdx.x * BIN_EDGES + jj;
+            int pos = atomicAdd(&L.tilecount[tile], (int)__builtin_popcount(mask));
+            int2* dst = L.tilelist + (size_t)tile * L.list_cap;
+#pragma unroll
+            for (int l = 0; l < TP_NLINES; l++)
+                if ((mask >> l) & 1u) {
+                    if (pos < L.list_cap) dst[pos] = make_int2(ee * TP_NLINES + l, visit * TP_NLINES + l);
+                    else atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
+                    pos++;
+                }
         }
+        __syncthreads();  // the table is rewritten by the next pass
     }
+    TP_STAMP(0, 4);
 }
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s) {
-    // coarse meshes on large rasters (long edges, hundreds of tiles each): sixteen rows of lanes per edge
-    const long long tiles = (long long)L.tiles_x * L.tiles_y;
-    if (4LL * L.NE >= tiles) hipLaunchKernelGGL(k_bin<1>, dim3((unsigned)((L.NE + 15) / 16)), dim3(BIN_THREADS), 0, s, L);
-    else hipLaunchKernelGGL(k_bin<16>, dim3((unsigned)L.NE), dim3(BIN_THREADS), 0, s, L);
+    hipLaunchKernelGGL(k_bin, dim3((unsigned)((L.NE + BIN_EDGES - 1) / BIN_EDGES)), dim3(BIN_THREADS), 0, s, L);
 }
 
 // LDS prefix entry (12 bytes), per row exclusive prefix over the tile's 128 columns, 16-bit fields packed in pairs:
@@ -293,11 +328,6 @@ __device__ __forceinline__ pix3 operator+(pix3 a, pix3 b) { return {a.x + b.x, a
 #define ROW_WORDS 387 // 3 * 129; 387 = 3 (mod 32): lanes of consecutive ROWS store to distinct banks
 size_t tp_accumulate_lds_bytes() { return (size_t)(TH * ROW_WORDS + 1) * sizeof(uint32_t); }
 
-#ifdef TPOSE_DEBUG
-#define TP_STAMP(k) do { if (tid == 0 && blockIdx.x < 4096) L.dbg[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
-#else
-#define TP_STAMP(k) do { } while (0)
-#endif
 
 __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  // 6 workgroups per CU
     extern __shared__ __attribute__((aligned(16))) uint32_t P[];  // [TH][ROW_WORDS]
@@ -311,7 +341,7 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
     if (blockIdx.x == 0 && tid == 0) L.state->rebin_req = 0;  // consumed by the k_bin that ran before us
     if ((int)(blockIdx.x >> 3) >= chunk || tile >= ntiles) return;
     const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
-    TP_STAMP(0);
+    TP_STAMP(1, 0);
 
     // the tile's pixels: lane = (row, segment of 8 pixels), 32 bytes per lane, + the packed prefix at the segment's
     // start from the static table.  Consecutive lanes take consecutive rows (conflict-free LDS stores); a wave
@@ -360,9 +390,9 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
         if (seg == 15) { row[24] = run.x; row[25] = run.y; row[26] = run.z; }  // entry 128: the whole row
     }
 #endif
-    TP_STAMP(1);
+    TP_STAMP(1, 1);
     __syncthreads();
-    TP_STAMP(2);
+    TP_STAMP(1, 2);
 
     // ---- phase 2: the lines ------------------------------------------------------------------------
     const int row0 = ty * TH;
@@ -427,7 +457,7 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
             out[0] = make_uint2(sx, ao); out[1] = make_uint2(ar, ag); out[2] = make_uint2(ab, aq);
         }
     }
-    TP_STAMP(3);
+    TP_STAMP(1, 3);
 }
 
 static int accumulate_grid(const tp_launch& L) {
@@ -451,79 +481,102 @@ void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t st
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-variant moments = signed sum of three line sums; a line sum = its static part (k_bin) + the tile-local
-// records of the tiles it is live in (k_accumulate).  G adjacent lanes share a variant (coarse meshes: hundreds
-// of visits per edge): lane `part` takes visits part, part + G, ... and the partial moments are combined with
-// shuffles -- every lane returns the full moments.
+// Line sums.  W(line) = its static part (k_bin) + the tile-local records of the tiles it is live in
+// (k_accumulate): six values {sum x, n_odd, sum r, sum g, sum b, q}.  Fine meshes sum the handful of records
+// where they are needed; coarse meshes on large rasters (hundreds of tiles per edge) run k_linesum first --
+// one wave per line -- and everything downstream reads `wline`.
 // ------------------------------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ tp_moments variant_moments(const tp_launch& L, int t, int i, int part) {
+__device__ __forceinline__ void add_record(uint64_t a[TP_W_WORDS], bool live, const uint2 r0, const uint2 r1, const uint2 r2) {
+    a[0] += live ? r0.x : 0u; a[1] += live ? r0.y : 0u;
+    a[2] += live ? r1.x : 0u; a[3] += live ? r1.y : 0u;
+    a[4] += live ? r2.x : 0u;
+    a[5] += live ? r2.y - r0.y : 0u;  // q: the record holds q + n_odd
+}
+
+// visits first + j0, first + j0 + stride, ... of an edge, for line version `ver`: eight visits per trip, all of
+// their loads in flight together (an ordinary edge has about six visits: one round trip)
+__device__ __forceinline__ void sum_records(const tp_launch& L, int first, int n, int ver, int j0, int stride, uint64_t a[TP_W_WORDS]) {
+    for (int j = j0; j < n; j += 8 * stride) {
+        uint32_t lv[8];
+        uint2 r[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int jj = j + u * stride;
+            const bool on = jj < n;
+            const size_t visit = (size_t)first + (on ? jj : j);
+            lv[u] = on ? (uint32_t)L.vmask[visit] : 0u;
+            const uint2* rec = reinterpret_cast<const uint2*>(L.visits + (visit * TP_NLINES + ver) * TP_REC_DWORDS);
+            r[u][0] = rec[0]; r[u][1] = rec[1]; r[u][2] = rec[2];  // garbage unless live: selected below
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) add_record(a, (lv[u] >> ver) & 1u, r[u][0], r[u][1], r[u][2]);
+    }
+}
+
+__device__ __forceinline__ void line_sum(const tp_launch& L, int e, int ver, int64_t w[TP_W_WORDS]) {
+    const size_t line = (size_t)e * TP_NLINES + ver;
+    if (L.wline) {  // coarse meshes: summed by k_linesum
+#pragma unroll
+        for (int q = 0; q < TP_W_WORDS; q++) w[q] = L.wline[line * TP_W_WORDS + q];
+        return;
+    }
+    const int2 ev = L.edge_visit[e];  // first visit, number of visits
+    int64_t st[TP_T2_WORDS];
+#pragma unroll
+    for (int q = 0; q < TP_T2_WORDS; q++) st[q] = L.line_static[line * TP_T2_WORDS + q];
+    uint64_t a[TP_W_WORDS] = {0, 0, 0, 0, 0, 0};
+    sum_records(L, ev.x, ev.y, ver, 0, 1, a);
+    w[0] = (int64_t)a[0];
+#pragma unroll
+    for (int q = 1; q < TP_W_WORDS; q++) w[q] = (int64_t)a[q] + st[q - 1];
+}
+
+// coarse meshes: one wave per line
+__global__ __launch_bounds__(64) void k_linesum(tp_launch L) {
+    const int line = blockIdx.x, lane = threadIdx.x;
+    const int e = line / TP_NLINES, ver = line - e * TP_NLINES;
+    const int2 ev = L.edge_visit[e];
+    uint64_t a[TP_W_WORDS] = {0, 0, 0, 0, 0, 0};
+    sum_records(L, ev.x, ev.y, ver, lane, 64, a);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+#pragma unroll
+        for (int q = 0; q < TP_W_WORDS; q++) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)a[q], o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(a[q] >> 32), o);
+            a[q] += ((uint64_t)hi << 32) | lo;
+        }
+    if (lane < TP_W_WORDS) {
+        uint64_t v = lane == 0 ? a[0] : lane == 1 ? a[1] : lane == 2 ? a[2] : lane == 3 ? a[3] : lane == 4 ? a[4] : a[5];
+        if (lane > 0) v += (uint64_t)L.line_static[(size_t)line * TP_T2_WORDS + lane - 1];
+        L.wline[(size_t)line * TP_W_WORDS + lane] = (int64_t)v;
+    }
+}
+bool tp_coarse_mesh(const tp_launch& L) { return (long long)L.tiles_x * L.tiles_y > 4LL * L.NE; }
+void tp_launch_linesum(const tp_launch& L, hipStream_t s) {
+    hipLaunchKernelGGL(k_linesum, dim3((unsigned)(L.NE * TP_NLINES)), dim3(64), 0, s, L);
+}
+
+// per-variant moments = signed sum of three line sums
+__device__ __forceinline__ tp_moments variant_moments(const tp_launch& L, int t, int i) {
     const int4 tri = L.tris[t];
     const int vid[3] = {tri.x, tri.y, tri.z};
     const int ms = i > 0 ? (i - 1) >> 2 : 3, mm = i > 0 ? ((i - 1) & 3) + 1 : 0;
     int32_t X[3], Y[3], c[3];
-    int2 ev[3];
-    int ver[3], line[3];
+    int64_t w[3][TP_W_WORDS];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {  // the records do not depend on the coefficients: request everything first
+    for (int k = 0; k < 3; k++) {
         const int he = L.he_edge[3 * t + k];
-        ver[k] = tp_edge_version(i, k, he & 1);
-        line[k] = (he >> 1) * TP_NLINES + ver[k];
-        ev[k] = L.edge_visit[he >> 1];  // first visit, number of visits
+        line_sum(L, he >> 1, tp_edge_version(i, k, he & 1), w[k]);
     }
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         const int2 q = L.vpos[(size_t)vid[s] * 5 + (s == ms ? mm : 0)];
         X[s] = q.x; Y[s] = q.y;
     }
-    int64_t st[3][TP_T2_WORDS];
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-#pragma unroll
-        for (int q = 0; q < TP_T2_WORDS; q++) st[k][q] = part == 0 ? L.line_static[(size_t)line[k] * TP_T2_WORDS + q] : 0;
-    // the visits of the three edges side by side: masks and records of a trip are in flight together
-    uint64_t a[3][TP_W_WORDS] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
-    const int nmax = max(ev[0].y, max(ev[1].y, ev[2].y));
-    for (int j = part; j < nmax; j += 2 * G) {
-        uint2 r[2][3][3];
-        uint32_t live[2][3];
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int jj = j + u * G;
-                const bool on = jj < ev[k].y;
-                const size_t visit = (size_t)ev[k].x + (on ? jj : 0);
-                live[u][k] = on ? (L.vmask[visit] >> ver[k]) & 1u : 0u;
-                const uint2* rec = reinterpret_cast<const uint2*>(L.visits + (visit * TP_NLINES + ver[k]) * TP_REC_DWORDS);
-                r[u][k][0] = rec[0]; r[u][k][1] = rec[1]; r[u][k][2] = rec[2];  // garbage unless live: selected below
-            }
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const bool lv = live[u][k] != 0;
-                a[k][0] += lv ? r[u][k][0].x : 0u; a[k][1] += lv ? r[u][k][0].y : 0u;
-                a[k][2] += lv ? r[u][k][1].x : 0u; a[k][3] += lv ? r[u][k][1].y : 0u;
-                a[k][4] += lv ? r[u][k][2].x : 0u;
-                a[k][5] += lv ? r[u][k][2].y - r[u][k][0].y : 0u;  // q: the record holds q + n_odd
-            }
-    }
     tp_variant_coeffs(X, Y, c);
-    int64_t m[TP_W_WORDS] = {0, 0, 0, 0, 0, 0};
+    int64_t m[TP_W_WORDS];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        m[0] += (int64_t)c[k] * (int64_t)a[k][0];
-#pragma unroll
-        for (int q = 1; q < TP_W_WORDS; q++) m[q] += (int64_t)c[k] * ((int64_t)a[k][q] + st[k][q - 1]);
-    }
-#pragma unroll
-    for (int o = 1; o < G; o <<= 1)  // the G lanes are adjacent and always active together
-#pragma unroll
-        for (int q = 0; q < TP_W_WORDS; q++) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)m[q], o), hi = (uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)m[q] >> 32), o);
-            m[q] += (int64_t)(((uint64_t)hi << 32) | lo);
-        }
+    for (int q = 0; q < TP_W_WORDS; q++) m[q] = (int64_t)c[0] * w[0][q] + (int64_t)c[1] * w[1][q] + (int64_t)c[2] * w[2][q];
     tp_moments res = {m[0], m[1], m[2], m[3], m[4], m[5]};
     return res;
 }
@@ -549,28 +602,16 @@ __device__ __forceinline__ int32_t emit_variant(const tp_launch& L, int flavour,
     return e32;
 }
 
-// how many lanes share a variant: records per line grow with tiles per edge
-static int lanes_per_variant(const tp_launch& L) {
-    const long long tiles = (long long)L.tiles_x * L.tiles_y;
-    return tiles < 2LL * L.NE ? 1 : tiles < 16LL * L.NE ? 4 : 16;
-}
-
-// k_finalize (tp_energy): G lanes per (triangle, variant); id = i*NT + t in the outputs
-template <int G>
+// k_finalize (tp_energy): thread per (triangle, variant); id = i*NT + t in the outputs
 __global__ __launch_bounds__(256) void k_finalize(tp_launch L, int flavour, int write_moments) {
-    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / G, part = threadIdx.x % G;
-    if (gid >= L.NT * TP_NVARIANTS) return;  // whole groups leave together
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= L.NT * TP_NVARIANTS) return;
     const int t = gid / TP_NVARIANTS, i = gid - t * TP_NVARIANTS;
-    const tp_moments m = variant_moments<G>(L, t, i, part);
-    if (part == 0) emit_variant(L, flavour, t, i, m, write_moments != 0);
+    emit_variant(L, flavour, t, i, variant_moments(L, t, i), write_moments != 0);
 }
 void tp_launch_finalize(const tp_launch& L, int flavour, bool write_moments, hipStream_t s) {
-    const int G = lanes_per_variant(L);
-    const long long n = (long long)L.NT * TP_NVARIANTS * G;
-    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (G == 1) hipLaunchKernelGGL(k_finalize<1>, grid, block, 0, s, L, flavour, write_moments ? 1 : 0);
-    else if (G == 4) hipLaunchKernelGGL(k_finalize<4>, grid, block, 0, s, L, flavour, write_moments ? 1 : 0);
-    else hipLaunchKernelGGL(k_finalize<16>, grid, block, 0, s, L, flavour, write_moments ? 1 : 0);
+    const int n = L.NT * TP_NVARIANTS;
+    hipLaunchKernelGGL(k_finalize, dim3((n + 255) / 256), dim3(256), 0, s, L, flavour, write_moments ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -605,124 +646,168 @@ void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_update: k_finalize + k_shift in ONE launch (used by tp_iterate).  G lanes per variant; the
-// four displacements of a vertex slot sit in adjacent lane groups, so the central differences are two
-// shuffles.  The quad leader adds them to its vertex with one returning 64-bit atomic per component
-// -- (difference << 32) + 1 -- so the thread that completes the vertex's arrival count already
-// holds the whole (wrapping int32) gradient component and takes the shift.cs step for it.  x and y
-// never interact in shift.cs, so they settle independently; integer sums commute, so the result
-// does not depend on arrival order.  Without a margin every launch re-arms the work lists for the next
-// k_bin; with one, the last block to finish knows whether any vertex left its margin.
+// k_update: k_finalize + k_shift in ONE launch (used by tp_iterate), organised by VERTEX: one wave per vertex.
+// A vertex's gradient needs the 4 displaced variants of each incident (triangle, slot); those use, per incident
+// triangle, nine line sums: the opposite edge's base line and the four displaced versions of either edge at the
+// vertex.  Lane (a, l) = (incident triangle a of a chunk of seven, line l of nine) forms one line sum and parks it
+// in LDS; lane (a, m) then combines three of them into the moments of variant (t, 4s + m), writes `colnum`,
+// `colacc`, `tenergy` (reference layout) and keeps the energy; central differences are a lane-pair subtraction and
+// the vertex's gradient (wrapping int32, like the reference's atomics -- integer sums commute) a wave reduction.
+// Lane 0 takes the shift.cs step.  No atomics, no arrival counters.  The base variants (i = 0) do not enter any
+// gradient: extra workgroups behind the vertices write their outputs, one thread per triangle.
+// Without a margin every launch re-arms the work lists for the next k_bin; with one, the last block to finish
+// knows whether any vertex left its margin.
 // ------------------------------------------------------------------------------------------------
-#define UPD_THREADS 64  // small workgroups: 13 NT threads are only ~600 waves, spread them over all CUs
-template <int G>
+#define UPD_THREADS 64
+#define UPD_CHUNK 7  // incident triangles per pass: 7 x 9 = 63 lanes
 __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour, float rate) {
+    __shared__ int64_t S[UPD_CHUNK][TP_NLINES][TP_W_WORDS];
     __shared__ int s_last;
-    const int tidg = blockIdx.x * blockDim.x + threadIdx.x;
-    const int gid = tidg / G, part = threadIdx.x % G;
+    const int lane = threadIdx.x;
+    const int tidg = blockIdx.x * UPD_THREADS + lane;
     // a work list overflowed in this or an earlier iteration: the line sums are incomplete.  Do not
     // step -- the host grows the lists and replays from the last good iteration (check_flags)
     if (L.state->flags) return;
     if (tidg == 0) L.state->iters_done++;
     if (L.margin_px < 2) {
         // work lists are rebuilt every iteration: k_accumulate has consumed them, re-arm them here
-        for (int k = tidg; k < L.tiles_x * L.tiles_y; k += gridDim.x * blockDim.x) L.tilecount[k] = 0;
+        for (int k = tidg; k < L.tiles_x * L.tiles_y; k += gridDim.x * UPD_THREADS) L.tilecount[k] = 0;
         if (tidg == 0) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
     }
-
-    // variants [0, 12 NT): quads (t, s, k); variants [12 NT, 13 NT): the base variants
-    const int NT = L.NT;
-    const bool live = gid < 13 * NT;
-    int t = 0, i = 0;
-    if (gid < 12 * NT) { t = gid / 12; i = gid - 12 * t + 1; }
-    else if (live) { t = gid - 12 * NT; i = 0; }
-    const bool leader = live && part == 0 && i > 0 && ((i - 1) & 3) == 0;
-    // the quad leader's vertex data does not depend on the energies: fetch it early
-    int v = 0, deg = 0;
-    float2 p = make_float2(0.0f, 0.0f), pb = p;
-    if (leader) {
-        const int s = (i - 1) >> 2;
-        const int4 tri = L.tris[t];
-        v = s == 0 ? tri.x : s == 1 ? tri.y : tri.z;
-        deg = L.vtx_off[v + 1] - L.vtx_off[v];
-        p = L.points[v];
-        if (L.margin_px >= 2) pb = L.points_binned[v];
-    }
-    int32_t e = 0;
-    if (live) {
-        const tp_moments m = variant_moments<G>(L, t, i, part);
-        if (part == 0) e = emit_variant(L, flavour, t, i, m, false);
-    }
-    // central differences inside the quad: groups 4q+0/1 hold E(+dx)/E(-dx), 4q+2/3 E(+dy)/E(-dy)
-    const uint32_t e1 = (uint32_t)__shfl_xor(e, G);
-    const uint32_t gx = (uint32_t)e - e1;                         // valid on even groups of the quad
-    const uint32_t gy = (uint32_t)__shfl_down((int)gx, 2 * G);    // group 4q+0 fetches group 4q+2's value
     int need = 0;
-    if (leader) {
-        const float R = L.vw.ratio;
-        const float lim = (float)(L.margin_px - 1);
-        // both components settle with one returning atomic each, issued back to back
-        const unsigned long long ox = atomicAdd(&L.gacc[2 * v], ((unsigned long long)gx << 32) + 1ull);
-        const unsigned long long oy = atomicAdd(&L.gacc[2 * v + 1], ((unsigned long long)gy << 32) + 1ull);
-        if ((int)(ox & 0xffffffffull) == deg - 1) {
-            const uint32_t tot = (uint32_t)(ox >> 32) + gx;
-            L.gacc[2 * v] = 0ull;
-            reinterpret_cast<int*>(L.gr)[2 * v] = (int)tot;
-            if (v >= 4) {
-                float x = p.x, tg = (float)(int)tot;
-                if (x <= -R) { x = -R; tg = 0.0f; } else if (x >= R) { x = R; tg = 0.0f; }
-                x = tp_fsub(x, tp_fdiv(tp_fdiv(tp_fmul(rate, tg), 256.0f), 256.0f));
-                reinterpret_cast<float*>(L.points)[2 * v] = x;
-                need |= !(fabsf(x - pb.x) * (L.vw.halfW / R) <= lim);
+    TP_STAMP(2, 0);
+    if ((int)blockIdx.x >= L.NP) {
+        // base variants: 21 triangles per workgroup, lane (a, k) sums the base line of edge k, lane a combines
+        int64_t(*SB)[3][TP_W_WORDS] = reinterpret_cast<int64_t(*)[3][TP_W_WORDS]>(&S[0][0][0]);  // [21][3][6]
+        const int tb = ((int)blockIdx.x - L.NP) * 21;
+        {
+            const int a = lane / 3, k = lane - 3 * a, t = tb + a;
+            if (a < 21 && t < L.NT) {
+                const int he = L.he_edge[3 * t + k];
+                int64_t w[TP_W_WORDS];
+                line_sum(L, he >> 1, 0, w);
+#pragma unroll
+                for (int q = 0; q < TP_W_WORDS; q++) SB[a][k][q] = w[q];
             }
         }
-        if ((int)(oy & 0xffffffffull) == deg - 1) {
-            const uint32_t tot = (uint32_t)(oy >> 32) + gy;
-            L.gacc[2 * v + 1] = 0ull;
-            reinterpret_cast<int*>(L.gr)[2 * v + 1] = (int)tot;
-            if (v >= 4) {
-                float y = p.y, tg = (float)(int)tot;
-                if (y <= -1.0f) { y = -1.0f; tg = 0.0f; } else if (y >= 1.0f) { y = 1.0f; tg = 0.0f; }
-                y = tp_fsub(y, tp_fdiv(tp_fdiv(tp_fmul(rate, tg), 256.0f), 256.0f));
-                reinterpret_cast<float*>(L.points)[2 * v + 1] = y;
-                need |= !(fabsf(y - pb.y) * L.vw.halfH <= lim);
+        __syncthreads();
+        const int t = tb + lane;
+        if (lane < 21 && t < L.NT) {
+            const int4 tri = L.tris[t];
+            const int vid[3] = {tri.x, tri.y, tri.z};
+            int32_t X[3], Y[3], c[3];
+#pragma unroll
+            for (int ss = 0; ss < 3; ss++) {
+                const int2 q = L.vpos[(size_t)vid[ss] * 5];
+                X[ss] = q.x; Y[ss] = q.y;
+            }
+            tp_variant_coeffs(X, Y, c);
+            int64_t mo[TP_W_WORDS];
+#pragma unroll
+            for (int q = 0; q < TP_W_WORDS; q++)
+                mo[q] = (int64_t)c[0] * SB[lane][0][q] + (int64_t)c[1] * SB[lane][1][q] + (int64_t)c[2] * SB[lane][2][q];
+            const tp_moments mm = {mo[0], mo[1], mo[2], mo[3], mo[4], mo[5]};
+            emit_variant(L, flavour, t, 0, mm, false);
+        }
+    } else {
+        const int v = blockIdx.x;
+        const int k0 = L.vtx_off[v], deg = L.vtx_off[v + 1] - k0;
+        float2 p = make_float2(0.0f, 0.0f), pb = p;
+        if (lane == 0) { p = L.points[v]; if (L.margin_px >= 2) pb = L.points_binned[v]; }
+        uint32_t gx = 0, gy = 0;
+        for (int base = 0; base < deg; base += UPD_CHUNK) {
+            {   // line sums: lane (a, l)
+                const int a = lane / TP_NLINES, l = lane - a * TP_NLINES;
+                if (a < UPD_CHUNK && base + a < deg) {
+                    const int h = L.vtx_adj[k0 + base + a], t = h / 3, s = h - 3 * t;
+                    // l = 0: the opposite edge's base line; 1..4: the edge leaving the vertex, vertex displaced by
+                    // move l; 5..8: the edge arriving at the vertex, vertex displaced by move l - 4
+                    const int m = l == 0 ? 0 : ((l - 1) & 3) + 1;
+                    const int k = l == 0 ? (s == 2 ? 0 : s + 1) : l <= 4 ? s : (s == 0 ? 2 : s - 1);
+                    const int he = L.he_edge[3 * t + k];
+                    int64_t w[TP_W_WORDS];
+                    line_sum(L, he >> 1, tp_edge_version(l == 0 ? 0 : 4 * s + m, k, he & 1), w);
+#pragma unroll
+                    for (int q = 0; q < TP_W_WORDS; q++) S[a][l][q] = w[q];
+                }
+            }
+            __syncthreads();
+            TP_STAMP(2, 1);
+            int32_t e = 0;
+            {   // variants: lane (a, m - 1)
+                const int a = lane >> 2, m = (lane & 3) + 1;
+                if (a < UPD_CHUNK && base + a < deg) {
+                    const int h = L.vtx_adj[k0 + base + a], t = h / 3, s = h - 3 * t;
+                    const int i = 4 * s + m;
+                    const int4 tri = L.tris[t];
+                    const int vid[3] = {tri.x, tri.y, tri.z};
+                    int32_t X[3], Y[3], c[3];
+#pragma unroll
+                    for (int ss = 0; ss < 3; ss++) {
+                        const int2 q = L.vpos[(size_t)vid[ss] * 5 + (ss == s ? m : 0)];
+                        X[ss] = q.x; Y[ss] = q.y;
+                    }
+                    tp_variant_coeffs(X, Y, c);
+                    const int kn = s == 2 ? 0 : s + 1, kp = s == 0 ? 2 : s - 1;
+                    const int cs = s == 0 ? c[0] : s == 1 ? c[1] : c[2];
+                    const int cn = kn == 0 ? c[0] : kn == 1 ? c[1] : c[2];
+                    const int cp = kp == 0 ? c[0] : kp == 1 ? c[1] : c[2];
+                    int64_t mo[TP_W_WORDS];
+#pragma unroll
+                    for (int q = 0; q < TP_W_WORDS; q++)
+                        mo[q] = (int64_t)cs * S[a][m][q] + (int64_t)cp * S[a][4 + m][q] + (int64_t)cn * S[a][0][q];
+                    const tp_moments mm = {mo[0], mo[1], mo[2], mo[3], mo[4], mo[5]};
+                    e = emit_variant(L, flavour, t, i, mm, false);
+                }
+            }
+            // central differences: lanes 4a+0/1 hold E(+dx)/E(-dx), 4a+2/3 E(+dy)/E(-dy)
+            const uint32_t d = (uint32_t)e - (uint32_t)__shfl_xor(e, 1);
+            if ((lane & 3) == 0) gx += d;
+            if ((lane & 3) == 2) gy += d;
+            TP_STAMP(2, 2);
+            __syncthreads();  // S is rewritten by the next chunk
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { gx += (uint32_t)__shfl_xor((int)gx, o); gy += (uint32_t)__shfl_xor((int)gy, o); }
+        if (lane == 0) {
+            if (deg > 0) L.gr[v] = make_int2((int)gx, (int)gy);  // vertices no triangle uses: the gradient is never touched
+            if (v >= 4) {  // shift.cs:20 -- the four corners never move
+                const float R = L.vw.ratio;
+                const float lim = (float)(L.margin_px - 1);
+                float tgx = (float)(int)gx, tgy = (float)(int)gy;
+                float x = p.x, y = p.y;
+                if (x <= -R) { x = -R; tgx = 0.0f; } else if (x >= R) { x = R; tgx = 0.0f; }
+                if (y <= -1.0f) { y = -1.0f; tgy = 0.0f; } else if (y >= 1.0f) { y = 1.0f; tgy = 0.0f; }
+                if (deg > 0) {  // (unused vertices are only clamped: shift.cs:25-43 runs for every i in [4, NPoints))
+                    x = tp_fsub(x, tp_fdiv(tp_fdiv(tp_fmul(rate, tgx), 256.0f), 256.0f));
+                    y = tp_fsub(y, tp_fdiv(tp_fdiv(tp_fmul(rate, tgy), 256.0f), 256.0f));
+                }
+                L.points[v] = make_float2(x, y);
+                need = !(fabsf(x - pb.x) * (L.vw.halfW / R) <= lim) || !(fabsf(y - pb.y) * L.vw.halfH <= lim);
             }
         }
     }
-    // vertices no triangle uses get no arrival, but shift.cs still clamps them to the domain (shift.cs:25-43
-    // runs for every i in [4, NPoints); their gradient is never touched)
-    if (tidg >= 4 && tidg < L.NP && L.vtx_off[tidg + 1] == L.vtx_off[tidg]) {
-        float2 q = L.points[tidg];
-        const float R = L.vw.ratio;
-        q.x = q.x <= -R ? -R : (q.x >= R ? R : q.x);
-        q.y = q.y <= -1.0f ? -1.0f : (q.y >= 1.0f ? 1.0f : q.y);
-        L.points[tidg] = q;
-    }
-    if (L.margin_px < 2) return;
+    TP_STAMP(2, 3);
+    if (L.margin_px < 2) return;  // no margin: every launch re-arms the lists
     need = __syncthreads_or(need);
-    if (threadIdx.x == 0) {
-        const uint32_t old = atomicAdd(&L.state->arrive, 1u + (need ? 0x10000u : 0u));
-        const uint32_t now = old + 1u + (need ? 0x10000u : 0u);
-        s_last = ((now & 0xffffu) == gridDim.x) ? ((now >> 16) ? 2 : 1) : 0;
+    if (lane == 0) {
+        const unsigned long long inc = 1ull + (need ? 1ull << 32 : 0ull);
+        const unsigned long long now = atomicAdd(&L.state->arrive, inc) + inc;
+        s_last = ((uint32_t)now == gridDim.x) ? ((now >> 32) ? 2 : 1) : 0;
     }
     __syncthreads();
     if (s_last) {
         if (s_last == 2)
-            for (int k = threadIdx.x; k < L.tiles_x * L.tiles_y; k += blockDim.x) L.tilecount[k] = 0;
-        if (threadIdx.x == 0) {
-            L.state->arrive = 0;
+            for (int k = lane; k < L.tiles_x * L.tiles_y; k += UPD_THREADS) L.tilecount[k] = 0;
+        if (lane == 0) {
+            L.state->arrive = 0ull;
             if (s_last == 2) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
         }
     }
 }
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s) {
-    const int G = lanes_per_variant(L);
-    long long n = 13LL * L.NT * G;  // G lanes per variant, and at least one thread per vertex
-    if (n < L.NP) n = L.NP;
-    const dim3 grid((unsigned)((n + UPD_THREADS - 1) / UPD_THREADS)), block(UPD_THREADS);
-    if (G == 1) hipLaunchKernelGGL(k_update<1>, grid, block, 0, s, L, flavour, rate);
-    else if (G == 4) hipLaunchKernelGGL(k_update<4>, grid, block, 0, s, L, flavour, rate);
-    else hipLaunchKernelGGL(k_update<16>, grid, block, 0, s, L, flavour, rate);
+    const int nblocks = L.NP + (L.NT + 20) / 21;  // a wave per vertex, then the base variants (21 triangles per wave)
+    hipLaunchKernelGGL(k_update, dim3((unsigned)nblocks), dim3(UPD_THREADS), 0, s, L, flavour, rate);
 }
 
 // tpose::upload colour replication (source/triangulation.hpp:633-641): col[i*NT + k] = colors[k]
