@@ -1,8 +1,8 @@
-export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r2f; mkdir -p $O
+export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r2j; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests/ -q -m gpu -x 2>&1 | tail -15 > $O/pytest.txt; cat $O/pytest.txt
-for v in base nowalk neither; do TPOSE_HIP_LIB=$PWD/tpose_amd/variants/libtpose_hip_$v.so python tools/time_acc.py >> $O/ab.jsonl 2>$O/ab_$v.err; done
-cat $O/ab.jsonl
+python tools/time_acc.py > $O/time.json 2>$O/time.err; cat $O/time.json
+python tools/kernel_timeline.py > $O/timeline.json 2> $O/timeline.err; tail -2 $O/timeline.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python bench.py --no-cpu-baseline --no-pmc --steps 512 --warmup 64 > $O/kt.log 2>&1
 find $O -name "*kernel_trace.csv" -delete
 head -5 $O/kt/kt_kernel_stats.csv | cut -c1-150

@@ -65,6 +65,8 @@ struct tp_context {
     int4* colors = nullptr;
     int* vtx_off = nullptr;
     int* vtx_adj = nullptr;
+    int* vref = nullptr;   // per-upload reference tables of k_update
+    int* vvar = nullptr;
     // work lists
     int tiles_x = 0, tiles_y = 0;
     int* tilecount = nullptr;
@@ -80,9 +82,7 @@ struct tp_context {
     int visit_cap = 0;
     longlong2* line_xs = nullptr;  // per-iteration line table: nine whole-line walkers per edge
     int2* line_rows = nullptr;
-    int64_t* line_static = nullptr;
     int64_t* wline = nullptr;      // whole line sums, coarse meshes only (allocated on first use)
-    uint16_t* vmask = nullptr;     // per (edge, tile) visit: which of the nine lines are live there
     uint32_t* segex[2] = {nullptr, nullptr};  // static per-image packed segment prefixes
     int64_t* t2[2] = {nullptr, nullptr};   // static per-image tables
     uint32_t* seg_scratch = nullptr;
@@ -100,6 +100,7 @@ struct tp_context {
     float dp_override = 0.0f;  // <= 0: reference law
     int last_flavour = 0;
     uint64_t generation = 1;
+    uint32_t sweeps = 0;  // k_bin launches so far == tp_device_state::sweep once the stream has drained
     std::vector<graph_entry> graphs;
     // fused iterations enqueued since the last successful check of the device flags: when a work list
     // overflowed, k_update stopped stepping; the host grows the lists and replays what is missing
@@ -152,13 +153,14 @@ void drop_graphs(tp_context* c) {
 }
 
 void free_triangulation(tp_context* c) {
+    hipFree(c->vref); hipFree(c->vvar); c->vref = nullptr; c->vvar = nullptr;
     hipFree(c->points); hipFree(c->points_binned); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
     hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->edge_visit); hipFree(c->visits);
-    hipFree(c->line_xs); hipFree(c->line_rows); hipFree(c->line_static); hipFree(c->vmask); hipFree(c->tilelist); hipFree(c->wline);
+    hipFree(c->line_xs); hipFree(c->line_rows); hipFree(c->tilelist); hipFree(c->wline);
     hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
     c->points = nullptr; c->points_binned = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
     c->edge_uv = nullptr; c->he_edge = nullptr; c->vpos = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
-    c->line_xs = nullptr; c->line_rows = nullptr; c->line_static = nullptr; c->vmask = nullptr; c->tilelist = nullptr; c->capE = 0;
+    c->line_xs = nullptr; c->line_rows = nullptr; c->tilelist = nullptr; c->capE = 0;
     c->wline = nullptr;
     c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
     c->capT = c->capP = 0;
@@ -175,11 +177,11 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.points = c->points; L.points_binned = c->points_binned; L.margin_px = c->margin_px;
     L.tris = c->tris; L.colors = c->colors;
     L.NT = c->NT; L.NP = c->NP;
-    L.vtx_off = c->vtx_off; L.vtx_adj = c->vtx_adj;
+    L.vtx_off = c->vtx_off; L.vtx_adj = c->vtx_adj; L.vref = c->vref; L.vvar = c->vvar;
     L.tilecount = c->tilecount; L.tilelist = c->tilelist; L.list_cap = c->list_cap;
     L.edge_uv = c->edge_uv; L.he_edge = c->he_edge; L.vpos = c->vpos; L.NE = c->NE;
     L.edge_visit = c->edge_visit; L.visits = c->visits; L.visit_cap = c->visit_cap;
-    L.line_xs = c->line_xs; L.line_rows = c->line_rows; L.line_static = c->line_static; L.vmask = c->vmask;
+    L.line_xs = c->line_xs; L.line_rows = c->line_rows;
     L.segex = c->segex[slot];
     L.wline = nullptr;
     if (tp_coarse_mesh(L)) L.wline = c->wline;  // hundreds of tiles per edge: k_linesum sums the records of a line once
@@ -214,6 +216,19 @@ hipError_t force_rebin(tp_context* c) {
     return hipMemsetD32Async((hipDeviceptr_t)&c->state->rebin_req, 1, 1, c->stream);
 }
 
+// Every k_bin launch starts a sweep and numbers it (records carry the number of the sweep that wrote them).  Long
+// before the 32-bit number could come round again, the records are wiped and the count restarts.
+hipError_t count_sweeps(tp_context* c, uint32_t n) {
+    if (c->sweeps > (1u << 30)) {
+        hipError_t e = hipMemsetAsync(c->visits, 0, (size_t)c->visit_cap * TP_NLINES * TP_REC_DWORDS * sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)&c->state->sweep, 0, 1, c->stream);
+        if (e != hipSuccess) return e;
+        c->sweeps = 0;
+    }
+    c->sweeps += n;
+    return hipSuccess;
+}
+
 // enqueue one grad-iter on the context stream (no sync)
 void enqueue_iter(tp_context* c, const tp_params& p, float dp) {
     tp_launch L = make_launch(c, p.image_slot, dp);
@@ -238,11 +253,10 @@ bool grow_lists(tp_context* c, uint32_t flags, hipError_t* err) {
             size_t vcap = (size_t)c->visit_cap * 2;
             if (vcap > limit) vcap = limit;
             uint32_t* fresh = nullptr;
-            uint16_t* fresh_mask = nullptr;
             if ((*err = dev_alloc(&fresh, vcap * TP_NLINES * TP_REC_DWORDS)) == hipSuccess &&
-                (*err = dev_alloc(&fresh_mask, vcap)) == hipSuccess) {
-                hipFree(c->visits); hipFree(c->vmask);
-                c->visits = fresh; c->vmask = fresh_mask;
+                (*err = hipMemset(fresh, 0, vcap * TP_NLINES * TP_REC_DWORDS * sizeof(uint32_t))) == hipSuccess) {  // no record carries a sweep number yet
+                hipFree(c->visits);
+                c->visits = fresh;
                 c->visit_cap = (int)vcap;
                 grown = true;
             } else
@@ -465,6 +479,8 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         HIP_TRY(c, dev_alloc(&c->gr, capP));
         HIP_TRY(c, dev_alloc(&c->gacc, (size_t)2 * capP));
         HIP_TRY(c, dev_alloc(&c->vtx_off, capP + 1));
+        HIP_TRY(c, dev_alloc(&c->vref, (size_t)capP * 64));
+        HIP_TRY(c, dev_alloc(&c->vvar, (size_t)capP * 8));
         HIP_TRY(c, dev_alloc(&c->tris, capT));
         HIP_TRY(c, dev_alloc(&c->colors, capT));
         HIP_TRY(c, dev_alloc(&c->vtx_adj, (size_t)3 * capT));
@@ -519,21 +535,19 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
     }
     if (NE > c->capE) {
         hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->line_xs); hipFree(c->line_rows);
-        hipFree(c->line_static); hipFree(c->vmask); hipFree(c->wline);
+        hipFree(c->wline);
         c->wline = nullptr;
         c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr; c->line_xs = nullptr; c->line_rows = nullptr;
-        c->line_static = nullptr; c->vmask = nullptr;
         const int capE = NE + NE / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->edge_uv, capE));
         HIP_TRY(c, dev_alloc(&c->edge_visit, capE));
         HIP_TRY(c, dev_alloc(&c->line_xs, (size_t)capE * TP_NLINES));
         HIP_TRY(c, dev_alloc(&c->line_rows, (size_t)capE * TP_NLINES));
-        HIP_TRY(c, dev_alloc(&c->line_static, (size_t)capE * TP_NLINES * TP_T2_WORDS));
         // (edge, tile) visits: typical edges cross a handful of tiles, a few long ones many
         size_t vcap = (size_t)capE * 24 + (size_t)ntiles * 8;
         if (vcap > ((size_t)1 << 24)) vcap = (size_t)1 << 24;
         HIP_TRY(c, dev_alloc(&c->visits, vcap * TP_NLINES * TP_REC_DWORDS));
-        HIP_TRY(c, dev_alloc(&c->vmask, vcap));
+        HIP_TRY(c, hipMemsetAsync(c->visits, 0, vcap * TP_NLINES * TP_REC_DWORDS * sizeof(uint32_t), c->stream));  // no record carries a sweep number yet
         c->visit_cap = (int)vcap;
         c->capE = capE;
         c->tilelist_elems = 0;
@@ -596,12 +610,19 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
     }
     c->NT = NT; c->NP = NP;
     c->have_colors = colors != nullptr;
+    {   // reference tables of the fused update (device side: reads the arrays just copied)
+        tp_launch L = make_launch(c, 0, 0.0f);
+        tp_launch_vertex_refs(L, c->vref, c->vvar, c->stream);
+        HIP_TRY(c, hipGetLastError());
+    }
     if (colors) {
         tp_launch L = make_launch(c, 0, 0.0f);
         tp_launch_replicate_colors(L, c->stream);
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipMemsetAsync(c->state, 0, sizeof(tp_device_state), c->stream));
+    // ... except the sweep number: records of earlier triangulations must stay recognisably old
+    HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)&c->state->sweep, (int)c->sweeps, 1, c->stream));
     c->pending.clear(); c->done_base = 0;
     c->lists_dp = -1.0f;  // forces a rebuild of the work lists at the next use
     HIP_TRY(c, hipMemsetAsync(c->gacc, 0, sizeof(unsigned long long) * 2 * (size_t)c->capP, c->stream));
@@ -625,6 +646,7 @@ int tp_accumulate(tp_context* c, int flavour, int slot) {
     for (int round = 0;; round++) {
         tp_launch L = make_launch(c, slot, resolve_dp(c, flavour, c->dp_override));
         HIP_TRY(c, force_rebin(c));  // the piecewise API rebuilds the work lists on every sweep
+        HIP_TRY(c, count_sweeps(c, 1));
         c->lists_dp = L.vw.dp; c->lists_ratio = c->ratio;
         tp_launch_bin(L, c->stream);
         tp_launch_accumulate(L, c->stream);
@@ -748,6 +770,7 @@ int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
         HIP_TRY(c, force_rebin(c));
         c->lists_dp = dp; c->lists_ratio = c->ratio;
     }
+    HIP_TRY(c, count_sweeps(c, (uint32_t)n_iters));
     int left = n_iters;
     if (left >= CHUNK) {
         graph_entry* g = nullptr;
@@ -804,6 +827,7 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
     // a graph replay runs ~1-2 us shorter -- see profiles/.)
     std::vector<hipEvent_t> ev((size_t)2 * n_iters);
     for (auto& e : ev) HIP_TRY(c, hipEventCreate(&e));
+    HIP_TRY(c, count_sweeps(c, (uint32_t)n_iters));
     for (int k = 0; k < n_iters; k++) {
         tp_launch L = make_launch(c, p->image_slot, dp);
         tp_launch_bin(L, c->stream);
@@ -835,6 +859,7 @@ int tp_profile_accumulate(tp_context* c, const tp_params* p, int launches, doubl
     HIP_TRY(c, force_rebin(c));
     c->lists_dp = dp; c->lists_ratio = c->ratio;
     tp_launch L = make_launch(c, p->image_slot, dp);
+    HIP_TRY(c, count_sweeps(c, 1));
     tp_launch_bin(L, c->stream);  // work lists of the current state; every accumulate launch below consumes the same ones
     HIP_TRY(c, hipGetLastError());
     hipGraphExec_t exec = nullptr;

@@ -8,8 +8,9 @@
 #define TP_TILE_H 16
 #define TP_NLINES 9        /* lines per undirected edge: base + 4 moves of either endpoint */
 #define TP_W_WORDS 6       /* values per line sum: sum x, n_odd, sum r, sum g, sum b, q */
-#define TP_REC_DWORDS 6    /* per-tile record of a line, 24 bytes: u32 sum x (absolute columns), then the TILE-LOCAL sums
-                              n_odd, r, g, b, q + n_odd over its counted rows (<= 16 rows x 128 columns: < 2^29) */
+#define TP_REC_DWORDS 8    /* per-tile record of a line, 32 bytes: u32 sum x (absolute columns), then the TILE-LOCAL sums
+                              n_odd, r, g, b, q + n_odd over its counted rows (<= 16 rows x 128 columns: < 2^29), the
+                              number of the sweep that wrote it (a record is valid for that sweep only), 0 */
 #define TP_SEG_ENTRIES 17  /* static packed prefixes per (row, tile column): at the start of each 8-pixel segment + the row total */
 #define TP_T2_WORDS 5      /* int64 per static-table entry: n_odd, sum r, sum g, sum b, q */
 
@@ -23,7 +24,7 @@ struct tp_device_state {
     uint32_t rebin_req;    // 1: k_bin must rebuild the work lists (upload, or a vertex left its margin)
     uint32_t rebin_count;  // statistics: rebuilds so far
     uint32_t iters_done;   // fused iterations k_update completed (it does not step while a flag is up)
-    uint32_t pad;
+    uint32_t sweep;        // number of the current sweep: k_bin counts, k_accumulate stamps its records, readers compare
     unsigned long long arrive;  // k_update: blocks arrived | (blocks voting for a rebuild) << 32
 };
 
@@ -46,19 +47,19 @@ struct tp_launch {
     const int* vtx_adj;
     const int2* edge_uv;    // [NE] endpoints of every undirected edge, u <= v; bit 30: this edge publishes the vertex (vpos)
     const int* he_edge;     // [3 NT] edge id * 2 + (half-edge runs v -> u)
+    const int* vref;        // [NP][64] per upload: the line (edge << 4 | version) each lane of k_update sums, -1 none; see k_vertex_refs
+    const int* vvar;        // [NP][8]  per upload: per incident triangle 3t + s | out-edge slot << 20 | in-edge slot << 24, -1 none
     int2* vpos;             // [NP][5] snapped 24.8 position of every vertex: unmoved, +dx, -dx, +dy, -dy
     // per-iteration line table: the nine lines of every edge, set up once (tp_setup_line)
     longlong2* line_xs;     // [NE][TP_NLINES] (x, s) 24.40 walker at row ra and its step
     int2* line_rows;        // [NE][TP_NLINES] (ra, rb) rows of the line inside the raster
-    int64_t* line_static;   // [NE][TP_NLINES][TP_T2_WORDS] static part of the line sums: everything left of the tile
-                            // column in each of the line's rows (differences of t2 per column run)
     // work lists
     int* tilecount;           // [tiles]
     int2* tilelist;           // [tiles * list_cap] (line = edge * 9 + version, record = visit * 9 + version): LIVE lines only
     int list_cap;
     int2* edge_visit;         // [NE] (first visit, #visits = tiles the band of the edge's lines can touch)
-    uint16_t* vmask;          // [visit_cap] which of the nine lines of the visit's edge are live in that tile
-    uint32_t* visits;         // [visit_cap][TP_NLINES][TP_REC_DWORDS] per-tile line records (live lines only are written)
+    uint32_t* visits;         // [visit_cap][TP_NLINES][TP_REC_DWORDS] per-tile line records; only live lines are written,
+                              // the others keep the stamp of an older sweep
     int visit_cap;
     int64_t* wline;           // [NE][TP_NLINES][TP_W_WORDS] whole line sums -- only for coarse meshes (k_linesum), else null
     tp_device_state* state;
@@ -82,6 +83,7 @@ void tp_launch_linesum(const tp_launch& L, hipStream_t s);
 void tp_launch_finalize(const tp_launch& L, int flavour, bool write_moments, hipStream_t s);
 void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s);
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s);
+void tp_launch_vertex_refs(const tp_launch& L, int* vref, int* vvar, hipStream_t s);  // once per upload
 void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s);
 // static per-image table: t2[r][tc] = moments of all pixels in rows < r and columns < tc * TP_TILE_W
 // also rewrites the alpha bytes of the padded plane and fills the packed segment prefixes `segex`

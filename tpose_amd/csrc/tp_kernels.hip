@@ -139,8 +139,8 @@ void tp_launch_static_table(uint8_t* img, int pitch, int W, int H, int Hp, int t
 //            the static part of its sums
 //   pass A   the tiles the band of the nine lines can touch, tile row by tile row (lane q takes tile rows
 //            ty0 + q, + 16, ...): counted, scanned -> consecutive visit ids per edge, then entered in an LDS table
-//   pass B   ONE LANE PER VISIT: an exact liveness test for each of the nine lines, one returning atomic that
-//            reserves list slots for the live ones (every visit's atomic is in flight at once), the entries.
+//   pass B   an exact liveness test per (visit, line), then ONE LANE PER VISIT: one returning atomic reserves list
+//            slots for the live lines (every visit's atomic is in flight at once), then the entries.
 // ------------------------------------------------------------------------------------------------
 #define BIN_THREADS 256
 #define BIN_EDGES 16
@@ -154,8 +154,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
     __shared__ int64_t s_lx[BIN_EDGES][TP_NLINES][2];
     __shared__ int s_lr[BIN_EDGES][TP_NLINES][2];
     __shared__ int s_vis[BIN_VISITS];    // (edge of the block << 27) | tile
+    __shared__ uint32_t s_mask[BIN_VISITS];  // live lines of the visit
     const int tid = threadIdx.x;
     const uint32_t rebin_word = L.state->rebin_req;  // consumed late: the loads below do not wait for it
+    if (blockIdx.x == 0 && tid == 0) L.state->sweep++;  // records of this sweep carry its number (single writer)
     const int j = tid >> 4, q = tid & 15;
     const int e = blockIdx.x * BIN_EDGES + j;
     tp_band band = {0, 0, 0, 0, 0, 0};
@@ -184,20 +186,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
                 L.line_xs[li] = make_longlong2(ln.x, ln.s);
                 L.line_rows[li] = make_int2(ln.ra, ln.rb);
                 s_lx[j][q][0] = ln.x; s_lx[j][q][1] = ln.s; s_lr[j][q][0] = ln.ra; s_lr[j][q][1] = ln.rb;
-                // static part of the line sums: per run of rows inside one tile column, everything left of that
-                // column = a difference of the cumulative static table
-                int64_t st[TP_T2_WORDS] = {0, 0, 0, 0, 0};
-                const int64_t* t2 = L.t2;
-                const int tx1 = L.tiles_x + 1;
-                tp_line_column_runs(ln, L.vw.W, TW, L.tiles_x, [&](int32_t tc, int32_t ra, int32_t rb) {
-                    if (tc == 0) return;  // nothing is left of the first tile column
-                    const int64_t* a = t2 + ((size_t)ra * tx1 + tc) * TP_T2_WORDS;
-                    const int64_t* b = t2 + ((size_t)(rb + 1) * tx1 + tc) * TP_T2_WORDS;
-#pragma unroll
-                    for (int k = 0; k < TP_T2_WORDS; k++) st[k] += b[k] - a[k];
-                });
-#pragma unroll
-                for (int k = 0; k < TP_T2_WORDS; k++) L.line_static[li * TP_T2_WORDS + k] = st[k];
             }
         }
         band.dX = row_max16(dX) + 256 * L.margin_px;
@@ -261,28 +249,31 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
         }
         __syncthreads();
         TP_STAMP(0, 3);
-        // ---- pass B: a lane per visit
+        // ---- pass B1: lane (visit, line) -> exact liveness, one bit per line OR-ed into the visit's mask in LDS
         const int nv = min(total - v0, BIN_VISITS);
+        for (int t = tid; t < nv; t += BIN_THREADS) s_mask[t] = 0;
+        __syncthreads();
+        if (L.margin_px < 2) {
+            for (int u = tid; u < nv * 16; u += BIN_THREADS) {
+                const int t = u >> 4, l = u & 15;
+                if (l >= TP_NLINES) continue;
+                const int w = s_vis[t], jj = w >> 27, tile = w & 0x7ffffff;
+                const int ty = tile / L.tiles_x, tx = tile - ty * L.tiles_x;
+                const int row0 = ty * TH, row1 = min(row0 + TH - 1, L.vw.H - 1);
+                const int col0 = tx * TW;
+                const int lim = tx == L.tiles_x - 1 ? L.vw.W - col0 + 1 : TW;
+                tp_line ln; ln.x = s_lx[jj][l][0]; ln.s = s_lx[jj][l][1]; ln.ra = s_lr[jj][l][0]; ln.rb = s_lr[jj][l][1];
+                if (tp_line_live(ln, row0, row1, col0, lim, L.vw.W)) atomicOr(&s_mask[t], 1u << l);
+            }
+            __syncthreads();
+        }
+        // ---- pass B2: a lane per visit: every visit's returning atomic is in flight at once
         for (int t = tid; t < nv; t += BIN_THREADS) {
             const int w = s_vis[t], jj = w >> 27, tile = w & 0x7ffffff;
             const int visit = (int)base + v0 + t;
-            const int ty = tile / L.tiles_x, tx = tile - ty * L.tiles_x;
-            const int row0 = ty * TH, row1 = min(row0 + TH - 1, L.vw.H - 1);
-            const int col0 = tx * TW;
-            const int lim = tx == L.tiles_x - 1 ? L.vw.W - col0 + 1 : TW;
-            uint32_t mask = 0;
-            if (L.margin_px >= 2) {
-                // lists kept across iterations (tp_set_margin) must hold every line of the band: a line can become
-                // live in a tile, or non-empty at all, while the vertices move inside the margin
-                mask = (1u << TP_NLINES) - 1u;
-            } else {
-#pragma unroll
-                for (int l = 0; l < TP_NLINES; l++) {
-                    tp_line ln; ln.x = s_lx[jj][l][0]; ln.s = s_lx[jj][l][1]; ln.ra = s_lr[jj][l][0]; ln.rb = s_lr[jj][l][1];
-                    mask |= tp_line_live(ln, row0, row1, col0, lim, L.vw.W) ? 1u << l : 0u;
-                }
-            }
-            L.vmask[visit] = (uint16_t)mask;
+            // lists kept across iterations (tp_set_margin) must hold every line of the band: a line can become
+            // live in a tile, or non-empty at all, while the vertices move inside the margin
+            const uint32_t mask = L.margin_px >= 2 ? (1u << TP_NLINES) - 1u : s_mask[t];
             if (mask == 0) continue;
             const int ee = blockIdx.x * BIN_EDGES + jj;
             int pos = atomicAdd(&L.tilecount[tile], (int)__builtin_popcount(mask));
@@ -333,6 +324,7 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
     extern __shared__ __attribute__((aligned(16))) uint32_t P[];  // [TH][ROW_WORDS]
 
     const int tid = threadIdx.x;
+    const uint32_t sweep = L.state->sweep;  // stamped into the records
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD one contiguous band of tile rows so
     // that the lines, list entries and raster rows a tile shares with its neighbours stay in that XCD's L2
     const int ntiles = L.tiles_x * L.tiles_y;
@@ -403,7 +395,7 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
     const int pr = TH >> lsplit;  // rows per part
 
 #if defined(TPOSE_ABLATE) && (TPOSE_ABLATE & 2)  // timing experiments only: no walk
-    if ((lxs.x ^ lrows.x) == 0x1234567 && ent.y < L.visit_cap * TP_NLINES) L.visits[(size_t)ent.y * TP_REC_DWORDS] = 1;
+    if ((lxs.x ^ lrows.x) == 0x1234567 && ent.y < L.visit_cap * TP_NLINES) L.visits[(size_t)ent.y * TP_REC_DWORDS] = sweep;
     if (false)
 #endif
     for (; item < nitems; item += ACC_THREADS) {
@@ -452,9 +444,9 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
             aq += (uint32_t)__shfl_xor((int)aq, o);
         }
         if (part != 0) continue;
-        if (ent.y < L.visit_cap * TP_NLINES) {  // 24-byte record
-            uint2* out = reinterpret_cast<uint2*>(L.visits + (size_t)ent.y * TP_REC_DWORDS);
-            out[0] = make_uint2(sx, ao); out[1] = make_uint2(ar, ag); out[2] = make_uint2(ab, aq);
+        if (ent.y < L.visit_cap * TP_NLINES) {  // 32-byte record
+            uint4* out = reinterpret_cast<uint4*>(L.visits + (size_t)ent.y * TP_REC_DWORDS);
+            out[0] = make_uint4(sx, ao, ar, ag); out[1] = make_uint4(ab, aq, sweep, 0u);
         }
     }
     TP_STAMP(1, 3);
@@ -486,34 +478,54 @@ void tp_launch_accumulate_timed(const tp_launch& L, hipStream_t s, hipEvent_t st
 // where they are needed; coarse meshes on large rasters (hundreds of tiles per edge) run k_linesum first --
 // one wave per line -- and everything downstream reads `wline`.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void add_record(uint64_t a[TP_W_WORDS], bool live, const uint2 r0, const uint2 r1, const uint2 r2) {
+__device__ __forceinline__ void add_record(uint64_t a[TP_W_WORDS], bool live, const uint4 r0, const uint4 r1) {
     a[0] += live ? r0.x : 0u; a[1] += live ? r0.y : 0u;
-    a[2] += live ? r1.x : 0u; a[3] += live ? r1.y : 0u;
-    a[4] += live ? r2.x : 0u;
-    a[5] += live ? r2.y - r0.y : 0u;  // q: the record holds q + n_odd
+    a[2] += live ? r0.z : 0u; a[3] += live ? r0.w : 0u;
+    a[4] += live ? r1.x : 0u;
+    a[5] += live ? r1.y - r0.y : 0u;  // q: the record holds q + n_odd
 }
 
 // visits first + j0, first + j0 + stride, ... of an edge, for line version `ver`: eight visits per trip, all of
-// their loads in flight together (an ordinary edge has about six visits: one round trip)
-__device__ __forceinline__ void sum_records(const tp_launch& L, int first, int n, int ver, int j0, int stride, uint64_t a[TP_W_WORDS]) {
+// their loads in flight together (an ordinary edge has about six visits: one round trip).  A record counts when
+// it carries the number of the current sweep: the line was live in that tile.
+__device__ __forceinline__ void sum_records(const tp_launch& L, uint32_t sweep, int first, int n, int ver, int j0, int stride,
+                                            uint64_t a[TP_W_WORDS]) {
     for (int j = j0; j < n; j += 8 * stride) {
-        uint32_t lv[8];
-        uint2 r[8][3];
+        uint4 r[8][2];
+        bool on[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int jj = j + u * stride;
-            const bool on = jj < n;
-            const size_t visit = (size_t)first + (on ? jj : j);
-            lv[u] = on ? (uint32_t)L.vmask[visit] : 0u;
-            const uint2* rec = reinterpret_cast<const uint2*>(L.visits + (visit * TP_NLINES + ver) * TP_REC_DWORDS);
-            r[u][0] = rec[0]; r[u][1] = rec[1]; r[u][2] = rec[2];  // garbage unless live: selected below
+            on[u] = jj < n;
+            const size_t visit = (size_t)first + (on[u] ? jj : j);
+            const uint4* rec = reinterpret_cast<const uint4*>(L.visits + (visit * TP_NLINES + ver) * TP_REC_DWORDS);
+            r[u][0] = rec[0]; r[u][1] = rec[1];
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) add_record(a, (lv[u] >> ver) & 1u, r[u][0], r[u][1], r[u][2]);
+        for (int u = 0; u < 8; u++) add_record(a, on[u] && r[u][1].z == sweep, r[u][0], r[u][1]);
     }
 }
 
-__device__ __forceinline__ void line_sum(const tp_launch& L, int e, int ver, int64_t w[TP_W_WORDS]) {
+// static part of a line's sums: per run of rows inside one tile column, everything left of that column = a
+// difference of the cumulative per-image table (the walk only produces tile-local sums)
+__device__ __forceinline__ void line_static_part(const tp_launch& L, size_t line, int64_t st[TP_T2_WORDS]) {
+    const longlong2 xs = L.line_xs[line];
+    const int2 rows = L.line_rows[line];
+    tp_line ln; ln.x = xs.x; ln.s = xs.y; ln.ra = rows.x; ln.rb = rows.y;
+#pragma unroll
+    for (int k = 0; k < TP_T2_WORDS; k++) st[k] = 0;
+    const int64_t* t2 = L.t2;
+    const int tx1 = L.tiles_x + 1;
+    tp_line_column_runs(ln, L.vw.W, TW, L.tiles_x, [&](int32_t tc, int32_t ra, int32_t rb) {
+        if (tc == 0) return;  // nothing is left of the first tile column
+        const int64_t* a = t2 + ((size_t)ra * tx1 + tc) * TP_T2_WORDS;
+        const int64_t* b = t2 + ((size_t)(rb + 1) * tx1 + tc) * TP_T2_WORDS;
+#pragma unroll
+        for (int k = 0; k < TP_T2_WORDS; k++) st[k] += b[k] - a[k];
+    });
+}
+
+__device__ __forceinline__ void line_sum(const tp_launch& L, uint32_t sweep, int e, int ver, int64_t w[TP_W_WORDS]) {
     const size_t line = (size_t)e * TP_NLINES + ver;
     if (L.wline) {  // coarse meshes: summed by k_linesum
 #pragma unroll
@@ -521,11 +533,10 @@ __device__ __forceinline__ void line_sum(const tp_launch& L, int e, int ver, int
         return;
     }
     const int2 ev = L.edge_visit[e];  // first visit, number of visits
-    int64_t st[TP_T2_WORDS];
-#pragma unroll
-    for (int q = 0; q < TP_T2_WORDS; q++) st[q] = L.line_static[line * TP_T2_WORDS + q];
     uint64_t a[TP_W_WORDS] = {0, 0, 0, 0, 0, 0};
-    sum_records(L, ev.x, ev.y, ver, 0, 1, a);
+    sum_records(L, sweep, ev.x, ev.y, ver, 0, 1, a);
+    int64_t st[TP_T2_WORDS];
+    line_static_part(L, line, st);
     w[0] = (int64_t)a[0];
 #pragma unroll
     for (int q = 1; q < TP_W_WORDS; q++) w[q] = (int64_t)a[q] + st[q - 1];
@@ -537,7 +548,7 @@ __global__ __launch_bounds__(64) void k_linesum(tp_launch L) {
     const int e = line / TP_NLINES, ver = line - e * TP_NLINES;
     const int2 ev = L.edge_visit[e];
     uint64_t a[TP_W_WORDS] = {0, 0, 0, 0, 0, 0};
-    sum_records(L, ev.x, ev.y, ver, lane, 64, a);
+    sum_records(L, L.state->sweep, ev.x, ev.y, ver, lane, 64, a);
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1)
 #pragma unroll
@@ -545,10 +556,12 @@ __global__ __launch_bounds__(64) void k_linesum(tp_launch L) {
             const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)a[q], o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(a[q] >> 32), o);
             a[q] += ((uint64_t)hi << 32) | lo;
         }
-    if (lane < TP_W_WORDS) {
-        uint64_t v = lane == 0 ? a[0] : lane == 1 ? a[1] : lane == 2 ? a[2] : lane == 3 ? a[3] : lane == 4 ? a[4] : a[5];
-        if (lane > 0) v += (uint64_t)L.line_static[(size_t)line * TP_T2_WORDS + lane - 1];
-        L.wline[(size_t)line * TP_W_WORDS + lane] = (int64_t)v;
+    if (lane == 0) {
+        int64_t st[TP_T2_WORDS];
+        line_static_part(L, (size_t)line, st);
+        L.wline[(size_t)line * TP_W_WORDS] = (int64_t)a[0];
+#pragma unroll
+        for (int q = 1; q < TP_W_WORDS; q++) L.wline[(size_t)line * TP_W_WORDS + q] = (int64_t)a[q] + st[q - 1];
     }
 }
 bool tp_coarse_mesh(const tp_launch& L) { return (long long)L.tiles_x * L.tiles_y > 4LL * L.NE; }
@@ -566,7 +579,7 @@ __device__ __forceinline__ tp_moments variant_moments(const tp_launch& L, int t,
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int he = L.he_edge[3 * t + k];
-        line_sum(L, he >> 1, tp_edge_version(i, k, he & 1), w[k]);
+        line_sum(L, L.state->sweep, he >> 1, tp_edge_version(i, k, he & 1), w[k]);
     }
 #pragma unroll
     for (int s = 0; s < 3; s++) {
@@ -582,19 +595,21 @@ __device__ __forceinline__ tp_moments variant_moments(const tp_launch& L, int t,
 }
 
 __device__ __forceinline__ int32_t emit_variant(const tp_launch& L, int flavour, int t, int i, const tp_moments& m,
-                                                bool write_moments) {
+                                                bool write_moments, bool store = true) {
     const int id = i * L.NT + t;
     int64_t E;
     if (flavour == 0) {
         E = tp_energy_triangulate(m);
-        L.ca[id] = make_int4(tp_wrap32(m.sr), tp_wrap32(m.sg), tp_wrap32(m.sb), 0);
+        if (store) L.ca[id] = make_int4(tp_wrap32(m.sr), tp_wrap32(m.sg), tp_wrap32(m.sb), 0);
     } else {
         const int4 col = L.ca[id];  // stored colour, replicated x13 by upload
         E = tp_energy64(m, col.x, col.y, col.z);
     }
     const int32_t e32 = tp_wrap32(E);
-    L.ten[id] = e32;
-    L.cn[id] = tp_wrap32(m.n);
+    if (store) {
+        L.ten[id] = e32;
+        L.cn[id] = tp_wrap32(m.n);
+    }
     if (write_moments) {
         int64_t* o = L.moments + (size_t)id * 6;
         o[0] = m.n; o[1] = m.nodd; o[2] = m.sr; o[3] = m.sg; o[4] = m.sb; o[5] = m.q;
@@ -659,35 +674,107 @@ void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s) {
 // knows whether any vertex left its margin.
 // ------------------------------------------------------------------------------------------------
 #define UPD_THREADS 64
-#define UPD_CHUNK 7  // incident triangles per pass: 7 x 9 = 63 lanes
+#define UPD_CHUNK 7  // generic path: incident triangles per pass, 7 x 9 = 63 lanes
+#define UPD_FAN 8    // fast path: up to eight incident triangles and eight incident edges
+
+// line l of nine for the incident (triangle, slot) h = 3t + s of a vertex, packed edge << 4 | version:
+// l = 0: the opposite edge's base line; 1..4: the edge leaving the vertex, vertex displaced by move l;
+// 5..8: the edge arriving at the vertex, vertex displaced by move l - 4
+__device__ __forceinline__ int vertex_line_ref(const tp_launch& L, int h, int l) {
+    const int t = h / 3, s = h - 3 * t;
+    const int m = l == 0 ? 0 : ((l - 1) & 3) + 1;
+    const int k = l == 0 ? (s == 2 ? 0 : s + 1) : l <= 4 ? s : (s == 0 ? 2 : s - 1);
+    const int he = L.he_edge[3 * t + k];
+    return ((he >> 1) << 4) | tp_edge_version(l == 0 ? 0 : 4 * s + m, k, he & 1);
+}
+
+// Per upload: what the lanes of k_update's wave for vertex v work on (instead of three dependent loads per iteration).
+// Fast layout, for a vertex with at most UPD_FAN incident triangles and incident edges:
+//   vref[v][4 b + m - 1], b < 8, m = 1..4   incident edge b with the vertex displaced by move m   (edge << 4 | version)
+//   vref[v][32 + a], a < 8                    the edge opposite the vertex in incident triangle a, base version
+//   vvar[v][a]                                3t + s | slot of the edge leaving the vertex << 20 | slot of the edge arriving << 24
+// Otherwise vref[v][0] = -2 and k_update derives everything itself, seven triangles at a time.
+__global__ void k_vertex_refs(tp_launch L, int* vref, int* vvar) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= L.NP) return;
+    const int k0 = L.vtx_off[v], deg = L.vtx_off[v + 1] - k0;
+    int* r = vref + (size_t)v * 64;
+    int* c = vvar + (size_t)v * 8;
+    for (int k = 0; k < 64; k++) r[k] = -1;
+    for (int k = 0; k < 8; k++) c[k] = -1;
+    if (deg > UPD_FAN) { r[0] = -2; return; }
+    int edges[UPD_FAN], flips[UPD_FAN], ne = 0;  // incident edges and whether the vertex is their second endpoint
+    for (int a = 0; a < deg; a++) {
+        const int h = L.vtx_adj[k0 + a], t = h / 3, s = h - 3 * t;
+        const int he_out = L.he_edge[3 * t + s], he_in = L.he_edge[3 * t + (s == 0 ? 2 : s - 1)];
+        int slot[2];
+        for (int w = 0; w < 2; w++) {
+            const int he = w == 0 ? he_out : he_in;
+            // leaving edge: the vertex is its origin -- second endpoint when the half-edge is flipped; arriving: the other way
+            const int second = w == 0 ? (he & 1) : !(he & 1);
+            int b = 0;
+            while (b < ne && edges[b] != (he >> 1)) b++;
+            if (b == ne) {
+                if (ne == UPD_FAN) { for (int k = 0; k < 64; k++) r[k] = -1; r[0] = -2; return; }
+                edges[ne] = he >> 1; flips[ne] = second; ne++;
+            }
+            slot[w] = b;
+        }
+        c[a] = h | (slot[0] << 20) | (slot[1] << 24);
+        r[32 + a] = ((L.he_edge[3 * t + (s == 2 ? 0 : s + 1)] >> 1) << 4) | 0;
+    }
+    for (int b = 0; b < ne; b++)
+        for (int m = 1; m <= 4; m++) r[4 * b + m - 1] = (edges[b] << 4) | (flips[b] ? 4 + m : m);
+}
+void tp_launch_vertex_refs(const tp_launch& L, int* vref, int* vvar, hipStream_t s) {
+    hipLaunchKernelGGL(k_vertex_refs, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L, vref, vvar);
+}
+
 __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour, float rate) {
-    __shared__ int64_t S[UPD_CHUNK][TP_NLINES][TP_W_WORDS];
+    __shared__ int64_t S[64][TP_W_WORDS];  // line sums of the wave: [lane] (fast path), [a][l] (generic), [a][k] (base variants)
     __shared__ int s_last;
     const int lane = threadIdx.x;
     const int tidg = blockIdx.x * UPD_THREADS + lane;
-    // a work list overflowed in this or an earlier iteration: the line sums are incomplete.  Do not
-    // step -- the host grows the lists and replays from the last good iteration (check_flags)
-    if (L.state->flags) return;
-    if (tidg == 0) L.state->iters_done++;
-    if (L.margin_px < 2) {
-        // work lists are rebuilt every iteration: k_accumulate has consumed them, re-arm them here
-        for (int k = tidg; k < L.tiles_x * L.tiles_y; k += gridDim.x * UPD_THREADS) L.tilecount[k] = 0;
-        if (tidg == 0) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
-    }
+    // A work list overflowed in this or an earlier iteration: the line sums are incomplete.  Do not step -- the host
+    // grows the lists and replays from the last good iteration (check_flags).  The flag word is requested here and
+    // looked at only where something would be written, so that the loads below do not queue behind it.
+    const uint32_t flags = L.state->flags;
+    const uint32_t sweep = L.state->sweep;
     int need = 0;
     TP_STAMP(2, 0);
+    // one variant: signed sum of three parked line sums -> outputs; returns the energy
+    auto variant = [&](int h, int m, const int64_t* Sout, const int64_t* Sin, const int64_t* Sopp) -> int32_t {
+        const int t = h / 3, s = h - 3 * t;
+        const int4 tri = L.tris[t];
+        const int vid[3] = {tri.x, tri.y, tri.z};
+        int32_t X[3], Y[3], c[3];
+#pragma unroll
+        for (int ss = 0; ss < 3; ss++) {
+            const int2 q = L.vpos[(size_t)vid[ss] * 5 + (ss == s ? m : 0)];
+            X[ss] = q.x; Y[ss] = q.y;
+        }
+        tp_variant_coeffs(X, Y, c);
+        const int kn = s == 2 ? 0 : s + 1, kp = s == 0 ? 2 : s - 1;
+        const int cs = s == 0 ? c[0] : s == 1 ? c[1] : c[2];
+        const int cn = kn == 0 ? c[0] : kn == 1 ? c[1] : c[2];
+        const int cp = kp == 0 ? c[0] : kp == 1 ? c[1] : c[2];
+        int64_t mo[TP_W_WORDS];
+#pragma unroll
+        for (int q = 0; q < TP_W_WORDS; q++) mo[q] = (int64_t)cs * Sout[q] + (int64_t)cp * Sin[q] + (int64_t)cn * Sopp[q];
+        const tp_moments mm = {mo[0], mo[1], mo[2], mo[3], mo[4], mo[5]};
+        return emit_variant(L, flavour, t, 4 * s + m, mm, false, flags == 0);
+    };
     if ((int)blockIdx.x >= L.NP) {
         // base variants: 21 triangles per workgroup, lane (a, k) sums the base line of edge k, lane a combines
-        int64_t(*SB)[3][TP_W_WORDS] = reinterpret_cast<int64_t(*)[3][TP_W_WORDS]>(&S[0][0][0]);  // [21][3][6]
         const int tb = ((int)blockIdx.x - L.NP) * 21;
         {
             const int a = lane / 3, k = lane - 3 * a, t = tb + a;
             if (a < 21 && t < L.NT) {
                 const int he = L.he_edge[3 * t + k];
                 int64_t w[TP_W_WORDS];
-                line_sum(L, he >> 1, 0, w);
+                line_sum(L, sweep, he >> 1, 0, w);
 #pragma unroll
-                for (int q = 0; q < TP_W_WORDS; q++) SB[a][k][q] = w[q];
+                for (int q = 0; q < TP_W_WORDS; q++) S[lane][q] = w[q];
             }
         }
         __syncthreads();
@@ -705,71 +792,73 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
             int64_t mo[TP_W_WORDS];
 #pragma unroll
             for (int q = 0; q < TP_W_WORDS; q++)
-                mo[q] = (int64_t)c[0] * SB[lane][0][q] + (int64_t)c[1] * SB[lane][1][q] + (int64_t)c[2] * SB[lane][2][q];
+                mo[q] = (int64_t)c[0] * S[3 * lane][q] + (int64_t)c[1] * S[3 * lane + 1][q] + (int64_t)c[2] * S[3 * lane + 2][q];
             const tp_moments mm = {mo[0], mo[1], mo[2], mo[3], mo[4], mo[5]};
-            emit_variant(L, flavour, t, 0, mm, false);
+            emit_variant(L, flavour, t, 0, mm, false, flags == 0);
         }
     } else {
         const int v = blockIdx.x;
-        const int k0 = L.vtx_off[v], deg = L.vtx_off[v + 1] - k0;
+        const int ref = L.vref[(size_t)v * 64 + lane];
+        const int comb = lane < 4 * UPD_FAN ? L.vvar[(size_t)v * 8 + (lane >> 2)] : -1;
         float2 p = make_float2(0.0f, 0.0f), pb = p;
         if (lane == 0) { p = L.points[v]; if (L.margin_px >= 2) pb = L.points_binned[v]; }
         uint32_t gx = 0, gy = 0;
-        for (int base = 0; base < deg; base += UPD_CHUNK) {
-            {   // line sums: lane (a, l)
-                const int a = lane / TP_NLINES, l = lane - a * TP_NLINES;
-                if (a < UPD_CHUNK && base + a < deg) {
-                    const int h = L.vtx_adj[k0 + base + a], t = h / 3, s = h - 3 * t;
-                    // l = 0: the opposite edge's base line; 1..4: the edge leaving the vertex, vertex displaced by
-                    // move l; 5..8: the edge arriving at the vertex, vertex displaced by move l - 4
-                    const int m = l == 0 ? 0 : ((l - 1) & 3) + 1;
-                    const int k = l == 0 ? (s == 2 ? 0 : s + 1) : l <= 4 ? s : (s == 0 ? 2 : s - 1);
-                    const int he = L.he_edge[3 * t + k];
-                    int64_t w[TP_W_WORDS];
-                    line_sum(L, he >> 1, tp_edge_version(l == 0 ? 0 : 4 * s + m, k, he & 1), w);
+        const int generic = __shfl(ref, 0) == -2;
+        int deg = 1;
+        if (!generic) {
+            // fast path: lane 4 b + m - 1 sums the line of incident edge b displaced by move m, lane 32 + a the base line
+            // opposite the vertex in incident triangle a; then lane 4 a + m - 1 forms variant (t_a, 4 s_a + m)
+            if (ref >= 0) {
+                int64_t w[TP_W_WORDS];
+                line_sum(L, sweep, ref >> 4, ref & 15, w);
 #pragma unroll
-                    for (int q = 0; q < TP_W_WORDS; q++) S[a][l][q] = w[q];
-                }
+                for (int q = 0; q < TP_W_WORDS; q++) S[lane][q] = w[q];
             }
             __syncthreads();
             TP_STAMP(2, 1);
             int32_t e = 0;
-            {   // variants: lane (a, m - 1)
-                const int a = lane >> 2, m = (lane & 3) + 1;
-                if (a < UPD_CHUNK && base + a < deg) {
-                    const int h = L.vtx_adj[k0 + base + a], t = h / 3, s = h - 3 * t;
-                    const int i = 4 * s + m;
-                    const int4 tri = L.tris[t];
-                    const int vid[3] = {tri.x, tri.y, tri.z};
-                    int32_t X[3], Y[3], c[3];
-#pragma unroll
-                    for (int ss = 0; ss < 3; ss++) {
-                        const int2 q = L.vpos[(size_t)vid[ss] * 5 + (ss == s ? m : 0)];
-                        X[ss] = q.x; Y[ss] = q.y;
-                    }
-                    tp_variant_coeffs(X, Y, c);
-                    const int kn = s == 2 ? 0 : s + 1, kp = s == 0 ? 2 : s - 1;
-                    const int cs = s == 0 ? c[0] : s == 1 ? c[1] : c[2];
-                    const int cn = kn == 0 ? c[0] : kn == 1 ? c[1] : c[2];
-                    const int cp = kp == 0 ? c[0] : kp == 1 ? c[1] : c[2];
-                    int64_t mo[TP_W_WORDS];
-#pragma unroll
-                    for (int q = 0; q < TP_W_WORDS; q++)
-                        mo[q] = (int64_t)cs * S[a][m][q] + (int64_t)cp * S[a][4 + m][q] + (int64_t)cn * S[a][0][q];
-                    const tp_moments mm = {mo[0], mo[1], mo[2], mo[3], mo[4], mo[5]};
-                    e = emit_variant(L, flavour, t, i, mm, false);
-                }
+            if (comb >= 0) {
+                const int m = (lane & 3) + 1, a = lane >> 2;
+                e = variant(comb & 0xfffff, m, S[4 * ((comb >> 20) & 15) + m - 1], S[4 * ((comb >> 24) & 15) + m - 1], S[32 + a]);
             }
             // central differences: lanes 4a+0/1 hold E(+dx)/E(-dx), 4a+2/3 E(+dy)/E(-dy)
             const uint32_t d = (uint32_t)e - (uint32_t)__shfl_xor(e, 1);
             if ((lane & 3) == 0) gx += d;
             if ((lane & 3) == 2) gy += d;
+            deg = __any(comb >= 0) ? 1 : 0;
             TP_STAMP(2, 2);
-            __syncthreads();  // S is rewritten by the next chunk
+        } else {
+            // generic path (a vertex of more than eight triangles): seven incident triangles per pass, lane (a, l) sums
+            // line l of nine of triangle a, lane (a, m) forms its variant
+            const int k0 = L.vtx_off[v];
+            deg = L.vtx_off[v + 1] - k0;
+            for (int base = 0; base < deg; base += UPD_CHUNK) {
+                {
+                    const int a = lane / TP_NLINES, l = lane - a * TP_NLINES;
+                    if (a < UPD_CHUNK && base + a < deg) {
+                        const int r = vertex_line_ref(L, L.vtx_adj[k0 + base + a], l);
+                        int64_t w[TP_W_WORDS];
+                        line_sum(L, sweep, r >> 4, r & 15, w);
+#pragma unroll
+                        for (int q = 0; q < TP_W_WORDS; q++) S[lane][q] = w[q];
+                    }
+                }
+                __syncthreads();
+                int32_t e = 0;
+                {
+                    const int a = lane >> 2, m = (lane & 3) + 1;
+                    if (a < UPD_CHUNK && base + a < deg)
+                        e = variant(L.vtx_adj[k0 + base + a], m, S[9 * a + m], S[9 * a + 4 + m], S[9 * a]);
+                }
+                const uint32_t d = (uint32_t)e - (uint32_t)__shfl_xor(e, 1);
+                if ((lane & 3) == 0) gx += d;
+                if ((lane & 3) == 2) gy += d;
+                __syncthreads();  // S is rewritten by the next pass
+            }
         }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { gx += (uint32_t)__shfl_xor((int)gx, o); gy += (uint32_t)__shfl_xor((int)gy, o); }
-        if (lane == 0) {
+        if (lane == 0 && flags == 0) {
             if (deg > 0) L.gr[v] = make_int2((int)gx, (int)gy);  // vertices no triangle uses: the gradient is never touched
             if (v >= 4) {  // shift.cs:20 -- the four corners never move
                 const float R = L.vw.ratio;
@@ -788,7 +877,14 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
         }
     }
     TP_STAMP(2, 3);
-    if (L.margin_px < 2) return;  // no margin: every launch re-arms the lists
+    if (flags) return;  // (uniform) nothing was stepped; the host repairs and replays
+    if (tidg == 0) L.state->iters_done++;
+    if (L.margin_px < 2) {
+        // work lists are rebuilt every iteration: k_accumulate has consumed them, re-arm them here
+        for (int k = tidg; k < L.tiles_x * L.tiles_y; k += gridDim.x * UPD_THREADS) L.tilecount[k] = 0;
+        if (tidg == 0) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
+        return;
+    }
     need = __syncthreads_or(need);
     if (lane == 0) {
         const unsigned long long inc = 1ull + (need ? 1ull << 32 : 0ull);
