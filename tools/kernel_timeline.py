@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib_path = os.path.join(ROOT, "tpose_amd", "variants", "libtpose_hip_debug.so")
+lib_path = os.environ.get("TPOSE_TIMELINE_LIB") or os.path.join(ROOT, "tpose_amd", "variants", "libtpose_hip_debug.so")
 os.environ["TPOSE_HIP_LIB"] = lib_path  # before tpose_amd.capi is imported
 from tpose_amd import build as tb  # noqa: E402
 

@@ -82,6 +82,7 @@ struct tp_context {
     int visit_cap = 0;
     longlong2* line_xs = nullptr;  // per-iteration line table: nine whole-line walkers per edge
     int2* line_rows = nullptr;
+    int64_t* line_static = nullptr;
     int64_t* wline = nullptr;      // whole line sums, coarse meshes only (allocated on first use)
     uint32_t* segex[2] = {nullptr, nullptr};  // static per-image packed segment prefixes
     int64_t* t2[2] = {nullptr, nullptr};   // static per-image tables
@@ -156,11 +157,11 @@ void free_triangulation(tp_context* c) {
     hipFree(c->vref); hipFree(c->vvar); c->vref = nullptr; c->vvar = nullptr;
     hipFree(c->points); hipFree(c->points_binned); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
     hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->edge_visit); hipFree(c->visits);
-    hipFree(c->line_xs); hipFree(c->line_rows); hipFree(c->tilelist); hipFree(c->wline);
+    hipFree(c->line_xs); hipFree(c->line_rows); hipFree(c->line_static); hipFree(c->tilelist); hipFree(c->wline);
     hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
     c->points = nullptr; c->points_binned = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
     c->edge_uv = nullptr; c->he_edge = nullptr; c->vpos = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
-    c->line_xs = nullptr; c->line_rows = nullptr; c->tilelist = nullptr; c->capE = 0;
+    c->line_xs = nullptr; c->line_rows = nullptr; c->line_static = nullptr; c->tilelist = nullptr; c->capE = 0;
     c->wline = nullptr;
     c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
     c->capT = c->capP = 0;
@@ -181,7 +182,7 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.tilecount = c->tilecount; L.tilelist = c->tilelist; L.list_cap = c->list_cap;
     L.edge_uv = c->edge_uv; L.he_edge = c->he_edge; L.vpos = c->vpos; L.NE = c->NE;
     L.edge_visit = c->edge_visit; L.visits = c->visits; L.visit_cap = c->visit_cap;
-    L.line_xs = c->line_xs; L.line_rows = c->line_rows;
+    L.line_xs = c->line_xs; L.line_rows = c->line_rows; L.line_static = c->line_static;
     L.segex = c->segex[slot];
     L.wline = nullptr;
     if (tp_coarse_mesh(L)) L.wline = c->wline;  // hundreds of tiles per edge: k_linesum sums the records of a line once
@@ -535,14 +536,15 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
     }
     if (NE > c->capE) {
         hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->line_xs); hipFree(c->line_rows);
-        hipFree(c->wline);
-        c->wline = nullptr;
+        hipFree(c->wline); hipFree(c->line_static);
+        c->wline = nullptr; c->line_static = nullptr;
         c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr; c->line_xs = nullptr; c->line_rows = nullptr;
         const int capE = NE + NE / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->edge_uv, capE));
         HIP_TRY(c, dev_alloc(&c->edge_visit, capE));
         HIP_TRY(c, dev_alloc(&c->line_xs, (size_t)capE * TP_NLINES));
         HIP_TRY(c, dev_alloc(&c->line_rows, (size_t)capE * TP_NLINES));
+        HIP_TRY(c, dev_alloc(&c->line_static, (size_t)capE * TP_NLINES * TP_T2_WORDS));
         // (edge, tile) visits: typical edges cross a handful of tiles, a few long ones many
         size_t vcap = (size_t)capE * 24 + (size_t)ntiles * 8;
         if (vcap > ((size_t)1 << 24)) vcap = (size_t)1 << 24;

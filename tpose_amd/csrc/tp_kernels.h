@@ -53,6 +53,8 @@ struct tp_launch {
     // per-iteration line table: the nine lines of every edge, set up once (tp_setup_line)
     longlong2* line_xs;     // [NE][TP_NLINES] (x, s) 24.40 walker at row ra and its step
     int2* line_rows;        // [NE][TP_NLINES] (ra, rb) rows of the line inside the raster
+    int64_t* line_static;   // [NE][TP_NLINES][TP_T2_WORDS] static part of the line sums: everything left of the tile
+                            // column in each of the line's rows (differences of t2 per column run)
     // work lists
     int* tilecount;           // [tiles]
     int2* tilelist;           // [tiles * list_cap] (line = edge * 9 + version, record = visit * 9 + version): LIVE lines only

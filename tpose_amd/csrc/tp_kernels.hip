@@ -135,16 +135,19 @@ void tp_launch_static_table(uint8_t* img, int pitch, int W, int H, int Hp, int t
 
 // ------------------------------------------------------------------------------------------------
 // k_bin: sixteen edges per workgroup, a row of 16 lanes each.
-//   phase 0  lane q < 9 of a row owns line q of the edge: vertex stage, the whole-line walker (line table) and
-//            the static part of its sums
+//   phase 0  lane q < 9 of a row owns line q of the edge: vertex stage, the whole-line walker (line table), and per
+//            tile row of the line the range of tile columns it crosses there (exact; LDS)
 //   pass A   the tiles the band of the nine lines can touch, tile row by tile row (lane q takes tile rows
 //            ty0 + q, + 16, ...): counted, scanned -> consecutive visit ids per edge, then entered in an LDS table
-//   pass B   an exact liveness test per (visit, line), then ONE LANE PER VISIT: one returning atomic reserves list
-//            slots for the live lines (every visit's atomic is in flight at once), then the entries.
+//   pass B   ONE LANE PER VISIT: which of the nine lines are live there (nine range look-ups), one returning atomic
+//            reserves list slots for the live ones -- every visit's atomic is in flight at once -- then the entries
+//   static   the static part of every line's sums (everything left of the tile column, per run of rows inside one
+//            tile column a difference of the cumulative per-image table): its loads fly beside the atomics
 // ------------------------------------------------------------------------------------------------
 #define BIN_THREADS 256
 #define BIN_EDGES 16
 #define BIN_VISITS 1024  // visits per pass of the LDS table (more: further passes)
+#define BIN_TROWS 8      // tile rows per line with precomputed column ranges (longer lines: tested per visit)
 
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
     __shared__ int s_cnt[BIN_EDGES];     // visits per edge
@@ -153,17 +156,18 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
     __shared__ uint32_t s_base;
     __shared__ int64_t s_lx[BIN_EDGES][TP_NLINES][2];
     __shared__ int s_lr[BIN_EDGES][TP_NLINES][2];
+    __shared__ uint16_t s_rng[BIN_EDGES][TP_NLINES][BIN_TROWS];  // first | last << 8 tile column of the line in tile row ty_line0 + k
     __shared__ int s_vis[BIN_VISITS];    // (edge of the block << 27) | tile
-    __shared__ uint32_t s_mask[BIN_VISITS];  // live lines of the visit
     const int tid = threadIdx.x;
     const uint32_t rebin_word = L.state->rebin_req;  // consumed late: the loads below do not wait for it
     if (blockIdx.x == 0 && tid == 0) L.state->sweep++;  // records of this sweep carry its number (single writer)
     const int j = tid >> 4, q = tid & 15;
     const int e = blockIdx.x * BIN_EDGES + j;
     tp_band band = {0, 0, 0, 0, 0, 0};
+    tp_line ln; ln.x = 0; ln.s = 0; ln.ra = 1; ln.rb = 0;
+    const bool owner = e < L.NE && q < TP_NLINES;
     TP_STAMP(0, 0);
     {   // phase 0
-        tp_line ln; ln.x = 0; ln.s = 0; ln.ra = 1; ln.rb = 0;
         int dX = 0, dY = 0;
         if (e < L.NE) {
             const int2 uv = L.edge_uv[e];
@@ -192,101 +196,175 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
         band.dY = row_max16(dY) + 256 * L.margin_px;
     }
     TP_STAMP(0, 1);
-    if (rebin_word == 0) return;  // lists still valid (tp_set_margin); uniform
-    if (L.margin_px >= 2)  // only the margin vote of k_update reads it
-        for (int v = blockIdx.x * BIN_THREADS + tid; v < L.NP; v += gridDim.x * BIN_THREADS) L.points_binned[v] = L.points[v];
-
-    // ---- pass A: visits (tiles of the band), lane q takes the tile rows ty0 + q, + 16, ...
-    int ty0 = 0, ty1 = -1;
-    if (e < L.NE) {
-        int32_t r0, r1;
-        tp_band_rows(band, L.vw.H, r0, r1);
-        if (r0 <= r1) { ty0 = r0 / TH; ty1 = r1 / TH; }
-    }
-    int cnt = 0;
-    for (int ty = ty0 + q; ty <= ty1; ty += 16) {
-        int32_t tx0, tx1;
-        const int row0 = ty * TH;
-        if (tp_band_cols(band, row0, min(row0 + TH - 1, L.vw.H - 1), L.vw.W, TW, L.tiles_x, tx0, tx1)) cnt += tx1 - tx0 + 1;
-    }
-    const int inc = (int)row_scan16((uint32_t)cnt);
-    if (q == 15) s_cnt[j] = inc;
-    __syncthreads();  // (also publishes the lines of phase 0)
-    if (tid < 64) {  // wave 0: scan of the per-edge counts, visit ids for the block
-        const int v = tid < BIN_EDGES ? s_cnt[tid] : 0;
-        const int incl = (int)row_scan16((uint32_t)v);
-        if (tid < BIN_EDGES) s_first[tid] = incl - v;
-        if (tid == BIN_EDGES - 1) {
-            // visit ids: every block owns a slice of the lower half of the record buffer (no global
-            // atomic on the common path); a block with long edges draws from the shared upper half
-            const uint32_t half = (uint32_t)L.visit_cap / 2, slice = half / gridDim.x;
-            uint32_t base = blockIdx.x * slice;
-            if ((uint32_t)incl > slice) {
-                base = half + atomicAdd(&L.state->visit_total, (uint32_t)incl);
-                if (base + (uint32_t)incl > (uint32_t)L.visit_cap) atomicOr(&L.state->flags, TP_FLAG_VISIT_OVERFLOW);
+    // Static part of the line sums, first half: the runs of rows inside one tile column (almost always one or two)
+    // and the loads of the cumulative per-image table for them.  Called once per thread, right after the thread's
+    // list atomic was issued: the arithmetic and the loads run beside it.
+    int64_t st[TP_T2_WORDS] = {0, 0, 0, 0, 0};
+    int64_t sa[2][TP_T2_WORDS], sb[2][TP_T2_WORDS];
+    int nruns = 0;
+    bool static_done = false;
+    auto static_first_half = [&]() {
+    if (owner) {
+        const int64_t* t2 = L.t2;
+        const int tx1 = L.tiles_x + 1;
+        int rtc[2] = {0, 0}, rra[2] = {0, 0}, rrb[2] = {0, 0};
+        tp_line_column_runs(ln, L.vw.W, TW, L.tiles_x, [&](int32_t tc, int32_t ra, int32_t rb) {
+            if (tc == 0) return;  // nothing is left of the first tile column
+            if (nruns == 0) { rtc[0] = tc; rra[0] = ra; rrb[0] = rb; }
+            else if (nruns == 1) { rtc[1] = tc; rra[1] = ra; rrb[1] = rb; }
+            else {  // a third run and beyond (long or nearly horizontal lines): summed on the spot
+                const int64_t* a = t2 + ((size_t)ra * tx1 + tc) * TP_T2_WORDS;
+                const int64_t* b = t2 + ((size_t)(rb + 1) * tx1 + tc) * TP_T2_WORDS;
+#pragma unroll
+                for (int k = 0; k < TP_T2_WORDS; k++) st[k] += b[k] - a[k];
             }
-            s_base = base;
-            s_total = incl;
-        }
+            nruns++;
+        });
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            if (r < nruns) {
+                const int64_t* a = t2 + ((size_t)rra[r] * tx1 + rtc[r]) * TP_T2_WORDS;
+                const int64_t* b = t2 + ((size_t)(rrb[r] + 1) * tx1 + rtc[r]) * TP_T2_WORDS;
+#pragma unroll
+                for (int k = 0; k < TP_T2_WORDS; k++) { sa[r][k] = a[k]; sb[r][k] = b[k]; }
+            }
     }
-    __syncthreads();
-    TP_STAMP(0, 2);
-    const int total = s_total;
-    const uint32_t base = s_base;
-    const bool fits = (long long)base + total <= (long long)L.visit_cap;  // overflow is flagged; everyone stays in bounds
-    if (q == 15 && e < L.NE) L.edge_visit[e] = make_int2(fits ? (int)base + s_first[j] : 0, fits ? inc : 0);
-    if (!fits) return;  // uniform
+    };
+    if (rebin_word != 0) {  // (uniform) lists still valid otherwise (tp_set_margin)
+        if (L.margin_px >= 2)  // only the margin vote of k_update reads it
+            for (int v = blockIdx.x * BIN_THREADS + tid; v < L.NP; v += gridDim.x * BIN_THREADS) L.points_binned[v] = L.points[v];
+        // the line's tile-column range in each of its first BIN_TROWS tile rows: the crossing column is monotone in the
+        // row, so the two end rows of the overlap bound it (exactly the test of tp_line_live)
+        if (owner && ln.ra <= ln.rb) {
+            const int t0 = ln.ra / TH;
+            for (int k = 0; k < BIN_TROWS && (t0 + k) * TH <= ln.rb; k++) {
+                const int rlo = max(ln.ra, (t0 + k) * TH), rhi = min(ln.rb, (t0 + k) * TH + TH - 1);
+                const int ca = min(tp_line_col(ln, rlo, L.vw.W) / TW, L.tiles_x - 1), cb = min(tp_line_col(ln, rhi, L.vw.W) / TW, L.tiles_x - 1);
+                s_rng[j][q][k] = (uint16_t)(min(ca, cb) | (max(ca, cb) << 8));
+            }
+        }
 
-    for (int v0 = 0; v0 < total; v0 += BIN_VISITS) {
-        // the visits [v0, v0 + BIN_VISITS) of the block -> LDS table, in the order they were counted
-        int k = s_first[j] + (inc - cnt) - v0;
+        // ---- pass A: visits (tiles of the band), lane q takes the tile rows ty0 + q, + 16, ...
+        int ty0 = 0, ty1 = -1;
+        if (e < L.NE) {
+            int32_t r0, r1;
+            tp_band_rows(band, L.vw.H, r0, r1);
+            if (r0 <= r1) { ty0 = r0 / TH; ty1 = r1 / TH; }
+        }
+        int cnt = 0;
         for (int ty = ty0 + q; ty <= ty1; ty += 16) {
             int32_t tx0, tx1;
             const int row0 = ty * TH;
-            if (!tp_band_cols(band, row0, min(row0 + TH - 1, L.vw.H - 1), L.vw.W, TW, L.tiles_x, tx0, tx1)) continue;
-            for (int tx = tx0; tx <= tx1; tx++, k++)
-                if (k >= 0 && k < BIN_VISITS) s_vis[k] = (j << 27) | (ty * L.tiles_x + tx);
+            if (tp_band_cols(band, row0, min(row0 + TH - 1, L.vw.H - 1), L.vw.W, TW, L.tiles_x, tx0, tx1)) cnt += tx1 - tx0 + 1;
+        }
+        const int inc = (int)row_scan16((uint32_t)cnt);
+        if (q == 15) s_cnt[j] = inc;
+        __syncthreads();  // (also publishes the lines and ranges of phase 0)
+        if (tid < 64) {  // wave 0: scan of the per-edge counts, visit ids for the block
+            const int v = tid < BIN_EDGES ? s_cnt[tid] : 0;
+            const int incl = (int)row_scan16((uint32_t)v);
+            if (tid < BIN_EDGES) s_first[tid] = incl - v;
+            if (tid == BIN_EDGES - 1) {
+                // visit ids: every block owns a slice of the lower half of the record buffer (no global
+                // atomic on the common path); a block with long edges draws from the shared upper half
+                const uint32_t half = (uint32_t)L.visit_cap / 2, slice = half / gridDim.x;
+                uint32_t base = blockIdx.x * slice;
+                if ((uint32_t)incl > slice) {
+                    base = half + atomicAdd(&L.state->visit_total, (uint32_t)incl);
+                    if (base + (uint32_t)incl > (uint32_t)L.visit_cap) atomicOr(&L.state->flags, TP_FLAG_VISIT_OVERFLOW);
+                }
+                s_base = base;
+                s_total = incl;
+            }
         }
         __syncthreads();
-        TP_STAMP(0, 3);
-        // ---- pass B1: lane (visit, line) -> exact liveness, one bit per line OR-ed into the visit's mask in LDS
-        const int nv = min(total - v0, BIN_VISITS);
-        for (int t = tid; t < nv; t += BIN_THREADS) s_mask[t] = 0;
-        __syncthreads();
-        if (L.margin_px < 2) {
-            for (int u = tid; u < nv * 16; u += BIN_THREADS) {
-                const int t = u >> 4, l = u & 15;
-                if (l >= TP_NLINES) continue;
-                const int w = s_vis[t], jj = w >> 27, tile = w & 0x7ffffff;
-                const int ty = tile / L.tiles_x, tx = tile - ty * L.tiles_x;
-                const int row0 = ty * TH, row1 = min(row0 + TH - 1, L.vw.H - 1);
-                const int col0 = tx * TW;
-                const int lim = tx == L.tiles_x - 1 ? L.vw.W - col0 + 1 : TW;
-                tp_line ln; ln.x = s_lx[jj][l][0]; ln.s = s_lx[jj][l][1]; ln.ra = s_lr[jj][l][0]; ln.rb = s_lr[jj][l][1];
-                if (tp_line_live(ln, row0, row1, col0, lim, L.vw.W)) atomicOr(&s_mask[t], 1u << l);
+        TP_STAMP(0, 2);
+        const int total = s_total;
+        const uint32_t base = s_base;
+        const bool fits = (long long)base + total <= (long long)L.visit_cap;  // overflow is flagged; everyone stays in bounds
+        if (q == 15 && e < L.NE) L.edge_visit[e] = make_int2(fits ? (int)base + s_first[j] : 0, fits ? inc : 0);
+
+        for (int v0 = 0; fits && v0 < total; v0 += BIN_VISITS) {
+            // the visits [v0, v0 + BIN_VISITS) of the block -> LDS table, in the order they were counted
+            int k = s_first[j] + (inc - cnt) - v0;
+            for (int ty = ty0 + q; ty <= ty1; ty += 16) {
+                int32_t tx0, tx1;
+                const int row0 = ty * TH;
+                if (!tp_band_cols(band, row0, min(row0 + TH - 1, L.vw.H - 1), L.vw.W, TW, L.tiles_x, tx0, tx1)) continue;
+                for (int tx = tx0; tx <= tx1; tx++, k++)
+                    if (k >= 0 && k < BIN_VISITS) s_vis[k] = (j << 27) | (ty * L.tiles_x + tx);
             }
             __syncthreads();
-        }
-        // ---- pass B2: a lane per visit: every visit's returning atomic is in flight at once
-        for (int t = tid; t < nv; t += BIN_THREADS) {
-            const int w = s_vis[t], jj = w >> 27, tile = w & 0x7ffffff;
-            const int visit = (int)base + v0 + t;
-            // lists kept across iterations (tp_set_margin) must hold every line of the band: a line can become
-            // live in a tile, or non-empty at all, while the vertices move inside the margin
-            const uint32_t mask = L.margin_px >= 2 ? (1u << TP_NLINES) - 1u : s_mask[t];
-            if (mask == 0) continue;
-            const int ee = blockIdx.x * BIN_EDGES + jj;
-            int pos = atomicAdd(&L.tilecount[tile], (int)__builtin_popcount(mask));
-            int2* dst = L.tilelist + (size_t)tile * L.list_cap;
+            TP_STAMP(0, 3);
+            // ---- pass B: a lane per visit
+            const int nv = min(total - v0, BIN_VISITS);
+            for (int t = tid; t < nv || (t == tid && !static_done); t += BIN_THREADS) {
+                uint32_t mask = 0;
+                int tile = 0, jj = 0, visit = 0, pos = 0;
+                if (t < nv) {
+                    const int w = s_vis[t];
+                    jj = w >> 27; tile = w & 0x7ffffff;
+                    visit = (int)base + v0 + t;
+                    const int ty = tile / L.tiles_x, tx = tile - ty * L.tiles_x;
+                    if (L.margin_px >= 2) {
+                        // lists kept across iterations (tp_set_margin) must hold every line of the band: a line can become
+                        // live in a tile, or non-empty at all, while the vertices move inside the margin
+                        mask = (1u << TP_NLINES) - 1u;
+                    } else {
 #pragma unroll
-            for (int l = 0; l < TP_NLINES; l++)
-                if ((mask >> l) & 1u) {
-                    if (pos < L.list_cap) dst[pos] = make_int2(ee * TP_NLINES + l, visit * TP_NLINES + l);
-                    else atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
-                    pos++;
+                        for (int l = 0; l < TP_NLINES; l++) {
+                            const int ra = s_lr[jj][l][0], rb = s_lr[jj][l][1];
+                            const int k = ty - ra / TH;  // which of the line's tile rows
+                            bool live = ra <= rb && k >= 0 && ty * TH <= rb;
+                            if (live) {
+                                if (k < BIN_TROWS) {
+                                    const uint32_t r = s_rng[jj][l][k];
+                                    live = tx >= (int)(r & 0xffu) && tx <= (int)(r >> 8);
+                                } else {  // a long line (coarse mesh): tested here
+                                    tp_line ll; ll.x = s_lx[jj][l][0]; ll.s = s_lx[jj][l][1]; ll.ra = ra; ll.rb = rb;
+                                    const int col0 = tx * TW;
+                                    live = tp_line_live(ll, ty * TH, min(ty * TH + TH - 1, L.vw.H - 1), col0,
+                                                        tx == L.tiles_x - 1 ? L.vw.W - col0 + 1 : TW, L.vw.W);
+                                }
+                            }
+                            mask |= live ? 1u << l : 0u;
+                        }
+                    }
+#if defined(TPOSE_ABLATE) && (TPOSE_ABLATE & 256)  // timing experiment: no returning atomic
+                    pos = (visit & 15) * 9;
+#else
+                    if (mask) pos = atomicAdd(&L.tilecount[tile], (int)__builtin_popcount(mask));
+#endif
                 }
+                if (!static_done) { static_first_half(); static_done = true; }  // VALU + loads beside the atomic in flight
+                if (mask == 0) continue;
+                const int ee = blockIdx.x * BIN_EDGES + jj;
+                int2* dst = L.tilelist + (size_t)tile * L.list_cap;
+#if defined(TPOSE_ABLATE) && (TPOSE_ABLATE & 512)  // timing experiment: no entries
+                if (pos == 0x7fffffff)
+#endif
+#pragma unroll
+                for (int l = 0; l < TP_NLINES; l++)
+                    if ((mask >> l) & 1u) {
+                        if (pos < L.list_cap) dst[pos] = make_int2(ee * TP_NLINES + l, visit * TP_NLINES + l);
+                        else atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
+                        pos++;
+                    }
+            }
+            if (v0 + BIN_VISITS < total) __syncthreads();  // the table is rewritten by the next pass
         }
-        __syncthreads();  // the table is rewritten by the next pass
+    }
+    // ---- static part of the line sums, second half
+    if (!static_done) static_first_half();
+    if (owner) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            if (r < nruns)
+#pragma unroll
+                for (int k = 0; k < TP_T2_WORDS; k++) st[k] += sb[r][k] - sa[r][k];
+        const size_t li = (size_t)e * TP_NLINES + q;
+#pragma unroll
+        for (int k = 0; k < TP_T2_WORDS; k++) L.line_static[li * TP_T2_WORDS + k] = st[k];
     }
     TP_STAMP(0, 4);
 }
@@ -506,25 +584,6 @@ __device__ __forceinline__ void sum_records(const tp_launch& L, uint32_t sweep, 
     }
 }
 
-// static part of a line's sums: per run of rows inside one tile column, everything left of that column = a
-// difference of the cumulative per-image table (the walk only produces tile-local sums)
-__device__ __forceinline__ void line_static_part(const tp_launch& L, size_t line, int64_t st[TP_T2_WORDS]) {
-    const longlong2 xs = L.line_xs[line];
-    const int2 rows = L.line_rows[line];
-    tp_line ln; ln.x = xs.x; ln.s = xs.y; ln.ra = rows.x; ln.rb = rows.y;
-#pragma unroll
-    for (int k = 0; k < TP_T2_WORDS; k++) st[k] = 0;
-    const int64_t* t2 = L.t2;
-    const int tx1 = L.tiles_x + 1;
-    tp_line_column_runs(ln, L.vw.W, TW, L.tiles_x, [&](int32_t tc, int32_t ra, int32_t rb) {
-        if (tc == 0) return;  // nothing is left of the first tile column
-        const int64_t* a = t2 + ((size_t)ra * tx1 + tc) * TP_T2_WORDS;
-        const int64_t* b = t2 + ((size_t)(rb + 1) * tx1 + tc) * TP_T2_WORDS;
-#pragma unroll
-        for (int k = 0; k < TP_T2_WORDS; k++) st[k] += b[k] - a[k];
-    });
-}
-
 __device__ __forceinline__ void line_sum(const tp_launch& L, uint32_t sweep, int e, int ver, int64_t w[TP_W_WORDS]) {
     const size_t line = (size_t)e * TP_NLINES + ver;
     if (L.wline) {  // coarse meshes: summed by k_linesum
@@ -533,10 +592,11 @@ __device__ __forceinline__ void line_sum(const tp_launch& L, uint32_t sweep, int
         return;
     }
     const int2 ev = L.edge_visit[e];  // first visit, number of visits
+    int64_t st[TP_T2_WORDS];
+#pragma unroll
+    for (int q = 0; q < TP_T2_WORDS; q++) st[q] = L.line_static[line * TP_T2_WORDS + q];
     uint64_t a[TP_W_WORDS] = {0, 0, 0, 0, 0, 0};
     sum_records(L, sweep, ev.x, ev.y, ver, 0, 1, a);
-    int64_t st[TP_T2_WORDS];
-    line_static_part(L, line, st);
     w[0] = (int64_t)a[0];
 #pragma unroll
     for (int q = 1; q < TP_W_WORDS; q++) w[q] = (int64_t)a[q] + st[q - 1];
@@ -556,12 +616,10 @@ __global__ __launch_bounds__(64) void k_linesum(tp_launch L) {
             const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)a[q], o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(a[q] >> 32), o);
             a[q] += ((uint64_t)hi << 32) | lo;
         }
-    if (lane == 0) {
-        int64_t st[TP_T2_WORDS];
-        line_static_part(L, (size_t)line, st);
-        L.wline[(size_t)line * TP_W_WORDS] = (int64_t)a[0];
-#pragma unroll
-        for (int q = 1; q < TP_W_WORDS; q++) L.wline[(size_t)line * TP_W_WORDS + q] = (int64_t)a[q] + st[q - 1];
+    if (lane < TP_W_WORDS) {
+        uint64_t v = lane == 0 ? a[0] : lane == 1 ? a[1] : lane == 2 ? a[2] : lane == 3 ? a[3] : lane == 4 ? a[4] : a[5];
+        if (lane > 0) v += (uint64_t)L.line_static[(size_t)line * TP_T2_WORDS + lane - 1];
+        L.wline[(size_t)line * TP_W_WORDS + lane] = (int64_t)v;
     }
 }
 bool tp_coarse_mesh(const tp_launch& L) { return (long long)L.tiles_x * L.tiles_y > 4LL * L.NE; }
