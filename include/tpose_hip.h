@@ -89,9 +89,9 @@ int tp_get_ratio(const tp_context* ctx, float* ratio);
  * dp <= 0 restores the reference law.  tp_iterate takes its dp from tp_params instead. */
 int tp_set_dp(tp_context* ctx, float dp);
 
-/* tuning: the fused iteration keeps its per-tile work lists while no vertex has moved more than
- * margin_px - 1 pixels since they were built (lists are built over bounding boxes inflated by
- * margin_px); 0 or 1 rebuilds them every iteration.  Results are identical for every margin. */
+/* Kept for ABI compatibility (round 1 could keep its per-tile work lists while no vertex had moved more than
+ * margin_px - 1 pixels).  Since round 2 a list entry embeds its line's walker, so the lists are rebuilt every
+ * iteration and the value (0..1024) has no effect.  Results never depended on it. */
 int tp_set_margin(tp_context* ctx, int margin_px);
 
 /* `Texture tex(IMG)` (software/triangulate/main.cpp:74, warp/main.cpp:118-119): RGBA8, row 0 = top,

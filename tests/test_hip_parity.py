@@ -195,8 +195,8 @@ def test_device_whole_line_walker_is_exact():
 
 @pytest.mark.parametrize("margin", [0, 2, 6, 40])
 def test_work_list_reuse_never_changes_results(margin):
-    """The fused iteration reuses its per-tile work lists while vertices stay inside a margin; any
-    margin must give the oracle's bits.  A high step rate makes vertices travel many pixels."""
+    """tp_set_margin is a tuning hint (round 1 kept work lists while vertices stayed inside a margin; round 2 rebuilds
+    them every iteration): any value must give the oracle's bits.  A high step rate makes vertices travel many pixels."""
     W, H, grid = 300, 200, (15, 5)
     img, imgB, pts, tris, ratio, colors = case(W, H, grid)
     ctx = capi.Context(0, W, H)
@@ -212,10 +212,7 @@ def test_work_list_reuse_never_changes_results(margin):
     moved = np.abs(ref["points"] - pts).max() * H / 2
     rebuilds = ctx.info(6)
     assert moved > 3.0, moved                      # the test really moves vertices
-    if margin < 2:
-        assert rebuilds >= 39                      # margin off: rebuilt every iteration
-    elif margin == 40:
-        assert rebuilds == 0
+    assert rebuilds >= 39                          # rebuilt every iteration
     ctx.close()
 
 

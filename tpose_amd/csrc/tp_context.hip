@@ -58,8 +58,7 @@ struct tp_context {
     // triangulation
     int NT = 0, NP = 0, capT = 0, capP = 0;
     float2* points = nullptr;
-    float2* points_binned = nullptr;
-    int margin_px = 0;  // 0: rebuild the work lists every iteration (tp_set_margin)
+    int margin_px = 0;  // tp_set_margin: accepted, no effect since round 2 (lists are rebuilt every iteration)
     float lists_dp = -1.0f, lists_ratio = -1.0f;  // geometry parameters the current work lists were built for
     int4* tris = nullptr;
     int4* colors = nullptr;
@@ -70,7 +69,7 @@ struct tp_context {
     // work lists
     int tiles_x = 0, tiles_y = 0;
     int* tilecount = nullptr;
-    int2* tilelist = nullptr;
+    int4* tilelist = nullptr;     // 2 x int4 per entry
     size_t tilelist_elems = 0;
     int list_cap = 0;
     int NE = 0, capE = 0;
@@ -80,11 +79,8 @@ struct tp_context {
     int2* edge_visit = nullptr;
     uint32_t* visits = nullptr;
     int visit_cap = 0;
-    longlong2* line_xs = nullptr;  // per-iteration line table: nine whole-line walkers per edge
-    int2* line_rows = nullptr;
     int64_t* line_static = nullptr;
     int64_t* wline = nullptr;      // whole line sums, coarse meshes only (allocated on first use)
-    uint32_t* segex[2] = {nullptr, nullptr};  // static per-image packed segment prefixes
     int64_t* t2[2] = {nullptr, nullptr};   // static per-image tables
     uint32_t* seg_scratch = nullptr;
     tp_device_state* state = nullptr;
@@ -155,13 +151,13 @@ void drop_graphs(tp_context* c) {
 
 void free_triangulation(tp_context* c) {
     hipFree(c->vref); hipFree(c->vvar); c->vref = nullptr; c->vvar = nullptr;
-    hipFree(c->points); hipFree(c->points_binned); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
+    hipFree(c->points); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
     hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->edge_visit); hipFree(c->visits);
-    hipFree(c->line_xs); hipFree(c->line_rows); hipFree(c->line_static); hipFree(c->tilelist); hipFree(c->wline);
+    hipFree(c->line_static); hipFree(c->tilelist); hipFree(c->wline);
     hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
-    c->points = nullptr; c->points_binned = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
+    c->points = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
     c->edge_uv = nullptr; c->he_edge = nullptr; c->vpos = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
-    c->line_xs = nullptr; c->line_rows = nullptr; c->line_static = nullptr; c->tilelist = nullptr; c->capE = 0;
+    c->line_static = nullptr; c->tilelist = nullptr; c->capE = 0;
     c->wline = nullptr;
     c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
     c->capT = c->capP = 0;
@@ -175,15 +171,14 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.vw.halfW = 0.5f * (float)c->W; L.vw.halfH = 0.5f * (float)c->H;
     L.vw.W = c->W; L.vw.H = c->H;
     L.tiles_x = c->tiles_x; L.tiles_y = c->tiles_y;
-    L.points = c->points; L.points_binned = c->points_binned; L.margin_px = c->margin_px;
+    L.points = c->points;
     L.tris = c->tris; L.colors = c->colors;
     L.NT = c->NT; L.NP = c->NP;
     L.vtx_off = c->vtx_off; L.vtx_adj = c->vtx_adj; L.vref = c->vref; L.vvar = c->vvar;
     L.tilecount = c->tilecount; L.tilelist = c->tilelist; L.list_cap = c->list_cap;
     L.edge_uv = c->edge_uv; L.he_edge = c->he_edge; L.vpos = c->vpos; L.NE = c->NE;
     L.edge_visit = c->edge_visit; L.visits = c->visits; L.visit_cap = c->visit_cap;
-    L.line_xs = c->line_xs; L.line_rows = c->line_rows; L.line_static = c->line_static;
-    L.segex = c->segex[slot];
+    L.line_static = c->line_static;
     L.wline = nullptr;
     if (tp_coarse_mesh(L)) L.wline = c->wline;  // hundreds of tiles per edge: k_linesum sums the records of a line once
     L.t2 = c->t2[slot];
@@ -268,8 +263,8 @@ bool grow_lists(tp_context* c, uint32_t flags, hipError_t* err) {
         if (c->list_cap < c->capE * TP_NLINES) {  // a tile never holds more than one entry per line
             size_t cap = (size_t)c->list_cap * 2;
             if (cap > (size_t)c->capE * TP_NLINES) cap = (size_t)c->capE * TP_NLINES;
-            int2* fresh = nullptr;
-            if ((*err = dev_alloc(&fresh, cap * ntiles)) == hipSuccess) {
+            int4* fresh = nullptr;
+            if ((*err = dev_alloc(&fresh, 2 * cap * ntiles)) == hipSuccess) {
                 hipFree(c->tilelist);
                 c->tilelist = fresh;
                 c->tilelist_elems = cap * ntiles;
@@ -381,7 +376,7 @@ int tp_destroy(tp_context* c) {
     drop_graphs(c);
     free_triangulation(c);
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->tilecount); hipFree(c->state);
-    hipFree(c->t2[0]); hipFree(c->t2[1]); hipFree(c->seg_scratch); hipFree(c->segex[0]); hipFree(c->segex[1]);
+    hipFree(c->t2[0]); hipFree(c->t2[1]); hipFree(c->seg_scratch);
     hipFree(c->render_pic); hipFree(c->render_pts);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->up_pinned) hipHostFree(c->up_pinned);
@@ -412,7 +407,7 @@ int tp_set_margin(tp_context* c, int margin_px) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     if (margin_px < 0 || margin_px > 1024) return fail(c, TP_ERR_INVALID, "margin %d outside 0..1024", margin_px);
-    if (margin_px != c->margin_px) { c->margin_px = margin_px; c->lists_dp = -1.0f; c->generation++; }
+    c->margin_px = margin_px;
     return TP_OK;
 }
 
@@ -437,9 +432,8 @@ static int set_image_common(tp_context* c, int slot, const void* src, size_t str
     // static table of this image: moments of everything above a row and left of a tile column
     if (!c->t2[slot]) HIP_TRY(c, dev_alloc(&c->t2[slot], (size_t)(c->H + 1) * (c->tiles_x + 1) * TP_T2_WORDS));
     if (!c->seg_scratch) HIP_TRY(c, dev_alloc(&c->seg_scratch, (size_t)c->H * c->tiles_x * 5));
-    if (!c->segex[slot]) HIP_TRY(c, dev_alloc(&c->segex[slot], (size_t)c->Hp * c->tiles_x * TP_SEG_ENTRIES * 3));
     // (the alpha bytes of the context's copy are replaced by the pixel parity: the sweep, like the reference, never reads alpha)
-    tp_launch_static_table(c->img[slot], c->Wp * 4, c->W, c->H, c->Hp, c->tiles_x, c->seg_scratch, c->t2[slot], c->segex[slot], c->stream);
+    tp_launch_static_table(c->img[slot], c->Wp * 4, c->W, c->H, c->Hp, c->tiles_x, c->seg_scratch, c->t2[slot], c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_img[slot] = true;
@@ -476,7 +470,6 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         free_triangulation(c);
         const int capT = NT + NT / 2 + 64, capP = NP + NP / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->points, capP));
-        HIP_TRY(c, dev_alloc(&c->points_binned, capP));
         HIP_TRY(c, dev_alloc(&c->gr, capP));
         HIP_TRY(c, dev_alloc(&c->gacc, (size_t)2 * capP));
         HIP_TRY(c, dev_alloc(&c->vtx_off, capP + 1));
@@ -535,15 +528,13 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         }
     }
     if (NE > c->capE) {
-        hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->line_xs); hipFree(c->line_rows);
+        hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits);
         hipFree(c->wline); hipFree(c->line_static);
         c->wline = nullptr; c->line_static = nullptr;
-        c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr; c->line_xs = nullptr; c->line_rows = nullptr;
+        c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
         const int capE = NE + NE / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->edge_uv, capE));
         HIP_TRY(c, dev_alloc(&c->edge_visit, capE));
-        HIP_TRY(c, dev_alloc(&c->line_xs, (size_t)capE * TP_NLINES));
-        HIP_TRY(c, dev_alloc(&c->line_rows, (size_t)capE * TP_NLINES));
         HIP_TRY(c, dev_alloc(&c->line_static, (size_t)capE * TP_NLINES * TP_T2_WORDS));
         // (edge, tile) visits: typical edges cross a handful of tiles, a few long ones many
         size_t vcap = (size_t)capE * 24 + (size_t)ntiles * 8;
@@ -566,7 +557,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         if (cap > (size_t)c->capE * TP_NLINES) cap = (size_t)c->capE * TP_NLINES;
         if (cap * ntiles > c->tilelist_elems) {
             hipFree(c->tilelist); c->tilelist = nullptr;
-            HIP_TRY(c, dev_alloc(&c->tilelist, cap * ntiles));
+            HIP_TRY(c, dev_alloc(&c->tilelist, 2 * cap * ntiles));
             c->tilelist_elems = cap * ntiles;
         }
         c->list_cap = (int)(c->tilelist_elems / ntiles);

@@ -11,7 +11,6 @@
 #define TP_REC_DWORDS 8    /* per-tile record of a line, 32 bytes: u32 sum x (absolute columns), then the TILE-LOCAL sums
                               n_odd, r, g, b, q + n_odd over its counted rows (<= 16 rows x 128 columns: < 2^29), the
                               number of the sweep that wrote it (a record is valid for that sweep only), 0 */
-#define TP_SEG_ENTRIES 17  /* static packed prefixes per (row, tile column): at the start of each 8-pixel segment + the row total */
 #define TP_T2_WORDS 5      /* int64 per static-table entry: n_odd, sum r, sum g, sum b, q */
 
 // device-side flag bits (tp_device_state::flags)
@@ -21,11 +20,11 @@
 struct tp_device_state {
     uint32_t visit_total;  // (edge, tile) visits drawn from the shared half of the record buffer
     uint32_t flags;        // sticky overflow flags
-    uint32_t rebin_req;    // 1: k_bin must rebuild the work lists (upload, or a vertex left its margin)
+    uint32_t rebin_req;    // 1: k_bin must rebuild the work lists (always, except for profiling replays of one sweep)
     uint32_t rebin_count;  // statistics: rebuilds so far
     uint32_t iters_done;   // fused iterations k_update completed (it does not step while a flag is up)
     uint32_t sweep;        // number of the current sweep: k_bin counts, k_accumulate stamps its records, readers compare
-    unsigned long long arrive;  // k_update: blocks arrived | (blocks voting for a rebuild) << 32
+    unsigned long long pad;
 };
 
 struct tp_launch {
@@ -33,13 +32,10 @@ struct tp_launch {
     const uint8_t* img;  // padded RGBA8 plane; the alpha byte holds (r + g + b) & 1 (tp_set_image rewrites it)
     int pitch;           // bytes per padded row
     const int64_t* t2;   // static table of the swept image: [H+1][tiles_x+1][TP_T2_WORDS]
-    const uint32_t* segex;  // static: [Hp][tiles_x][TP_SEG_ENTRIES][3] packed tile-local prefix at every 8th column
     tp_view vw;
     int tiles_x, tiles_y;
     // triangulation
     float2* points;
-    float2* points_binned;  // vertex positions when the work lists were last built
-    int margin_px;          // work lists stay valid while no vertex moved more than margin_px - 1 pixels
     const int4* tris;
     const int4* colors;     // stored colours ivec4[NT] (warp) -- may be null
     int NT, NP, NE;
@@ -50,14 +46,12 @@ struct tp_launch {
     const int* vref;        // [NP][64] per upload: the line (edge << 4 | version) each lane of k_update sums, -1 none; see k_vertex_refs
     const int* vvar;        // [NP][8]  per upload: per incident triangle 3t + s | out-edge slot << 20 | in-edge slot << 24, -1 none
     int2* vpos;             // [NP][5] snapped 24.8 position of every vertex: unmoved, +dx, -dx, +dy, -dy
-    // per-iteration line table: the nine lines of every edge, set up once (tp_setup_line)
-    longlong2* line_xs;     // [NE][TP_NLINES] (x, s) 24.40 walker at row ra and its step
-    int2* line_rows;        // [NE][TP_NLINES] (ra, rb) rows of the line inside the raster
     int64_t* line_static;   // [NE][TP_NLINES][TP_T2_WORDS] static part of the line sums: everything left of the tile
                             // column in each of the line's rows (differences of t2 per column run)
     // work lists
     int* tilecount;           // [tiles]
-    int2* tilelist;           // [tiles * list_cap] (line = edge * 9 + version, record = visit * 9 + version): LIVE lines only
+    int4* tilelist;           // [tiles * list_cap][2] 32-byte entries, LIVE lines only: the line's 24.40 walker (x at row ra, step
+                              // per row), its rows (ra, rb) inside the raster, its record = visit * 9 + version, 0
     int list_cap;
     int2* edge_visit;         // [NE] (first visit, #visits = tiles the band of the edge's lines can touch)
     uint32_t* visits;         // [visit_cap][TP_NLINES][TP_REC_DWORDS] per-tile line records; only live lines are written,
@@ -88,9 +82,9 @@ void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s
 void tp_launch_vertex_refs(const tp_launch& L, int* vref, int* vvar, hipStream_t s);  // once per upload
 void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s);
 // static per-image table: t2[r][tc] = moments of all pixels in rows < r and columns < tc * TP_TILE_W
-// also rewrites the alpha bytes of the padded plane and fills the packed segment prefixes `segex`
+// also rewrites the alpha bytes of the padded plane (pixel parity)
 void tp_launch_static_table(uint8_t* img, int pitch, int W, int H, int Hp, int tiles_x, uint32_t* seg_scratch,
-                            int64_t* t2, uint32_t* segex, hipStream_t s);
+                            int64_t* t2, hipStream_t s);
 size_t tp_accumulate_lds_bytes();
 hipError_t tp_kernels_init();  // per-device function attributes
 void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s);

@@ -14,9 +14,8 @@
 //                 work lists of the LIVE (line, record) pairs
 //   k_accumulate  THE hot kernel: one 256-thread workgroup per 128x16-pixel tile (six resident per CU, the
 //                 dispatcher balances the rest); the tile's RGBA8 pixels are read once (32 B per lane), turned
-//                 into per-row prefix sums of the pixel moments in LDS (12-byte packed entries; running sums seeded
-//                 from a static per-image table, so no scan), and every live (line, tile) pair is walked by one to
-//                 four lanes: per row one exact crossing column from the line's walker and ONE LDS entry.  No
+//                 into per-row prefix sums of the pixel moments in LDS (12-byte packed entries; DPP row scan), and
+//                 every live (line, tile) pair is walked by one to four lanes: per row one exact crossing column from the line's walker and ONE LDS entry.  No
 //                 atomics, no per-fragment work.
 //   k_update      per variant: signed sum of its three lines (static part + tile records) -> exact moments ->
 //                 `colnum`, `colacc`, `tenergy` (reference layout); central differences; per-vertex arrival
@@ -73,23 +72,6 @@ __global__ void k_static_alpha(uint8_t* img, int pitch, int Wp, int Hp) {
     *p = w | ((((w & 0xffu) + ((w >> 8) & 0xffu) + (w >> 16)) & 1u) << 24);
 }
 
-// packed tile-local prefix (the LDS entry format of k_accumulate) at the start of every 8-pixel segment of
-// every (row, tile column), and the row total: the sweep seeds its running sums with them
-__global__ void k_static_segex(const uint8_t* img, int pitch, int Hp, int tiles_x, uint32_t* segex) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= Hp * tiles_x) return;
-    const int r = gid / tiles_x, tc = gid - r * tiles_x;
-    const uint32_t* row = reinterpret_cast<const uint32_t*>(img + (size_t)r * pitch) + tc * TP_TILE_W;
-    uint32_t* out = segex + (size_t)gid * TP_SEG_ENTRIES * 3;
-    uint32_t x = 0, y = 0, z = 0;
-    for (int c = 0; c <= TP_TILE_W; c++) {
-        if ((c & 7) == 0) { out[(c >> 3) * 3] = x; out[(c >> 3) * 3 + 1] = y; out[(c >> 3) * 3 + 2] = z; }
-        if (c == TP_TILE_W) break;
-        const uint32_t w = row[c], rr = w & 0xffu, gg = (w >> 8) & 0xffu, bb = (w >> 16) & 0xffu, f = w >> 24;
-        x += rr | (gg << 16); y += bb | (f << 16); z += rr * rr + gg * gg + bb * bb + f;
-    }
-}
-
 // seg[r][tc][5]: moments of row r inside tile column tc
 __global__ void k_static_seg(const uint8_t* img, int pitch, int W, int H, int tiles_x, uint32_t* seg) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,11 +105,9 @@ __global__ void k_static_rows(int H, int tiles_x, int64_t* t2) {
     for (int tc = 1; tc <= tiles_x; tc++)
         for (int k = 0; k < 5; k++) { run[k] += row[tc * TP_T2_WORDS + k]; row[tc * TP_T2_WORDS + k] = run[k]; }
 }
-void tp_launch_static_table(uint8_t* img, int pitch, int W, int H, int Hp, int tiles_x, uint32_t* seg, int64_t* t2,
-                            uint32_t* segex, hipStream_t s) {
+void tp_launch_static_table(uint8_t* img, int pitch, int W, int H, int Hp, int tiles_x, uint32_t* seg, int64_t* t2, hipStream_t s) {
     const int Wp = tiles_x * TW;
     hipLaunchKernelGGL(k_static_alpha, dim3((unsigned)(((size_t)Wp * Hp + 255) / 256)), dim3(256), 0, s, img, pitch, Wp, Hp);
-    hipLaunchKernelGGL(k_static_segex, dim3((Hp * tiles_x + 63) / 64), dim3(64), 0, s, img, pitch, Hp, tiles_x, segex);
     hipLaunchKernelGGL(k_static_seg, dim3((H * tiles_x + 255) / 256), dim3(256), 0, s, img, pitch, W, H, tiles_x, seg);
     hipLaunchKernelGGL(k_static_cols, dim3((tiles_x * 5 + 63) / 64), dim3(64), 0, s, seg, H, tiles_x, t2);
     hipLaunchKernelGGL(k_static_rows, dim3((H + 1 + 255) / 256), dim3(256), 0, s, H, tiles_x, t2);
@@ -186,14 +166,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
                 // one edge per vertex publishes its snapped positions (k_update reads them)
                 if (mv == 0 && ((uv.x >> 30) & 1)) L.vpos[(size_t)u * 5 + mu] = make_int2(Xa, Ya);
                 if (mu == 0 && ((uv.y >> 30) & 1)) L.vpos[(size_t)v * 5 + mv] = make_int2(Xb, Yb);
-                const size_t li = (size_t)e * TP_NLINES + q;
-                L.line_xs[li] = make_longlong2(ln.x, ln.s);
-                L.line_rows[li] = make_int2(ln.ra, ln.rb);
                 s_lx[j][q][0] = ln.x; s_lx[j][q][1] = ln.s; s_lr[j][q][0] = ln.ra; s_lr[j][q][1] = ln.rb;
             }
         }
-        band.dX = row_max16(dX) + 256 * L.margin_px;
-        band.dY = row_max16(dY) + 256 * L.margin_px;
+        band.dX = row_max16(dX);
+        band.dY = row_max16(dY);
     }
     TP_STAMP(0, 1);
     // Static part of the line sums, first half: the runs of rows inside one tile column (almost always one or two)
@@ -230,9 +207,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
             }
     }
     };
-    if (rebin_word != 0) {  // (uniform) lists still valid otherwise (tp_set_margin)
-        if (L.margin_px >= 2)  // only the margin vote of k_update reads it
-            for (int v = blockIdx.x * BIN_THREADS + tid; v < L.NP; v += gridDim.x * BIN_THREADS) L.points_binned[v] = L.points[v];
+    if (rebin_word != 0) {  // (uniform) profiling replays the sweep over unchanged lists (tp_profile_accumulate)
         // the line's tile-column range in each of its first BIN_TROWS tile rows: the crossing column is monotone in the
         // row, so the two end rows of the overlap bound it (exactly the test of tp_line_live)
         if (owner && ln.ra <= ln.rb) {
@@ -306,11 +281,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
                     jj = w >> 27; tile = w & 0x7ffffff;
                     visit = (int)base + v0 + t;
                     const int ty = tile / L.tiles_x, tx = tile - ty * L.tiles_x;
-                    if (L.margin_px >= 2) {
-                        // lists kept across iterations (tp_set_margin) must hold every line of the band: a line can become
-                        // live in a tile, or non-empty at all, while the vertices move inside the margin
-                        mask = (1u << TP_NLINES) - 1u;
-                    } else {
+                    {
 #pragma unroll
                         for (int l = 0; l < TP_NLINES; l++) {
                             const int ra = s_lr[jj][l][0], rb = s_lr[jj][l][1];
@@ -338,16 +309,19 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
                 }
                 if (!static_done) { static_first_half(); static_done = true; }  // VALU + loads beside the atomic in flight
                 if (mask == 0) continue;
-                const int ee = blockIdx.x * BIN_EDGES + jj;
-                int2* dst = L.tilelist + (size_t)tile * L.list_cap;
+                uint4* dst = reinterpret_cast<uint4*>(L.tilelist + (size_t)tile * L.list_cap * 2);
 #if defined(TPOSE_ABLATE) && (TPOSE_ABLATE & 512)  // timing experiment: no entries
                 if (pos == 0x7fffffff)
 #endif
 #pragma unroll
                 for (int l = 0; l < TP_NLINES; l++)
                     if ((mask >> l) & 1u) {
-                        if (pos < L.list_cap) dst[pos] = make_int2(ee * TP_NLINES + l, visit * TP_NLINES + l);
-                        else atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
+                        if (pos < L.list_cap) {  // the entry is self-contained: the line's walker, its rows, where its record goes
+                            const uint64_t x = (uint64_t)s_lx[jj][l][0], sl = (uint64_t)s_lx[jj][l][1];
+                            dst[2 * pos] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)sl, (uint32_t)(sl >> 32));
+                            dst[2 * pos + 1] = make_uint4((uint32_t)s_lr[jj][l][0], (uint32_t)s_lr[jj][l][1], (uint32_t)(visit * TP_NLINES + l), 0u);
+                        } else
+                            atomicOr(&L.state->flags, TP_FLAG_LIST_OVERFLOW);
                         pos++;
                     }
             }
@@ -394,7 +368,7 @@ __device__ __forceinline__ pix3 operator+(pix3 a, pix3 b) { return {a.x + b.x, a
 // lane = (live edge line of the tile's work list, 1/split of the tile's rows) for the walk.
 // ------------------------------------------------------------------------------------------------
 #define WALK_ROWS 4   // rows per unrolled trip of the line walk
-#define ROW_WORDS 387 // 3 * 129; 387 = 3 (mod 32): lanes of consecutive ROWS store to distinct banks
+#define ROW_WORDS 387 // 3 * 129
 size_t tp_accumulate_lds_bytes() { return (size_t)(TH * ROW_WORDS + 1) * sizeof(uint32_t); }
 
 
@@ -403,136 +377,146 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
 
     const int tid = threadIdx.x;
     const uint32_t sweep = L.state->sweep;  // stamped into the records
-    // XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD one contiguous band of tile rows so
-    // that the lines, list entries and raster rows a tile shares with its neighbours stay in that XCD's L2
+    // Every workgroup is resident (six per CU) and takes tiles slot, slot + nslots, ... of its XCD: workgroup b runs on
+    // XCD b % 8, and every XCD owns one contiguous band of tile rows, so that the raster rows, list entries and records a
+    // tile shares with its neighbours stay in that XCD's L2.  The loads of a workgroup's NEXT tile are issued before it
+    // works on the current one: the second round of tiles never waits for memory.
     const int ntiles = L.tiles_x * L.tiles_y;
-    const int chunk = (ntiles + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    const int chunk = (ntiles + 7) >> 3;            // tiles per XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int tile_end = min((xcd + 1) * chunk, ntiles);
     if (blockIdx.x == 0 && tid == 0) L.state->rebin_req = 0;  // consumed by the k_bin that ran before us
-    if ((int)(blockIdx.x >> 3) >= chunk || tile >= ntiles) return;
-    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
+    const int prow = tid >> 4, seg = tid & 15;  // the 16 lanes of a DPP row are the 16 segments of a tile row
+    const int W = L.vw.W;
+
+    struct fetched { uint4 px[2]; int nlist; };
+    auto fetch = [&](int tile, fetched& f) {
+        const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
+        const uint4* src = reinterpret_cast<const uint4*>(L.img + (size_t)(ty * TH + prow) * L.pitch + (size_t)(tx * TW + seg * 8) * 4);
+        f.px[0] = src[0]; f.px[1] = src[1];
+        f.nlist = min(L.tilecount[tile], L.list_cap);
+    };
+    int tile = xcd * chunk + slot;
+    if (tile >= tile_end) return;
+    fetched cur, nxt;
+    fetch(tile, cur);
     TP_STAMP(1, 0);
 
-    // the tile's pixels: lane = (row, segment of 8 pixels), 32 bytes per lane, + the packed prefix at the segment's
-    // start from the static table.  Consecutive lanes take consecutive rows (conflict-free LDS stores); a wave
-    // covers 16 rows x 4 segments = 128 contiguous bytes per row
-    const int prow = tid & 15, seg = tid >> 4;
-    uint4 px[2];
-    pix3 run;
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(L.img + (size_t)(ty * TH + prow) * L.pitch + (size_t)(tx * TW + seg * 8) * 4);
-        px[0] = src[0]; px[1] = src[1];
-        const uint32_t* se = L.segex + (((size_t)(ty * TH + prow) * L.tiles_x + tx) * TP_SEG_ENTRIES + seg) * 3;
-        run.x = se[0]; run.y = se[1]; run.z = se[2];
-    }
-    int nlist = L.tilecount[tile];
-    if (nlist > L.list_cap) nlist = L.list_cap;
-    const int2* list = L.tilelist + (size_t)tile * L.list_cap;
-    // work unit = (live line, 1/split of the tile's rows): `split` adjacent lanes share a line while all parts fit
-    // the workgroup
-    const int lsplit = nlist * 4 <= ACC_THREADS ? 2 : nlist * 2 <= ACC_THREADS ? 1 : 0;  // log2(split)
-    const int split = 1 << lsplit;
-    const int nitems = nlist << lsplit;
-    // this lane's first work item is requested now: nothing after the barrier waits on global memory twice
-    int item = tid;
-    int2 ent = make_int2(0, 0);
-    longlong2 lxs = make_longlong2(0, 0);
-    int2 lrows = make_int2(1, 0);
-    if (item < nitems) {
-        ent = list[item >> lsplit];
-        lxs = L.line_xs[ent.x];
-        lrows = L.line_rows[ent.x];
-    }
-    if (nlist == 0) return;  // nothing crosses this tile (uniform)
+    for (; tile < tile_end; tile += nslots, cur = nxt) {
+        const int next = tile + nslots;
+        if (next < tile_end) fetch(next, nxt);  // in flight while this tile is processed
+        const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
+        const int nlist = cur.nlist;
+        const uint4* list = reinterpret_cast<const uint4*>(L.tilelist + (size_t)tile * L.list_cap * 2);
+        // work unit = (live line, 1/split of the tile's rows): `split` adjacent lanes share a line while all parts fit
+        // the workgroup
+        const int lsplit = nlist * 4 <= ACC_THREADS ? 2 : nlist * 2 <= ACC_THREADS ? 1 : 0;  // log2(split)
+        const int split = 1 << lsplit;
+        const int nitems = nlist << lsplit;
+        int item = tid;
+        uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(1, 0, 0, 0);  // this lane's first work item, requested now
+        if (item < nitems) { e0 = list[2 * (item >> lsplit)]; e1 = list[2 * (item >> lsplit) + 1]; }
 
-    // ---- phase 1: pixels -> row prefix sums in LDS (running sums seeded by the static table: no scan) -------
+        // ---- phase 1: pixels -> row prefix sums in LDS (running sums seeded by the static table: no scan) -------
+        if (nlist > 0) {
 #if defined(TPOSE_ABLATE) && (TPOSE_ABLATE & 1)  // timing experiments only (tools/build_variants.py): no prefix build
-    if ((px[0].x ^ px[1].w ^ run.x) == 0x12345u) P[tid] = 1;
+            if ((cur.px[0].x ^ cur.px[1].w) == 0x12345u) P[tid] = 1;
 #else
-    {
-        uint32_t* row = P + prow * ROW_WORDS + seg * 24;
+            pix3 run;
+            uint32_t* row = P + prow * ROW_WORDS + seg * 24;
+            {   // everything left of the lane's segment: a DPP scan of the segment totals over the row's 16 lanes
+                pix3 tot = {0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t w = k % 4 == 0 ? px[k / 4].x : k % 4 == 1 ? px[k / 4].y : k % 4 == 2 ? px[k / 4].z : px[k / 4].w;
-            row[3 * k] = run.x; row[3 * k + 1] = run.y; row[3 * k + 2] = run.z;
-            run = run + pixel_moments(w);
-        }
-        if (seg == 15) { row[24] = run.x; row[25] = run.y; row[26] = run.z; }  // entry 128: the whole row
-    }
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t w = k % 4 == 0 ? cur.px[k / 4].x : k % 4 == 1 ? cur.px[k / 4].y : k % 4 == 2 ? cur.px[k / 4].z : cur.px[k / 4].w;
+                    tot = tot + pixel_moments(w);
+                }
+                run.x = row_scan16(tot.x) - tot.x; run.y = row_scan16(tot.y) - tot.y; run.z = row_scan16(tot.z) - tot.z;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t w = k % 4 == 0 ? cur.px[k / 4].x : k % 4 == 1 ? cur.px[k / 4].y : k % 4 == 2 ? cur.px[k / 4].z : cur.px[k / 4].w;
+                row[3 * k] = run.x; row[3 * k + 1] = run.y; row[3 * k + 2] = run.z;
+                run = run + pixel_moments(w);
+            }
+            if (seg == 15) { row[24] = run.x; row[25] = run.y; row[26] = run.z; }  // entry 128: the whole row
 #endif
-    TP_STAMP(1, 1);
-    __syncthreads();
-    TP_STAMP(1, 2);
+        }
+        TP_STAMP(1, 1);
+        __syncthreads();
+        TP_STAMP(1, 2);
 
-    // ---- phase 2: the lines ------------------------------------------------------------------------
-    const int row0 = ty * TH;
-    const int col0 = tx * TW;
-    const int W = L.vw.W;
-    // columns of this tile column: [col0, col0 + TW), the last one also takes the clamp value W
-    const uint32_t lim = tx == L.tiles_x - 1 ? (uint32_t)(W - col0 + 1) : (uint32_t)TW;
-    const int pr = TH >> lsplit;  // rows per part
+        // ---- phase 2: the lines ------------------------------------------------------------------------
+        const int row0 = ty * TH;
+        const int col0 = tx * TW;
+        // columns of this tile column: [col0, col0 + TW), the last one also takes the clamp value W
+        const uint32_t lim = tx == L.tiles_x - 1 ? (uint32_t)(W - col0 + 1) : (uint32_t)TW;
+        const int pr = TH >> lsplit;  // rows per part
 
 #if defined(TPOSE_ABLATE) && (TPOSE_ABLATE & 2)  // timing experiments only: no walk
-    if ((lxs.x ^ lrows.x) == 0x1234567 && ent.y < L.visit_cap * TP_NLINES) L.visits[(size_t)ent.y * TP_REC_DWORDS] = sweep;
-    if (false)
+        if ((e0.x ^ e1.x) == 0x1234567 && e1.z < (uint32_t)L.visit_cap * TP_NLINES) L.visits[(size_t)e1.z * TP_REC_DWORDS] = sweep;
+        if (false)
 #endif
-    for (; item < nitems; item += ACC_THREADS) {
-        const int part = item & (split - 1);
-        if (item != tid) {  // rare: more items than lanes
-            ent = list[item >> lsplit];
-            lxs = L.line_xs[ent.x];
-            lrows = L.line_rows[ent.x];
-        }
-        const int j0 = part * pr;                       // first tile row of this part
-        const int koff = lrows.x - row0 - j0;           // part-relative index of the line's first row
-        const uint32_t nvalid = (uint32_t)max(lrows.y - lrows.x + 1, 0);
-        tp_line ln; ln.x = lxs.x; ln.s = lxs.y; ln.ra = lrows.x; ln.rb = lrows.y;
-        tp_walker wk = tp_line_at(ln, row0 + j0);       // exact 32.32 walker for this tile's rows
-        // packed sums of two rows never carry (2 x 32640 < 2^16); unpacked into 32-bit sums per pair of rows
-        uint32_t ar = 0, ag = 0, ab = 0, ao = 0, aq = 0, sx = 0;
-        const uint32_t* Pp = P + j0 * ROW_WORDS;
-        for (int c0 = 0; c0 < pr; c0 += WALK_ROWS, Pp += WALK_ROWS * ROW_WORDS) {
-            // rows outside the line's rows, or whose crossing column falls into another tile column, read the
-            // all-zero entry 0 of the row and are not counted; a trip no lane of the wave needs is skipped
-            if (!__any((int)nvalid + koff - c0 > 0 && koff - c0 < WALK_ROWS)) { wk.x += WALK_ROWS * wk.s; continue; }
-            pix3 entv[WALK_ROWS];
+        for (; item < nitems; item += ACC_THREADS) {
+            const int part = item & (split - 1);
+            if (item != tid) { e0 = list[2 * (item >> lsplit)]; e1 = list[2 * (item >> lsplit) + 1]; }  // rare: more items than lanes
+            tp_line ln;
+            ln.x = (int64_t)((uint64_t)e0.x | ((uint64_t)e0.y << 32)); ln.s = (int64_t)((uint64_t)e0.z | ((uint64_t)e0.w << 32));
+            ln.ra = (int)e1.x; ln.rb = (int)e1.y;
+            const uint32_t rec = e1.z;
+            const int j0 = part * pr;                       // first tile row of this part
+            const int koff = ln.ra - row0 - j0;             // part-relative index of the line's first row
+            const uint32_t nvalid = (uint32_t)max(ln.rb - ln.ra + 1, 0);
+            tp_walker wk = tp_line_at(ln, row0 + j0);       // exact 32.32 walker for this tile's rows
+            // packed sums of two rows never carry (2 x 32640 < 2^16); unpacked into 32-bit sums per pair of rows
+            uint32_t ar = 0, ag = 0, ab = 0, ao = 0, aq = 0, sx = 0;
+            const uint32_t* Pp = P + j0 * ROW_WORDS;
+            for (int c0 = 0; c0 < pr; c0 += WALK_ROWS, Pp += WALK_ROWS * ROW_WORDS) {
+                // rows outside the line's rows, or whose crossing column falls into another tile column, read the
+                // all-zero entry 0 of the row and are not counted; a trip no lane of the wave needs is skipped
+                if (!__any((int)nvalid + koff - c0 > 0 && koff - c0 < WALK_ROWS)) { wk.x += WALK_ROWS * wk.s; continue; }
+                pix3 entv[WALK_ROWS];
 #pragma unroll
-            for (int k = 0; k < WALK_ROWS; k++) {
-                const int32_t x = min(max((int32_t)(wk.x >> 32), 0), W);
-                wk.x += wk.s;
-                const uint32_t xl = (uint32_t)(x - col0);
-                const bool in = xl < lim && (uint32_t)(c0 + k - koff) < nvalid;
-                const uint32_t* ep = Pp + k * ROW_WORDS + (in ? __umul24(xl, 3u) : 0u);
-                entv[k].x = ep[0]; entv[k].y = ep[1]; entv[k].z = ep[2];
-                sx += in ? (uint32_t)x : 0u;
-            }
+                for (int k = 0; k < WALK_ROWS; k++) {
+                    const int32_t x = min(max((int32_t)(wk.x >> 32), 0), W);
+                    wk.x += wk.s;
+                    const uint32_t xl = (uint32_t)(x - col0);
+                    const bool in = xl < lim && (uint32_t)(c0 + k - koff) < nvalid;
+                    const uint32_t* ep = Pp + k * ROW_WORDS + (in ? __umul24(xl, 3u) : 0u);
+                    entv[k].x = ep[0]; entv[k].y = ep[1]; entv[k].z = ep[2];
+                    sx += in ? (uint32_t)x : 0u;
+                }
 #pragma unroll
-            for (int k = 0; k < WALK_ROWS; k += 2) {
-                const uint32_t px2 = entv[k].x + entv[k + 1].x, py2 = entv[k].y + entv[k + 1].y;
-                ar += px2 & 0xffffu; ag += px2 >> 16;
-                ab += py2 & 0xffffu; ao += py2 >> 16;
-                aq += entv[k].z + entv[k + 1].z;
+                for (int k = 0; k < WALK_ROWS; k += 2) {
+                    const uint32_t px2 = entv[k].x + entv[k + 1].x, py2 = entv[k].y + entv[k + 1].y;
+                    ar += px2 & 0xffffu; ag += px2 >> 16;
+                    ab += py2 & 0xffffu; ao += py2 >> 16;
+                    aq += entv[k].z + entv[k + 1].z;
+                }
+            }
+            // combine the parts (adjacent lanes; a line's lanes are always active together)
+            for (int o = 1; o < split; o <<= 1) {
+                sx += (uint32_t)__shfl_xor((int)sx, o);
+                ar += (uint32_t)__shfl_xor((int)ar, o); ag += (uint32_t)__shfl_xor((int)ag, o);
+                ab += (uint32_t)__shfl_xor((int)ab, o); ao += (uint32_t)__shfl_xor((int)ao, o);
+                aq += (uint32_t)__shfl_xor((int)aq, o);
+            }
+            if (part != 0) continue;
+            if (rec < (uint32_t)L.visit_cap * TP_NLINES) {  // 32-byte record
+                uint4* out = reinterpret_cast<uint4*>(L.visits + (size_t)rec * TP_REC_DWORDS);
+                out[0] = make_uint4(sx, ao, ar, ag); out[1] = make_uint4(ab, aq, sweep, 0u);
             }
         }
-        // combine the parts (adjacent lanes; a line's lanes are always active together)
-        for (int o = 1; o < split; o <<= 1) {
-            sx += (uint32_t)__shfl_xor((int)sx, o);
-            ar += (uint32_t)__shfl_xor((int)ar, o); ag += (uint32_t)__shfl_xor((int)ag, o);
-            ab += (uint32_t)__shfl_xor((int)ab, o); ao += (uint32_t)__shfl_xor((int)ao, o);
-            aq += (uint32_t)__shfl_xor((int)aq, o);
-        }
-        if (part != 0) continue;
-        if (ent.y < L.visit_cap * TP_NLINES) {  // 32-byte record
-            uint4* out = reinterpret_cast<uint4*>(L.visits + (size_t)ent.y * TP_REC_DWORDS);
-            out[0] = make_uint4(sx, ao, ar, ag); out[1] = make_uint4(ab, aq, sweep, 0u);
-        }
+        TP_STAMP(1, 3);
+        if (next < tile_end) __syncthreads();  // the table is rebuilt for the next tile
     }
-    TP_STAMP(1, 3);
 }
 
 static int accumulate_grid(const tp_launch& L) {
+    // every workgroup resident: 6 per CU on 256 CUs, a multiple of 8 (XCDs); fewer when there are fewer tiles
     const int ntiles = L.tiles_x * L.tiles_y;
-    return ((ntiles + 7) >> 3) * 8;
+    const int per_xcd = (ntiles + 7) >> 3;
+    return 8 * (per_xcd < 192 ? per_xcd : 192);
 }
 
 hipError_t tp_kernels_init() {
@@ -728,8 +712,7 @@ void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s) {
 // the vertex's gradient (wrapping int32, like the reference's atomics -- integer sums commute) a wave reduction.
 // Lane 0 takes the shift.cs step.  No atomics, no arrival counters.  The base variants (i = 0) do not enter any
 // gradient: extra workgroups behind the vertices write their outputs, one thread per triangle.
-// Without a margin every launch re-arms the work lists for the next k_bin; with one, the last block to finish
-// knows whether any vertex left its margin.
+// Every launch re-arms the work lists for the next k_bin.
 // ------------------------------------------------------------------------------------------------
 #define UPD_THREADS 64
 #define UPD_CHUNK 7  // generic path: incident triangles per pass, 7 x 9 = 63 lanes
@@ -790,7 +773,6 @@ void tp_launch_vertex_refs(const tp_launch& L, int* vref, int* vvar, hipStream_t
 
 __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour, float rate) {
     __shared__ int64_t S[64][TP_W_WORDS];  // line sums of the wave: [lane] (fast path), [a][l] (generic), [a][k] (base variants)
-    __shared__ int s_last;
     const int lane = threadIdx.x;
     const int tidg = blockIdx.x * UPD_THREADS + lane;
     // A work list overflowed in this or an earlier iteration: the line sums are incomplete.  Do not step -- the host
@@ -798,7 +780,6 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
     // looked at only where something would be written, so that the loads below do not queue behind it.
     const uint32_t flags = L.state->flags;
     const uint32_t sweep = L.state->sweep;
-    int need = 0;
     TP_STAMP(2, 0);
     // one variant: signed sum of three parked line sums -> outputs; returns the energy
     auto variant = [&](int h, int m, const int64_t* Sout, const int64_t* Sin, const int64_t* Sopp) -> int32_t {
@@ -858,8 +839,8 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
         const int v = blockIdx.x;
         const int ref = L.vref[(size_t)v * 64 + lane];
         const int comb = lane < 4 * UPD_FAN ? L.vvar[(size_t)v * 8 + (lane >> 2)] : -1;
-        float2 p = make_float2(0.0f, 0.0f), pb = p;
-        if (lane == 0) { p = L.points[v]; if (L.margin_px >= 2) pb = L.points_binned[v]; }
+        float2 p = make_float2(0.0f, 0.0f);
+        if (lane == 0) p = L.points[v];
         uint32_t gx = 0, gy = 0;
         const int generic = __shfl(ref, 0) == -2;
         int deg = 1;
@@ -920,7 +901,6 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
             if (deg > 0) L.gr[v] = make_int2((int)gx, (int)gy);  // vertices no triangle uses: the gradient is never touched
             if (v >= 4) {  // shift.cs:20 -- the four corners never move
                 const float R = L.vw.ratio;
-                const float lim = (float)(L.margin_px - 1);
                 float tgx = (float)(int)gx, tgy = (float)(int)gy;
                 float x = p.x, y = p.y;
                 if (x <= -R) { x = -R; tgx = 0.0f; } else if (x >= R) { x = R; tgx = 0.0f; }
@@ -930,34 +910,15 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
                     y = tp_fsub(y, tp_fdiv(tp_fdiv(tp_fmul(rate, tgy), 256.0f), 256.0f));
                 }
                 L.points[v] = make_float2(x, y);
-                need = !(fabsf(x - pb.x) * (L.vw.halfW / R) <= lim) || !(fabsf(y - pb.y) * L.vw.halfH <= lim);
             }
         }
     }
     TP_STAMP(2, 3);
     if (flags) return;  // (uniform) nothing was stepped; the host repairs and replays
     if (tidg == 0) L.state->iters_done++;
-    if (L.margin_px < 2) {
-        // work lists are rebuilt every iteration: k_accumulate has consumed them, re-arm them here
-        for (int k = tidg; k < L.tiles_x * L.tiles_y; k += gridDim.x * UPD_THREADS) L.tilecount[k] = 0;
-        if (tidg == 0) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
-        return;
-    }
-    need = __syncthreads_or(need);
-    if (lane == 0) {
-        const unsigned long long inc = 1ull + (need ? 1ull << 32 : 0ull);
-        const unsigned long long now = atomicAdd(&L.state->arrive, inc) + inc;
-        s_last = ((uint32_t)now == gridDim.x) ? ((now >> 32) ? 2 : 1) : 0;
-    }
-    __syncthreads();
-    if (s_last) {
-        if (s_last == 2)
-            for (int k = lane; k < L.tiles_x * L.tiles_y; k += UPD_THREADS) L.tilecount[k] = 0;
-        if (lane == 0) {
-            L.state->arrive = 0ull;
-            if (s_last == 2) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
-        }
-    }
+    // the work lists are rebuilt every iteration: k_accumulate has consumed them, re-arm them here
+    for (int k = tidg; k < L.tiles_x * L.tiles_y; k += gridDim.x * UPD_THREADS) L.tilecount[k] = 0;
+    if (tidg == 0) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
 }
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s) {
     const int nblocks = L.NP + (L.NT + 20) / 21;  // a wave per vertex, then the base variants (21 triangles per wave)
