@@ -1,7 +1,7 @@
-export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r2p; mkdir -p $O
+export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r2q; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/ -q -m gpu 2>&1 | tail -15 > $O/pytest.txt; cat $O/pytest.txt
-python tools/time_acc.py > $O/time.json 2>$O/time.err; cat $O/time.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python bench.py --no-cpu-baseline --no-pmc --steps 512 --warmup 64 > $O/kt.log 2>&1
-find $O -name "*kernel_trace.csv" -delete
-head -5 $O/kt/kt_kernel_stats.csv | cut -c1-150
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_20_5.json 2> $O/bench_20_5.err; python -c "
+import json; d=json.load(open('$O/bench_20_5.json')); print('20/5:', d['value'], d['ms_per_step'], d['roofline']['kernel_us'], d['roofline']['kernel_us_hip_events'], d['roofline']['frac'], d['roofline']['traffic'])"
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; python -c "
+import json; d=json.load(open('$O/bench_default.json')); print('default:', d['value'], d['ms_per_step'], d['timing'], d['roofline']['kernel_us'], d['roofline']['kernel_us_hip_events'], d['roofline']['frac'], d['roofline']['traffic'], d['roofline']['kernel_trace_us'], d['cpu_baseline'])"
+tail -3 $O/bench_default.err

@@ -16,7 +16,7 @@ def init(backend=None):
     if backend == "nccl":
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
     else:
         device = torch.device("cpu")
         dist.init_process_group(backend)
