@@ -23,7 +23,7 @@ def write_ppm(path, img):
         f.write(np.ascontiguousarray(img[:, :, :3]).tobytes())
 
 
-def build_cpu(name):
+def build_cpu(name, flags=()):
     """harness `name` linked against the oracle-backed C ABI (tests only)"""
     os.makedirs(BUILD, exist_ok=True)
     obj = os.path.join(BUILD, "oracle_backend.o")
@@ -31,8 +31,8 @@ def build_cpu(name):
     ora = os.path.join(BUILD, "tp_oracle.o")
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-c", os.path.join(ROOT, "oracle", "tp_oracle.c"), "-o", ora])
     exe = os.path.join(BUILD, name + "_cpu")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + HOST,
-                           os.path.join(HOST, name + ".cpp"), obj, ora, "-fopenmp", "-lm", "-o", exe])
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + HOST] + list(flags) +
+                          [os.path.join(HOST, name + ".cpp"), obj, ora, "-fopenmp", "-lm", "-pthread", "-o", exe])
     return exe
 
 
@@ -151,3 +151,61 @@ def test_fundamental_harness_on_cpu(scene):
     out = run(exe, "-matches", os.path.join(HERE, "golden", "sfm_matches.txt"), "-image", "960x540")
     vals = [float(l.split(":")[1]) for l in out.splitlines() if "mean squared Sampson distance" in l]
     assert len(vals) == 3 and all(np.isfinite(v) and v < 1e-3 for v in vals)
+
+
+# ---- the two-GPU C++ driver (tpose_amd/host/warp2.cpp) --------------------------------------------------------------
+def _hierarchies(scene, build):
+    for n in ("a", "b"):
+        if not os.path.exists(str(scene / ("h_%s.tri" % n))):
+            run(build, "-i", str(scene / (n + ".ppm")), "-o", str(scene / ("h_%s.tri" % n)), "-maxframes", "2500", "-maxtris", "110", "-quiet")
+        assert len(records(str(scene / ("h_%s.tri" % n)))) >= 2
+
+
+def _mutual_vs_two_ranks(scene, warp_exe, warp2_exe, tag, extra=()):
+    """`warp -schedule mutual` (one process, four descents per level) against two `warp2` processes exchanging their
+    meshes: the .tri.warp files must be the same bytes"""
+    import shutil
+    for who in ("one", "two"):
+        for n in ("a", "b"):
+            shutil.copy(str(scene / ("h_%s.tri" % n)), str(scene / ("%s_%s_%s.tri" % (tag, who, n))))
+    common = ["-ia", str(scene / "a.ppm"), "-ib", str(scene / "b.ppm"), "-levelframes", "120", "-quiet"]
+    ta, tb = (str(scene / ("%s_one_%s.tri" % (tag, n))) for n in ("a", "b"))
+    run(warp_exe, *common, "-ta", ta, "-tb", tb, "-schedule", "mutual")
+    ta2, tb2 = (str(scene / ("%s_two_%s.tri" % (tag, n))) for n in ("a", "b"))
+    idfile = str(scene / ("%s_link" % tag))
+    procs = [subprocess.Popen([warp2_exe, "-rank", str(r), "-idfile", idfile, "-transport", "fifo", *common, "-ta", ta2, "-tb", tb2, *extra],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "rank 0 frames" in outs[0] and "rank 1 frames" in outs[1]
+    for one, two in ((ta, ta2), (tb, tb2)):
+        a, b = open(one + ".warp", "rb").read(), open(two + ".warp", "rb").read()
+        assert len(a) > 0 and a == b
+    assert len(records(ta + ".warp")) == len(records(str(scene / "h_a.tri"))) or len(records(ta + ".warp")) == len(records(str(scene / "h_b.tri")))
+
+
+def test_warp2_two_ranks_match_single_process_on_cpu_backend(scene):
+    """world size 2 without a GPU: the C++ two-rank driver over named pipes, against the oracle-backed C ABI"""
+    cpu_t = build_cpu("triangulate")
+    _hierarchies(scene, cpu_t)
+    _mutual_vs_two_ranks(scene, build_cpu("warp"), build_cpu("warp2", flags=["-DWARP2_NO_RCCL"]), "cpu")
+
+
+@pytest.mark.gpu
+def test_warp2_two_ranks_match_single_process_on_gpu(scene):
+    """the same on the HIP path: two ranks share GPU 0 (RCCL refuses two ranks on one device, so the pipes carry the
+    meshes here), and the bytes also equal the CPU backend's"""
+    cpu_t = build_cpu("triangulate")
+    _hierarchies(scene, cpu_t)
+    _mutual_vs_two_ranks(scene, build_gpu("warp"), build_gpu("warp2"), "gpu", extra=["-device", "0"])
+    _mutual_vs_two_ranks(scene, build_cpu("warp"), build_cpu("warp2", flags=["-DWARP2_NO_RCCL"]), "cpu")
+    for n in ("a", "b"):
+        assert open(str(scene / ("gpu_one_%s.tri.warp" % n)), "rb").read() == open(str(scene / ("cpu_one_%s.tri.warp" % n)), "rb").read()
+
+
+@pytest.mark.gpu
+def test_warp2_rccl_self_exchange(scene):
+    """RCCL itself from the C++ driver: communicator, stream, device buffers, one grouped ncclSend / ncclRecv"""
+    exe = build_gpu("warp2")
+    out = run(exe, "-selftest", "-idfile", str(scene / "rccl_id"))
+    assert "RCCL self exchange OK" in out

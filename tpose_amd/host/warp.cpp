@@ -11,6 +11,8 @@
 //               never true after the first convergence), then both triangulations are written to
 //               <tri>.warp and the next finer level is read, warped on read.
 //   two_way:    both directions per level (the README's description; `||` instead of `&&`).
+//   mutual:     the two-way form with independent directions inside a phase (warp_core.hpp) -- what warp2 runs on two
+//               GPUs at once; here its four descents per level run one after the other.  Same bytes.
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -19,8 +21,37 @@
 #include "tpose/io.hpp"
 #include "tpose/triangulation.hpp"
 #include "image_io.hpp"
+#include "warp_core.hpp"
 
 using namespace tpose;
+
+// -schedule mutual on one GPU
+static int run_mutual(const std::string& ta, const std::string& tb, long levelframes) {
+    warpcore::direction A, B;
+    A.warpA = true; B.warpA = false;
+    io::read(&A.tr, ta);
+    io::read(&B.tr, tb);
+    long frames = 0;
+    int level = 0;
+    while (true) {
+        frames += warpcore::descend(A, levelframes);   // phase 1
+        frames += warpcore::descend(B, levelframes);
+        triangulation peerA, peerB;                      // the meshes handed over
+        warpcore::unpack(warpcore::pack(A.tr), peerA);
+        warpcore::unpack(warpcore::pack(B.tr), peerB);
+        warpcore::reseed(A, peerB);
+        warpcore::reseed(B, peerA);
+        frames += warpcore::descend(A, levelframes);   // phase 2
+        frames += warpcore::descend(B, levelframes);
+        io::write(&A.tr, ta + ".warp");
+        io::write(&B.tr, tb + ".warp");
+        level++;
+        const bool moreA = io::read(&A.tr, ta, true), moreB = io::read(&B.tr, tb, true);
+        if (!moreA || !moreB) break;
+    }
+    std::cout << "frames " << frames << " levels " << level << std::endl;
+    return 0;
+}
 
 int main(int argc, char** argv) {
     std::string ia, ib, ta, tb, schedule = "as_written";
@@ -55,6 +86,11 @@ int main(int argc, char** argv) {
     tpose::image(TP_IMAGE_A, A.rgba.data(), (size_t)A.w * 4);
     tpose::image(TP_IMAGE_B, B.rgba.data(), (size_t)B.w * 4);
 
+    if (schedule == "mutual") {
+        const int rc = run_mutual(ta, tb, levelframes);
+        tpose::quit();
+        return rc;
+    }
     triangulation trA, trB;
     io::read(&trA, ta);
     io::read(&trB, tb);

@@ -1,0 +1,236 @@
+// warp2 -- the two-way consistent hierarchical warp on TWO GPUs, one image (one direction) per GPU, vertex buffers
+// exchanged with RCCL over xGMI.  C++ host code over the C ABI (include/tpose_hip.h); no Python, no torch.
+//
+//   rank 0:  warp2 -rank 0 -idfile F -ia A.ppm -ib B.ppm -ta A.tri -tb B.tri [-levelframes N] [-device D]
+//   rank 1:  warp2 -rank 1 -idfile F ...                       (same arguments; one process per GPU)
+//
+// Rank 0 holds raster B and descends T(A) against it; rank 1 holds raster A and descends T(B) (the reference runs the
+// two directions one after the other on one GPU, software/warp/main.cpp:214-283).  Schedule "mutual" of warp_core.hpp:
+// per level and phase the two descents run concurrently; between the phases each rank sends its descended mesh
+// {NT, NP, triangles, points, originpoints} (tens of KB, latency-bound) and receives the peer's -- ONE grouped
+// ncclSend / ncclRecv pair -- re-seeds its own points through the peer's reverse warp
+// (source/triangulation.hpp:492-520), descends again and appends its level to <tri>.warp.  The output is byte-identical
+// to `warp -schedule mutual` on one GPU.
+//
+//   -transport rccl   (default) ncclSend / ncclRecv between the two GPUs; the unique id travels through -idfile
+//   -transport fifo   two named pipes <idfile>.0to1 / <idfile>.1to0 -- for the CPU test of the schedule (built with
+//                     -DWARP2_NO_RCCL against the oracle-backed C ABI) and for one-GPU boxes, where RCCL refuses
+//                     two ranks on the same device
+//   -selftest         one rank sends a mesh-sized buffer to itself through RCCL and checks it (exercises the library,
+//                     the stream and the device buffers on a one-GPU box)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fcntl.h>
+#include <iostream>
+#include <string>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+
+#include "tpose/io.hpp"
+#include "tpose/triangulation.hpp"
+#include "image_io.hpp"
+#include "warp_core.hpp"
+
+#ifndef WARP2_NO_RCCL
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#endif
+
+using namespace tpose;
+
+namespace {
+
+[[noreturn]] void die(const std::string& what) {
+    std::cerr << "warp2: " << what << std::endl;
+    std::exit(1);
+}
+
+// send `out` to the peer and receive its message
+struct transport {
+    virtual ~transport() {}
+    virtual std::vector<int32_t> exchange(const std::vector<int32_t>& out) = 0;
+};
+
+// ---- named pipes ---------------------------------------------------------------------------------------------
+struct fifo_transport : transport {
+    int rank, wr = -1, rd = -1;
+    fifo_transport(int rank_, const std::string& base) : rank(rank_) {
+        const std::string p01 = base + ".0to1", p10 = base + ".1to0";
+        mkfifo(p01.c_str(), 0600);  // either rank may come first
+        mkfifo(p10.c_str(), 0600);
+        if (rank == 0) { wr = open(p01.c_str(), O_WRONLY); rd = open(p10.c_str(), O_RDONLY); }
+        else { rd = open(p01.c_str(), O_RDONLY); wr = open(p10.c_str(), O_WRONLY); }
+        if (wr < 0 || rd < 0) die("cannot open the pipes " + base + ".*");
+    }
+    ~fifo_transport() override { if (wr >= 0) close(wr); if (rd >= 0) close(rd); }
+    void put(const void* p, size_t n) { const char* c = (const char*)p; while (n) { ssize_t k = write(wr, c, n); if (k <= 0) die("pipe write"); c += k; n -= (size_t)k; } }
+    void get(void* p, size_t n) { char* c = (char*)p; while (n) { ssize_t k = read(rd, c, n); if (k <= 0) die("pipe read"); c += k; n -= (size_t)k; } }
+    std::vector<int32_t> exchange(const std::vector<int32_t>& out) override {
+        uint64_t n_out = out.size(), n_in = 0;
+        std::vector<int32_t> in;
+        if (rank == 0) {  // rank 0 talks first: messages may exceed the pipe buffer
+            put(&n_out, sizeof n_out); put(out.data(), n_out * sizeof(int32_t));
+            get(&n_in, sizeof n_in); in.resize(n_in); get(in.data(), n_in * sizeof(int32_t));
+        } else {
+            get(&n_in, sizeof n_in); in.resize(n_in); get(in.data(), n_in * sizeof(int32_t));
+            put(&n_out, sizeof n_out); put(out.data(), n_out * sizeof(int32_t));
+        }
+        return in;
+    }
+};
+
+#ifndef WARP2_NO_RCCL
+#define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) die(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define NCCLCHECK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) die(std::string(#x) + ": " + ncclGetErrorString(r_)); } while (0)
+
+// ---- RCCL: one grouped send/recv per message, device buffers on this rank's GPU -------------------------------
+struct rccl_transport : transport {
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    int rank, nranks, peer;
+    int32_t *dsend = nullptr, *drecv = nullptr;
+    size_t cap = 0;
+    rccl_transport(int rank_, int nranks_, int device, const std::string& idfile) : rank(rank_), nranks(nranks_), peer(nranks_ == 1 ? 0 : 1 - rank_) {
+        HIPCHECK(hipSetDevice(device));
+        ncclUniqueId id;
+        if (rank == 0) {
+            NCCLCHECK(ncclGetUniqueId(&id));
+            const std::string tmp = idfile + ".tmp";
+            FILE* f = std::fopen(tmp.c_str(), "wb");
+            if (!f || std::fwrite(&id, sizeof id, 1, f) != 1) die("cannot write " + tmp);
+            std::fclose(f);
+            if (std::rename(tmp.c_str(), idfile.c_str()) != 0) die("cannot publish " + idfile);
+        } else {
+            FILE* f = nullptr;
+            for (int tries = 0; tries < 3000 && !(f = std::fopen(idfile.c_str(), "rb")); tries++)
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            if (!f || std::fread(&id, sizeof id, 1, f) != 1) die("no RCCL id in " + idfile);
+            std::fclose(f);
+        }
+        NCCLCHECK(ncclCommInitRank(&comm, nranks, id, rank));
+        HIPCHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    }
+    ~rccl_transport() override {
+        if (comm) ncclCommDestroy(comm);
+        if (dsend) (void)hipFree(dsend);
+        if (drecv) (void)hipFree(drecv);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    void reserve(size_t n) {
+        if (n <= cap) return;
+        if (dsend) HIPCHECK(hipFree(dsend));
+        if (drecv) HIPCHECK(hipFree(drecv));
+        cap = n + n / 2 + 1024;
+        HIPCHECK(hipMalloc((void**)&dsend, cap * sizeof(int32_t)));
+        HIPCHECK(hipMalloc((void**)&drecv, cap * sizeof(int32_t)));
+    }
+    void swap_device(size_t n_send, size_t n_recv) {  // ONE grouped send / recv
+        NCCLCHECK(ncclGroupStart());
+        NCCLCHECK(ncclSend(dsend, n_send, ncclInt32, peer, comm, stream));
+        NCCLCHECK(ncclRecv(drecv, n_recv, ncclInt32, peer, comm, stream));
+        NCCLCHECK(ncclGroupEnd());
+        HIPCHECK(hipStreamSynchronize(stream));
+    }
+    std::vector<int32_t> exchange(const std::vector<int32_t>& out) override {
+        // sizes first (two int32 words), then the payload
+        reserve(out.size() + 2);
+        int32_t n_out[2] = {(int32_t)out.size(), 0}, n_in[2] = {0, 0};
+        HIPCHECK(hipMemcpyAsync(dsend, n_out, sizeof n_out, hipMemcpyHostToDevice, stream));
+        swap_device(2, 2);
+        HIPCHECK(hipMemcpy(n_in, drecv, sizeof n_in, hipMemcpyDeviceToHost));
+        reserve((size_t)n_in[0] + 2);
+        HIPCHECK(hipMemcpyAsync(dsend, out.data(), out.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        swap_device(out.size(), (size_t)n_in[0]);
+        std::vector<int32_t> in((size_t)n_in[0]);
+        HIPCHECK(hipMemcpy(in.data(), drecv, in.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        return in;
+    }
+};
+#endif
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    std::string ia, ib, ta, tb, idfile, how = "rccl";
+    long levelframes = 1L << 40;
+    int device = -1, rank = -1;
+    bool quiet = false, selftest = false;
+    for (int a = 1; a < argc; a++) {
+        const std::string k = argv[a];
+        auto val = [&]() -> const char* { if (a + 1 >= argc) die("missing value for " + k); return argv[++a]; };
+        if (k == "-ia") ia = val();
+        else if (k == "-ib") ib = val();
+        else if (k == "-ta") ta = val();
+        else if (k == "-tb") tb = val();
+        else if (k == "-rank") rank = std::atoi(val());
+        else if (k == "-idfile") idfile = val();
+        else if (k == "-transport") how = val();
+        else if (k == "-levelframes") levelframes = std::atol(val());
+        else if (k == "-device") device = std::atoi(val());
+        else if (k == "-quiet") quiet = true;
+        else if (k == "-selftest") selftest = true;
+        else die("unknown option " + k);
+    }
+    if (selftest) {
+#ifndef WARP2_NO_RCCL
+        if (idfile.empty()) die("-selftest needs -idfile");
+        rccl_transport t(0, 1, device < 0 ? 0 : device, idfile);
+        std::vector<int32_t> msg(20000);
+        for (size_t i = 0; i < msg.size(); i++) msg[i] = (int32_t)(i * 2654435761u);
+        const std::vector<int32_t> back = t.exchange(msg);
+        if (back != msg) die("RCCL self exchange returned different data");
+        int ver = 0;
+        ncclGetVersion(&ver);
+        std::cout << "RCCL self exchange OK (" << msg.size() * 4 << " bytes, library version " << ver << ")" << std::endl;
+        return 0;
+#else
+        die("built without RCCL");
+#endif
+    }
+    if (rank != 0 && rank != 1) die("-rank 0 or -rank 1");
+    if (ia.empty() || ib.empty() || ta.empty() || tb.empty() || idfile.empty()) die("need -ia -ib -ta -tb -idfile");
+    if (device < 0) device = rank;  // one process per GPU
+    Raster A, B;
+    if (!load_raster(ia, A) || !load_raster(ib, B)) die("failed to load the images");
+    if (A.w != B.w || A.h != B.h) die("images do not have the same dimension");
+    io::verbose = !quiet;
+
+    transport* link = nullptr;
+    if (how == "fifo") link = new fifo_transport(rank, idfile);
+#ifndef WARP2_NO_RCCL
+    else if (how == "rccl") link = new rccl_transport(rank, 2, device, idfile);
+#endif
+    else die("unknown transport " + how);
+
+    RATIO = (float)A.w / (float)A.h;
+    tpose::init(A.w, A.h, device);
+    tpose::flavour = TP_WARP;
+    // one image per GPU: the raster this rank's direction sweeps (rank 0: T(A) against B)
+    if (rank == 0) tpose::image(TP_IMAGE_B, B.rgba.data(), (size_t)B.w * 4);
+    else tpose::image(TP_IMAGE_A, A.rgba.data(), (size_t)A.w * 4);
+
+    warpcore::direction mine;
+    mine.warpA = rank == 0;
+    const std::string my_tri = rank == 0 ? ta : tb;
+    io::read(&mine.tr, my_tri);
+    long frames = 0;
+    int level = 0;
+    while (true) {
+        frames += warpcore::descend(mine, levelframes);                      // phase 1
+        triangulation peer;
+        warpcore::unpack(link->exchange(warpcore::pack(mine.tr)), peer);    // hand-over
+        warpcore::reseed(mine, peer);
+        frames += warpcore::descend(mine, levelframes);                      // phase 2
+        io::write(&mine.tr, my_tri + ".warp");
+        level++;
+        const int32_t more = io::read(&mine.tr, my_tri, true) ? 1 : 0;
+        const std::vector<int32_t> theirs = link->exchange(std::vector<int32_t>(1, more));
+        if (!more || theirs.empty() || !theirs[0]) break;  // stacks may differ in depth: stop together
+    }
+    std::cout << "rank " << rank << " frames " << frames << " levels " << level << std::endl;
+    delete link;
+    tpose::quit();
+    return 0;
+}
