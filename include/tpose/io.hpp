@@ -28,7 +28,8 @@ inline void put(std::ofstream& s, const T& v) { s.write(reinterpret_cast<const c
 
 inline bool verbose = true;
 
-// "xA yA xB yB" per line; lines that do not parse are skipped
+// "xA yA xB yB" per line; lines that do not parse are skipped.  Like the reference's loop (source/io.hpp:20-60: getline,
+// then break on eof before parsing), a last line WITHOUT a trailing newline is dropped.
 inline bool readmatches(std::string file, std::vector<vec2>& A, std::vector<vec2>& B) {
     if (verbose) std::cout << "Importing from file " << file << std::endl;
     std::ifstream f(file, std::ios::in);
@@ -38,6 +39,7 @@ inline bool readmatches(std::string file, std::vector<vec2>& A, std::vector<vec2
     }
     std::string line;
     while (std::getline(f, line)) {
+        if (f.eof()) break;  // the unterminated last line (getline hit end-of-file inside it)
         vec2 a, b;
         if (std::sscanf(line.c_str(), "%f %f %f %f", &a.x, &a.y, &b.x, &b.y) == 4) {
             A.push_back(a);

@@ -457,9 +457,11 @@ inline Pose GetPose(const Matrix3f& Essential) {
 
 // optimal two-view correction (Hartley & Sturm): moves A and B the least (sum of squared
 // distances) so that B^T F A = 0 exactly  (:416-520).
-// reference: the candidate loop evaluates the cost at the loop INDEX (`S(r)` instead of `S(R[r])`,
-// :496) and starts from an eigenvalue order this build cannot reproduce; the cost is evaluated at the
-// roots here, and at t = infinity as the method prescribes.
+// Two deliberate deviations from the reference, both listed in DESIGN.md (parity notes): its candidate loop evaluates
+// the cost at the loop INDEX (`S(r)` instead of `S(R[r])`, :496) and starts from an eigenvalue order this build cannot
+// reproduce; here the cost is evaluated at the real roots R[r] themselves.  Like the reference, the asymptotic
+// candidate t -> infinity of the method (cost 1/m^2 + c^2 / (a^2 + n^2 c^2)) is NOT examined, and nothing is
+// corrected when the polynomial has no real root.
 inline void triangulate(Matrix3f F, vec2& A, vec2& B) {
     Matrix3f TA = Matrix3f::Identity(), TB = Matrix3f::Identity();
     TA(0, 2) = -A.x; TA(1, 2) = -A.y;

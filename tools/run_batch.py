@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--triangles", type=int, default=12000)
     ap.add_argument("--backend", default=None)
     ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses GPU 0")
+    ap.add_argument("--split-directions", action="store_true",
+                    help="one DIRECTION per GPU instead of one pair per GPU: direction d of pair k runs on rank (2k + d) mod N -- "
+                         "with N = 4 and 2 pairs this is the '2 pairs x 2 directions' substitute for splitting one pair over 4 GPUs")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -40,11 +43,16 @@ def main():
     records = []
     t_all = time.perf_counter()
     busy = 0.0
-    for k in range(rank, args.pairs, world):
+    for k in range(args.pairs):
+        mine = [d for d in (0, 1) if ((2 * k + d) % world == rank if args.split_directions else k % world == rank)]
+        if not mine:
+            continue
         A, pts, tris, he, ratio = synth.workload(W, H, args.triangles, seed=4000 + k)
         B = synth.displaced_raster(A)
         ctxs = []
         for d, (src, dst) in enumerate(((A, B), (B, A))):  # direction 0: T(A) against raster B; 1: T(B) against raster A
+            if d not in mine:
+                continue
             c = capi.Context(gpu, W, H)
             c.set_image(capi.IMAGE_A, src)
             c.set_image(capi.IMAGE_B, dst)
@@ -65,7 +73,7 @@ def main():
         busy += dt
         e1 = [int(c.retrieve(capi.BUF_TENERGY)[: args.triangles].astype(np.int64).sum()) for c in ctxs]
         moved = [float(np.abs(c.retrieve(capi.BUF_POINTS) - pts).max()) for c in ctxs]
-        records.append(dict(pair=k, rank=rank, seconds=dt, energy_before=e0, energy_after=e1, max_vertex_shift=moved))
+        records.append(dict(pair=k, rank=rank, directions=mine, seconds=dt, energy_before=e0, energy_after=e1, max_vertex_shift=moved))
         for c in ctxs:
             c.close()
     wall = time.perf_counter() - t_all
@@ -76,11 +84,12 @@ def main():
     else:
         gathered = [dict(records=records, busy=busy, wall=wall)]
     if rank == 0:
-        recs = sorted((r for g in gathered for r in g["records"]), key=lambda r: r["pair"])
+        recs = sorted((r for g in gathered for r in g["records"]), key=lambda r: (r["pair"], r["directions"]))
         slowest = max(g["busy"] for g in gathered)
         work = args.pairs * 2 * args.triangles * args.iters
         print(json.dumps(dict(config="%d pairs of %dx%d, %d triangles, %d warp grad-iters per direction" % (args.pairs, W, H, args.triangles, args.iters),
-                              n_gpus=world, triangles_iters_per_s=work / slowest, seconds_iterating_slowest_rank=slowest,
+                              n_gpus=world, mapping="one direction per GPU" if args.split_directions else "one pair (both directions) per GPU",
+                              triangles_iters_per_s=work / slowest, seconds_iterating_slowest_rank=slowest,
                               seconds_wall_incl_setup_slowest_rank=max(g["wall"] for g in gathered), pairs=recs)))
     if dist is not None:
         dist.destroy_process_group()

@@ -184,6 +184,17 @@ int main(int argc, char** argv) {
         int ver = 0;
         ncclGetVersion(&ver);
         std::cout << "RCCL self exchange OK (" << msg.size() * 4 << " bytes, library version " << ver << ")" << std::endl;
+        // what one hand-over costs when nothing else is in the way: grouped send + recv of a seam-sized message that is
+        // already on the device, stream synchronised (a lower bound for a second GPU across xGMI)
+        for (size_t words : {(size_t)16, (size_t)16384, (size_t)475000}) {
+            t.reserve(words);
+            for (int k = 0; k < 20; k++) t.swap_device(words, words);
+            const auto t0 = std::chrono::steady_clock::now();
+            const int reps = 200;
+            for (int k = 0; k < reps; k++) t.swap_device(words, words);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+            std::cout << "RCCL grouped send+recv to self, " << words * 4 << " bytes: " << us << " us per exchange" << std::endl;
+        }
         return 0;
 #else
         die("built without RCCL");
