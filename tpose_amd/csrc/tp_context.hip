@@ -205,7 +205,7 @@ int check_slot(tp_context* c, int slot) {
 
 // make the next k_bin rebuild the work lists (host side: upload, changed dp / RATIO, piecewise API)
 hipError_t force_rebin(tp_context* c) {
-    hipError_t e = hipMemsetAsync(c->tilecount, 0, sizeof(int) * (size_t)c->tiles_x * c->tiles_y, c->stream);
+    hipError_t e = hipMemsetAsync(c->tilecount, 0, sizeof(int) * TP_COUNT_STRIDE * (size_t)c->tiles_x * c->tiles_y, c->stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(&c->state->visit_total, 0, sizeof(uint32_t), c->stream);
     if (e != hipSuccess) return e;
@@ -353,7 +353,7 @@ int tp_create(int device, int width, int height, tp_context** out) {
     c->Wp = c->tiles_x * TP_TILE_W; c->Hp = c->tiles_y * TP_TILE_H;
     c->ratio = (float)width / (float)height;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = dev_alloc(&c->tilecount, (size_t)c->tiles_x * c->tiles_y);
+    if (e == hipSuccess) e = dev_alloc(&c->tilecount, TP_COUNT_STRIDE * (size_t)c->tiles_x * c->tiles_y);
     if (e == hipSuccess) e = dev_alloc(&c->state, 1);
     if (e == hipSuccess) e = hipMemset(c->state, 0, sizeof(tp_device_state));
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);

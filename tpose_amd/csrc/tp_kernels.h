@@ -12,6 +12,7 @@
                               n_odd, r, g, b, q + n_odd over its counted rows (<= 16 rows x 128 columns: < 2^29), the
                               number of the sweep that wrote it (a record is valid for that sweep only), 0 */
 #define TP_T2_WORDS 5      /* int64 per static-table entry: n_odd, sum r, sum g, sum b, q */
+#define TP_COUNT_STRIDE 32  /* ints between per-tile list counters: atomics on one memory line serialise, whatever the word */
 
 // device-side flag bits (tp_device_state::flags)
 #define TP_FLAG_LIST_OVERFLOW 1u
@@ -49,7 +50,7 @@ struct tp_launch {
     int64_t* line_static;   // [NE][TP_NLINES][TP_T2_WORDS] static part of the line sums: everything left of the tile
                             // column in each of the line's rows (differences of t2 per column run)
     // work lists
-    int* tilecount;           // [tiles]
+    int* tilecount;           // [tiles][TP_COUNT_STRIDE] entries per tile (word 0 of a 128-byte line of its own)
     int4* tilelist;           // [tiles * list_cap][2] 32-byte entries, LIVE lines only: the line's 24.40 walker (x at row ra, step
                               // per row), its rows (ra, rb) inside the raster, its record = visit * 9 + version, 0
     int list_cap;

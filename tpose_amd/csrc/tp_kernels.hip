@@ -127,6 +127,8 @@ void tp_launch_static_table(uint8_t* img, int pitch, int W, int H, int Hp, int t
 #define BIN_THREADS 256
 #define BIN_EDGES 16
 #define BIN_VISITS 1024  // visits per pass of the LDS table (more: further passes)
+#define BIN_HASH_LOG 11
+#define BIN_HASH (1 << BIN_HASH_LOG)
 #define BIN_TROWS 8      // tile rows per line with precomputed column ranges (longer lines: tested per visit)
 
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
     __shared__ int s_lr[BIN_EDGES][TP_NLINES][2];
     __shared__ uint16_t s_rng[BIN_EDGES][TP_NLINES][BIN_TROWS];  // first | last << 8 tile column of the line in tile row ty_line0 + k
     __shared__ int s_vis[BIN_VISITS];    // (edge of the block << 27) | tile
+    __shared__ int h_key[BIN_HASH], h_cnt[BIN_HASH], h_base[BIN_HASH];  // the block's visits grouped by tile
     const int tid = threadIdx.x;
     const uint32_t rebin_word = L.state->rebin_req;  // consumed late: the loads below do not wait for it
     if (blockIdx.x == 0 && tid == 0) L.state->sweep++;  // records of this sweep carry its number (single writer)
@@ -269,50 +272,68 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
                 for (int tx = tx0; tx <= tx1; tx++, k++)
                     if (k >= 0 && k < BIN_VISITS) s_vis[k] = (j << 27) | (ty * L.tiles_x + tx);
             }
+            for (int i = tid; i < BIN_HASH; i += BIN_THREADS) { h_key[i] = -1; h_cnt[i] = 0; }
             __syncthreads();
             TP_STAMP(0, 3);
-            // ---- pass B: a lane per visit
+            // ---- pass B: a lane per visit.  The block first groups its visits by tile in an LDS hash table, so that
+            // every distinct tile costs ONE returning global atomic per block (visits of neighbouring edges share tiles:
+            // the atomics are fewer and far less contended), then every visit writes its entries.
             const int nv = min(total - v0, BIN_VISITS);
-            for (int t = tid; t < nv || (t == tid && !static_done); t += BIN_THREADS) {
-                uint32_t mask = 0;
-                int tile = 0, jj = 0, visit = 0, pos = 0;
-                if (t < nv) {
-                    const int w = s_vis[t];
-                    jj = w >> 27; tile = w & 0x7ffffff;
-                    visit = (int)base + v0 + t;
-                    const int ty = tile / L.tiles_x, tx = tile - ty * L.tiles_x;
-                    {
+            uint32_t vmask[BIN_VISITS / BIN_THREADS];
+            int vslot[BIN_VISITS / BIN_THREADS], vrank[BIN_VISITS / BIN_THREADS];
 #pragma unroll
-                        for (int l = 0; l < TP_NLINES; l++) {
-                            const int ra = s_lr[jj][l][0], rb = s_lr[jj][l][1];
-                            const int k = ty - ra / TH;  // which of the line's tile rows
-                            bool live = ra <= rb && k >= 0 && ty * TH <= rb;
-                            if (live) {
-                                if (k < BIN_TROWS) {
-                                    const uint32_t r = s_rng[jj][l][k];
-                                    live = tx >= (int)(r & 0xffu) && tx <= (int)(r >> 8);
-                                } else {  // a long line (coarse mesh): tested here
-                                    tp_line ll; ll.x = s_lx[jj][l][0]; ll.s = s_lx[jj][l][1]; ll.ra = ra; ll.rb = rb;
-                                    const int col0 = tx * TW;
-                                    live = tp_line_live(ll, ty * TH, min(ty * TH + TH - 1, L.vw.H - 1), col0,
-                                                        tx == L.tiles_x - 1 ? L.vw.W - col0 + 1 : TW, L.vw.W);
-                                }
+            for (int r = 0; r < BIN_VISITS / BIN_THREADS; r++) {
+                const int t = tid + r * BIN_THREADS;
+                uint32_t mask = 0;
+                vslot[r] = 0; vrank[r] = 0;
+                if (t < nv) {
+                    const int w = s_vis[t], jj = w >> 27, tile = w & 0x7ffffff;
+                    const int ty = tile / L.tiles_x, tx = tile - ty * L.tiles_x;
+#pragma unroll
+                    for (int l = 0; l < TP_NLINES; l++) {
+                        const int ra = s_lr[jj][l][0], rb = s_lr[jj][l][1];
+                        const int k = ty - ra / TH;  // which of the line's tile rows
+                        bool live = ra <= rb && k >= 0 && ty * TH <= rb;
+                        if (live) {
+                            if (k < BIN_TROWS) {
+                                const uint32_t rg = s_rng[jj][l][k];
+                                live = tx >= (int)(rg & 0xffu) && tx <= (int)(rg >> 8);
+                            } else {  // a long line (coarse mesh): tested here
+                                tp_line ll; ll.x = s_lx[jj][l][0]; ll.s = s_lx[jj][l][1]; ll.ra = ra; ll.rb = rb;
+                                const int col0 = tx * TW;
+                                live = tp_line_live(ll, ty * TH, min(ty * TH + TH - 1, L.vw.H - 1), col0,
+                                                    tx == L.tiles_x - 1 ? L.vw.W - col0 + 1 : TW, L.vw.W);
                             }
-                            mask |= live ? 1u << l : 0u;
                         }
+                        mask |= live ? 1u << l : 0u;
                     }
-#if defined(TPOSE_ABLATE) && (TPOSE_ABLATE & 256)  // timing experiment: no returning atomic
-                    pos = (visit & 15) * 9;
-#else
-                    if (mask) pos = atomicAdd(&L.tilecount[tile], (int)__builtin_popcount(mask));
-#endif
+                    if (mask) {
+                        int hs = (int)(((uint32_t)tile * 2654435761u) >> (32 - BIN_HASH_LOG));
+                        while (true) {  // open addressing: at most BIN_VISITS distinct keys for twice as many slots
+                            const int old = atomicCAS(&h_key[hs], -1, tile);
+                            if (old == -1 || old == tile) break;
+                            hs = (hs + 1) & (BIN_HASH - 1);
+                        }
+                        vslot[r] = hs;
+                        vrank[r] = atomicAdd(&h_cnt[hs], (int)__builtin_popcount(mask));
+                    }
                 }
-                if (!static_done) { static_first_half(); static_done = true; }  // VALU + loads beside the atomic in flight
+                vmask[r] = mask;
+            }
+            __syncthreads();
+            for (int i = tid; i < BIN_HASH; i += BIN_THREADS)
+                if (h_key[i] >= 0) h_base[i] = atomicAdd(&L.tilecount[(size_t)h_key[i] * TP_COUNT_STRIDE], h_cnt[i]);
+            if (!static_done) { static_first_half(); static_done = true; }  // arithmetic and loads beside the atomics in flight
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < BIN_VISITS / BIN_THREADS; r++) {
+                const int t = tid + r * BIN_THREADS;
+                const uint32_t mask = vmask[r];
                 if (mask == 0) continue;
+                const int w = s_vis[t], jj = w >> 27, tile = w & 0x7ffffff;
+                const int visit = (int)base + v0 + t;
+                int pos = h_base[vslot[r]] + vrank[r];
                 uint4* dst = reinterpret_cast<uint4*>(L.tilelist + (size_t)tile * L.list_cap * 2);
-#if defined(TPOSE_ABLATE) && (TPOSE_ABLATE & 512)  // timing experiment: no entries
-                if (pos == 0x7fffffff)
-#endif
 #pragma unroll
                 for (int l = 0; l < TP_NLINES; l++)
                     if ((mask >> l) & 1u) {
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
         const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
         const uint4* src = reinterpret_cast<const uint4*>(L.img + (size_t)(ty * TH + prow) * L.pitch + (size_t)(tx * TW + seg * 8) * 4);
         f.px[0] = src[0]; f.px[1] = src[1];
-        f.nlist = min(L.tilecount[tile], L.list_cap);
+        f.nlist = min(L.tilecount[(size_t)tile * TP_COUNT_STRIDE], L.list_cap);
     };
     int tile = xcd * chunk + slot;
     if (tile >= tile_end) return;
@@ -782,16 +803,10 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
     const uint32_t sweep = L.state->sweep;
     TP_STAMP(2, 0);
     // one variant: signed sum of three parked line sums -> outputs; returns the energy
-    auto variant = [&](int h, int m, const int64_t* Sout, const int64_t* Sin, const int64_t* Sopp) -> int32_t {
+    auto variant_at = [&](int h, int m, const int32_t X[3], const int32_t Y[3], const int64_t* Sout, const int64_t* Sin,
+                          const int64_t* Sopp) -> int32_t {
         const int t = h / 3, s = h - 3 * t;
-        const int4 tri = L.tris[t];
-        const int vid[3] = {tri.x, tri.y, tri.z};
-        int32_t X[3], Y[3], c[3];
-#pragma unroll
-        for (int ss = 0; ss < 3; ss++) {
-            const int2 q = L.vpos[(size_t)vid[ss] * 5 + (ss == s ? m : 0)];
-            X[ss] = q.x; Y[ss] = q.y;
-        }
+        int32_t c[3];
         tp_variant_coeffs(X, Y, c);
         const int kn = s == 2 ? 0 : s + 1, kp = s == 0 ? 2 : s - 1;
         const int cs = s == 0 ? c[0] : s == 1 ? c[1] : c[2];
@@ -802,6 +817,18 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
         for (int q = 0; q < TP_W_WORDS; q++) mo[q] = (int64_t)cs * Sout[q] + (int64_t)cp * Sin[q] + (int64_t)cn * Sopp[q];
         const tp_moments mm = {mo[0], mo[1], mo[2], mo[3], mo[4], mo[5]};
         return emit_variant(L, flavour, t, 4 * s + m, mm, false, flags == 0);
+    };
+    auto variant = [&](int h, int m, const int64_t* Sout, const int64_t* Sin, const int64_t* Sopp) -> int32_t {
+        const int t = h / 3, s = h - 3 * t;
+        const int4 tri = L.tris[t];
+        const int vid[3] = {tri.x, tri.y, tri.z};
+        int32_t X[3], Y[3];
+#pragma unroll
+        for (int ss = 0; ss < 3; ss++) {
+            const int2 q = L.vpos[(size_t)vid[ss] * 5 + (ss == s ? m : 0)];
+            X[ss] = q.x; Y[ss] = q.y;
+        }
+        return variant_at(h, m, X, Y, Sout, Sin, Sopp);
     };
     if ((int)blockIdx.x >= L.NP) {
         // base variants: 21 triangles per workgroup, lane (a, k) sums the base line of edge k, lane a combines
@@ -846,7 +873,19 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
         int deg = 1;
         if (!generic) {
             // fast path: lane 4 b + m - 1 sums the line of incident edge b displaced by move m, lane 32 + a the base line
-            // opposite the vertex in incident triangle a; then lane 4 a + m - 1 forms variant (t_a, 4 s_a + m)
+            // opposite the vertex in incident triangle a; then lane 4 a + m - 1 forms variant (t_a, 4 s_a + m).
+            // The variant's three snapped vertices are requested first: they fly beside the records.
+            int32_t VX[3] = {0, 0, 0}, VY[3] = {0, 0, 0};
+            if (comb >= 0) {
+                const int h = comb & 0xfffff, t = h / 3, s = h - 3 * t, m = (lane & 3) + 1;
+                const int4 tri = L.tris[t];
+                const int vid[3] = {tri.x, tri.y, tri.z};
+#pragma unroll
+                for (int ss = 0; ss < 3; ss++) {
+                    const int2 q = L.vpos[(size_t)vid[ss] * 5 + (ss == s ? m : 0)];
+                    VX[ss] = q.x; VY[ss] = q.y;
+                }
+            }
             if (ref >= 0) {
                 int64_t w[TP_W_WORDS];
                 line_sum(L, sweep, ref >> 4, ref & 15, w);
@@ -858,7 +897,7 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
             int32_t e = 0;
             if (comb >= 0) {
                 const int m = (lane & 3) + 1, a = lane >> 2;
-                e = variant(comb & 0xfffff, m, S[4 * ((comb >> 20) & 15) + m - 1], S[4 * ((comb >> 24) & 15) + m - 1], S[32 + a]);
+                e = variant_at(comb & 0xfffff, m, VX, VY, S[4 * ((comb >> 20) & 15) + m - 1], S[4 * ((comb >> 24) & 15) + m - 1], S[32 + a]);
             }
             // central differences: lanes 4a+0/1 hold E(+dx)/E(-dx), 4a+2/3 E(+dy)/E(-dy)
             const uint32_t d = (uint32_t)e - (uint32_t)__shfl_xor(e, 1);
@@ -917,7 +956,7 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
     if (flags) return;  // (uniform) nothing was stepped; the host repairs and replays
     if (tidg == 0) L.state->iters_done++;
     // the work lists are rebuilt every iteration: k_accumulate has consumed them, re-arm them here
-    for (int k = tidg; k < L.tiles_x * L.tiles_y; k += gridDim.x * UPD_THREADS) L.tilecount[k] = 0;
+    for (int k = tidg; k < L.tiles_x * L.tiles_y; k += gridDim.x * UPD_THREADS) L.tilecount[(size_t)k * TP_COUNT_STRIDE] = 0;
     if (tidg == 0) { L.state->visit_total = 0; L.state->rebin_req = 1; L.state->rebin_count++; }
 }
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s) {
