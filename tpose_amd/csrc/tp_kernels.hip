@@ -389,7 +389,15 @@ __device__ __forceinline__ pix3 operator+(pix3 a, pix3 b) { return {a.x + b.x, a
 // lane = (live edge line of the tile's work list, 1/split of the tile's rows) for the walk.
 // ------------------------------------------------------------------------------------------------
 #define WALK_ROWS 4   // rows per unrolled trip of the line walk
-#define ROW_WORDS 387 // 3 * 129
+// LDS prefix table: entry x of a row (x = 0..128, exclusive prefix over the tile's columns) lives at word
+// 3 x + TP_SEG_PAD (x >> 3): pad words after every eight entries, so that the sixteen lanes of a tile row -- each
+// storing eight consecutive entries -- start SEG_WORDS apart and one store instruction spreads over the banks
+// (without padding the lanes are 24 words apart and only four bank groups are hit: 4-way conflicts on every store).
+#ifndef TP_SEG_PAD
+#define TP_SEG_PAD 1
+#endif
+#define SEG_WORDS (24 + TP_SEG_PAD)
+#define ROW_WORDS (16 * SEG_WORDS + 3 + (TP_SEG_PAD == 1 ? 1 : 0))  // pad 1: 404 (20 mod 32); pad 2: 419 (3 mod 32); pad 0: 387
 size_t tp_accumulate_lds_bytes() { return (size_t)(TH * ROW_WORDS + 1) * sizeof(uint32_t); }
 
 
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
             if ((cur.px[0].x ^ cur.px[1].w) == 0x12345u) P[tid] = 1;
 #else
             pix3 run;
-            uint32_t* row = P + prow * ROW_WORDS + seg * 24;
+            uint32_t* row = P + prow * ROW_WORDS + seg * SEG_WORDS;
             {   // everything left of the lane's segment: a DPP scan of the segment totals over the row's 16 lanes
                 pix3 tot = {0, 0, 0};
 #pragma unroll
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
                 row[3 * k] = run.x; row[3 * k + 1] = run.y; row[3 * k + 2] = run.z;
                 run = run + pixel_moments(w);
             }
-            if (seg == 15) { row[24] = run.x; row[25] = run.y; row[26] = run.z; }  // entry 128: the whole row
+            if (seg == 15) { row[SEG_WORDS] = run.x; row[SEG_WORDS + 1] = run.y; row[SEG_WORDS + 2] = run.z; }  // entry 128: the whole row
 #endif
         }
         TP_STAMP(1, 1);
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(ACC_THREADS, 6) void k_accumulate(tp_launch L) {  /
                     wk.x += wk.s;
                     const uint32_t xl = (uint32_t)(x - col0);
                     const bool in = xl < lim && (uint32_t)(c0 + k - koff) < nvalid;
-                    const uint32_t* ep = Pp + k * ROW_WORDS + (in ? __umul24(xl, 3u) : 0u);
+                    const uint32_t* ep = Pp + k * ROW_WORDS + (in ? __umul24(xl, 3u) + (TP_SEG_PAD ? (xl >> 3) * TP_SEG_PAD : 0u) : 0u);
                     entv[k].x = ep[0]; entv[k].y = ep[1]; entv[k].z = ep[2];
                     sx += in ? (uint32_t)x : 0u;
                 }
