@@ -76,6 +76,7 @@ struct tp_context {
     int2* edge_uv = nullptr;
     int* he_edge = nullptr;
     int2* vpos = nullptr;
+    float2* epos = nullptr;       // endpoint positions per edge
     int2* edge_visit = nullptr;
     uint32_t* visits = nullptr;
     int visit_cap = 0;
@@ -152,11 +153,11 @@ void drop_graphs(tp_context* c) {
 void free_triangulation(tp_context* c) {
     hipFree(c->vref); hipFree(c->vvar); c->vref = nullptr; c->vvar = nullptr;
     hipFree(c->points); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
-    hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->edge_visit); hipFree(c->visits);
+    hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->epos); hipFree(c->edge_visit); hipFree(c->visits);
     hipFree(c->line_static); hipFree(c->tilelist); hipFree(c->wline);
     hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
     c->points = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
-    c->edge_uv = nullptr; c->he_edge = nullptr; c->vpos = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
+    c->edge_uv = nullptr; c->he_edge = nullptr; c->vpos = nullptr; c->epos = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
     c->line_static = nullptr; c->tilelist = nullptr; c->capE = 0;
     c->wline = nullptr;
     c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
@@ -176,7 +177,7 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.NT = c->NT; L.NP = c->NP;
     L.vtx_off = c->vtx_off; L.vtx_adj = c->vtx_adj; L.vref = c->vref; L.vvar = c->vvar;
     L.tilecount = c->tilecount; L.tilelist = c->tilelist; L.list_cap = c->list_cap;
-    L.edge_uv = c->edge_uv; L.he_edge = c->he_edge; L.vpos = c->vpos; L.NE = c->NE;
+    L.edge_uv = c->edge_uv; L.he_edge = c->he_edge; L.vpos = c->vpos; L.epos = c->epos; L.NE = c->NE;
     L.edge_visit = c->edge_visit; L.visits = c->visits; L.visit_cap = c->visit_cap;
     L.line_static = c->line_static;
     L.wline = nullptr;
@@ -528,12 +529,14 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         }
     }
     if (NE > c->capE) {
-        hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits);
+        hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->epos);
+        c->epos = nullptr;
         hipFree(c->wline); hipFree(c->line_static);
         c->wline = nullptr; c->line_static = nullptr;
         c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
         const int capE = NE + NE / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->edge_uv, capE));
+        HIP_TRY(c, dev_alloc(&c->epos, (size_t)2 * capE));
         HIP_TRY(c, dev_alloc(&c->edge_visit, capE));
         HIP_TRY(c, dev_alloc(&c->line_static, (size_t)capE * TP_NLINES * TP_T2_WORDS));
         // (edge, tile) visits: typical edges cross a handful of tiles, a few long ones many

@@ -47,6 +47,7 @@ struct tp_launch {
     const int* vref;        // [NP][64] per upload: the line (edge << 4 | version) each lane of k_update sums, -1 none; see k_vertex_refs
     const int* vvar;        // [NP][8]  per upload: per incident triangle 3t + s | out-edge slot << 20 | in-edge slot << 24, -1 none
     int2* vpos;             // [NP][5] snapped 24.8 position of every vertex: unmoved, +dx, -dx, +dy, -dy
+    float2* epos;           // [NE][2] the positions of every edge's two endpoints (kept by whoever moves a vertex)
     int64_t* line_static;   // [NE][TP_NLINES][TP_T2_WORDS] static part of the line sums: everything left of the tile
                             // column in each of the line's rows (differences of t2 per column run)
     // work lists

@@ -153,9 +153,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
     {   // phase 0
         int dX = 0, dY = 0;
         if (e < L.NE) {
-            const int2 uv = L.edge_uv[e];
+            const int2 uv = L.edge_uv[e];  // (only for the vpos stores below: nothing waits for it)
             const int u = uv.x & 0x3fffffff, v = uv.y & 0x3fffffff;
-            const float2 pu = L.points[u], pv = L.points[v];
+            // the endpoints' positions, filed per edge by whoever moved the vertex (k_update, k_shift, upload): one
+            // coalesced load instead of ids -> positions
+            const float4 ep = reinterpret_cast<const float4*>(L.epos)[e];
+            const float2 pu = make_float2(ep.x, ep.y), pv = make_float2(ep.z, ep.w);
             tp_vertex_stage(pu.x, pu.y, 0, 0, L.vw, band.Xa, band.Ya);
             tp_vertex_stage(pv.x, pv.y, 0, 0, L.vw, band.Xb, band.Yb);
             if (q < TP_NLINES) {  // line q: endpoint u displaced by move mu, endpoint v by move mv
@@ -700,6 +703,34 @@ void tp_launch_finalize(const tp_launch& L, int flavour, bool write_moments, hip
     hipLaunchKernelGGL(k_finalize, dim3((n + 255) / 256), dim3(256), 0, s, L, flavour, write_moments ? 1 : 0);
 }
 
+#define UPD_THREADS 64
+#define UPD_CHUNK 7  // generic path: incident triangles per pass, 7 x 9 = 63 lanes
+#define UPD_FAN 8    // fast path: up to eight incident triangles and eight incident edges
+
+// file vertex v's position p with every edge it ends (epos[edge][side]); `lane`, `nlanes`: the lanes sharing the work.
+// Which side is decided by the edge's own endpoint list (an edge of a triangle soup can name the same vertex twice).
+__device__ __forceinline__ void publish_to_edge(const tp_launch& L, int e, int v, float2 p) {
+    const int2 uv = L.edge_uv[e];
+    if ((uv.x & 0x3fffffff) == v) L.epos[(size_t)e * 2] = p;
+    if ((uv.y & 0x3fffffff) == v) L.epos[(size_t)e * 2 + 1] = p;
+}
+__device__ __forceinline__ void publish_position(const tp_launch& L, int v, float2 p, int lane, int nlanes) {
+    const int r0 = L.vref[(size_t)v * 64];
+    if (r0 != -2) {  // fast layout: slot 4 b names incident edge b
+        for (int b = lane; b < UPD_FAN; b += nlanes) {
+            const int r = L.vref[(size_t)v * 64 + 4 * b];
+            if (r >= 0) publish_to_edge(L, r >> 4, v, p);
+        }
+    } else {         // more than eight incident triangles: through the adjacency
+        const int k0 = L.vtx_off[v], deg = L.vtx_off[v + 1] - k0;
+        for (int a = lane; a < deg; a += nlanes) {
+            const int h = L.vtx_adj[k0 + a], t = h / 3, sl = h - 3 * t;
+            publish_to_edge(L, L.he_edge[3 * t + sl] >> 1, v, p);                      // the edge leaving the vertex
+            publish_to_edge(L, L.he_edge[3 * t + (sl == 0 ? 2 : sl - 1)] >> 1, v, p);  // the edge arriving at it
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_shift (tp_shift): gradient.cs gathered per vertex (no atomics) + shift.cs
 // ------------------------------------------------------------------------------------------------
@@ -726,6 +757,7 @@ __global__ __launch_bounds__(256) void k_shift(tp_launch L, float rate) {
     p.x = tp_fsub(p.x, tp_fdiv(tp_fdiv(tp_fmul(rate, tgx), 256.0f), 256.0f));
     p.y = tp_fsub(p.y, tp_fdiv(tp_fdiv(tp_fmul(rate, tgy), 256.0f), 256.0f));
     L.points[gid] = p;
+    publish_position(L, gid, p, 0, 1);
 }
 void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s) {
     hipLaunchKernelGGL(k_shift, dim3((L.NP + 255) / 256), dim3(256), 0, s, L, rate);
@@ -743,9 +775,6 @@ void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s) {
 // gradient: extra workgroups behind the vertices write their outputs, one thread per triangle.
 // Every launch re-arms the work lists for the next k_bin.
 // ------------------------------------------------------------------------------------------------
-#define UPD_THREADS 64
-#define UPD_CHUNK 7  // generic path: incident triangles per pass, 7 x 9 = 63 lanes
-#define UPD_FAN 8    // fast path: up to eight incident triangles and eight incident edges
 
 // line l of nine for the incident (triangle, slot) h = 3t + s of a vertex, packed edge << 4 | version:
 // l = 0: the opposite edge's base line; 1..4: the edge leaving the vertex, vertex displaced by move l;
@@ -796,8 +825,14 @@ __global__ void k_vertex_refs(tp_launch L, int* vref, int* vvar) {
     for (int b = 0; b < ne; b++)
         for (int m = 1; m <= 4; m++) r[4 * b + m - 1] = (edges[b] << 4) | (flips[b] ? 4 + m : m);
 }
+// per upload, after k_vertex_refs: every vertex files its position with its edges
+__global__ void k_publish_positions(tp_launch L) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < L.NP) publish_position(L, v, L.points[v], 0, 1);
+}
 void tp_launch_vertex_refs(const tp_launch& L, int* vref, int* vvar, hipStream_t s) {
     hipLaunchKernelGGL(k_vertex_refs, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L, vref, vvar);
+    hipLaunchKernelGGL(k_publish_positions, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L);
 }
 
 __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour, float rate) {
@@ -944,6 +979,8 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
         }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { gx += (uint32_t)__shfl_xor((int)gx, o); gy += (uint32_t)__shfl_xor((int)gy, o); }
+        float2 newp = make_float2(0.0f, 0.0f);
+        int moved = 0;
         if (lane == 0 && flags == 0) {
             if (deg > 0) L.gr[v] = make_int2((int)gx, (int)gy);  // vertices no triangle uses: the gradient is never touched
             if (v >= 4) {  // shift.cs:20 -- the four corners never move
@@ -957,8 +994,11 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
                     y = tp_fsub(y, tp_fdiv(tp_fdiv(tp_fmul(rate, tgy), 256.0f), 256.0f));
                 }
                 L.points[v] = make_float2(x, y);
+                newp = make_float2(x, y); moved = 1;
             }
         }
+        // the new position goes to every edge the vertex ends (k_bin reads endpoints by edge)
+        if (__shfl(moved, 0)) publish_position(L, v, make_float2(__shfl(newp.x, 0), __shfl(newp.y, 0)), lane, UPD_THREADS);
     }
     TP_STAMP(2, 3);
     if (flags) return;  // (uniform) nothing was stepped; the host repairs and replays
