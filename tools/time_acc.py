@@ -8,6 +8,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("TPOSE_TIME_ACC_TORCH"):  # rocprofv3 --kernel-trace only survives this script with torch's runtime loaded first
+    import torch  # noqa: F401
 from tpose_amd import capi, synth  # noqa: E402
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 2048

@@ -131,7 +131,7 @@ void tp_launch_static_table(uint8_t* img, int pitch, int W, int H, int Hp, int t
 #define BIN_HASH (1 << BIN_HASH_LOG)
 #define BIN_TROWS 8      // tile rows per line with precomputed column ranges (longer lines: tested per visit)
 
-__global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
+__global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L, int epb) {  // epb: edges per workgroup, 16 or (coarse meshes) 1
     __shared__ int s_cnt[BIN_EDGES];     // visits per edge
     __shared__ int s_first[BIN_EDGES];   // exclusive scan
     __shared__ int s_total;
@@ -141,11 +141,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
     __shared__ uint16_t s_rng[BIN_EDGES][TP_NLINES][BIN_TROWS];  // first | last << 8 tile column of the line in tile row ty_line0 + k
     __shared__ int s_vis[BIN_VISITS];    // (edge of the block << 27) | tile
     __shared__ int h_key[BIN_HASH], h_cnt[BIN_HASH], h_base[BIN_HASH];  // the block's visits grouped by tile
+    __shared__ unsigned long long s_st[TP_NLINES][TP_T2_WORDS];         // coarse meshes: static sums gathered from 16 chunks per line
     const int tid = threadIdx.x;
     const uint32_t rebin_word = L.state->rebin_req;  // consumed late: the loads below do not wait for it
     if (blockIdx.x == 0 && tid == 0) L.state->sweep++;  // records of this sweep carry its number (single writer)
     const int j = tid >> 4, q = tid & 15;
-    const int e = blockIdx.x * BIN_EDGES + j;
+    const int e = j < epb ? blockIdx.x * epb + j : L.NE;  // coarse meshes: one edge per workgroup, the other rows help
     tp_band band = {0, 0, 0, 0, 0, 0};
     tp_line ln; ln.x = 0; ln.s = 0; ln.ra = 1; ln.rb = 0;
     const bool owner = e < L.NE && q < TP_NLINES;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
             __syncthreads();
             for (int i = tid; i < BIN_HASH; i += BIN_THREADS)
                 if (h_key[i] >= 0) h_base[i] = atomicAdd(&L.tilecount[(size_t)h_key[i] * TP_COUNT_STRIDE], h_cnt[i]);
-            if (!static_done) { static_first_half(); static_done = true; }  // arithmetic and loads beside the atomics in flight
+            if (!static_done && epb != 1) { static_first_half(); static_done = true; }  // arithmetic and loads beside the atomics in flight
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < BIN_VISITS / BIN_THREADS; r++) {
@@ -353,6 +354,44 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
         }
     }
     // ---- static part of the line sums, second half
+    if (epb == 1) {
+        // Coarse meshes: a line crosses many tile columns (a run and a bisection per column).  The workgroup has one
+        // edge: 16 lanes per line take a sixteenth of the line's rows each -- a sub-line with the same walker -- and
+        // their partial sums meet in LDS.
+        if (tid < TP_NLINES * TP_T2_WORDS) s_st[tid / TP_T2_WORDS][tid % TP_T2_WORDS] = 0ull;
+        __syncthreads();  // (also: the lines of phase 0 are in LDS)
+        const int l = tid >> 4, c = tid & 15;
+        if (l < TP_NLINES && blockIdx.x < (unsigned)L.NE) {
+            tp_line whole; whole.x = s_lx[0][l][0]; whole.s = s_lx[0][l][1]; whole.ra = s_lr[0][l][0]; whole.rb = s_lr[0][l][1];
+            const int rows = whole.rb - whole.ra + 1;
+            if (rows > 0) {
+                tp_line sub = whole;
+                sub.ra = whole.ra + (int)(((long long)rows * c) >> 4);
+                sub.rb = whole.ra + (int)(((long long)rows * (c + 1)) >> 4) - 1;
+                sub.x = whole.x + (int64_t)(sub.ra - whole.ra) * whole.s;
+                int64_t part[TP_T2_WORDS] = {0, 0, 0, 0, 0};
+                const int64_t* t2 = L.t2;
+                const int tx1 = L.tiles_x + 1;
+                tp_line_column_runs(sub, L.vw.W, TW, L.tiles_x, [&](int32_t tc, int32_t ra, int32_t rb) {
+                    if (tc == 0) return;
+                    const int64_t* a = t2 + ((size_t)ra * tx1 + tc) * TP_T2_WORDS;
+                    const int64_t* b = t2 + ((size_t)(rb + 1) * tx1 + tc) * TP_T2_WORDS;
+#pragma unroll
+                    for (int k = 0; k < TP_T2_WORDS; k++) part[k] += b[k] - a[k];
+                });
+#pragma unroll
+                for (int k = 0; k < TP_T2_WORDS; k++) atomicAdd(&s_st[l][k], (unsigned long long)part[k]);
+            }
+        }
+        __syncthreads();
+        if (owner) {
+            const size_t li = (size_t)e * TP_NLINES + q;
+#pragma unroll
+            for (int k = 0; k < TP_T2_WORDS; k++) L.line_static[li * TP_T2_WORDS + k] = (int64_t)s_st[q][k];
+        }
+        TP_STAMP(0, 4);
+        return;
+    }
     if (!static_done) static_first_half();
     if (owner) {
 #pragma unroll
@@ -368,7 +407,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(tp_launch L) {
 }
 
 void tp_launch_bin(const tp_launch& L, hipStream_t s) {
-    hipLaunchKernelGGL(k_bin, dim3((unsigned)((L.NE + BIN_EDGES - 1) / BIN_EDGES)), dim3(BIN_THREADS), 0, s, L);
+    // coarse meshes on large rasters (long edges, hundreds of tiles each): one edge per workgroup
+    const int epb = tp_coarse_mesh(L) ? 1 : BIN_EDGES;
+    hipLaunchKernelGGL(k_bin, dim3((unsigned)((L.NE + epb - 1) / epb)), dim3(BIN_THREADS), 0, s, L, epb);
 }
 
 // LDS prefix entry (12 bytes), per row exclusive prefix over the tile's 128 columns, 16-bit fields packed in pairs:
