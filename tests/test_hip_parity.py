@@ -210,9 +210,7 @@ def test_work_list_reuse_never_changes_results(margin):
     assert np.array_equal(ctx.retrieve(capi.BUF_TENERGY), ref["ten"])
     assert np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
     moved = np.abs(ref["points"] - pts).max() * H / 2
-    rebuilds = ctx.info(6)
     assert moved > 3.0, moved                      # the test really moves vertices
-    assert rebuilds >= 39                          # rebuilt every iteration
     ctx.close()
 
 

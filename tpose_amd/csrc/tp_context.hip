@@ -47,7 +47,7 @@ struct graph_entry {
 
 struct tp_context {
     int device = 0;
-    int W = 0, H = 0, Wp = 0, Hp = 0;
+    int W = 0, H = 0;
     float ratio = 1.0f;
     hipStream_t stream = nullptr;
     std::string error;
@@ -58,53 +58,35 @@ struct tp_context {
     // triangulation
     int NT = 0, NP = 0, capT = 0, capP = 0;
     float2* points = nullptr;
-    int margin_px = 0;  // tp_set_margin: accepted, no effect since round 2 (lists are rebuilt every iteration)
-    float lists_dp = -1.0f, lists_ratio = -1.0f;  // geometry parameters the current work lists were built for
+    int margin_px = 0;  // tp_set_margin: accepted, no effect since round 2
     int4* tris = nullptr;
     int4* colors = nullptr;
     int* vtx_off = nullptr;
     int* vtx_adj = nullptr;
     int* vref = nullptr;   // per-upload reference tables of k_update
     int* vvar = nullptr;
-    // work lists
-    int tiles_x = 0, tiles_y = 0;
-    int* tilecount = nullptr;
-    int4* tilelist = nullptr;     // 2 x int4 per entry
-    size_t tilelist_elems = 0;
-    int list_cap = 0;
     int NE = 0, capE = 0;
     int2* edge_uv = nullptr;
     int* he_edge = nullptr;
     int2* vpos = nullptr;
     float2* epos = nullptr;       // endpoint positions per edge
-    int2* edge_visit = nullptr;
-    uint32_t* visits = nullptr;
-    int visit_cap = 0;
-    int64_t* line_static = nullptr;
-    int64_t* wline = nullptr;      // whole line sums, coarse meshes only (allocated on first use)
-    int64_t* t2[2] = {nullptr, nullptr};   // static per-image tables
-    uint32_t* seg_scratch = nullptr;
-    tp_device_state* state = nullptr;
+    int64_t* wline = nullptr;      // whole line sums [capE][9][6] (k_lines)
+    int lanes_per_line = 1;        // k_lines: lanes per line, from the mean number of rows of an edge at upload
+    uint4* prefix[2] = {nullptr, nullptr};   // per-image row prefix tables
+    int prefix_pitch = 0;
     // outputs
     int32_t* ten = nullptr;
     int32_t* cn = nullptr;
     int4* ca = nullptr;
     int2* gr = nullptr;
     int64_t* moments = nullptr;
-    unsigned long long* gacc = nullptr;
 
     bool uploaded = false, accumulated = false, energized = false, have_colors = false;
     int acc_slot = 0, acc_flavour = 0;
     float dp_override = 0.0f;  // <= 0: reference law
     int last_flavour = 0;
     uint64_t generation = 1;
-    uint32_t sweeps = 0;  // k_bin launches so far == tp_device_state::sweep once the stream has drained
     std::vector<graph_entry> graphs;
-    // fused iterations enqueued since the last successful check of the device flags: when a work list
-    // overflowed, k_update stopped stepping; the host grows the lists and replays what is missing
-    struct segment { tp_params p; int n; };
-    std::vector<segment> pending;
-    uint32_t done_base = 0;  // tp_device_state::iters_done when pending[0] started
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t* pinned = nullptr;   // host-pinned staging for readbacks (one synchronisation per batch)
     size_t pinned_bytes = 0;
@@ -153,40 +135,30 @@ void drop_graphs(tp_context* c) {
 void free_triangulation(tp_context* c) {
     hipFree(c->vref); hipFree(c->vvar); c->vref = nullptr; c->vvar = nullptr;
     hipFree(c->points); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
-    hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->epos); hipFree(c->edge_visit); hipFree(c->visits);
-    hipFree(c->line_static); hipFree(c->tilelist); hipFree(c->wline);
-    hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments); hipFree(c->gacc);
+    hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->epos); hipFree(c->wline);
+    hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments);
     c->points = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
-    c->edge_uv = nullptr; c->he_edge = nullptr; c->vpos = nullptr; c->epos = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
-    c->line_static = nullptr; c->tilelist = nullptr; c->capE = 0;
-    c->wline = nullptr;
-    c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr; c->gacc = nullptr;
-    c->capT = c->capP = 0;
+    c->edge_uv = nullptr; c->he_edge = nullptr; c->vpos = nullptr; c->epos = nullptr; c->wline = nullptr;
+    c->ten = nullptr; c->cn = nullptr; c->ca = nullptr; c->gr = nullptr; c->moments = nullptr;
+    c->capT = c->capP = c->capE = 0;
 }
 
 tp_launch make_launch(const tp_context* c, int slot, float dp) {
     tp_launch L{};
     L.img = c->img[slot];
-    L.pitch = c->Wp * 4;
+    L.pitch = c->W * 4;
+    L.prefix = c->prefix[slot]; L.prefix_pitch = c->prefix_pitch;
     L.vw.dp = dp; L.vw.ratio = c->ratio;
     L.vw.halfW = 0.5f * (float)c->W; L.vw.halfH = 0.5f * (float)c->H;
     L.vw.W = c->W; L.vw.H = c->H;
-    L.tiles_x = c->tiles_x; L.tiles_y = c->tiles_y;
     L.points = c->points;
     L.tris = c->tris; L.colors = c->colors;
     L.NT = c->NT; L.NP = c->NP;
     L.vtx_off = c->vtx_off; L.vtx_adj = c->vtx_adj; L.vref = c->vref; L.vvar = c->vvar;
-    L.tilecount = c->tilecount; L.tilelist = c->tilelist; L.list_cap = c->list_cap;
     L.edge_uv = c->edge_uv; L.he_edge = c->he_edge; L.vpos = c->vpos; L.epos = c->epos; L.NE = c->NE;
-    L.edge_visit = c->edge_visit; L.visits = c->visits; L.visit_cap = c->visit_cap;
-    L.line_static = c->line_static;
-    L.wline = nullptr;
-    if (tp_coarse_mesh(L)) L.wline = c->wline;  // hundreds of tiles per edge: k_linesum sums the records of a line once
-    L.t2 = c->t2[slot];
-    L.state = c->state;
+    L.wline = c->wline; L.lanes_per_line = c->lanes_per_line;
     L.ten = c->ten; L.cn = c->cn; L.ca = c->ca; L.gr = c->gr; L.moments = c->moments;
-    L.gacc = c->gacc;
-#ifdef TPOSE_DEBUG  // debug flavour of the library (tools/acc_timeline.py): per-block phase timestamps
+#ifdef TPOSE_DEBUG  // debug flavour of the library (tools/kernel_timeline.py): per-block phase timestamps
     static unsigned long long* dbgbuf = nullptr;
     if (!dbgbuf) { hipMalloc((void**)&dbgbuf, 3 * 4096 * 8 * sizeof(unsigned long long)); hipMemset(dbgbuf, 0, 3 * 4096 * 8 * 8); }
     L.dbg = dbgbuf;
@@ -204,119 +176,14 @@ int check_slot(tp_context* c, int slot) {
     return TP_OK;
 }
 
-// make the next k_bin rebuild the work lists (host side: upload, changed dp / RATIO, piecewise API)
-hipError_t force_rebin(tp_context* c) {
-    hipError_t e = hipMemsetAsync(c->tilecount, 0, sizeof(int) * TP_COUNT_STRIDE * (size_t)c->tiles_x * c->tiles_y, c->stream);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(&c->state->visit_total, 0, sizeof(uint32_t), c->stream);
-    if (e != hipSuccess) return e;
-    return hipMemsetD32Async((hipDeviceptr_t)&c->state->rebin_req, 1, 1, c->stream);
-}
-
-// Every k_bin launch starts a sweep and numbers it (records carry the number of the sweep that wrote them).  Long
-// before the 32-bit number could come round again, the records are wiped and the count restarts.
-hipError_t count_sweeps(tp_context* c, uint32_t n) {
-    if (c->sweeps > (1u << 30)) {
-        hipError_t e = hipMemsetAsync(c->visits, 0, (size_t)c->visit_cap * TP_NLINES * TP_REC_DWORDS * sizeof(uint32_t), c->stream);
-        if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)&c->state->sweep, 0, 1, c->stream);
-        if (e != hipSuccess) return e;
-        c->sweeps = 0;
-    }
-    c->sweeps += n;
-    return hipSuccess;
-}
-
 // enqueue one grad-iter on the context stream (no sync)
 void enqueue_iter(tp_context* c, const tp_params& p, float dp) {
     tp_launch L = make_launch(c, p.image_slot, dp);
-    tp_launch_bin(L, c->stream);  // vertex stage + line table; rebuilds the work lists when requested
-    tp_launch_accumulate(L, c->stream);
-    if (L.wline) tp_launch_linesum(L, c->stream);
-    tp_launch_update(L, p.flavour, p.rate, c->stream);  // line sums + finalize + gradient + shift; re-arms the lists
+    tp_launch_lines(L, c->stream);                       // vertex stage + the nine line sums of every edge
+    tp_launch_update(L, p.flavour, p.rate, c->stream);  // variants + gradient + shift
 }
 
 int enqueue_iters(tp_context* c, const tp_params* p, int n_iters);
-
-// grow whichever work list overflowed (flags: TP_FLAG_*); false when nothing can grow any further.  The new
-// buffer is allocated BEFORE the old one is released: when the allocation fails the context keeps its old lists
-// and capacities (and stays usable); graphs are dropped whenever an address changed.
-bool grow_lists(tp_context* c, uint32_t flags, hipError_t* err) {
-    const int ntiles = c->tiles_x * c->tiles_y;
-    bool grown = false;
-    *err = hipSuccess;
-    if (flags & TP_FLAG_VISIT_OVERFLOW) {
-        const size_t limit = (size_t)1 << 24;  // 4.8 GB of records
-        if ((size_t)c->visit_cap < limit) {
-            size_t vcap = (size_t)c->visit_cap * 2;
-            if (vcap > limit) vcap = limit;
-            uint32_t* fresh = nullptr;
-            if ((*err = dev_alloc(&fresh, vcap * TP_NLINES * TP_REC_DWORDS)) == hipSuccess &&
-                (*err = hipMemset(fresh, 0, vcap * TP_NLINES * TP_REC_DWORDS * sizeof(uint32_t))) == hipSuccess) {  // no record carries a sweep number yet
-                hipFree(c->visits);
-                c->visits = fresh;
-                c->visit_cap = (int)vcap;
-                grown = true;
-            } else
-                hipFree(fresh);
-        }
-    }
-    if (*err == hipSuccess && (flags & TP_FLAG_LIST_OVERFLOW)) {
-        if (c->list_cap < c->capE * TP_NLINES) {  // a tile never holds more than one entry per line
-            size_t cap = (size_t)c->list_cap * 2;
-            if (cap > (size_t)c->capE * TP_NLINES) cap = (size_t)c->capE * TP_NLINES;
-            int4* fresh = nullptr;
-            if ((*err = dev_alloc(&fresh, 2 * cap * ntiles)) == hipSuccess) {
-                hipFree(c->tilelist);
-                c->tilelist = fresh;
-                c->tilelist_elems = cap * ntiles;
-                c->list_cap = (int)cap;
-                grown = true;
-            }
-        }
-    }
-    if (grown) { c->generation++; drop_graphs(c); }  // captured graphs bake addresses and capacities
-    return grown && *err == hipSuccess;
-}
-
-// Reads the device flags (the stream must be idle).  A work-list overflow is repaired here: k_update
-// does not step while a flag is up, so the triangulation is still the one of the last good
-// iteration; the lists are grown and the missing iterations replayed -- the caller never sees it,
-// unless the lists cannot grow any further (TP_ERR_CAPACITY).
-int check_flags(tp_context* c) {
-    for (int round = 0; round < 40; round++) {
-        tp_device_state st{};
-        HIP_TRY(c, hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
-        if (!st.flags) {
-            c->pending.clear();
-            c->done_base = st.iters_done;
-            return TP_OK;
-        }
-        hipError_t err = hipSuccess;
-        if (!grow_lists(c, st.flags, &err)) {
-            c->pending.clear();
-            c->done_base = st.iters_done;
-            if (err != hipSuccess) return fail(c, TP_ERR_HIP, "growing the work lists: %s", hipGetErrorString(err));
-            return fail(c, TP_ERR_CAPACITY, "device work list overflow (flags=%u, list_cap=%d, visit_cap=%d)",
-                        st.flags, c->list_cap, c->visit_cap);
-        }
-        uint32_t done = st.iters_done - c->done_base;
-        std::vector<tp_context::segment> todo;
-        for (auto& sg : c->pending) {
-            const uint32_t skip = done < (uint32_t)sg.n ? done : (uint32_t)sg.n;
-            done -= skip;
-            if ((uint32_t)sg.n > skip) todo.push_back({sg.p, sg.n - (int)skip});
-        }
-        c->pending.clear();
-        c->done_base = st.iters_done;
-        const uint32_t zero = 0;
-        HIP_TRY(c, hipMemcpy(&c->state->flags, &zero, sizeof zero, hipMemcpyHostToDevice));
-        c->lists_dp = -1.0f;  // rebuild the lists
-        for (auto& sg : todo)
-            if (int rc = enqueue_iters(c, &sg.p, sg.n)) return rc;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    return fail(c, TP_ERR_CAPACITY, "device work lists keep overflowing");
-}
 
 }  // namespace
 
@@ -349,17 +216,11 @@ int tp_create(int device, int width, int height, tp_context** out) {
     HIP_TRY(nullptr, hipSetDevice(device));
     tp_context* c = new tp_context();
     c->device = device; c->W = width; c->H = height;
-    c->tiles_x = (width + TP_TILE_W - 1) / TP_TILE_W;
-    c->tiles_y = (height + TP_TILE_H - 1) / TP_TILE_H;
-    c->Wp = c->tiles_x * TP_TILE_W; c->Hp = c->tiles_y * TP_TILE_H;
+    c->prefix_pitch = (width + 1 + 7) & ~7;
     c->ratio = (float)width / (float)height;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = dev_alloc(&c->tilecount, TP_COUNT_STRIDE * (size_t)c->tiles_x * c->tiles_y);
-    if (e == hipSuccess) e = dev_alloc(&c->state, 1);
-    if (e == hipSuccess) e = hipMemset(c->state, 0, sizeof(tp_device_state));
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = tp_kernels_init();
     if (e != hipSuccess) {
         int rc = fail(nullptr, TP_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
         tp_destroy(c);
@@ -376,8 +237,7 @@ int tp_destroy(tp_context* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     drop_graphs(c);
     free_triangulation(c);
-    hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->tilecount); hipFree(c->state);
-    hipFree(c->t2[0]); hipFree(c->t2[1]); hipFree(c->seg_scratch);
+    hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->prefix[0]); hipFree(c->prefix[1]);
     hipFree(c->render_pic); hipFree(c->render_pts);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->up_pinned) hipHostFree(c->up_pinned);
@@ -424,17 +284,11 @@ static int set_image_common(tp_context* c, int slot, const void* src, size_t str
     if (!src) return fail(c, TP_ERR_INVALID, "image pointer is NULL");
     if (stride < (size_t)c->W * 4) return fail(c, TP_ERR_INVALID, "stride %zu < 4*width", stride);
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->img[slot]) {
-        // padded plane: whole tiles, zero filled, so the accumulate kernel needs no bounds checks
-        HIP_TRY(c, dev_alloc(&c->img[slot], (size_t)c->Wp * c->Hp * 4));
-        HIP_TRY(c, hipMemsetAsync(c->img[slot], 0, (size_t)c->Wp * c->Hp * 4, c->stream));
-    }
-    HIP_TRY(c, hipMemcpy2DAsync(c->img[slot], (size_t)c->Wp * 4, src, stride, (size_t)c->W * 4, c->H, kind, c->stream));
-    // static table of this image: moments of everything above a row and left of a tile column
-    if (!c->t2[slot]) HIP_TRY(c, dev_alloc(&c->t2[slot], (size_t)(c->H + 1) * (c->tiles_x + 1) * TP_T2_WORDS));
-    if (!c->seg_scratch) HIP_TRY(c, dev_alloc(&c->seg_scratch, (size_t)c->H * c->tiles_x * 5));
-    // (the alpha bytes of the context's copy are replaced by the pixel parity: the sweep, like the reference, never reads alpha)
-    tp_launch_static_table(c->img[slot], c->Wp * 4, c->W, c->H, c->Hp, c->tiles_x, c->seg_scratch, c->t2[slot], c->stream);
+    if (!c->img[slot]) HIP_TRY(c, dev_alloc(&c->img[slot], (size_t)c->W * c->H * 4));
+    HIP_TRY(c, hipMemcpy2DAsync(c->img[slot], (size_t)c->W * 4, src, stride, (size_t)c->W * 4, c->H, kind, c->stream));
+    // row prefix table of this image (16 bytes per pixel): what the line sums read, iteration after iteration
+    if (!c->prefix[slot]) HIP_TRY(c, dev_alloc(&c->prefix[slot], (size_t)c->H * c->prefix_pitch));
+    tp_launch_prefix_table(c->img[slot], c->W * 4, c->W, c->H, c->prefix_pitch, c->prefix[slot], c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_img[slot] = true;
@@ -466,13 +320,11 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
 
-    const int ntiles = c->tiles_x * c->tiles_y;
     if (NT > c->capT || NP > c->capP) {
         free_triangulation(c);
         const int capT = NT + NT / 2 + 64, capP = NP + NP / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->points, capP));
         HIP_TRY(c, dev_alloc(&c->gr, capP));
-        HIP_TRY(c, dev_alloc(&c->gacc, (size_t)2 * capP));
         HIP_TRY(c, dev_alloc(&c->vtx_off, capP + 1));
         HIP_TRY(c, dev_alloc(&c->vref, (size_t)capP * 64));
         HIP_TRY(c, dev_alloc(&c->vvar, (size_t)capP * 8));
@@ -490,7 +342,6 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         HIP_TRY(c, hipMemset(c->cn, 0, sizeof(int32_t) * 13 * (size_t)capT));
         HIP_TRY(c, hipMemset(c->gr, 0, sizeof(int2) * (size_t)capP));
         c->capT = capT; c->capP = capP;
-        c->tilelist_elems = 0;
     }
     // undirected edges: every half-edge (o -> d) maps to the edge {min, max} and a direction bit.  Flat
     // open-addressing table kept in the context (uploads follow every topology update of the schedule).
@@ -529,42 +380,27 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         }
     }
     if (NE > c->capE) {
-        hipFree(c->edge_uv); hipFree(c->edge_visit); hipFree(c->visits); hipFree(c->epos);
-        c->epos = nullptr;
-        hipFree(c->wline); hipFree(c->line_static);
-        c->wline = nullptr; c->line_static = nullptr;
-        c->edge_uv = nullptr; c->edge_visit = nullptr; c->visits = nullptr;
+        hipFree(c->edge_uv); hipFree(c->epos); hipFree(c->wline);
+        c->edge_uv = nullptr; c->epos = nullptr; c->wline = nullptr;
         const int capE = NE + NE / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->edge_uv, capE));
         HIP_TRY(c, dev_alloc(&c->epos, (size_t)2 * capE));
-        HIP_TRY(c, dev_alloc(&c->edge_visit, capE));
-        HIP_TRY(c, dev_alloc(&c->line_static, (size_t)capE * TP_NLINES * TP_T2_WORDS));
-        // (edge, tile) visits: typical edges cross a handful of tiles, a few long ones many
-        size_t vcap = (size_t)capE * 24 + (size_t)ntiles * 8;
-        if (vcap > ((size_t)1 << 24)) vcap = (size_t)1 << 24;
-        HIP_TRY(c, dev_alloc(&c->visits, vcap * TP_NLINES * TP_REC_DWORDS));
-        HIP_TRY(c, hipMemsetAsync(c->visits, 0, vcap * TP_NLINES * TP_REC_DWORDS * sizeof(uint32_t), c->stream));  // no record carries a sweep number yet
-        c->visit_cap = (int)vcap;
+        HIP_TRY(c, dev_alloc(&c->wline, (size_t)capE * TP_NLINES * TP_W_WORDS));
         c->capE = capE;
-        c->tilelist_elems = 0;
     }
     c->NE = NE;
-    if ((long long)ntiles > 4LL * NE && !c->wline)  // coarse mesh (tp_coarse_mesh): whole line sums by k_linesum
-        HIP_TRY(c, dev_alloc(&c->wline, (size_t)c->capE * TP_NLINES * TP_W_WORDS));
-    // per-tile list capacity in (live line) entries: never more than 9 NE; a generous multiple of the mean otherwise
-    // (about 40 live lines per edge over all tiles at 16-row tiles); grows on demand (grow_lists)
+    // lanes per line of k_lines: about eight rows per lane at the mean height of an edge (a speed hint only)
     {
-        size_t mean = ((size_t)c->capE * 40) / (size_t)ntiles + 64;
-        size_t cap = mean * 4;
-        if (cap < 512) cap = 512;
-        if (cap > (size_t)c->capE * TP_NLINES) cap = (size_t)c->capE * TP_NLINES;
-        if (cap * ntiles > c->tilelist_elems) {
-            hipFree(c->tilelist); c->tilelist = nullptr;
-            HIP_TRY(c, dev_alloc(&c->tilelist, 2 * cap * ntiles));
-            c->tilelist_elems = cap * ntiles;
+        double rows = 0.0;
+        for (int e = 0; e < NE; e++) {
+            const int u = edge_uv[(size_t)2 * e] & 0x3fffffff, v = edge_uv[(size_t)2 * e + 1] & 0x3fffffff;
+            const double dy = (double)points[2 * (size_t)u + 1] - (double)points[2 * (size_t)v + 1];
+            rows += dy < 0 ? -dy : dy;
         }
-        c->list_cap = (int)(c->tilelist_elems / ntiles);
-        if ((size_t)c->list_cap > (size_t)c->capE * TP_NLINES) c->list_cap = c->capE * TP_NLINES;
+        rows = rows * 0.5 * (double)c->H / (double)(NE > 0 ? NE : 1);
+        int lpl = 1;
+        while (lpl < 64 && rows > 8.0 * lpl) lpl <<= 1;
+        c->lanes_per_line = lpl;
     }
 
     // vertex -> outgoing half-edge ids (3t+s), the gather form of gradient.cs' scatter
@@ -616,12 +452,6 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         tp_launch_replicate_colors(L, c->stream);
         HIP_TRY(c, hipGetLastError());
     }
-    HIP_TRY(c, hipMemsetAsync(c->state, 0, sizeof(tp_device_state), c->stream));
-    // ... except the sweep number: records of earlier triangulations must stay recognisably old
-    HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)&c->state->sweep, (int)c->sweeps, 1, c->stream));
-    c->pending.clear(); c->done_base = 0;
-    c->lists_dp = -1.0f;  // forces a rebuild of the work lists at the next use
-    HIP_TRY(c, hipMemsetAsync(c->gacc, 0, sizeof(unsigned long long) * 2 * (size_t)c->capP, c->stream));
     c->generation++;  // captured graphs bake NT, NP, dp and buffer addresses
     c->uploaded = true; c->accumulated = c->energized = false;
     return TP_OK;
@@ -634,42 +464,9 @@ int tp_accumulate(tp_context* c, int flavour, int slot) {
     if (!c->uploaded) return fail(c, TP_ERR_STATE, "accumulate before upload");
     if (int rc = check_slot(c, slot)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    // fused iterations still in flight settle first (and are replayed if a work list overflowed)
-    if (!c->pending.empty()) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (int rc = check_flags(c)) return rc;
-    }
-    for (int round = 0;; round++) {
-        tp_launch L = make_launch(c, slot, resolve_dp(c, flavour, c->dp_override));
-        HIP_TRY(c, force_rebin(c));  // the piecewise API rebuilds the work lists on every sweep
-        HIP_TRY(c, count_sweeps(c, 1));
-        c->lists_dp = L.vw.dp; c->lists_ratio = c->ratio;
-        tp_launch_bin(L, c->stream);
-        tp_launch_accumulate(L, c->stream);
-        if (L.wline) tp_launch_linesum(L, c->stream);
-        HIP_TRY(c, hipGetLastError());
-        // a sweep over overflowed work lists is incomplete: grow them and sweep again (the flag word rides the
-        // stream into pinned memory: one wait)
-        if (c->pinned_bytes < 256) {
-            if (c->pinned) hipHostFree(c->pinned);
-            c->pinned = nullptr; c->pinned_bytes = 0;
-            HIP_TRY(c, hipHostMalloc((void**)&c->pinned, 1 << 20, hipHostMallocDefault));
-            c->pinned_bytes = 1 << 20;
-        }
-        HIP_TRY(c, hipMemcpyAsync(c->pinned, &c->state->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        uint32_t flags = 0;
-        memcpy(&flags, c->pinned, sizeof flags);
-        if (!flags) break;
-        hipError_t err = hipSuccess;
-        if (round >= 40 || !grow_lists(c, flags, &err)) {
-            if (err != hipSuccess) return fail(c, TP_ERR_HIP, "growing the work lists: %s", hipGetErrorString(err));
-            return fail(c, TP_ERR_CAPACITY, "device work list overflow (flags=%u, list_cap=%d, visit_cap=%d)",
-                        flags, c->list_cap, c->visit_cap);
-        }
-        const uint32_t zero = 0;
-        HIP_TRY(c, hipMemcpy(&c->state->flags, &zero, sizeof zero, hipMemcpyHostToDevice));
-    }
+    tp_launch L = make_launch(c, slot, resolve_dp(c, flavour, c->dp_override));
+    tp_launch_lines(L, c->stream);
+    HIP_TRY(c, hipGetLastError());
     c->acc_slot = slot; c->acc_flavour = flavour;
     c->accumulated = true; c->energized = false;
     return TP_OK;
@@ -698,7 +495,6 @@ int tp_shift(tp_context* c, float rate) {
     tp_launch_shift(L, rate, c->stream);
     HIP_TRY(c, hipGetLastError());
     c->accumulated = c->energized = false;  // geometry moved
-    c->lists_dp = -1.0f;  // ... without the margin vote of the fused update: the next fused iteration rebuilds the work lists
     return TP_OK;
 }
 
@@ -762,11 +558,6 @@ int chunk_graph(tp_context* c, const tp_params* p, float dp, graph_entry** out) 
 int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
     const float dp = resolve_dp(c, p->flavour, p->dp);
 
-    if (c->lists_dp != dp || c->lists_ratio != c->ratio) {
-        HIP_TRY(c, force_rebin(c));
-        c->lists_dp = dp; c->lists_ratio = c->ratio;
-    }
-    HIP_TRY(c, count_sweeps(c, (uint32_t)n_iters));
     int left = n_iters;
     if (left >= CHUNK) {
         graph_entry* g = nullptr;
@@ -780,8 +571,6 @@ int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
     HIP_TRY(c, hipGetLastError());
     c->acc_slot = p->image_slot; c->last_flavour = p->flavour;
     c->accumulated = c->energized = false;
-    if (!c->pending.empty() && memcmp(&c->pending.back().p, p, sizeof *p) == 0) c->pending.back().n += n_iters;
-    else c->pending.push_back({*p, n_iters});
     return TP_OK;
 }
 }  // namespace
@@ -813,25 +602,17 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
     if (int rc = validate_params(c, p, n_iters)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     const float dp = resolve_dp(c, p->flavour, p->dp);
-    if (c->lists_dp != dp || c->lists_ratio != c->ratio) {
-        HIP_TRY(c, force_rebin(c));
-        c->lists_dp = dp; c->lists_ratio = c->ratio;
-    }
-    // Eager launches enqueued back to back (no host sync in between); every accumulate dispatch
+    // Eager launches enqueued back to back (no host sync in between); every k_lines dispatch
     // carries its own begin/end timestamps in an event pair.  (Timed launches record nothing when
     // captured into a hipGraph, so the fused path itself cannot be bracketed; the same kernel inside
     // a graph replay runs ~1-2 us shorter -- see profiles/.)
     std::vector<hipEvent_t> ev((size_t)2 * n_iters);
     for (auto& e : ev) HIP_TRY(c, hipEventCreate(&e));
-    HIP_TRY(c, count_sweeps(c, (uint32_t)n_iters));
     for (int k = 0; k < n_iters; k++) {
         tp_launch L = make_launch(c, p->image_slot, dp);
-        tp_launch_bin(L, c->stream);
-        tp_launch_accumulate_timed(L, c->stream, ev[2 * k], ev[2 * k + 1]);
-        if (L.wline) tp_launch_linesum(L, c->stream);
+        tp_launch_lines(L, c->stream, ev[2 * k], ev[2 * k + 1]);
         tp_launch_update(L, p->flavour, p->rate, c->stream);
     }
-    c->pending.push_back({*p, n_iters});
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     double total_ms = 0.0;
     for (int k = 0; k < n_iters; k++) {
@@ -842,7 +623,7 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
     for (auto& e : ev) hipEventDestroy(e);
     *accumulate_us = n_iters ? total_ms * 1000.0 / n_iters : 0.0;
     c->accumulated = c->energized = false;
-    return check_flags(c);
+    return TP_OK;
 }
 
 int tp_profile_accumulate(tp_context* c, const tp_params* p, int launches, double* accumulate_us) {
@@ -852,15 +633,10 @@ int tp_profile_accumulate(tp_context* c, const tp_params* p, int launches, doubl
     if (launches < 1) return fail(c, TP_ERR_INVALID, "launches < 1");
     if (int rc = tp_synchronize(c)) return rc;
     const float dp = resolve_dp(c, p->flavour, p->dp);
-    HIP_TRY(c, force_rebin(c));
-    c->lists_dp = dp; c->lists_ratio = c->ratio;
     tp_launch L = make_launch(c, p->image_slot, dp);
-    HIP_TRY(c, count_sweeps(c, 1));
-    tp_launch_bin(L, c->stream);  // work lists of the current state; every accumulate launch below consumes the same ones
-    HIP_TRY(c, hipGetLastError());
     hipGraphExec_t exec = nullptr;
     hipError_t err;
-    if (int rc = capture_graph(c, [&] { for (int k = 0; k < launches; k++) tp_launch_accumulate(L, c->stream); }, &exec)) return rc;
+    if (int rc = capture_graph(c, [&] { for (int k = 0; k < launches; k++) tp_launch_lines(L, c->stream); }, &exec)) return rc;
     if (!c->ev0) { HIP_TRY(c, hipEventCreate(&c->ev0)); HIP_TRY(c, hipEventCreate(&c->ev1)); }
     float ms = 0.0f;
     err = hipGraphLaunch(exec, c->stream);  // warm-up replay
@@ -872,9 +648,8 @@ int tp_profile_accumulate(tp_context* c, const tp_params* p, int launches, doubl
     hipGraphExecDestroy(exec);
     if (err != hipSuccess) return fail(c, TP_ERR_HIP, "profile_accumulate: %s", hipGetErrorString(err));
     *accumulate_us = (double)ms * 1000.0 / launches;
-    // the lists stay valid for the unchanged positions (k_accumulate consumed the rebuild request)
     c->accumulated = c->energized = false;
-    return check_flags(c);
+    return TP_OK;
 }
 
 int tp_synchronize(tp_context* c) {
@@ -882,8 +657,7 @@ int tp_synchronize(tp_context* c) {
     if (!c) return TP_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // only fused iterations can leave an overflow flag behind (tp_accumulate settles its own)
-    return c->pending.empty() ? TP_OK : check_flags(c);
+    return TP_OK;
 }
 
 namespace {
@@ -921,8 +695,6 @@ int tp_retrieve_many(tp_context* c, int n, const int* what, void* const* dst, co
     if (n < 0 || (n && (!what || !dst || !count))) return fail(c, TP_ERR_INVALID, "retrieve: bad arguments");
     if (!c->uploaded) return fail(c, TP_ERR_STATE, "retrieve before upload");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->pending.empty())  // fused iterations outstanding: settle them (and replay after an overflow) first
-        if (int rc = tp_synchronize(c)) return rc;
     std::vector<const void*> src(n);
     std::vector<size_t> bytes(n), off(n);
     size_t total = 0;
@@ -1041,20 +813,9 @@ int tp_get_info(tp_context* c, int what, int64_t* value) {
     api_guard api_lock;
     if (!c || !value) return TP_ERR_INVALID;
     switch (what) {
-        case 0: *value = c->tiles_x; return TP_OK;
-        case 1: *value = c->tiles_y; return TP_OK;
-        case 2: *value = TP_TILE_W; return TP_OK;
-        case 3: *value = TP_TILE_H; return TP_OK;
-        case 4:
-        case 5:
-        case 6: {
-            HIP_TRY(c, hipSetDevice(c->device));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            tp_device_state st{};
-            HIP_TRY(c, hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
-            *value = what == 4 ? st.visit_total : what == 5 ? st.flags : st.rebin_count;
-            return TP_OK;
-        }
+        case 0: *value = c->prefix_pitch; return TP_OK;
+        case 1: *value = c->lanes_per_line; return TP_OK;
+        case 2: case 3: case 4: case 5: case 6: *value = 0; return TP_OK;  // (work-list statistics of earlier rounds)
         default: return fail(c, TP_ERR_INVALID, "unknown info %d", what);
     }
 }
