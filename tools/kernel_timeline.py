@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""In-kernel timelines of the three kernels of a grad-iter at the headline workload.  Uses the DEBUG flavour of the
+"""In-kernel timelines of the two kernels of a fused grad-iter at the headline workload.  Uses the DEBUG flavour of the
 library (built here with -DTPOSE_DEBUG into tpose_amd/variants/; the product library has no such hooks): thread 0 of
 every workgroup stamps the 100 MHz wall clock at its phase boundaries.  Needs an MI355X.  Prints one JSON object:
 per kernel, when workgroups start / reach each stamp / end, in microseconds after the kernel's first stamp."""
@@ -33,8 +33,7 @@ ctx.synchronize()
 lib = ctx.lib
 lib.tp_debug_dump.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 NB = 4096
-names = {0: ("k_bin", ["start", "phase 0 done", "visit ids", "table filled", "end"]),
-         1: ("k_accumulate", ["start", "prefix stored", "barrier", "end"]),
+names = {0: ("k_lines", ["start", "lines set up", "rows walked", "end"]),
          2: ("k_update", ["start", "line sums", "variants", "end"])}
 runs = []
 for rep in range(24):

@@ -5,6 +5,10 @@
 #include "../../include/tpose_hip.h"
 #include "tp_kernels.h"
 
+#ifndef TP_LINES_ROWS
+#define TP_LINES_ROWS 8  /* k_lines: rows per lane the number of groups per edge aims for */
+#endif
+
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -216,7 +220,7 @@ int tp_create(int device, int width, int height, tp_context** out) {
     HIP_TRY(nullptr, hipSetDevice(device));
     tp_context* c = new tp_context();
     c->device = device; c->W = width; c->H = height;
-    c->prefix_pitch = (width + 1 + 7) & ~7;
+    c->prefix_pitch = tp_prefix_pitch(width);
     c->ratio = (float)width / (float)height;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
@@ -287,7 +291,7 @@ static int set_image_common(tp_context* c, int slot, const void* src, size_t str
     if (!c->img[slot]) HIP_TRY(c, dev_alloc(&c->img[slot], (size_t)c->W * c->H * 4));
     HIP_TRY(c, hipMemcpy2DAsync(c->img[slot], (size_t)c->W * 4, src, stride, (size_t)c->W * 4, c->H, kind, c->stream));
     // row prefix table of this image (16 bytes per pixel): what the line sums read, iteration after iteration
-    if (!c->prefix[slot]) HIP_TRY(c, dev_alloc(&c->prefix[slot], (size_t)c->H * c->prefix_pitch));
+    if (!c->prefix[slot]) HIP_TRY(c, dev_alloc(&c->prefix[slot], (size_t)c->H * c->prefix_pitch * 2));
     tp_launch_prefix_table(c->img[slot], c->W * 4, c->W, c->H, c->prefix_pitch, c->prefix[slot], c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -399,7 +403,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         }
         rows = rows * 0.5 * (double)c->H / (double)(NE > 0 ? NE : 1);
         int lpl = 1;
-        while (lpl < 64 && rows > 8.0 * lpl) lpl <<= 1;
+        while (lpl < 64 && rows > (double)TP_LINES_ROWS * lpl) lpl <<= 1;
         c->lanes_per_line = lpl;
     }
 

@@ -11,8 +11,8 @@ struct tp_launch {
     // raster
     const uint8_t* img;   // RGBA8 plane (tp_render only)
     int pitch;            // bytes per row of img
-    const uint4* prefix;  // row prefix table of the swept image: [H][prefix_pitch] packed entries (k_prefix)
-    int prefix_pitch;     // entries per row: W + 1 rounded up to a multiple of 8 (rows start on 128-byte lines)
+    const uint4* prefix;  // row prefix table of the swept image: [H][prefix_pitch] 32-byte records (tp_raster.h), two uint4 each
+    int prefix_pitch;     // records per row (tp_prefix_pitch)
     tp_view vw;
     // triangulation
     float2* points;
@@ -46,7 +46,7 @@ void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s);
 void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s);
 void tp_launch_vertex_refs(const tp_launch& L, int* vref, int* vvar, hipStream_t s);  // once per upload
 void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s);
-// per-image row prefix table: P[row][c], c = 0..W = packed moments of the pixels x < c of the row
+// per-image row prefix table (tp_raster.h, "Per-image row prefix table")
 void tp_launch_prefix_table(const uint8_t* img, int pitch, int W, int H, int prefix_pitch, uint4* P, hipStream_t s);
 void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s);
 void tp_launch_selftest_line(const int4* ends, const int* H, int n, int rows, int32_t* out, hipStream_t s);

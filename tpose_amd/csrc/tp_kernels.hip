@@ -29,30 +29,25 @@
 #endif
 
 // ------------------------------------------------------------------------------------------------
-// Per-image row prefix table (built once per tp_set_image).  Entry c of a row, c = 0..W, packs the
-// moments of the pixels x < c:   .x = sum r (22 bits) | n_odd bits 0..9 << 22,   .y = sum g | n_odd bits
-// 10..14 << 22,   .z = sum b,   .w = sum (r^2 + g^2 + b^2)     (W <= 16384: 255 W < 2^22, 3 * 255^2 W < 2^32;
-// n_odd counts the pixels with r + g + b odd).
+// Per-image row prefix table (built once per tp_set_image): layout and arithmetic in tp_raster.h.
 // ------------------------------------------------------------------------------------------------
-static_assert(TP_MAX_RASTER <= 16384, "packing of the prefix table entries");
+static_assert(TP_MAX_RASTER <= 16384, "packing of the prefix table records");
 
-__device__ __forceinline__ uint4 prefix_pack(const uint32_t m[5]) {  // m: n_odd, r, g, b, q
-    return make_uint4(m[1] | (m[0] << 22), m[2] | ((m[0] >> 10) << 22), m[3], m[4]);
-}
 __device__ __forceinline__ void px_moments5(uint32_t rgba, uint32_t m[5]) {
     const uint32_t r = rgba & 0xffu, g = (rgba >> 8) & 0xffu, b = (rgba >> 16) & 0xffu;
     m[0] += (r + g + b) & 1u; m[1] += r; m[2] += g; m[3] += b; m[4] += r * r + g * g + b * b;
 }
 
-// one 256-thread workgroup per row; thread t owns the pixels [t C, (t + 1) C), C = ceil(W / 256)
+// one 256-thread workgroup per row; thread t owns the groups [t C, (t + 1) C), C = ceil(groups / 256)
 __global__ __launch_bounds__(256) void k_prefix(const uint8_t* img, int pitch, int W, int prefix_pitch, uint4* P) {
     __shared__ uint32_t wave_total[4][5];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int C = (W + 255) / 256;
-    const int c0 = min(W, tid * C), c1 = min(W, c0 + C);
+    const int NG = tp_prefix_groups(W);
+    const int C = (NG + 255) / 256;
+    const int g0 = min(NG, tid * C), g1 = min(NG, g0 + C);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(img + (size_t)row * pitch);
     uint32_t own[5] = {0, 0, 0, 0, 0};
-    for (int c = c0; c < c1; c++) px_moments5(src[c], own);
+    for (int c = 4 * g0; c < min(W, 4 * g1); c++) px_moments5(src[c], own);
     uint32_t inc[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -73,11 +68,15 @@ __global__ __launch_bounds__(256) void k_prefix(const uint8_t* img, int pitch, i
         for (int w = 0; w < wave; w++) before += wave_total[w][k];
         run[k] = before + inc[k] - own[k];
     }
-    uint4* dst = P + (size_t)row * prefix_pitch;
-    if (tid == 0) dst[0] = make_uint4(0, 0, 0, 0);
-    for (int c = c0; c < c1; c++) {
-        px_moments5(src[c], run);
-        dst[c + 1] = prefix_pack(run);
+    uint4* dst = P + (size_t)row * prefix_pitch * 2;
+    for (int g = g0; g < g1; g++) {
+        uint32_t px[4] = {0, 0, 0, 0}, rec[TP_PFX_WORDS];
+        const int npx = min(4, W - 4 * g);
+        for (int i = 0; i < npx; i++) px[i] = src[4 * g + i];
+        tp_prefix_pack(run, px, npx, rec);
+        dst[2 * g] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+        dst[2 * g + 1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+        for (int i = 0; i < npx; i++) px_moments5(px[i], run);
     }
 }
 void tp_launch_prefix_table(const uint8_t* img, int pitch, int W, int H, int prefix_pitch, uint4* P, hipStream_t s) {
@@ -85,89 +84,143 @@ void tp_launch_prefix_table(const uint8_t* img, int pitch, int W, int H, int pre
 }
 
 // ------------------------------------------------------------------------------------------------
-// Line sums.  W(line) = sum over the line's rows of the prefix entry at the crossing column: six values
+// Line sums.  W(line) = sum over the line's rows of the row prefix at the crossing column: six values
 // {sum x, n_odd, sum r, sum g, sum b, q}.
 // ------------------------------------------------------------------------------------------------
 struct line_acc {
     uint32_t xs, nodd;     // <= rows * W < 2^28
     uint64_t r, g, b, q;
 };
-__device__ __forceinline__ void acc_entry(line_acc& a, const uint4 d) {
-    a.nodd += (d.x >> 22) | ((d.y >> 22) << 10);
-    a.r += d.x & 0x3fffffu; a.g += d.y & 0x3fffffu; a.b += d.z; a.q += d.w;
+__device__ __forceinline__ void acc_entry(line_acc& a, int c, const uint4 d0, const uint4 d1) {
+    const uint32_t rec[TP_PFX_WORDS] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    uint32_t nodd, r, g, b, q;
+    tp_prefix_eval(rec, c, nodd, r, g, b, q);
+    a.nodd += nodd; a.r += r; a.g += g; a.b += b; a.q += q;
 }
-#define LINE_BATCH 8  // table entries requested together by one lane
+#ifndef LINE_BATCH
+#define LINE_BATCH 4  // table records requested together by one lane (58 VGPRs: every workgroup of a launch is resident at once)
+#endif
 
-// rows first, first + stride, ... <= ln.rb of the line: LINE_BATCH independent loads in flight per trip
-__device__ __forceinline__ void walk_rows(const tp_launch& L, const tp_line& ln, int first, int stride, line_acc& a) {
-    const uint4* P = L.prefix;
-    const int W = L.vw.W;
-    for (int r0 = first; r0 <= ln.rb; r0 += LINE_BATCH * stride) {
-        uint4 d[LINE_BATCH];
-#pragma unroll
-        for (int u = 0; u < LINE_BATCH; u++) {
-            const int r = r0 + u * stride;
-            const bool on = r <= ln.rb;
-            const int x = on ? tp_line_col(ln, r, W) : 0;
-            a.xs += (uint32_t)x;
-            // (entry 0 of a row is all zero: rows past the end add nothing)
-            d[u] = P[(size_t)(on ? r : ln.ra) * L.prefix_pitch + x];
+// k_lines.  A workgroup takes `eb` edges (seven: 63 lines, one lane short of a wave; or one, for coarse meshes whose
+// lines have hundreds of rows).  Wave 0 sets every line up ONCE, lane per line, and parks the walkers in LDS.  Then
+// thread (l, c) -- line l = tid mod LP, chunk c = tid / LP of TL -- takes the rows rmin + c, rmin + c + TL, ... of the
+// band the nine lines of its edge cover: the nine lines of an edge sit in adjacent lanes ON THE SAME ROW, and their
+// crossing columns lie within a few pixels of each other (the moves are small), so their table entries share a
+// cache line or two.  Chunks meet in LDS.
+struct lds_line { int64_t x, s; int32_t ra, rb; };
+#ifndef TP_LINES_LP_SHIFT
+#define TP_LINES_LP_SHIFT 5  // fine meshes: 32 lanes per chunk = the 27 lines of three edges (6: 64 lanes, seven edges -- fewer, larger workgroups: slower)
+#endif
+#define LINES_EB (((1 << TP_LINES_LP_SHIFT) / TP_NLINES))
+#ifndef TP_LINES_WAVES_PER_EU
+#define TP_LINES_WAVES_PER_EU 4
+#endif
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TP_LINES_WAVES_PER_EU))) void k_lines(tp_launch L, int eb, int lp_shift) {
+    __shared__ lds_line s_ln[64];
+    __shared__ int s_rmin[LINES_EB], s_rmax[LINES_EB];
+    __shared__ unsigned long long S[64][TP_W_WORDS];
+    const int tid = threadIdx.x;
+    const int TL = (int)blockDim.x >> lp_shift;
+    const int tl_log = 31 - __clz(TL);
+#ifndef TP_NO_XCD_MAP
+    // workgroup b runs on XCD b mod 8 (each with its own L2): give every XCD one contiguous run of edges -- neighbouring
+    // edges read neighbouring table lines
+    const int per = (int)gridDim.x >> 3;  // (the grid is padded to a multiple of 8)
+    const int blk = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (blk * eb >= L.NE) return;  // (uniform per workgroup)
+#else
+    const int blk = blockIdx.x;
+#endif
+    TP_STAMP(0, 0);
+    if (tid < 64) {  // (one wave: LDS keeps its program order)
+        const int j = tid / TP_NLINES, q = tid - j * TP_NLINES;
+        const int e = blk * eb + j;
+        const bool on = j < eb && e < L.NE;
+        if (tid < LINES_EB) { s_rmin[tid] = 0x3fffffff; s_rmax[tid] = -1; }
+        tp_line ln; ln.x = 0; ln.s = 0; ln.ra = 1; ln.rb = 0;
+        if (on) {
+            const int2 uv = L.edge_uv[e];
+            const float4 ep = reinterpret_cast<const float4*>(L.epos)[e];
+            // line q: endpoint u displaced by move mu, endpoint v by move mv
+            const int mu = (q >= 1 && q <= 4) ? q : 0, mv = q >= 5 ? q - 4 : 0;
+            int32_t Xa, Ya, Xb, Yb;
+            tp_vertex_stage(ep.x, ep.y, mu, 0, L.vw, Xa, Ya);
+            tp_vertex_stage(ep.z, ep.w, mv, 0, L.vw, Xb, Yb);
+            tp_setup_line(Xa, Ya, Xb, Yb, L.vw.H, ln);
+            // one edge per vertex publishes its snapped positions (k_finalize reads them)
+            if (mv == 0 && ((uv.x >> 30) & 1)) L.vpos[(size_t)(uv.x & 0x3fffffff) * 5 + mu] = make_int2(Xa, Ya);
+            if (mu == 0 && ((uv.y >> 30) & 1)) L.vpos[(size_t)(uv.y & 0x3fffffff) * 5 + mv] = make_int2(Xb, Yb);
+            if (ln.ra <= ln.rb) { atomicMin(&s_rmin[j], ln.ra); atomicMax(&s_rmax[j], ln.rb); }  // (after the initialisation: same wave, LDS keeps program order)
         }
+        s_ln[tid].x = ln.x; s_ln[tid].s = ln.s; s_ln[tid].ra = ln.ra; s_ln[tid].rb = ln.rb;
 #pragma unroll
-        for (int u = 0; u < LINE_BATCH; u++) acc_entry(a, d[u]);
+        for (int k = 0; k < TP_W_WORDS; k++) S[tid][k] = 0ull;
     }
-}
-
-__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int o) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// k_lines: LPL lanes per line (a power of two up to 64, chosen per upload from the mean number of rows of an edge);
-// lane c of a line takes its rows ra + c, ra + c + LPL, ...
-template <int LPL>
-__global__ __launch_bounds__(256) void k_lines(tp_launch L) {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int li = gid / LPL, c = gid - li * LPL;
-    const int e = li / TP_NLINES, q = li - e * TP_NLINES;
-    const bool on = e < L.NE;
-    tp_line ln; ln.x = 0; ln.s = 0; ln.ra = 1; ln.rb = 0;
-    if (on) {
-        const int2 uv = L.edge_uv[e];
-        const float4 ep = reinterpret_cast<const float4*>(L.epos)[e];
-        // line q: endpoint u displaced by move mu, endpoint v by move mv
-        const int mu = (q >= 1 && q <= 4) ? q : 0, mv = q >= 5 ? q - 4 : 0;
-        int32_t Xa, Ya, Xb, Yb;
-        tp_vertex_stage(ep.x, ep.y, mu, 0, L.vw, Xa, Ya);
-        tp_vertex_stage(ep.z, ep.w, mv, 0, L.vw, Xb, Yb);
-        tp_setup_line(Xa, Ya, Xb, Yb, L.vw.H, ln);
-        // one edge per vertex publishes its snapped positions (k_finalize reads them)
-        if (c == 0 && mv == 0 && ((uv.x >> 30) & 1)) L.vpos[(size_t)(uv.x & 0x3fffffff) * 5 + mu] = make_int2(Xa, Ya);
-        if (c == 0 && mu == 0 && ((uv.y >> 30) & 1)) L.vpos[(size_t)(uv.y & 0x3fffffff) * 5 + mv] = make_int2(Xb, Yb);
-    }
+    __syncthreads();
     TP_STAMP(0, 1);
+    const int l = tid & ((1 << lp_shift) - 1), c = tid >> lp_shift;
+    const int j = l / TP_NLINES;
+    const int e = blk * eb + j;
+    const bool on = l < eb * TP_NLINES && e < L.NE;
     line_acc a = {0, 0, 0, 0, 0, 0};
-    walk_rows(L, ln, ln.ra + c, LPL, a);
+    if (on) {
+        const lds_line ln = s_ln[l];
+        // this thread's rows of the line: first, first + TL, ... <= rb, where first is the first row >= ra on the
+        // thread's residue (rmin + c) mod TL of the band
+        const int base = s_rmin[j] + c;
+        const int first = base + ((ln.ra - base + TL - 1) & -TL);  // (ra >= rmin: the numerator is > -TL; TL is a power of two)
+        int n = ln.rb >= first ? ((ln.rb - first) >> tl_log) + 1 : 0;
+        // the walker of the line stepped by TL rows, and the table row pointer likewise
+        int64_t x = ln.x + (int64_t)(first - ln.ra) * ln.s;
+        const int64_t xs = ln.s * TL;
+        const uint4* row = L.prefix + (size_t)(n > 0 ? first : 0) * L.prefix_pitch * 2;
+        const size_t rs = (size_t)TL * L.prefix_pitch * 2;
+        const int W = L.vw.W;
+        for (; n > 0; n -= LINE_BATCH) {
+            uint4 d0[LINE_BATCH], d1[LINE_BATCH];
+            int col[LINE_BATCH];
 #pragma unroll
-    for (int o = 1; o < LPL; o <<= 1) {
-        a.xs += (uint32_t)__shfl_xor((int)a.xs, o); a.nodd += (uint32_t)__shfl_xor((int)a.nodd, o);
-        a.r += shfl_xor64(a.r, o); a.g += shfl_xor64(a.g, o); a.b += shfl_xor64(a.b, o); a.q += shfl_xor64(a.q, o);
-    }
-    if (on && c == 0) {
-        int64_t* w = L.wline + (size_t)li * TP_W_WORDS;
-        w[0] = a.xs; w[1] = a.nodd; w[2] = (int64_t)a.r; w[3] = (int64_t)a.g; w[4] = (int64_t)a.b; w[5] = (int64_t)a.q;
+            for (int u = 0; u < LINE_BATCH; u++) {
+                d0[u] = make_uint4(0, 0, 0, 0); d1[u] = d0[u]; col[u] = 0;
+                if (u < n) {
+                    const int xc = (int)(x >> TP_LINE_FRAC);
+                    col[u] = xc < 0 ? 0 : (xc > W ? W : xc);
+                    const uint4* rec = row + 2 * (col[u] >> 2);
+                    d0[u] = rec[0]; d1[u] = rec[1];
+                    x += xs; row += rs;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LINE_BATCH; u++) { a.xs += (uint32_t)col[u]; acc_entry(a, col[u], d0[u], d1[u]); }
+        }
     }
     TP_STAMP(0, 2);
+    int64_t* w = L.wline + ((size_t)blk * eb * TP_NLINES + l) * TP_W_WORDS;
+    if (TL == 1) {
+        if (on) { w[0] = a.xs; w[1] = a.nodd; w[2] = (int64_t)a.r; w[3] = (int64_t)a.g; w[4] = (int64_t)a.b; w[5] = (int64_t)a.q; }
+    } else {
+        if (on && (a.xs | a.nodd | a.r | a.q)) {
+            unsigned long long* sq = S[l];
+            atomicAdd(&sq[0], (unsigned long long)a.xs); atomicAdd(&sq[1], (unsigned long long)a.nodd);
+            atomicAdd(&sq[2], (unsigned long long)a.r); atomicAdd(&sq[3], (unsigned long long)a.g);
+            atomicAdd(&sq[4], (unsigned long long)a.b); atomicAdd(&sq[5], (unsigned long long)a.q);
+        }
+        __syncthreads();
+        if (on && c == 0) {
+#pragma unroll
+            for (int k = 0; k < TP_W_WORDS; k++) w[k] = (int64_t)S[l][k];
+        }
+    }
+    TP_STAMP(0, 3);
 }
 void tp_launch_lines(const tp_launch& L, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
-    const int lpl = L.lanes_per_line;
-    const unsigned blocks = (unsigned)(((size_t)L.NE * TP_NLINES * lpl + 255) / 256);
-#define TP_LINES_CASE(N) case N: hipExtLaunchKernelGGL(k_lines<N>, dim3(blocks), dim3(256), 0, s, start, stop, 0, L); break;
-    switch (lpl) {
-        TP_LINES_CASE(1) TP_LINES_CASE(2) TP_LINES_CASE(4) TP_LINES_CASE(8) TP_LINES_CASE(16) TP_LINES_CASE(32)
-        default: hipExtLaunchKernelGGL(k_lines<64>, dim3(blocks), dim3(256), 0, s, start, stop, 0, L); break;
-    }
-#undef TP_LINES_CASE
+    // lanes_per_line: chunks per line (1 .. 64).  Up to 16 chunks: seven edges per workgroup, 64 lanes per chunk;
+    // beyond (coarse meshes): one edge per workgroup, 16 lanes per chunk
+    const int tl = L.lanes_per_line;
+    const int eb = tl <= 16 ? LINES_EB : 1, lp_shift = tl <= 16 ? TP_LINES_LP_SHIFT : 4;
+    const unsigned blocks = (unsigned)((L.NE + eb - 1) / eb);
+    hipExtLaunchKernelGGL(k_lines, dim3((blocks + 7u) & ~7u), dim3((unsigned)(tl << lp_shift)), 0, s, start, stop, 0, L, eb, lp_shift);
 }
 
 __device__ __forceinline__ void line_sum(const tp_launch& L, int e, int ver, int64_t w[TP_W_WORDS]) {
