@@ -2,12 +2,13 @@
 """bench.py -- headline benchmark of the t-pose hot path on MI355X.
 
 Metric (BASELINE.json): triangles*grad-iters / second at a 2048x2048 RGBA8 raster, 3000 triangles,
-plus the achieved fraction of the HBM roofline of the dominant kernel (the per-pixel accumulate).
+plus the achieved fraction of the HBM roofline of the dominant kernel (k_lines: the pixel sums of every edge line,
+read from the per-image row prefix table).
 
   python bench.py --gpus N --steps K --warmup W
 
-A "step" is one grad-iter: accumulate (one sweep of the raster, 13 variants of every triangle) ->
-energy -> gradient -> shift, on inputs already resident in HBM, with no host round trip inside the
+A "step" is one grad-iter: the pixel moments of the 13 variants of every triangle -> energy -> gradient ->
+shift, on inputs already resident in HBM, with no host round trip inside the
 timed region.  N > 1 (launched by torch.distributed.run, one rank per GPU) runs independent
 replicas -- one image + triangulation per GPU, no data-path collective -- and
 reports the whole-job aggregate ("weak" scaling).  Rank 0 prints ONE JSON line.
@@ -25,6 +26,7 @@ import numpy as np  # noqa: E402
 
 W = H = 2048
 NT = 3000
+DOMINANT = "k_lines"  # the kernel the roofline figure is about
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -83,7 +85,7 @@ def cpu_baseline(img, pts, tris, ratio, budget_s=14.0):
 
 
 def live_pmc_traffic(timeout_s=150):
-    """HBM-side bytes per k_accumulate launch, collected NOW: two separate rocprofv3 --pmc passes (FETCH_SIZE,
+    """HBM-side bytes per k_lines launch, collected NOW: two separate rocprofv3 --pmc passes (FETCH_SIZE,
     WRITE_SIZE; counters only, no trace domains) over a child run of this script (64 fused grad-iters of the same
     workload), corrected as the MI355X guide prescribes for gfx950 (2 x FETCH_SIZE + WRITE_SIZE, units KB).
     Returns (bytes, note) or (None, reason)."""
@@ -107,11 +109,11 @@ def live_pmc_traffic(timeout_s=150):
                 return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
             tot, n = 0.0, 0
             for row in csv.DictReader(open(files[0])):
-                if row.get("Counter_Name") == counter and row.get("Kernel_Name", "").startswith("k_accumulate"):
+                if row.get("Counter_Name") == counter and row.get("Kernel_Name", "").startswith(DOMINANT):
                     tot += float(row["Counter_Value"])
                     n += 1
             if n == 0:
-                return None, "no k_accumulate rows in the %s pass" % counter
+                return None, "no %s rows in the %s pass" % (DOMINANT, counter)
             per_launch[counter] = tot / n
         except Exception as e:  # noqa: BLE001 -- measurement is best effort, the bench line must still appear
             return None, "%s pass: %s" % (counter, e)
@@ -236,7 +238,7 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    # dominant kernel: average k_accumulate launch duration, HIP events on the library's own stream, right
+    # dominant kernel: average k_lines launch duration, HIP events on the library's own stream, right
     # after the timed region, same workload and state: 4 x 64 back-to-back launches replayed as a graph (the
     # way the kernel runs in the fused path); the eager per-dispatch figure is kept beside it
     acc_samples = sorted(ctx.profile_accumulate(params, 64) for _ in range(5))
@@ -251,8 +253,8 @@ def main():
         ctx.synchronize()
         trace, trace_note = live_kernel_trace()
     acc_us_events = acc_us
-    if trace and "k_accumulate" in trace:
-        acc_us = trace["k_accumulate"]["avg_us"]
+    if trace and DOMINANT in trace:
+        acc_us = trace[DOMINANT]["avg_us"]
     achieved = bytes_iter / (acc_us * 1e-6) / 1e9
     # HBM-side traffic of the same kernel: 2 x FETCH_SIZE + WRITE_SIZE per launch (the gfx950 correction of the
     # guide), from two live counter passes over a child run; the committed passes are the fall-back
@@ -264,7 +266,7 @@ def main():
         why = traffic_source
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")))
-            traffic = pmc["k_accumulate"]["hbm_bytes_per_launch_corrected"]
+            traffic = pmc[DOMINANT]["hbm_bytes_per_launch_corrected"]
             traffic_source = "profiles/r02_pmc_hbm.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" + \
                 (" -- live passes unavailable: %s" % why if why else "")
         except Exception:
@@ -291,9 +293,9 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_source,
-                "kernel": "k_accumulate", "kernel_us": acc_us, "algorithmic_bytes": bytes_iter,
+                "kernel": DOMINANT, "kernel_us": acc_us, "algorithmic_bytes": bytes_iter,
                 "kernel_timing": ("average duration in a rocprofv3 --kernel-trace --stats pass over a child run (256 fused "
-                                  "grad-iters), collected by this command" if trace and "k_accumulate" in trace else
+                                  "grad-iters), collected by this command" if trace and DOMINANT in trace else
                                   "HIP events (kernel trace unavailable: %s)" % trace_note),
                 "kernel_trace_us": trace,
                 "kernel_us_hip_events": acc_us_events,

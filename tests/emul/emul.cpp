@@ -1,8 +1,9 @@
-// CPU emulation of the k_accumulate / k_finalize data flow (tests only, never shipped):
-// runs the SAME per-lane integer logic (tpose_amd/csrc/tp_raster.h) tile by tile, with the LDS
-// prefix table as a plain array.  Lets the span walker be checked against the oracle without a GPU.
+// CPU emulation of the device data flow (tests only, never shipped): runs the SAME per-lane integer logic
+// (tpose_amd/csrc/tp_raster.h) on the host -- the span walker of k_render window by window, and the table path of
+// k_prefix / k_lines / k_finalize record by record -- so that it can be checked against the oracle without a GPU.
 #include <stdint.h>
 #include <string.h>
+#include <map>
 #include <vector>
 #include "../../tpose_amd/csrc/tp_raster.h"
 
@@ -97,99 +98,30 @@ extern "C" void emul_walker(int64_t N0, int32_t step, int32_t d, int rows, int32
 }
 
 // ---------------------------------------------------------------------------------------------
-// Edge-centric form: W for every distinct edge line (walked in 32-row windows like the tiles do,
-// one full-row prefix lookup per row), then each variant = signed sum of three lines.
+// The table path (k_prefix + k_lines + k_finalize): the per-image row prefix table in its packed 32-byte records
+// (tp_prefix_pack), whole-line 24.40 walkers (tp_setup_line) stepped by `tl` rows at a time exactly as a lane of
+// k_lines steps them, one record per (line, row) evaluated with tp_prefix_eval, and every variant as the signed sum
+// of three line sums.
 // ---------------------------------------------------------------------------------------------
-#include <map>
-extern "C" int emul_moments_edges(const uint8_t* img, size_t stride, int W, int H, const float* points,
-                                  const int32_t* tris, int NT, int NP, float dp, float ratio, int64_t* mom) {
+extern "C" int emul_moments_table(const uint8_t* img, size_t stride, int W, int H, const float* points,
+                                  const int32_t* tris, int NT, int NP, float dp, float ratio, int tl, int64_t* mom) {
     tp_view vw;
     vw.dp = dp; vw.ratio = ratio; vw.halfW = 0.5f * (float)W; vw.halfH = 0.5f * (float)H; vw.W = W; vw.H = H;
-    // full-row prefix sums of the six per-pixel quantities (index 0: pixel count -> P = x itself)
-    std::vector<int64_t> P((size_t)H * (W + 1) * 5, 0);
-    for (int r = 0; r < H; r++)
-        for (int c = 0; c < W; c++) {
-            const uint8_t* p = img + (size_t)r * stride + 4 * (size_t)c;
-            const int64_t R = p[0], G = p[1], B = p[2];
-            const int64_t v[5] = {(R + G + B) & 1, R, G, B, R * R + G * G + B * B};
-            for (int k = 0; k < 5; k++) P[((size_t)r * (W + 1) + c + 1) * 5 + k] = P[((size_t)r * (W + 1) + c) * 5 + k] + v[k];
-        }
-    // per-vertex snapped positions for the five moves
-    std::vector<int32_t> vx((size_t)NP * 5), vy((size_t)NP * 5);
-    for (int v = 0; v < NP; v++)
-        for (int m = 0; m < 5; m++)
-            tp_vertex_stage(points[2 * v], points[2 * v + 1], m == 0 ? 0 : m, 0, vw, vx[v * 5 + m], vy[v * 5 + m]);
-    // undirected edges
-    std::map<std::pair<int, int>, int> eid;
-    std::vector<std::pair<int, int>> edges;
-    std::vector<int> he_edge(3 * (size_t)NT);
-    for (int t = 0; t < NT; t++)
-        for (int k = 0; k < 3; k++) {
-            const int o = tris[4 * t + k], d = tris[4 * t + (k + 1) % 3];
-            const std::pair<int, int> key(o < d ? o : d, o < d ? d : o);
-            auto it = eid.find(key);
-            if (it == eid.end()) { it = eid.emplace(key, (int)edges.size()).first; edges.push_back(key); }
-            he_edge[3 * t + k] = it->second * 2 + (o != key.first ? 1 : 0);
-        }
-    // W[edge][ver][6]
-    std::vector<int64_t> Wt(edges.size() * 9 * 6, 0);
-    for (size_t e = 0; e < edges.size(); e++)
-        for (int ver = 0; ver < 9; ver++) {
-            const int u = edges[e].first, v = edges[e].second;
-            const int mu = ver >= 1 && ver <= 4 ? ver : 0, mv = ver >= 5 ? ver - 4 : 0;
-            int64_t* w = &Wt[(e * 9 + ver) * 6];
-            for (int win = 0; win < H; win += 32) {
-                tp_edge_walk ew;
-                tp_setup_edge(vx[u * 5 + mu], vy[u * 5 + mu], vx[v * 5 + mv], vy[v * 5 + mv], win, tp_min(win + 31, H - 1), ew);
-                for (int r = ew.ra; r <= ew.rb; r++) {
-                    int32_t x = tp_walker_value(ew.w);
-                    ew.w.x += ew.w.s;
-                    x = x < 0 ? 0 : (x > W ? W : x);
-                    w[0] += x;
-                    for (int k = 0; k < 5; k++) w[1 + k] += P[((size_t)r * (W + 1) + x) * 5 + k];
-                }
+    const int NG = tp_prefix_groups(W), pitch = tp_prefix_pitch(W);
+    std::vector<uint32_t> T((size_t)H * pitch * TP_PFX_WORDS, 0);
+    for (int r = 0; r < H; r++) {
+        uint32_t run[5] = {0, 0, 0, 0, 0};
+        for (int g = 0; g < NG; g++) {
+            uint32_t px[4] = {0, 0, 0, 0};
+            const int npx = tp_min(4, W - 4 * g) < 0 ? 0 : tp_min(4, W - 4 * g);
+            for (int i = 0; i < npx; i++) memcpy(&px[i], img + (size_t)r * stride + 4 * (size_t)(4 * g + i), 4);
+            tp_prefix_pack(run, px, npx, &T[((size_t)r * pitch + g) * TP_PFX_WORDS]);
+            for (int i = 0; i < npx; i++) {
+                const uint32_t R = px[i] & 0xffu, G = (px[i] >> 8) & 0xffu, B = (px[i] >> 16) & 0xffu;
+                run[0] += (R + G + B) & 1u; run[1] += R; run[2] += G; run[3] += B; run[4] += R * R + G * G + B * B;
             }
         }
-    for (int t = 0; t < NT; t++)
-        for (int i = 0; i < 13; i++) {
-            int32_t X[3], Y[3], c[3];
-            for (int s = 0; s < 3; s++) {
-                const int v = tris[4 * t + s];
-                const int m = (i > 0 && ((i - 1) >> 2) == s) ? ((i - 1) & 3) + 1 : 0;
-                X[s] = vx[v * 5 + m]; Y[s] = vy[v * 5 + m];
-            }
-            tp_variant_coeffs(X, Y, c);
-            int64_t* m = mom + 6 * ((size_t)i * NT + t);
-            for (int q = 0; q < 6; q++) m[q] = 0;
-            for (int k = 0; k < 3; k++) {
-                const int he = he_edge[3 * t + k];
-                const int64_t* w = &Wt[((size_t)(he >> 1) * 9 + tp_edge_version(i, k, he & 1)) * 6];
-                for (int q = 0; q < 6; q++) m[q] += c[k] * w[q];
-            }
-        }
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Round-2 structure: whole-line 24.40 walkers (tp_setup_line), per-edge tile enumeration by tile row
-// (tp_band_rows / tp_band_cols), and per (line, tile) the derived 32.32 walker (tp_line_at) with the
-// kernel's own liveness tests.  A tile the band misses loses its contribution, so equality with the
-// oracle also proves the enumeration conservative.  `margin` inflates the band like tp_set_margin.
-// ---------------------------------------------------------------------------------------------
-extern "C" int emul_moments_lines(const uint8_t* img, size_t stride, int W, int H, const float* points,
-                                  const int32_t* tris, int NT, int NP, float dp, float ratio, int tile_w, int tile_h,
-                                  int margin, int64_t* mom, int64_t* nvisits) {
-    tp_view vw;
-    vw.dp = dp; vw.ratio = ratio; vw.halfW = 0.5f * (float)W; vw.halfH = 0.5f * (float)H; vw.W = W; vw.H = H;
-    const int tiles_x = (W + tile_w - 1) / tile_w, tiles_y = (H + tile_h - 1) / tile_h;
-    std::vector<int64_t> P((size_t)H * (W + 1) * 5, 0);
-    for (int r = 0; r < H; r++)
-        for (int c = 0; c < W; c++) {
-            const uint8_t* p = img + (size_t)r * stride + 4 * (size_t)c;
-            const int64_t R = p[0], G = p[1], B = p[2];
-            const int64_t v[5] = {(R + G + B) & 1, R, G, B, R * R + G * G + B * B};
-            for (int k = 0; k < 5; k++) P[((size_t)r * (W + 1) + c + 1) * 5 + k] = P[((size_t)r * (W + 1) + c) * 5 + k] + v[k];
-        }
+    }
     std::vector<int32_t> vx((size_t)NP * 5), vy((size_t)NP * 5);
     for (int v = 0; v < NP; v++)
         for (int m = 0; m < 5; m++)
@@ -206,70 +138,35 @@ extern "C" int emul_moments_lines(const uint8_t* img, size_t stride, int W, int 
             he_edge[3 * t + k] = it->second * 2 + (o != key.first ? 1 : 0);
         }
     std::vector<int64_t> Wt(edges.size() * 9 * 6, 0);
-    int64_t visits = 0;
-    // cumulative static table like the device's t2: T2[r][tc] = moments of rows < r, columns < tc * tile_w
-    std::vector<int64_t> T2((size_t)(H + 1) * (tiles_x + 1) * 5, 0);
-    for (int r = 0; r < H; r++)
-        for (int tc = 0; tc <= tiles_x; tc++) {
-            const int c = tp_min(tc * tile_w, W);
-            for (int k = 0; k < 5; k++)
-                T2[((size_t)(r + 1) * (tiles_x + 1) + tc) * 5 + k] = T2[((size_t)r * (tiles_x + 1) + tc) * 5 + k] + P[((size_t)r * (W + 1) + c) * 5 + k];
-        }
     for (size_t e = 0; e < edges.size(); e++) {
         const int u = edges[e].first, v = edges[e].second;
         tp_line ln[9];
-        tp_band b;
-        b.Xa = vx[u * 5]; b.Ya = vy[u * 5]; b.Xb = vx[v * 5]; b.Yb = vy[v * 5];
-        b.dX = 0; b.dY = 0;
-        for (int m = 1; m < 5; m++) {
-            b.dX = tp_max(b.dX, tp_max(abs(vx[u * 5 + m] - b.Xa), abs(vx[v * 5 + m] - b.Xb)));
-            b.dY = tp_max(b.dY, tp_max(abs(vy[u * 5 + m] - b.Ya), abs(vy[v * 5 + m] - b.Yb)));
-        }
-        b.dX += 256 * margin; b.dY += 256 * margin;
+        int rmin = 0x3fffffff;
         for (int ver = 0; ver < 9; ver++) {
             const int mu = ver >= 1 && ver <= 4 ? ver : 0, mv = ver >= 5 ? ver - 4 : 0;
             tp_setup_line(vx[u * 5 + mu], vy[u * 5 + mu], vx[v * 5 + mv], vy[v * 5 + mv], H, ln[ver]);
-            // static part: per run of rows inside one tile column, a difference of the cumulative table
-            int64_t* acc = &Wt[(e * 9 + ver) * 6];
-            tp_line_column_runs(ln[ver], W, tile_w, tiles_x, [&](int32_t tc, int32_t ra, int32_t rb) {
-                for (int k = 0; k < 5; k++)
-                    acc[1 + k] += T2[((size_t)(rb + 1) * (tiles_x + 1) + tc) * 5 + k] - T2[((size_t)ra * (tiles_x + 1) + tc) * 5 + k];
-            });
+            if (ln[ver].ra <= ln[ver].rb) rmin = tp_min(rmin, ln[ver].ra);
         }
-        int32_t r0, r1;
-        tp_band_rows(b, H, r0, r1);
-        if (r0 > r1) continue;
-        for (int ty = r0 / tile_h; ty <= r1 / tile_h; ty++) {
-            int32_t tx0, tx1;
-            const int row0 = ty * tile_h, row1 = tp_min(row0 + tile_h - 1, H - 1);
-            if (!tp_band_cols(b, row0, row1, W, tile_w, tiles_x, tx0, tx1)) continue;
-            for (int tx = tx0; tx <= tx1; tx++) {
-                visits++;
-                const int col0 = tx * tile_w;
-                const int lim = tx == tiles_x - 1 ? W - col0 + 1 : tile_w;
-                for (int ver = 0; ver < 9; ver++) {
-                    if (!tp_line_live(ln[ver], row0, row1, col0, lim, W)) continue;  // k_bin lists live lines only
-                    tp_walker w = tp_line_at(ln[ver], row0);
-                    const int koff = ln[ver].ra - row0;
-                    const uint32_t nvalid = (uint32_t)tp_max(ln[ver].rb - ln[ver].ra + 1, 0);
-                    int64_t* acc = &Wt[(e * 9 + ver) * 6];
-                    for (int j = 0; j < tile_h; j++) {
-                        int32_t x = tp_walker_value(w);
-                        w.x += w.s;
-                        x = x < 0 ? 0 : (x > W ? W : x);
-                        const uint32_t xl = (uint32_t)(x - col0);
-                        const bool in = xl < (uint32_t)lim && (uint32_t)(j - koff) < nvalid;
-                        if (!in) continue;
-                        acc[0] += x;
-                        // tile-local prefix = full-row prefix minus everything left of the tile column
-                        for (int k = 0; k < 5; k++)
-                            acc[1 + k] += P[((size_t)(row0 + j) * (W + 1) + x) * 5 + k] - P[((size_t)(row0 + j) * (W + 1) + col0) * 5 + k];
-                    }
+        for (int ver = 0; ver < 9; ver++) {
+            int64_t* acc = &Wt[(e * 9 + ver) * 6];
+            const tp_line& l = ln[ver];
+            if (l.ra > l.rb) continue;
+            for (int c = 0; c < tl; c++) {  // lane (line, chunk c) of k_lines
+                const int base = rmin + c;
+                const int first = base + ((l.ra - base + tl - 1) & -tl);
+                int64_t x = l.x + (int64_t)(first - l.ra) * l.s;
+                const int64_t xs = l.s * tl;
+                for (int r = first; r <= l.rb; r += tl, x += xs) {
+                    const int32_t xc = (int32_t)(x >> TP_LINE_FRAC);
+                    const int32_t col = xc < 0 ? 0 : (xc > W ? W : xc);
+                    if (col != tp_line_col(l, r, W)) return 1;  // stepping and direct evaluation agree
+                    uint32_t nodd, R, G, B, Q;
+                    tp_prefix_eval(&T[((size_t)r * pitch + (col >> 2)) * TP_PFX_WORDS], col, nodd, R, G, B, Q);
+                    acc[0] += col; acc[1] += nodd; acc[2] += R; acc[3] += G; acc[4] += B; acc[5] += Q;
                 }
             }
         }
     }
-    if (nvisits) *nvisits = visits;
     for (int t = 0; t < NT; t++)
         for (int i = 0; i < 13; i++) {
             int32_t X[3], Y[3], c[3];
@@ -290,9 +187,42 @@ extern "C" int emul_moments_lines(const uint8_t* img, size_t stride, int W, int 
     return 0;
 }
 
-// whole-line walker against exact integer arithmetic: rows ra..rb of the line through (Xa,Ya)-(Xb,Yb),
-// evaluated tile by tile (tile_h rows) exactly as the kernel does.  Returns the number of mismatches.
-extern "C" int emul_line_check(int32_t Xa, int32_t Ya, int32_t Xb, int32_t Yb, int32_t H, int tile_h, int32_t* first_bad) {
+// the packed prefix records against plain sums: every column c = 0..W of every row; returns the mismatches
+extern "C" int emul_prefix_check(const uint8_t* img, size_t stride, int W, int H) {
+    const int NG = tp_prefix_groups(W);
+    int bad = 0;
+    for (int r = 0; r < H; r++) {
+        uint32_t run[5] = {0, 0, 0, 0, 0};
+        uint64_t ref[5] = {0, 0, 0, 0, 0};
+        int c = 0;
+        for (int g = 0; g < NG; g++) {
+            uint32_t px[4] = {0, 0, 0, 0}, rec[TP_PFX_WORDS];
+            const int npx = tp_min(4, W - 4 * g) < 0 ? 0 : tp_min(4, W - 4 * g);
+            for (int i = 0; i < npx; i++) memcpy(&px[i], img + (size_t)r * stride + 4 * (size_t)(4 * g + i), 4);
+            tp_prefix_pack(run, px, npx, rec);
+            for (int k = 0; k < 4 && c <= W; k++, c++) {
+                if (c != 4 * g + k) return -1;
+                uint32_t nodd, R, G, B, Q;
+                tp_prefix_eval(rec, c, nodd, R, G, B, Q);
+                if (nodd != ref[0] || R != ref[1] || G != ref[2] || B != ref[3] || Q != ref[4]) bad++;
+                if (k < npx) {
+                    const uint64_t r8 = px[k] & 0xffu, g8 = (px[k] >> 8) & 0xffu, b8 = (px[k] >> 16) & 0xffu;
+                    ref[0] += (r8 + g8 + b8) & 1; ref[1] += r8; ref[2] += g8; ref[3] += b8; ref[4] += r8 * r8 + g8 * g8 + b8 * b8;
+                }
+            }
+            for (int i = 0; i < npx; i++) {
+                const uint32_t R = px[i] & 0xffu, G = (px[i] >> 8) & 0xffu, B = (px[i] >> 16) & 0xffu;
+                run[0] += (R + G + B) & 1u; run[1] += R; run[2] += G; run[3] += B; run[4] += R * R + G * G + B * B;
+            }
+        }
+        if (c != W + 1) return -2;
+    }
+    return bad;
+}
+
+// whole-line walker against exact integer arithmetic: rows ra..rb of the line through (Xa,Ya)-(Xb,Yb), evaluated
+// directly (tp_line_col without the clamp) and stepped by `tl` rows as k_lines steps it.  Returns the mismatches.
+extern "C" int emul_line_check(int32_t Xa, int32_t Ya, int32_t Xb, int32_t Yb, int32_t H, int tl, int32_t* first_bad) {
     tp_line ln;
     tp_setup_line(Xa, Ya, Xb, Yb, H, ln);
     const bool swap = Ya > Yb;
@@ -305,20 +235,19 @@ extern "C" int emul_line_check(int32_t Xa, int32_t Ya, int32_t Xb, int32_t Yb, i
     if (erb > H - 1) erb = H - 1;
     if (dy <= 0 || era > erb) return ln.ra > ln.rb ? 0 : 1;
     if (ln.ra != era || ln.rb != erb) { if (first_bad) *first_bad = -1; return 1; }
-    for (int row0 = (int)(era / tile_h) * tile_h; row0 <= erb; row0 += tile_h) {
-        tp_walker w = tp_line_at(ln, row0);
-        for (int j = 0; j < tile_h; j++) {
-            const int64_t r = row0 + j;
-            const int32_t got = tp_walker_value(w);
-            w.x += w.s;
-            if (r < era || r > erb) continue;
+    for (int c = 0; c < tl; c++) {
+        int64_t x = ln.x + (int64_t)c * ln.s;
+        const int64_t xs = ln.s * tl;
+        for (int64_t r = era + c; r <= erb; r += tl, x += xs) {
+            const int32_t got = (int32_t)(x >> TP_LINE_FRAC);
+            const int32_t direct = (int32_t)((ln.x + (r - ln.ra) * ln.s) >> TP_LINE_FRAC);
             // first column c with (256 c + 128 - Xt) dy >= dx (256 r + 128 - Yt)
             const __int128 rhs = (__int128)dx * (256 * r + 128 - Yt) - (__int128)(128 - Xt) * dy;  // 256 dy c >= rhs
             const __int128 den = (__int128)256 * dy;
-            __int128 c = rhs / den;
-            if (c * den < rhs) c++;          // ceil for positive remainder
-            while ((c - 1) * den >= rhs) c--;  // and for negative quotients (truncation toward zero)
-            if ((__int128)got != c) { if (!bad && first_bad) *first_bad = (int32_t)r; bad++; }
+            __int128 q = rhs / den;
+            if (q * den < rhs) q++;          // ceil for positive remainder
+            while ((q - 1) * den >= rhs) q--;  // and for negative quotients (truncation toward zero)
+            if ((__int128)got != q || got != direct) { if (!bad && first_bad) *first_bad = (int32_t)r; bad++; }
         }
     }
     return bad;

@@ -114,72 +114,30 @@ def test_walker_floor_is_exact(em):
                 assert int(out[r]) == exact, (N0, step, d, r, int(out[r]), exact)
 
 
-def emul_moments_edges(em, img, pts, tris, dp, ratio):
+# ---- the table path: packed row prefix records, whole-line 24.40 walkers stepped like a lane of k_lines ----------
+def emul_moments_table(em, img, pts, tris, dp, ratio, tl=8):
     NT, NP = tris.shape[0], pts.shape[0]
     H, W = img.shape[:2]
     mom = np.zeros((13 * NT, 6), np.int64)
-    em.emul_moments_edges(img.ctypes.data_as(C.c_void_p), C.c_size_t(img.strides[0]), W, H,
-                          pts.ctypes.data_as(C.c_void_p), tris.ctypes.data_as(C.c_void_p), NT, NP,
-                          C.c_float(dp), C.c_float(ratio), mom.ctypes.data_as(C.c_void_p))
+    rc = em.emul_moments_table(img.ctypes.data_as(C.c_void_p), C.c_size_t(img.strides[0]), W, H,
+                               pts.ctypes.data_as(C.c_void_p), tris.ctypes.data_as(C.c_void_p), NT, NP,
+                               C.c_float(dp), C.c_float(ratio), tl, mom.ctypes.data_as(C.c_void_p))
+    assert rc == 0
     return mom
-
-
-@pytest.mark.parametrize("W,H,grid", [(97, 61, (6, 4)), (300, 200, (15, 5)), (257, 131, (6, 4)), (200, 150, None)])
-@pytest.mark.parametrize("dp", [None, 0.2])
-def test_edge_centric_form_matches_oracle(em, W, H, grid, dp):
-    """moment(variant) = signed sum of three edge-line sums (one prefix lookup per line and row)"""
-    img, _, pts, tris, ratio, _ = case(W, H, grid)
-    d = O.dp(0, tris.shape[0]) if dp is None else dp
-    assert np.array_equal(emul_moments_edges(em, img, pts, tris, d, ratio), O.moments(img, pts, tris, d, ratio))
-
-
-def test_edge_centric_form_on_triangle_soup(em):
-    W, H = 200, 150
-    img = synth.voronoi_raster(W, H, seed=3, sites=10)
-    ratio = float(np.float32(W) / np.float32(H))
-    rng = np.random.default_rng(2)
-    for trial in range(30):
-        NP = 30
-        pts = (rng.random((NP, 2)).astype(np.float32) * 2 - 1) * np.float32(1.3)
-        pts[:, 0] *= np.float32(ratio)
-        if trial % 3 == 0:
-            pts = (np.round(pts * 8) / 8).astype(np.float32)
-        if trial % 5 == 0:
-            pts[:5] = pts[5:10]
-        tris = np.zeros((40, 4), np.int32)
-        tris[:, :3] = rng.integers(0, NP, (40, 3))
-        dp = [0.05, 0.0078125, 0.3][trial % 3]
-        assert np.array_equal(emul_moments_edges(em, img, pts, tris, dp, ratio), O.moments(img, pts, tris, dp, ratio)), trial
-
-
-# ---- round 2: whole-line 24.40 walkers, per-tile-row band enumeration ------------------------------------------
-def emul_moments_lines(em, img, pts, tris, dp, ratio, tile_w=128, tile_h=16, margin=0):
-    NT, NP = tris.shape[0], pts.shape[0]
-    H, W = img.shape[:2]
-    mom = np.zeros((13 * NT, 6), np.int64)
-    nv = C.c_int64(0)
-    em.emul_moments_lines(img.ctypes.data_as(C.c_void_p), C.c_size_t(img.strides[0]), W, H,
-                          pts.ctypes.data_as(C.c_void_p), tris.ctypes.data_as(C.c_void_p), NT, NP,
-                          C.c_float(dp), C.c_float(ratio), tile_w, tile_h, margin, mom.ctypes.data_as(C.c_void_p),
-                          C.byref(nv))
-    return mom, nv.value
 
 
 @pytest.mark.parametrize("W,H,grid", [(97, 61, (6, 4)), (300, 200, (15, 5)), (257, 131, (6, 4)), (200, 150, None),
                                       (640, 480, (50, 30))])
 @pytest.mark.parametrize("dp", [None, 0.2])
-@pytest.mark.parametrize("tile", [(128, 16), (128, 32), (32, 8)])
-def test_line_walkers_and_band_match_oracle(em, W, H, grid, dp, tile):
+@pytest.mark.parametrize("tl", [1, 8, 64])
+def test_table_path_matches_oracle(em, W, H, grid, dp, tl):
+    """moment(variant) = signed sum of three line sums, each one packed table record per row"""
     img, _, pts, tris, ratio, _ = case(W, H, grid)
     d = O.dp(0, tris.shape[0]) if dp is None else dp
-    ref = O.moments(img, pts, tris, d, ratio)
-    mom, nv = emul_moments_lines(em, img, pts, tris, d, ratio, tile[0], tile[1])
-    assert np.array_equal(mom, ref)
-    mom2, nv2 = emul_moments_lines(em, img, pts, tris, d, ratio, tile[0], tile[1], margin=5)
-    assert np.array_equal(mom2, ref) and nv2 >= nv
+    assert np.array_equal(emul_moments_table(em, img, pts, tris, d, ratio, tl), O.moments(img, pts, tris, d, ratio))
 
 
-def test_line_walkers_on_triangle_soup(em):
+def test_table_path_on_triangle_soup(em):
     W, H = 200, 150
     img = synth.voronoi_raster(W, H, seed=3, sites=10)
     ratio = float(np.float32(W) / np.float32(H))
@@ -199,13 +157,32 @@ def test_line_walkers_on_triangle_soup(em):
         tris = np.zeros((40, 4), np.int32)
         tris[:, :3] = rng.integers(0, NP, (40, 3))
         dp = [0.05, 0.0078125, 0.3][trial % 3]
-        tile = [(128, 16), (64, 16), (16, 4)][trial % 3]
-        mom, _ = emul_moments_lines(em, img, pts, tris, dp, ratio, tile[0], tile[1])
-        assert np.array_equal(mom, O.moments(img, pts, tris, dp, ratio)), trial
+        tl = [1, 4, 16][trial % 3]
+        assert np.array_equal(emul_moments_table(em, img, pts, tris, dp, ratio, tl), O.moments(img, pts, tris, dp, ratio)), trial
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (3, 2), (4, 3), (5, 2), (97, 5), (256, 2), (1011, 3)])
+def test_prefix_records_are_exact(em, W, H):
+    """every column 0..W of every row, from the packed 32-byte records (group prefix + masked pixel bytes)"""
+    rng = np.random.default_rng(W * 31 + H)
+    for kind in range(3):
+        img = rng.integers(0, 256, (H, W, 4), dtype=np.uint8) if kind == 0 else \
+            np.full((H, W, 4), 255, np.uint8) if kind == 1 else (rng.integers(0, 2, (H, W, 4), dtype=np.uint8) * 255)
+        img = np.ascontiguousarray(img)
+        assert em.emul_prefix_check(img.ctypes.data_as(C.c_void_p), C.c_size_t(img.strides[0]), W, H) == 0
+
+
+def test_prefix_records_widest_row(em):
+    """the packing limits: 16384 pixels of (255, 255, 255): 22-bit channel sums, 32-bit squares, 15-bit parity count"""
+    W = 16384
+    for val in ((255, 255, 255), (255, 254, 0), (1, 0, 0)):
+        img = np.zeros((1, W, 4), np.uint8)
+        img[..., :3] = val
+        assert em.emul_prefix_check(img.ctypes.data_as(C.c_void_p), C.c_size_t(img.strides[0]), W, 1) == 0
 
 
 def test_whole_line_walker_is_exact(em):
-    """every row of a line, evaluated tile by tile from ONE 24.40 set-up, equals exact integer arithmetic --
+    """every row of a line, evaluated directly and stepped chunk-wise from ONE 24.40 set-up, equals exact integer arithmetic --
     up to the largest raster (16384 rows), the largest coordinates, knife-edge and lattice-aligned lines"""
     rng = np.random.default_rng(9)
     em.emul_line_check.argtypes = [C.c_int32] * 6 + [C.c_void_p]
@@ -230,8 +207,8 @@ def test_whole_line_walker_is_exact(em):
             Xa, Ya, Xb, Yb = int(rng.choice([lo, hi])), lo, int(rng.choice([lo, hi])), hi
         else:
             Xa, Ya, Xb, Yb = (int(rng.integers(-30 * 256, 130 * 256)) for _ in range(4))
-        for th in (16, 32):
-            r = em.emul_line_check(Xa, Ya, Xb, Yb, H, th, C.byref(bad))
-            assert r == 0, (Xa, Ya, Xb, Yb, H, th, bad.value)
+        for tl in (1, 16):
+            r = em.emul_line_check(Xa, Ya, Xb, Yb, H, tl, C.byref(bad))
+            assert r == 0, (Xa, Ya, Xb, Yb, H, tl, bad.value)
             n += 1
     assert n == 6000

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel-level timing of the headline workload (2048^2 / 3000 triangles) for A/B builds of the library:
-TPOSE_HIP_LIB=<variant .so> python tools/time_acc.py [W H gx gy] -> one JSON line with the k_accumulate time
+TPOSE_HIP_LIB=<variant .so> python tools/time_acc.py [W H gx gy] -> one JSON line with the k_lines time
 (graph replays of back-to-back launches, HIP events) and the fused grad-iter time.  Needs an MI355X."""
 import json
 import os
@@ -42,7 +42,7 @@ for _ in range(5):
     its.append((time.perf_counter() - t0) / 1024 * 1e6)
 its.sort()
 print(json.dumps({"lib": os.path.basename(capi.LIB_PATH), "raster": [W, H], "triangles": tris.shape[0], "flavour": flavour,
-                  "k_accumulate_us": round(acc[2], 3), "k_accumulate_us_min": round(acc[0], 3),
+                  "k_lines_us": round(acc[2], 3), "k_lines_us_min": round(acc[0], 3),
                   "iter_us": round(its[2], 3), "iter_us_min": round(its[0], 3),
-                  "tiles": [ctx.info(0), ctx.info(1), ctx.info(2), ctx.info(3)]}), flush=True)
+                  "prefix_pitch": ctx.info(0), "chunks_per_line": ctx.info(1)}), flush=True)
 ctx.close()

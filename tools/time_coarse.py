@@ -24,5 +24,5 @@ for gx, gy in [(1, 1), (2, 2), (4, 4), (8, 8), (16, 16), (32, 24)]:
     ctx.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps(dict(raster=[W, H], triangles=int(tris.shape[0]), us_per_iter=dt / 512 * 1e6,
-                          visits=ctx.info(4), rebuilds=ctx.info(6))), flush=True)
+                          chunks_per_line=ctx.info(1))), flush=True)
     ctx.close()

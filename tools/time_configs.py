@@ -65,7 +65,7 @@ def run_readback(W, H, NT, steps):
 
 def run_cold(W, H, NT, nctx, reps):
     """cold-cache sweep: cycle through nctx contexts, each with its own plane, so that every
-    k_accumulate launch finds its raster neither in L2 nor in the 256 MB Infinity Cache"""
+    k_lines launch finds its table neither in L2 nor in the 256 MB Infinity Cache"""
     ctxs = []
     for k in range(nctx):
         img, pts, tris, he, ratio = synth.workload(W, H, NT, seed=1234 + k)

@@ -8,9 +8,12 @@
 //       pixel-centre sampling, vertices snapped to 1/256 px, integer edge functions, top-left rule,
 //       orientation agnostic (the reference disables culling, software/triangulate/main.cpp:56).
 //
-// Instead of testing every pixel, a lane walks the rows of ONE variant and gets the covered
-// column span [lo, hi) of each row in O(1) from three 32.32 fixed-point edge walkers whose floor
-// is provably exact (see tp_edge_walker).  Sums over a span come from row prefix sums (LDS).
+// Nothing tests pixels one by one.  The picture pass (k_render) walks the rows of a triangle and gets the covered
+// column span [lo, hi) of each row in O(1) from three 32.32 fixed-point edge walkers whose floor is provably exact
+// (tp_make_walker).  The cost function never visits the inside of a triangle at all: a variant's pixel moments are
+// the signed sum of three LINE sums ("Edge-centric form" below), a line sum reads one record of the per-image row
+// prefix table per row ("Per-image row prefix table"), and a line's crossing column of every row comes from ONE
+// 24.40 fixed-point set-up per line and iteration ("Whole-line walkers").
 //
 // Everything here is __host__ __device__ so that tests can run the same integer logic on the CPU
 // (tests/emul) -- the shipped library never executes it on the host.
@@ -301,27 +304,6 @@ TP_HD int64_t tp_energy_triangulate(const tp_moments& m) {
 // the base line + 4 displacements of either endpoint.  A line is walked once, with ONE prefix
 // lookup per row, and both triangles sharing it reuse the result.
 // =============================================================================================
-struct tp_edge_walk {
-    tp_walker w;     // value = f(r), advanced one row per step
-    int32_t ra, rb;  // absolute rows (inclusive) inside the window; empty when ra > rb
-};
-
-TP_HD void tp_setup_edge(int32_t Xa, int32_t Ya, int32_t Xb, int32_t Yb, int32_t win_r0, int32_t win_r1,
-                         tp_edge_walk& ew) {
-    const bool swap = Ya > Yb;
-    const int32_t Xt = swap ? Xb : Xa, Yt = swap ? Yb : Ya, Xq = swap ? Xa : Xb, Yq = swap ? Ya : Yb;
-    const int32_t dy = Yq - Yt, dx = Xq - Xt;
-    const int32_t ra = tp_max(win_r0, tp_first_centre(Yt));       // Yt <= 256r + 128
-    const int32_t rb = tp_min(win_r1, tp_first_centre(Yq) - 1);   // 256r + 128 < Yb
-    const int32_t d = dy > 0 ? dy : 1;
-    // (256c + 128 - Xt) dy >= dx (yc - Yt)   <=>   256 dy c >= N1,   N1 = dx (yc - Yt) + (Xt - 128) dy
-    const int64_t N1 = (int64_t)dx * (256LL * ra + 128 - Yt) + (int64_t)(Xt - 128) * dy;
-    const int64_t Nc = -((-N1) >> 8);  // ceil(N1 / 256); steps by dx per row
-    ew.w = tp_make_walker(Nc + d - 1, dx, d);  // floor((Nc + d - 1) / d) = ceil(Nc / d)
-    ew.ra = dy > 0 ? ra : 0;
-    ew.rb = dy > 0 ? rb : -1;
-}
-
 // signs with which the three edge sums enter a variant's moments: +1 right edge, -1 left edge, 0
 // horizontal or degenerate.  Edge k runs from vertex k to vertex (k+1)%3.
 TP_HD void tp_variant_coeffs(const int32_t X[3], const int32_t Y[3], int32_t c[3]) {
@@ -347,19 +329,17 @@ TP_HD int tp_edge_version(int variant, int k, int flipped) {
 }
 
 // =============================================================================================
-// Whole-line walkers (round 2).  A line is set up ONCE per iteration -- not once per (line, tile) --
-// as x(r) = x(ra) + (r - ra) * s in 24.40 fixed point, valid for every row of the line inside the
-// raster (up to TP_MAX_RASTER rows), and a tile derives its own 32.32 walker from it with two shifts.
+// Whole-line walkers (round 2).  A line is set up ONCE per iteration as x(r) = x(ra) + (r - ra) * s in 24.40
+// fixed point, valid for every row of the line inside the raster (up to TP_MAX_RASTER rows); a lane of k_lines steps
+// it by a fixed number of rows at a time (integer arithmetic: the same values).
 //
 // Error budget, in units of 2^-40 with u = 2^40 / d the spacing of the attainable fractions of N_r / d
 // (d = dy < 2^23.6 because snapped coordinates lie in [-2^22, 2^23]):  t = N_0 / d and ts = dx / d carry a
 // relative error <= 2^-50 (|t| <= 2^15 + 2: the crossing column of a row BETWEEN the line's endpoints;
 // |ts| < 2^16 whenever the line has two rows, i.e. d > 256), each truncation loses < 1 unit, so after R <=
-// 16383 steps   x_r - BIAS  lies in  (N_r/d - (R + 2) - 2^-8 u,  N_r/d + 2^-8 u].  The tile's walker
-// X(j) = (x(row0) >> 8) + j * (s >> 8), j < 32, in units of 2^-32, is below x(row0 + j) / 256 by less
-// than j + 1 units of 2^-32 = 256 (j + 1) units of 2^-40.  With BIAS = u / 2 the value therefore stays
-// strictly inside [N_r/d, N_r/d + u) as long as  R + 2 + 8448 + 2^-7 u < u / 2,  which holds for every
-// d < 2^23.6 (u > 86 000 > 2 * (16385 + 8448) / (1 - 2^-6)).  Hence floor(X(j)) == floor(N_r / d): EXACT.
+// 16383 steps   x_r - BIAS  lies in  (N_r/d - (R + 2) - 2^-8 u,  N_r/d + 2^-8 u].  With BIAS = u / 2 the value
+// therefore stays strictly inside [N_r/d, N_r/d + u) as long as  R + 2 + 2^-7 u < u / 2,  which holds for every
+// d < 2^23.6 (u > 86 000 > 2 * 16385 / (1 - 2^-6)).  Hence floor(x_r) == floor(N_r / d): EXACT.
 // Single-row lines store s = 0 (the slope of a nearly horizontal line does not fit the format and is
 // never used); empty lines have ra > rb.
 // =============================================================================================
@@ -402,101 +382,12 @@ TP_HD void tp_setup_line(int32_t Xa, int32_t Ya, int32_t Xb, int32_t Yb, int32_t
     ln.rb = live ? rb : 0;
 }
 
-// the tile's 32.32 walker for rows row0, row0 + 1, ... (row0 within 32767 rows of ra)
-TP_HD tp_walker tp_line_at(const tp_line& ln, int32_t row0) {
-    tp_walker w;
-    w.x = (ln.x + (int64_t)(row0 - ln.ra) * ln.s) >> (TP_LINE_FRAC - 32);
-    w.s = ln.s >> (TP_LINE_FRAC - 32);
-    return w;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Which tiles can the nine lines of an edge touch?  Every sample (row centre y, line abscissa x) of a
-// line whose endpoints are the base endpoints displaced by at most (dX, dY) lies in
-// base segment (+) box(dX, dY); the crossing COLUMN c of the sample satisfies 256 c in [x - 128, x + 128).
-// Per tile row this gives a conservative column interval (float arithmetic + one pixel of slack).
-// Columns are clamped like the walk clamps them: left of the raster contributes nothing (prefix 0),
-// right of it the full row (entry W of the last tile column).
-// ---------------------------------------------------------------------------------------------
-struct tp_band {
-    int32_t Xa, Ya, Xb, Yb;  // base endpoints (1/256 px)
-    int32_t dX, dY;          // reach of the endpoint moves (+ margin), 1/256 px
-};
-
-// pixel rows [r0, r1] any of the lines can have (empty when r0 > r1)
-TP_HD void tp_band_rows(const tp_band& b, int32_t H, int32_t& r0, int32_t& r1) {
-    const int32_t ymin = tp_min(b.Ya, b.Yb) - b.dY, ymax = tp_max(b.Ya, b.Yb) + b.dY;
-    r0 = tp_max(tp_first_centre(ymin), 0);
-    r1 = tp_min(tp_first_centre(ymax) - 1, H - 1);
-}
-
-// tile columns [tx0, tx1] of the tile row covering pixel rows [pr0, pr1]; false: none
-TP_HD bool tp_band_cols(const tp_band& b, int32_t pr0, int32_t pr1, int32_t W, int32_t tile_w, int32_t tiles_x,
-                        int32_t& tx0, int32_t& tx1) {
-    const int32_t Ymin = tp_min(b.Ya, b.Yb), Ymax = tp_max(b.Ya, b.Yb);
-    // base points that can reach these rows: y within dY of a row centre
-    const int32_t y0 = tp_max(256 * pr0 + 128 - b.dY, Ymin), y1 = tp_min(256 * pr1 + 128 + b.dY, Ymax);
-    if (y0 > y1) return false;
-    float xlo, xhi;
-    if (b.Ya == b.Yb) {
-        xlo = (float)tp_min(b.Xa, b.Xb); xhi = (float)tp_max(b.Xa, b.Xb);
-    } else {
-        const float slope = tp_fdiv((float)(b.Xb - b.Xa), (float)(b.Yb - b.Ya));
-        const float xa = tp_fadd((float)b.Xa, tp_fmul((float)(y0 - b.Ya), slope));
-        const float xb = tp_fadd((float)b.Xa, tp_fmul((float)(y1 - b.Ya), slope));
-        xlo = fminf(xa, xb); xhi = fmaxf(xa, xb);
-    }
-    const float reach = (float)(b.dX + 128 + 256);  // endpoint moves, column rounding, float slack
-    const float flo = floorf(tp_fmul(tp_fsub(xlo, reach), 1.0f / 256.0f));
-    const float fhi = floorf(tp_fmul(tp_fadd(xhi, reach), 1.0f / 256.0f));
-    if (fhi < 0.0f) return false;  // every crossing column clamps to 0: prefix 0, nothing to add
-    const int32_t c0 = flo < 0.0f ? 0 : (flo > (float)W ? W : (int32_t)flo);
-    const int32_t c1 = fhi > (float)W ? W : (int32_t)fhi;
-    tx0 = tp_min(c0 / tile_w, tiles_x - 1);
-    tx1 = tp_min(c1 / tile_w, tiles_x - 1);
-    return true;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Exact per-line helpers on top of the whole-line walker (k_bin uses them once per line and iteration).
-// ---------------------------------------------------------------------------------------------
 // exact crossing column of row r (ra <= r <= rb), clamped to [0, W] like the walk clamps it
 TP_HD int32_t tp_line_col(const tp_line& ln, int32_t r, int32_t W) {
     const int32_t x = (int32_t)((ln.x + (int64_t)(r - ln.ra) * ln.s) >> TP_LINE_FRAC);
     return x < 0 ? 0 : (x > W ? W : x);
 }
 
-// Can the line have a counted row in the tile (rows [row0, row1], columns [col0, col0 + lim))?  The crossing
-// column is monotone in the row, so every row of the overlap lies between the two end rows: never false
-// for a tile the line really crosses (it may be true for a line that jumps over the tile column in one row).
-TP_HD bool tp_line_live(const tp_line& ln, int32_t row0, int32_t row1, int32_t col0, int32_t lim, int32_t W) {
-    const int32_t rlo = tp_max(ln.ra, row0), rhi = tp_min(ln.rb, row1);
-    if (rlo > rhi) return false;
-    const int32_t xa = tp_line_col(ln, rlo, W), xb = tp_line_col(ln, rhi, W);
-    return tp_max(xa, xb) >= col0 && tp_min(xa, xb) < col0 + lim;
-}
-
-// The runs of consecutive rows a line spends in one tile column: f(tile column, first row, last row), in row
-// order.  The static part of the line's sums -- everything LEFT of the tile column in each of its rows -- is a
-// difference of the cumulative static table per run, so the walk itself only needs tile-local sums.
-template <class F>
-TP_HD void tp_line_column_runs(const tp_line& ln, int32_t W, int32_t tile_w, int32_t tiles_x, F&& f) {
-    if (ln.ra > ln.rb) return;
-    int32_t cur = ln.ra;
-    int32_t tc = tp_min(tp_line_col(ln, cur, W) / tile_w, tiles_x - 1);
-    const int32_t tcb = tp_min(tp_line_col(ln, ln.rb, W) / tile_w, tiles_x - 1);
-    while (tc != tcb) {
-        int32_t lo = cur, hi = ln.rb;  // tile column of lo is tc, of hi is not: bisect for the first row that left it
-        while (hi - lo > 1) {
-            const int32_t mid = lo + ((hi - lo) >> 1);
-            if (tp_min(tp_line_col(ln, mid, W) / tile_w, tiles_x - 1) == tc) lo = mid; else hi = mid;
-        }
-        f(tc, cur, hi - 1);
-        cur = hi;
-        tc = tp_min(tp_line_col(ln, hi, W) / tile_w, tiles_x - 1);
-    }
-    f(tc, cur, ln.rb);
-}
 
 // =============================================================================================
 // Per-image row prefix table (round 2b).  The raster does not change between iterations, so the full-row prefix
