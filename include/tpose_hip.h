@@ -57,7 +57,7 @@ enum tp_buffer {
     TP_BUF_PENERGY = 5,  /* int32[count]      `penergy`  (dead in the reference: lambda = 0,
                             triangle.vs:107) -- always zeros */
     TP_BUF_MOMENTS = 6   /* int64[6*13*NT]    {n, n_odd, sum r, sum g, sum b, sum r^2+g^2+b^2} per
-                            variant: the exact single-sweep moments the energies derive from */
+                            variant: the exact pixel moments the energies derive from */
 };
 
 /* parameters of a fused grad-iter; tp_default_params fills the reference's hard-coded values */
@@ -90,12 +90,14 @@ int tp_get_ratio(const tp_context* ctx, float* ratio);
 int tp_set_dp(tp_context* ctx, float dp);
 
 /* Kept for ABI compatibility (round 1 could keep its per-tile work lists while no vertex had moved more than
- * margin_px - 1 pixels).  Since round 2 a list entry embeds its line's walker, so the lists are rebuilt every
- * iteration and the value (0..1024) has no effect.  Results never depended on it. */
+ * margin_px - 1 pixels).  There are no work lists any more: the value (0..1024) has no effect.  Results never
+ * depended on it. */
 int tp_set_margin(tp_context* ctx, int margin_px);
 
 /* `Texture tex(IMG)` (software/triangulate/main.cpp:74, warp/main.cpp:118-119): RGBA8, row 0 = top,
- * width x height texels, `stride_bytes` between rows.  Host pointer. */
+ * width x height texels, `stride_bytes` between rows.  Host pointer.  Like the reference's texture the image
+ * is uploaded once and read by every iteration after it; the upload also builds the image's row prefix table
+ * (8 bytes per pixel of device memory), which is what the iterations actually read. */
 int tp_set_image(tp_context* ctx, int slot, const uint8_t* rgba, size_t stride_bytes);
 /* same, source already in device memory of this context's device (e.g. a torch tensor) */
 int tp_set_image_device(tp_context* ctx, int slot, const void* dev_rgba, size_t stride_bytes);
@@ -107,9 +109,9 @@ int tp_upload(tp_context* ctx, const float* points, int NP, const int32_t* trian
               const int32_t* colors);
 
 /* computecolors() / doreset() -- the mode-0 draw (triangulate/main.cpp:121-130, warp/main.cpp:140-151).
- * `flavour` says which program's vertex stage applies (its dp law).  One sweep of raster `slot`
- * -- for TP_WARP the image the following mode-1 pass samples -- yields exact per-variant moments,
- * from which `colnum`/`colacc` (and the mode-1 energies) derive. */
+ * `flavour` says which program's vertex stage applies (its dp law).  The pixel sums of every edge
+ * line over raster `slot` -- for TP_WARP the image the following mode-1 pass samples -- yield exact
+ * per-variant moments, from which `colnum`/`colacc` (and the mode-1 energies) derive. */
 int tp_accumulate(tp_context* ctx, int flavour, int slot);
 /* doenergy() -- the mode-1 draw (triangulate/main.cpp:132-141, warp/main.cpp:153-164): fills
  * `tenergy` (and `colnum`, `colacc` for TP_TRIANGULATE) from the moments of the last tp_accumulate. */
@@ -137,46 +139,44 @@ int tp_retrieve_many(tp_context* ctx, int n, const int* what, void* const* dst, 
 int tp_synchronize(tp_context* ctx);
 
 /* measurement hooks (bench.py): the HIP stream the kernels run on, and HIP-event timing of the
- * dominant kernel (the per-pixel accumulate) accumulated over launches since the last reset.
- * Timing is only collected on the un-fused path used by tp_profile_iterate. */
+ * dominant kernel (k_lines: the pixel sums of every edge line). */
 int tp_get_stream(tp_context* ctx, void** hip_stream);
-/* runs n_iters grad-iters eagerly with HIP events around every accumulate launch; returns the
- * average accumulate-kernel duration in microseconds */
+/* runs n_iters grad-iters eagerly with the dispatch's own timestamps around every k_lines launch; returns the
+ * average duration of that kernel in microseconds */
 int tp_profile_iterate(tp_context* ctx, const tp_params* p, int n_iters, double* accumulate_us);
-/* average duration of the accumulate kernel as it runs inside the fused path: the work lists of the current
- * state are built once (k_bin), then `launches` back-to-back launches of the kernel -- same lists, same raster,
- * idempotent -- are captured into one hipGraph and a replay is bracketed by two HIP events on the context's
- * stream; returns elapsed / launches in microseconds (includes the ~0.2 us between graph nodes).  The
- * triangulation is not advanced.  (tp_profile_iterate's per-dispatch timestamps need eager launches, which
+/* average duration of k_lines as it runs inside the fused path: `launches` back-to-back launches of the kernel
+ * on the current state -- idempotent -- are captured into one hipGraph and a replay is bracketed by two HIP events
+ * on the context's stream; returns elapsed / launches in microseconds (includes the gap between graph nodes).
+ * The triangulation is not advanced.  (tp_profile_iterate's per-dispatch timestamps need eager launches, which
  * run ~1 us longer than the same kernel inside a graph replay.) */
 int tp_profile_accumulate(tp_context* ctx, const tp_params* p, int launches, double* accumulate_us);
 
 /* Flat-shaded picture of the triangulation: every raster pixel gets the colour of the base triangle
- * that covers it (same coverage rule as the sweep, so every covered pixel is written exactly once),
+ * that covers it (same coverage rule as the cost function, so every covered pixel is written exactly once),
  * uncovered pixels are opaque black.  Replaces the display pass `mode == 2` of
  * software/triangulate/shader/triangle.fs:45-50 (source TP_RENDER_AVERAGE: colacc/colnum of the last
- * sweep, as the reference draws it) and of software/view/shader/triangle.fs (TP_RENDER_STORED: the
+ * evaluation, as the reference draws it) and of software/view/shader/triangle.fs (TP_RENDER_STORED: the
  * colours given to tp_upload).  `points` (float[2*NP], host) overrides the vertex positions for this
  * picture only -- software/view/shader/triangle.vs draws mix(points, originpoints, s) -- or NULL for
  * the context's current positions.  dst: RGBA8, row 0 on top, `stride` bytes per row. */
 enum { TP_RENDER_AVERAGE = 0, TP_RENDER_STORED = 1 };
 int tp_render(tp_context* ctx, int source, const float* points, uint8_t* dst_rgba, size_t stride);
 
-/* introspection for tests/benchmarks: 0 = tiles_x, 1 = tiles_y, 2 = tile width, 3 = tile height,
- * 4 = (edge,tile) record slots drawn from the shared part of the record buffer, 5 = device-side overflow flags,
- * 6 = number of work-list rebuilds requested by the device so far */
+/* introspection for tests/benchmarks: 0 = records per row of the prefix table, 1 = chunks per line of k_lines for the
+ * current triangulation (rows of a line are shared by that many lanes); 2..6 = 0 (work-list statistics of earlier
+ * rounds) */
 int tp_get_info(tp_context* ctx, int what, int64_t* value);
 
 /* device self-test of the exact span walker (tp_raster.h): for each (N0, step, d), the 32 values
- * floor((N0 + r*step)/d), r = 0..31, as the accumulate kernel derives them.  out = int32[32*n]. */
+ * floor((N0 + r*step)/d), r = 0..31, as the picture pass derives them.  out = int32[32*n]. */
 int tp_selftest_walker(tp_context* ctx, const int64_t* N0, const int32_t* step, const int32_t* d,
                        int n, int32_t* out);
 
 
-/* device self-test of the whole-line walker the sweep uses since round 2 (tp_raster.h, tp_setup_line): for line k
+/* device self-test of the whole-line walker of k_lines (tp_raster.h, tp_setup_line): for line k
  * through the snapped points (ends[4k], ends[4k+1]) - (ends[4k+2], ends[4k+3]) (1/256 pixel) on a raster of
  * H[k] rows, out[(rows+2)k] = first row, out[(rows+2)k+1] = last row (first > last: no row), and then the crossing
- * column of `rows` consecutive rows from the first, derived tile by tile exactly as the accumulate kernel does. */
+ * column (not clamped to the raster) of `rows` consecutive rows from the first, from the one set-up of the line. */
 int tp_selftest_line(tp_context* ctx, const int32_t* ends, const int32_t* H, int n, int rows, int32_t* out);
 
 #ifdef __cplusplus

@@ -11,7 +11,7 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_20_5.json 2> 
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python bench.py --no-cpu-baseline --no-pmc > $O/kt.log 2>&1
 find $O -name "*kernel_trace.csv" -delete
 # 3. hardware counters per kernel (separate passes, counters only)
-python tools/pmc_kernels.py $O/pmc.json > /dev/null 2> $O/pmc.err
+TPOSE_PMC_GROUPS=0,1,2,3,4,5,7 python tools/pmc_kernels.py $O/pmc.json > /dev/null 2> $O/pmc.err
 # 4. in-kernel timelines (debug flavour of the library)
 python tools/kernel_timeline.py > $O/timeline.json 2> $O/timeline.err
 # 5. other configurations

@@ -77,7 +77,7 @@ print(json.dumps({
     "speedup_bound_two_gpus_per_direction": round(full_us / two_band_us, 2),
     "speedup_bound_four_gpus_one_pair": round(2 * full_us / two_band_us, 2),
     "four_gpus_as_two_pairs_x_two_directions": 4.0,
-    "verdict": "a direction is three dependent kernels of a few microseconds each; two hand-overs of tens of microseconds "
-               "per grad-iter cost more than the half sweep they save -- the >= 3.5x at 4 GPUs is reached as 2 pairs x 2 "
+    "verdict": "a direction is two dependent kernels of a few microseconds each; two hand-overs of tens of microseconds "
+               "per grad-iter cost more than the half of the work they save -- the >= 3.5x at 4 GPUs is reached as 2 pairs x 2 "
                "directions (tools/run_batch.py --split-directions), not inside one pair",
 }, indent=1))

@@ -403,7 +403,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         }
         rows = rows * 0.5 * (double)c->H / (double)(NE > 0 ? NE : 1);
         int lpl = 1;
-        while (lpl < 64 && rows > (double)TP_LINES_ROWS * lpl) lpl <<= 1;
+        while (lpl < 1024 && rows > (double)TP_LINES_ROWS * lpl) lpl <<= 1;
         c->lanes_per_line = lpl;
     }
 

@@ -101,8 +101,8 @@ __device__ __forceinline__ void acc_entry(line_acc& a, int c, const uint4 d0, co
 #define LINE_BATCH 4  // table records requested together by one lane (58 VGPRs: every workgroup of a launch is resident at once)
 #endif
 
-// k_lines.  A workgroup takes `eb` edges (seven: 63 lines, one lane short of a wave; or one, for coarse meshes whose
-// lines have hundreds of rows).  Wave 0 sets every line up ONCE, lane per line, and parks the walkers in LDS.  Then
+// k_lines.  A workgroup takes `eb` edges (three: 27 lines; or, for coarse meshes whose lines have hundreds of rows,
+// eb == 0: ONE line).  Wave 0 sets every line up ONCE, lane per line, and parks the walkers in LDS.  Then
 // thread (l, c) -- line l = tid mod LP, chunk c = tid / LP of TL -- takes the rows rmin + c, rmin + c + TL, ... of the
 // band the nine lines of its edge cover: the nine lines of an edge sit in adjacent lanes ON THE SAME ROW, and their
 // crossing columns lie within a few pixels of each other (the moves are small), so their table entries share a
@@ -112,6 +112,9 @@ struct lds_line { int64_t x, s; int32_t ra, rb; };
 #define TP_LINES_LP_SHIFT 5  // fine meshes: 32 lanes per chunk = the 27 lines of three edges (6: 64 lanes, seven edges -- fewer, larger workgroups: slower)
 #endif
 #define LINES_EB (((1 << TP_LINES_LP_SHIFT) / TP_NLINES))
+#ifndef TP_LINES_FINE_MAX
+#define TP_LINES_FINE_MAX 16  // chunks per line up to which three edges share a workgroup
+#endif
 #ifndef TP_LINES_WAVES_PER_EU
 #define TP_LINES_WAVES_PER_EU 4
 #endif
@@ -128,15 +131,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TP_LINES_W
     // edges read neighbouring table lines
     const int per = (int)gridDim.x >> 3;  // (the grid is padded to a multiple of 8)
     const int blk = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-    if (blk * eb >= L.NE) return;  // (uniform per workgroup)
+    if ((eb ? blk * eb * TP_NLINES : blk) >= L.NE * TP_NLINES) return;  // (uniform per workgroup)
 #else
     const int blk = blockIdx.x;
 #endif
+    const int nl = eb ? eb * TP_NLINES : 1;           // lines of this workgroup (eb == 0: ONE line, coarse meshes)
+    const int line0 = eb ? blk * eb * TP_NLINES : blk;  // ... the first of them
     TP_STAMP(0, 0);
     if (tid < 64) {  // (one wave: LDS keeps its program order)
-        const int j = tid / TP_NLINES, q = tid - j * TP_NLINES;
-        const int e = blk * eb + j;
-        const bool on = j < eb && e < L.NE;
+        const int j = tid / TP_NLINES;  // edge of the workgroup
+        const int e = (line0 + tid) / TP_NLINES, q = line0 + tid - e * TP_NLINES;
+        const bool on = tid < nl && e < L.NE;
         if (tid < LINES_EB) { s_rmin[tid] = 0x3fffffff; s_rmax[tid] = -1; }
         tp_line ln; ln.x = 0; ln.s = 0; ln.ra = 1; ln.rb = 0;
         if (on) {
@@ -161,8 +166,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TP_LINES_W
     TP_STAMP(0, 1);
     const int l = tid & ((1 << lp_shift) - 1), c = tid >> lp_shift;
     const int j = l / TP_NLINES;
-    const int e = blk * eb + j;
-    const bool on = l < eb * TP_NLINES && e < L.NE;
+    const bool on = l < nl && line0 + l < L.NE * TP_NLINES;
     line_acc a = {0, 0, 0, 0, 0, 0};
     if (on) {
         const lds_line ln = s_ln[l];
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TP_LINES_W
         }
     }
     TP_STAMP(0, 2);
-    int64_t* w = L.wline + ((size_t)blk * eb * TP_NLINES + l) * TP_W_WORDS;
+    int64_t* w = L.wline + ((size_t)line0 + l) * TP_W_WORDS;
     if (TL == 1) {
         if (on) { w[0] = a.xs; w[1] = a.nodd; w[2] = (int64_t)a.r; w[3] = (int64_t)a.g; w[4] = (int64_t)a.b; w[5] = (int64_t)a.q; }
     } else {
@@ -215,11 +219,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TP_LINES_W
     TP_STAMP(0, 3);
 }
 void tp_launch_lines(const tp_launch& L, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
-    // lanes_per_line: chunks per line (1 .. 64).  Up to 16 chunks: seven edges per workgroup, 64 lanes per chunk;
-    // beyond (coarse meshes): one edge per workgroup, 16 lanes per chunk
+    // lanes_per_line: chunks per line (1 .. 1024).  Up to 16 chunks: three edges per workgroup, 32 lanes per chunk;
+    // beyond (coarse meshes, lines of hundreds of rows): one LINE per workgroup, a lane per chunk
     const int tl = L.lanes_per_line;
-    const int eb = tl <= 16 ? LINES_EB : 1, lp_shift = tl <= 16 ? TP_LINES_LP_SHIFT : 4;
-    const unsigned blocks = (unsigned)((L.NE + eb - 1) / eb);
+    const int eb = tl <= TP_LINES_FINE_MAX ? LINES_EB : 0, lp_shift = tl <= TP_LINES_FINE_MAX ? TP_LINES_LP_SHIFT : 0;
+    const unsigned blocks = eb ? (unsigned)((L.NE + eb - 1) / eb) : (unsigned)(L.NE * TP_NLINES);
     hipExtLaunchKernelGGL(k_lines, dim3((blocks + 7u) & ~7u), dim3((unsigned)(tl << lp_shift)), 0, s, start, stop, 0, L, eb, lp_shift);
 }
 
