@@ -16,6 +16,7 @@ W = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 NT = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
 flavour = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+pre = int(sys.argv[5]) if len(sys.argv) > 5 else 0  # grad-iters before anything is timed (the descent degrades the mesh)
 img, pts, tris, he, ratio = synth.workload(W, H, NT)
 ctx = capi.Context(0, W, H)
 ctx.set_image(capi.IMAGE_A, img)
@@ -26,7 +27,7 @@ if flavour == 1:
 ctx.upload(pts, tris, colors)
 p = capi.default_params(flavour)
 ctx.prepare(p)
-ctx.iterate(p, 64)
+ctx.iterate(p, 64 + pre)
 ctx.synchronize()
 if os.environ.get("TPOSE_TIME_ACC_SHORT"):  # under a counter pass: a few dozen launches are enough
     ctx.iterate(p, 32)
@@ -41,7 +42,7 @@ for _ in range(5):
     ctx.synchronize()
     its.append((time.perf_counter() - t0) / 1024 * 1e6)
 its.sort()
-print(json.dumps({"lib": os.path.basename(capi.LIB_PATH), "raster": [W, H], "triangles": tris.shape[0], "flavour": flavour,
+print(json.dumps({"lib": os.path.basename(capi.LIB_PATH), "raster": [W, H], "triangles": tris.shape[0], "flavour": flavour, "pre_iters": pre,
                   "k_lines_us": round(acc[2], 3), "k_lines_us_min": round(acc[0], 3),
                   "iter_us": round(its[2], 3), "iter_us_min": round(its[0], 3),
                   "prefix_pitch": ctx.info(0), "chunks_per_line": ctx.info(1)}), flush=True)
