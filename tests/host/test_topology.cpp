@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <set>
 #include <vector>
 
 #include "tpose/io.hpp"
@@ -149,6 +150,103 @@ int main(int argc, char** argv) {
             const int w = tr.halfedges[h];
             if (w >= 0) { CHECK(tr.halfedges[w] == h); CHECK(tr.org(h) == tr.dst(w) && tr.dst(h) == tr.org(w)); }
         }
+    }
+    {   // randomised operation sequences: the structural invariants of the half-edge mesh hold after EVERY operation
+        // (the reference's own headers cannot be built here, so there is no state-for-state oracle for these;
+        // the known answers above pin the individual operations)
+        RATIO = 1.5f;
+        uint64_t seed = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return (uint32_t)(seed >> 20); };
+        auto frand = [&]() { return (float)(rnd() & 0xffff) / 65536.0f; };
+        auto signed_area = [](const triangulation& tr, int t) {
+            const vec2 a = tr.points[tr.triangles[t].x], b = tr.points[tr.triangles[t].y], c = tr.points[tr.triangles[t].z];
+            return 0.5 * ((double)(b.x - a.x) * (c.y - a.y) - (double)(b.y - a.y) * (c.x - a.x));
+        };
+        // 0 = fine; otherwise which invariant broke
+        auto invariants = [&](const triangulation& tr, bool area_conserved, bool manifold) {
+            if (!((int)tr.triangles.size() == tr.NT && (int)tr.halfedges.size() == 3 * tr.NT &&
+                  (int)tr.points.size() == tr.NP && tr.NT >= 1)) return 1;  // (originpoints is only set by io::read, as in the reference)
+            std::set<std::pair<int, int>> directed;
+            double area = 0;
+            for (int t = 0; t < tr.NT; t++) {
+                for (int k = 0; k < 3; k++) {
+                    const int v = tr.triangles[t][k];
+                    if (v < 0 || v >= tr.NP) return 2;
+                }
+                area += signed_area(tr, t);
+            }
+            for (int h = 0; h < 3 * tr.NT; h++) {
+                const int w = tr.halfedges[h];
+                if (w < -1 || w >= 3 * tr.NT || w == h) return 3;
+                if (w >= 0 && tr.halfedges[w] != h) return 4;                                      // twins are mutual
+                if (w >= 0 && !(tr.org(h) == tr.dst(w) && tr.dst(h) == tr.org(w))) return 5;      // ... and run the same edge backwards
+                if (manifold && !directed.insert({tr.org(h), tr.dst(h)}).second) return 6;         // a directed edge belongs to one triangle
+            }
+            if (area_conserved && std::fabs(std::fabs(area) - 4.0 * RATIO) >= 1e-3) return 7;      // the triangles tile the domain
+            return 0;
+        };
+        int ops[5] = {0, 0, 0, 0, 0};
+        for (int trial = 0; trial < 150; trial++) {
+            triangulation tr;
+            bool tiling = true;  // holds as long as nothing was pruned or collapsed and no vertex was moved
+            const bool moves = trial % 3 == 2;
+            for (int step = 0; step < 80 && tr.NT < 400; step++) {
+                const int op = rnd() % (trial % 2 ? 5 : 3);
+                bool done = false;
+                if (op == 0) {  // the largest of three random triangles (keeps the shapes away from float-degenerate slivers)
+                    int t = (int)(rnd() % tr.NT);
+                    for (int k = 0; k < 2; k++) {
+                        const int u = (int)(rnd() % tr.NT);
+                        if (std::fabs(signed_area(tr, u)) > std::fabs(signed_area(tr, t))) t = u;
+                    }
+                    done = tr.split(t);
+                } else if (op == 1) done = tr.flip((int)(rnd() % (3 * tr.NT)), frand() < 0.5f ? PI : 0.8f * PI);
+                else if (op == 2) {
+                    const int nt = tr.NT, np = tr.NP;
+                    tr.optimize(); done = true;
+                    if (tr.NT != nt || tr.NP != np) tiling = false;  // it pruned or collapsed something
+                }
+                else if (op == 3) {
+                    // collapse needs a short edge: pull the origin of a random half-edge onto its destination first.
+                    // Only edges whose collapse keeps the mesh a manifold are tried (link condition: the two
+                    // endpoints share exactly the apexes of the edge's triangles) -- the operation itself, like the
+                    // reference's, does not check it
+                    const int h = (int)(rnd() % (3 * tr.NT));
+                    const int a = tr.org(h), b = tr.dst(h);
+                    std::set<int> na, nb;
+                    for (int g = 0; g < 3 * tr.NT; g++) {
+                        if (tr.org(g) == a) na.insert(tr.dst(g));
+                        if (tr.dst(g) == a) na.insert(tr.org(g));
+                        if (tr.org(g) == b) nb.insert(tr.dst(g));
+                        if (tr.dst(g) == b) nb.insert(tr.org(g));
+                    }
+                    int common = 0;
+                    for (int v : na) common += (int)nb.count(v);
+                    const int expect = tr.halfedges[h] >= 0 ? 2 : 1;
+                    if (a >= 4 && b >= 4 && common == expect && tr.NT > 4) {
+                        tr.points[a] = vec2(tr.points[b].x + 0.002f * (frand() - 0.5f), tr.points[b].y + 0.002f * (frand() - 0.5f));
+                        tiling = false;
+                        done = tr.collapse(h);
+                    }
+                } else {
+                    const int t = (int)(rnd() % tr.NT);
+                    done = tr.prune(t);
+                    if (done) tiling = false;
+                }
+                if (done) ops[op]++;
+                if (moves && tr.NP > 4) {  // the descent in between: interior vertices wander a little
+                    const int v = 4 + (int)(rnd() % (tr.NP - 4));
+                    if (!triangulation::boundary(tr.points[v])) {
+                        tr.points[v] = vec2(tr.points[v].x + 0.01f * (frand() - 0.5f), tr.points[v].y + 0.01f * (frand() - 0.5f));
+                    }
+                }
+                // (once vertices were moved or pulled together the embedding may be folded, and a flip judged on a folded
+                // quad can double an edge -- in the reference as here; twins, ids and sizes must hold regardless)
+                const int bad = invariants(tr, tiling && !moves, tiling && !moves);
+                if (bad) { std::printf("FAIL randomised sequence: invariant %d, trial %d step %d op %d NT %d NP %d\n", bad, trial, step, op, tr.NT, tr.NP); fails++; break; }
+            }
+        }
+        CHECK(ops[0] > 500 && ops[1] > 200 && ops[2] > 200 && ops[3] > 20);  // the sequences really exercised the operations
     }
     std::printf(fails ? "%d FAILED\n" : "host mirror OK\n", fails);
     return fails ? 1 : 0;

@@ -216,8 +216,8 @@ def test_work_list_reuse_never_changes_results(margin):
 
 @pytest.mark.parametrize("W,H", [(1011, 674), (2048, 2048)])
 def test_two_triangle_start_state_large_raster(W, H):
-    """The reference's 2-triangle start state on big rasters: edges spanning hundreds of tiles
-    (the un-culled, un-masked work-list path) against the oracle's moments."""
+    """The reference's 2-triangle start state on big rasters: lines of hundreds to thousands of rows
+    (one line per workgroup in k_lines) against the oracle's moments."""
     img = synth.voronoi_raster(W, H, seed=11, sites=24)
     ratio = float(np.float32(W) / np.float32(H))
     pts, tris, _ = synth.two_triangle(ratio)
@@ -230,6 +230,51 @@ def test_two_triangle_start_state_large_raster(W, H):
     assert np.array_equal(ctx.retrieve(capi.BUF_MOMENTS), mom)
     assert int(ctx.retrieve(capi.BUF_COLNUM)[:2].sum()) == W * H
     ctx.close()
+
+
+@pytest.mark.parametrize("grid", [(1, 1), (2, 2), (4, 3), (8, 6), (16, 12), (40, 30)])
+def test_every_chunking_of_k_lines_matches_oracle(grid):
+    """meshes from two triangles to 2400 on a 1024x768 raster: the chunk count per line (and with it the workgroup
+    shape of k_lines: three edges per workgroup up to 16 chunks, one line per workgroup beyond) follows the mesh;
+    three fused grad-iters, every integer buffer and the positions bit-equal to the oracle"""
+    W, H = 1024, 768
+    img = synth.voronoi_raster(W, H, seed=21, sites=40)
+    ratio = float(np.float32(W) / np.float32(H))
+    pts, tris, _ = synth.grid_triangulation(grid[0], grid[1], ratio=ratio)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts, tris)
+    chunks = ctx.info(1)
+    assert chunks >= 1 and (chunks & (chunks - 1)) == 0
+    ctx.iterate(capi.default_params(0), 3)
+    ref = O.iterate(img, pts, tris, 0, ratio, RATE[0], 3, literal=False)
+    assert np.array_equal(ctx.retrieve(capi.BUF_TENERGY), ref["ten"]), chunks
+    assert np.array_equal(ctx.retrieve(capi.BUF_COLNUM), ref["cn"])
+    assert np.array_equal(ctx.retrieve(capi.BUF_COLACC), ref["ca"])
+    assert np.array_equal(ctx.retrieve(capi.BUF_GRADIENT), ref["gr"])
+    assert np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
+    ctx.close()
+
+
+def test_widest_raster_saturated_pixels():
+    """the packing limits of the prefix table on the device: 16384 columns of (255, 255, 255) -- 22-bit channel
+    sums, a 32-bit square sum and a 15-bit parity count filled to the last bit -- and of odd pixels"""
+    W, H = 16384, 6
+    ratio = float(np.float32(W) / np.float32(H))
+    pts, tris, _ = synth.two_triangle(ratio)
+    for val in ((255, 255, 255), (255, 254, 0)):
+        img = np.zeros((H, W, 4), np.uint8)
+        img[..., :3] = val
+        img[..., 3] = 255
+        ctx = capi.Context(0, W, H)
+        ctx.set_image(capi.IMAGE_A, img)
+        ctx.upload(pts, tris)
+        ctx.accumulate(0, capi.IMAGE_A)
+        ctx.energy(0)
+        mom = O.moments(img, pts, tris, O.dp(0, 2), ratio)
+        assert np.array_equal(ctx.retrieve(capi.BUF_MOMENTS), mom)
+        assert int(ctx.retrieve(capi.BUF_COLNUM)[:2].sum()) == W * H
+        ctx.close()
 
 
 def test_batch_config_properties():

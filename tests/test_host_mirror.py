@@ -1,5 +1,8 @@
 """C++ host mirror (include/tpose/*.hpp): known-answer tests against the fixtures SURVEY.md section 8c
-lists for the reference's host half (topology ops, warp, geterr, .tri format).  CPU only."""
+lists for the reference's host half (topology ops, warp, geterr, .tri format), and 150 randomised sequences of
+split / flip / optimize / collapse / prune with vertex moves in between, whose half-edge invariants (mutual twins over
+the same edge, ids in range, sizes; while nothing was removed or moved also: one triangle per directed edge and the
+triangles tile the domain) are checked after every operation.  CPU only."""
 import os
 import subprocess
 
