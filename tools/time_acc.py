@@ -29,6 +29,11 @@ p = capi.default_params(flavour)
 ctx.prepare(p)
 ctx.iterate(p, 64 + pre)
 ctx.synchronize()
+if os.environ.get("TPOSE_TIME_ACC_REUPLOAD"):  # the degraded mesh uploaded afresh: the chunk count per line is chosen again
+    ctx.upload(ctx.retrieve(capi.BUF_POINTS).reshape(-1, 2), tris, colors)
+    ctx.prepare(p)
+    ctx.iterate(p, 64)
+    ctx.synchronize()
 if os.environ.get("TPOSE_TIME_ACC_SHORT"):  # under a counter pass: a few dozen launches are enough
     ctx.iterate(p, 32)
     ctx.synchronize()

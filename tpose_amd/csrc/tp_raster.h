@@ -393,10 +393,12 @@ TP_HD int32_t tp_line_col(const tp_line& ln, int32_t r, int32_t W) {
 // Per-image row prefix table (round 2b).  The raster does not change between iterations, so the full-row prefix
 // sums P_r(c) the line sums need are tabulated once per image.  To keep the table small (8 bytes per pixel) a row
 // is cut into groups of four pixels; the 32-byte record of group g holds
-//   words 0..3  the moments of the pixels x < 4g:  sum r (22 bits) | n_odd bits 0..9 << 22,  sum g | n_odd bits
-//               10..14 << 22,  sum b,  sum (r^2 + g^2 + b^2)      (W <= 16384: 255 W < 2^22, 3 * 255^2 W < 2^32)
-//   words 4..6  the r, g, b bytes of the group's four pixels (pixel i in byte i; zero beyond the raster), word 7: 0
-// and P_r(c) = record(c >> 2) + the first (c & 3) pixels of the group: three masks and six 4-byte dot products.
+//   words 0..3  the moments of the pixels x < 4g:  sum r, sum g, sum b, sum (r^2 + g^2 + b^2)
+//               (W <= 16384: 255 W < 2^22, 3 * 255^2 W < 2^32)
+//   words 4..6  the r, g, b bytes of the group's four pixels (pixel i in byte i; zero beyond the raster)
+//   word 7      n_odd of the pixels x < 4g
+// and P_r(c) = record(c >> 2) + the first (c & 3) pixels of the group: one mask, three ANDs, six 4-byte dot products
+// and a population count.
 // n_odd counts the pixels with r + g + b odd (parity of the sum = parity of r xor g xor b).
 // =============================================================================================
 #define TP_PFX_WORDS 8
@@ -421,20 +423,20 @@ TP_HD uint32_t tp_popc(uint32_t v) {
 
 // running moments m = {n_odd, r, g, b, q} of the pixels before a group, and the group's pixels -> record
 TP_HD void tp_prefix_pack(const uint32_t m[5], const uint32_t px[4], int npx, uint32_t rec[TP_PFX_WORDS]) {
-    rec[0] = m[1] | (m[0] << 22); rec[1] = m[2] | ((m[0] >> 10) << 22); rec[2] = m[3]; rec[3] = m[4];
+    rec[0] = m[1]; rec[1] = m[2]; rec[2] = m[3]; rec[3] = m[4];
     uint32_t R = 0, G = 0, B = 0;
     for (int i = 0; i < npx; i++) {
         R |= (px[i] & 0xffu) << (8 * i); G |= ((px[i] >> 8) & 0xffu) << (8 * i); B |= ((px[i] >> 16) & 0xffu) << (8 * i);
     }
-    rec[4] = R; rec[5] = G; rec[6] = B; rec[7] = 0;
+    rec[4] = R; rec[5] = G; rec[6] = B; rec[7] = m[0];
 }
 // the moments of the pixels x < c of the row whose record for group c >> 2 is `rec`
 TP_HD void tp_prefix_eval(const uint32_t rec[TP_PFX_WORDS], int32_t c, uint32_t& nodd, uint32_t& r, uint32_t& g, uint32_t& b, uint32_t& q) {
-    const uint32_t keep = (1u << (8 * (c & 3))) - 1u;  // the bytes of the first c & 3 pixels
+    const uint32_t keep = (1u << ((c << 3) & 31)) - 1u;  // the bytes of the first c & 3 pixels (v_bfm_b32)
     const uint32_t R = rec[4] & keep, G = rec[5] & keep, B = rec[6] & keep;
-    nodd = ((rec[0] >> 22) | ((rec[1] >> 22) << 10)) + tp_popc((R ^ G ^ B) & 0x01010101u);
-    r = tp_udot4(R, 0x01010101u, rec[0] & 0x3fffffu);
-    g = tp_udot4(G, 0x01010101u, rec[1] & 0x3fffffu);
+    nodd = rec[7] + tp_popc((R ^ G ^ B) & 0x01010101u);
+    r = tp_udot4(R, 0x01010101u, rec[0]);
+    g = tp_udot4(G, 0x01010101u, rec[1]);
     b = tp_udot4(B, 0x01010101u, rec[2]);
     q = tp_udot4(R, R, tp_udot4(G, G, tp_udot4(B, B, rec[3])));
 }
