@@ -592,8 +592,16 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
                 newp = make_float2(x, y); moved = 1;
             }
         }
-        // the new position goes to every edge the vertex ends (k_bin reads endpoints by edge)
-        if (__shfl(moved, 0)) publish_position(L, v, make_float2(__shfl(newp.x, 0), __shfl(newp.y, 0)), lane, UPD_THREADS);
+        // the new position goes to every edge the vertex ends (k_lines reads endpoints by edge)
+        if (__shfl(moved, 0)) {
+            const float2 q = make_float2(__shfl(newp.x, 0), __shfl(newp.y, 0));
+            if (!generic && !L.twice) {
+                // lane 4 b holds (incident edge b, version 1..4: the vertex is the edge's first endpoint, 5..8: its second):
+                // no table to look the side up in (publish_position's dependent load at the very end of the kernel)
+                if ((lane & 3) == 0 && lane < 4 * UPD_FAN && ref >= 0) L.epos[(size_t)(ref >> 4) * 2 + ((ref & 15) > 4 ? 1 : 0)] = q;
+            } else
+                publish_position(L, v, q, lane, UPD_THREADS);
+        }
     }
     TP_STAMP(2, 3);
 }
