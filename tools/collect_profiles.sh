@@ -19,6 +19,7 @@ for cfg in "2048 2048 3000 1" "4096 4096 12000 1" "4096 4096 12000 0" "674 449 1
   python tools/time_acc.py $cfg >> $O/configs.jsonl 2>> $O/configs.err
 done
 python tools/time_coarse.py > $O/coarse.jsonl 2>&1
+python tools/time_configs.py > $O/time_configs.jsonl 2>&1
 python tools/run_config2.py 600 > $O/config2.txt 2>&1
 python tools/run_config3.py > $O/config3.txt 2>&1
 python tools/run_batch.py --pairs 8 --iters 512 > $O/config4.json 2> $O/config4.err

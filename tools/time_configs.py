@@ -31,7 +31,7 @@ def run(name, W, H, NT, flavour, steps):
     acc = ctx.profile_iterate(p, 64)
     bytes_iter = 4 * W * H + 16 * NT + 24 * 13 * NT + 24 * pts.shape[0]
     out = dict(config=name, raster=[W, H], triangles=NT, flavour="warp" if flavour else "triangulate",
-               us_per_iter=dt / steps * 1e6, tri_iters_per_s=NT * steps / dt, accumulate_us=acc,
+               us_per_iter=dt / steps * 1e6, tri_iters_per_s=NT * steps / dt, k_lines_us=acc,
                roofline_frac=bytes_iter / (acc * 1e-6) / 8e12)
     ctx.close()
     print(json.dumps(out), flush=True)
@@ -83,8 +83,8 @@ def run_cold(W, H, NT, nctx, reps):
             n += 1
     warm = ctxs[0].profile_iterate(p, 64)
     bytes_iter = 4 * W * H + 16 * NT + 24 * 13 * NT + 24 * ctxs[0].NP
-    print(json.dumps(dict(config="cold cache %dx%d / %d, %d planes = %.0f MB cycled" % (W, H, NT, nctx, nctx * 4 * W * H / 1e6),
-                          accumulate_us_cold=tot / n, accumulate_us_warm_same_process=warm,
+    print(json.dumps(dict(config="cold cache %dx%d / %d, %d prefix tables = %.0f MB cycled" % (W, H, NT, nctx, nctx * 8 * W * H / 1e6),
+                          k_lines_us_cold=tot / n, k_lines_us_warm_same_process=warm,
                           roofline_frac_cold=bytes_iter / (tot / n * 1e-6) / 8e12)), flush=True)
     for c in ctxs:
         c.close()
