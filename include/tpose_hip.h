@@ -37,7 +37,7 @@ enum tp_status {
     TP_ERR_INVALID = 1,   /* bad argument */
     TP_ERR_NO_DEVICE = 2, /* no HIP device / device index out of range */
     TP_ERR_HIP = 3,       /* a HIP runtime call failed */
-    TP_ERR_CAPACITY = 4,  /* 13*NT > MAXT, raster too large, or a device-side work list overflowed */
+    TP_ERR_CAPACITY = 4,  /* 13*NT > MAXT or NP > MAXT, raster too large */
     TP_ERR_STATE = 5      /* call order violated (e.g. energy before accumulate/upload) */
 };
 
