@@ -87,6 +87,31 @@ def _torchrun(args, nproc, timeout=600):
 
 
 @pytest.mark.gpu
+def test_bench_line_contract_one_gpu():
+    """`python bench.py` with the driver's flags: ONE JSON line with the metric of BASELINE.json, the roofline object of
+    the dominant kernel (k_lines) and the CPU baseline; the kernel trace and the counter passes are collected live"""
+    import sys
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["higher_is_better"] is True
+    assert line["unit"] == "triangles*grad-iters/s" and line["vs_baseline"] is None and line["data"] == "synthetic"
+    assert abs(line["value"] - 3000 * 20 / (line["ms_per_step"] * 20e-3)) < 1e-6 * line["value"]
+    assert line["config"]["raster"] == [2048, 2048] and line["config"]["triangles"] == 3000 and "workload" in line["config"]
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "k_lines"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
+    assert abs(rf["achieved"] - rf["algorithmic_bytes"] / (rf["kernel_us"] * 1e-6) / 1e9) < 1e-6 * rf["achieved"]
+    assert rf["traffic"] is None or rf["traffic"] > rf["algorithmic_bytes"] // 2
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["single_thread_value"] > 0 and cb["cpu_model"]
+    assert line["ms_per_step_readback_every_iter"] > line["ms_per_step"]
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_on_one_gpu():
     """the driver's launch line for N > 1 (one rank per GPU over RCCL), here with both ranks on the one GPU of the
     test box and gloo for the two collectives: one JSON line from rank 0, whole-job aggregate, weak scaling"""
