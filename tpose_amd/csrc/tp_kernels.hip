@@ -398,16 +398,15 @@ __global__ void k_vertex_refs(tp_launch L, int* vref, int* vvar) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= L.NP) return;
     const int k0 = L.vtx_off[v], deg = L.vtx_off[v + 1] - k0;
-    int* r = vref + (size_t)v * 64;
-    int* c = vvar + (size_t)v * 8;
-    for (int k = 0; k < 64; k++) r[k] = -1;
-    for (int k = 0; k < 8; k++) c[k] = -1;
-    if (deg > UPD_FAN) { r[0] = -2; return; }
+    // gather everything first; the rows are written once, at the end (no exits from inside the loops)
     int edges[UPD_FAN], flips[UPD_FAN], ne = 0;  // incident edges and whether the vertex is their second endpoint
-    for (int a = 0; a < deg; a++) {
+    int comb[UPD_FAN], opp[UPD_FAN];
+    bool generic = deg > UPD_FAN;
+    for (int a = 0; a < UPD_FAN; a++) { comb[a] = -1; opp[a] = -1; }
+    for (int a = 0; a < deg && !generic; a++) {
         const int h = L.vtx_adj[k0 + a], t = h / 3, s = h - 3 * t;
         const int he_out = L.he_edge[3 * t + s], he_in = L.he_edge[3 * t + (s == 0 ? 2 : s - 1)];
-        int slot[2];
+        int slot[2] = {0, 0};
         for (int w = 0; w < 2; w++) {
             const int he = w == 0 ? he_out : he_in;
             // leaving edge: the vertex is its origin -- second endpoint when the half-edge is flipped; arriving: the other way
@@ -415,14 +414,20 @@ __global__ void k_vertex_refs(tp_launch L, int* vref, int* vvar) {
             int b = 0;
             while (b < ne && edges[b] != (he >> 1)) b++;
             if (b == ne) {
-                if (ne == UPD_FAN) { for (int k = 0; k < 64; k++) r[k] = -1; r[0] = -2; return; }
-                edges[ne] = he >> 1; flips[ne] = second; ne++;
+                if (ne == UPD_FAN) generic = true;  // a ninth incident edge
+                else { edges[ne] = he >> 1; flips[ne] = second; ne++; }
             }
             slot[w] = b;
         }
-        c[a] = h | (slot[0] << 20) | (slot[1] << 24);
-        r[32 + a] = ((L.he_edge[3 * t + (s == 2 ? 0 : s + 1)] >> 1) << 4) | 0;
+        comb[a] = h | (slot[0] << 20) | (slot[1] << 24);
+        opp[a] = ((L.he_edge[3 * t + (s == 2 ? 0 : s + 1)] >> 1) << 4) | 0;
     }
+    int* r = vref + (size_t)v * 64;
+    int* c = vvar + (size_t)v * 8;
+    for (int k = 0; k < 64; k++) r[k] = -1;
+    for (int k = 0; k < 8; k++) c[k] = -1;
+    if (generic) { r[0] = -2; return; }
+    for (int a = 0; a < UPD_FAN; a++) { c[a] = comb[a]; r[32 + a] = opp[a]; }
     for (int b = 0; b < ne; b++)
         for (int m = 1; m <= 4; m++) r[4 * b + m - 1] = (edges[b] << 4) | (flips[b] ? 4 + m : m);
 }
