@@ -70,7 +70,6 @@ struct tp_context {
     int* vref = nullptr;   // per-upload reference tables of k_update
     int* vvar = nullptr;
     int NE = 0, capE = 0;
-    int twice = 0;  // an edge with both ends at the same vertex exists (triangle soups)
     int2* edge_uv = nullptr;
     int* he_edge = nullptr;
     int2* vpos = nullptr;
@@ -161,7 +160,7 @@ tp_launch make_launch(const tp_context* c, int slot, float dp) {
     L.NT = c->NT; L.NP = c->NP;
     L.vtx_off = c->vtx_off; L.vtx_adj = c->vtx_adj; L.vref = c->vref; L.vvar = c->vvar;
     L.edge_uv = c->edge_uv; L.he_edge = c->he_edge; L.vpos = c->vpos; L.epos = c->epos; L.NE = c->NE;
-    L.wline = c->wline; L.lanes_per_line = c->lanes_per_line; L.twice = c->twice;
+    L.wline = c->wline; L.lanes_per_line = c->lanes_per_line;
     L.ten = c->ten; L.cn = c->cn; L.ca = c->ca; L.gr = c->gr; L.moments = c->moments;
 #ifdef TPOSE_DEBUG  // debug flavour of the library (tools/kernel_timeline.py): per-block phase timestamps
     static unsigned long long* dbgbuf = nullptr;
@@ -394,9 +393,6 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         c->capE = capE;
     }
     c->NE = NE;
-    c->twice = 0;
-    for (int e = 0; e < NE; e++)
-        if (((edge_uv[(size_t)2 * e] ^ edge_uv[(size_t)2 * e + 1]) & 0x3fffffff) == 0) { c->twice = 1; break; }
     // lanes per line of k_lines: about eight rows per lane at the mean height of an edge (a speed hint only)
     {
         double rows = 0.0;

@@ -19,7 +19,6 @@ struct tp_launch {
     const int4* tris;
     const int4* colors;     // stored colours ivec4[NT] (warp) -- may be null
     int NT, NP, NE;
-    int twice;              // some edge names the same vertex twice (triangle soups): positions are filed through edge_uv
     const int* vtx_off;     // CSR by origin vertex: half-edge ids 3t+s
     const int* vtx_adj;
     const int2* edge_uv;    // [NE] endpoints of every undirected edge, u <= v; bit 30: this edge publishes the vertex (vpos)

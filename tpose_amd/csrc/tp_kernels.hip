@@ -414,7 +414,10 @@ __global__ void k_vertex_refs(tp_launch L, int* vref, int* vvar) {
             int b = 0;
             while (b < ne && edges[b] != (he >> 1)) b++;
             if (b == ne) {
-                if (ne == UPD_FAN) generic = true;  // a ninth incident edge
+                const int2 uv = L.edge_uv[he >> 1];
+                // a ninth incident edge, or an edge of a triangle soup that names this vertex twice (the fast layout files a
+                // position with ONE end of an edge)
+                if (ne == UPD_FAN || ((uv.x ^ uv.y) & 0x3fffffff) == 0) generic = true;
                 else { edges[ne] = he >> 1; flips[ne] = second; ne++; }
             }
             slot[w] = b;
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
         // the new position goes to every edge the vertex ends (k_lines reads endpoints by edge)
         if (__shfl(moved, 0)) {
             const float2 q = make_float2(__shfl(newp.x, 0), __shfl(newp.y, 0));
-            if (!generic && !L.twice) {
+            if (!generic) {
                 // lane 4 b holds (incident edge b, version 1..4: the vertex is the edge's first endpoint, 5..8: its second):
                 // no table to look the side up in (publish_position's dependent load at the very end of the kernel)
                 if ((lane & 3) == 0 && lane < 4 * UPD_FAN && ref >= 0) L.epos[(size_t)(ref >> 4) * 2 + ((ref & 15) > 4 ? 1 : 0)] = q;
