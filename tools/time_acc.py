@@ -26,6 +26,8 @@ if flavour == 1:
     colors = synth.mean_colors(img, pts, tris, ratio)
 ctx.upload(pts, tris, colors)
 p = capi.default_params(flavour)
+if os.environ.get("TPOSE_TIME_ACC_RATE0"):  # timing experiments whose sums are wrong: nothing moves
+    p.rate = 0.0
 ctx.prepare(p)
 ctx.iterate(p, 64 + pre)
 ctx.synchronize()
