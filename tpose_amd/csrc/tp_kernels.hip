@@ -7,12 +7,13 @@
 // sums W(e) = sum over the line's rows of the FULL-ROW prefix sum of the pixel moments at the line's
 // crossing column.  The raster does not change between iterations (the reference uploads its texture
 // once, software/triangulate/main.cpp:74), so its row prefix sums are a per-image table built by
-// tp_set_image (k_prefix, 16 bytes per pixel): an iteration touches one table entry per (line, row)
+// tp_set_image (k_prefix, 8 bytes per pixel): an iteration touches one table record per (line, row)
 // -- work proportional to the total edge length, not to the raster area.
 //
-//   k_prefix      per image: P[row][c] = packed moments of the pixels x < c of the row
-//   k_lines       per edge line (nine per undirected edge): vertex stage of both endpoints, the line's
-//                 whole-line 24.40 walker, one table entry per row -> whole line sums `wline` (piecewise API)
+//   k_prefix      per image: 32-byte records per four pixels -- the packed moments of the pixels left of the group and
+//                 the group's r, g, b bytes (tp_raster.h, "Per-image row prefix table")
+//   k_lines       THE hot kernel (tp_iterate, tp_accumulate): per edge line (nine per undirected edge) the vertex stage of
+//                 both endpoints, the line's whole-line 24.40 walker, one table record per row -> line sums `wline`
 //   k_finalize    per variant: signed sum of its three line sums -> exact moments -> `colnum`, `colacc`,
 //                 `tenergy` (reference layout)
 //   k_shift       gradient.cs gathered per vertex + shift.cs
@@ -109,7 +110,7 @@ __device__ __forceinline__ void acc_records(line_acc& a, const int (&c)[N], cons
     a.xs += xs; a.nodd += nodd; a.r += r; a.g += g; a.b += b;
 }
 #ifndef LINE_BATCH
-#define LINE_BATCH 4  // table records requested together by one lane (58 VGPRs: every workgroup of a launch is resident at once)
+#define LINE_BATCH 4  // table records requested together by one lane (65 VGPRs: every workgroup of a launch is resident at once)
 #endif
 
 // k_lines.  A workgroup takes `eb` edges (three: 27 lines; or, for coarse meshes whose lines have hundreds of rows,
