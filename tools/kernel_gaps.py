@@ -1,12 +1,17 @@
-import csv,glob,sys
-f=glob.glob(sys.argv[1]+"/**/*kernel_trace.csv",recursive=True)[0]
-rows=[r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(("k_lines","k_update"))]
-rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-rows=rows[200:1200]
+#!/usr/bin/env python
+"""Durations and gaps of k_lines / k_update from a `rocprofv3 --kernel-trace --output-format csv` directory, early and
+late in the run (the descent changes the mesh).  usage: kernel_gaps.py <dir>"""
+import csv
+import glob
 import statistics as st
-g1=[];g2=[];d1=[];d2=[]
-for a,b in zip(rows,rows[1:]):
-    gap=int(b["Start_Timestamp"])-int(a["End_Timestamp"])
-    if a["Kernel_Name"].startswith("k_lines") and b["Kernel_Name"].startswith("k_update"): g1.append(gap); d1.append(int(a["End_Timestamp"])-int(a["Start_Timestamp"]))
-    if a["Kernel_Name"].startswith("k_update") and b["Kernel_Name"].startswith("k_lines"): g2.append(gap); d2.append(int(a["End_Timestamp"])-int(a["Start_Timestamp"]))
-print("k_lines dur med",st.median(d1),"gap lines->update med",st.median(g1),"k_update dur med",st.median(d2),"gap update->lines med",st.median(g2), "p90 gaps", sorted(g1)[int(.9*len(g1))], sorted(g2)[int(.9*len(g2))])
+import sys
+
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(("k_lines", "k_update"))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+for name, part in (("first", rows[200:1200]), ("last", rows[-1000:])):
+    d = {"k_lines": [], "k_update": []}
+    for r in part:
+        d[r["Kernel_Name"].split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    span = (int(part[-1]["End_Timestamp"]) - int(part[0]["Start_Timestamp"])) / (len(part) / 2)
+    print(name, "k_lines median ns", st.median(d["k_lines"]), "k_update median ns", st.median(d["k_update"]), "ns per grad-iter", round(span))
