@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TP_ABI_VERSION 1
+#define TP_ABI_VERSION 2
 #define TP_MAXT (2 << 18) /* tpose::triangulation::MAXT, source/triangulation.hpp:95; 13*NT <= MAXT */
 
 typedef struct tp_context tp_context;
@@ -89,10 +89,13 @@ int tp_get_ratio(const tp_context* ctx, float* ratio);
  * dp <= 0 restores the reference law.  tp_iterate takes its dp from tp_params instead. */
 int tp_set_dp(tp_context* ctx, float dp);
 
-/* Kept for ABI compatibility (round 1 could keep its per-tile work lists while no vertex had moved more than
- * margin_px - 1 pixels).  There are no work lists any more: the value (0..1024) has no effect.  Results never
- * depended on it. */
-int tp_set_margin(tp_context* ctx, int margin_px);
+/* Execution options (no counterpart in the reference, whose frame loop is fixed).  Results never depend on them.
+ * TP_OPT_PERSISTENT: TP_PERSIST_AUTO (default) lets tp_iterate run all but the last of >= 4 grad-iters inside
+ * persistent launches (one workgroup per patch of the mesh, K grad-iters per launch) when the device keeps a full grid
+ * resident; TP_PERSIST_OFF keeps every grad-iter on the two-kernel path (k_lines + k_update). */
+enum tp_option { TP_OPT_PERSISTENT = 1 };
+enum { TP_PERSIST_OFF = 0, TP_PERSIST_AUTO = 1 };
+int tp_set_option(tp_context* ctx, int option, int64_t value);
 
 /* `Texture tex(IMG)` (software/triangulate/main.cpp:74, warp/main.cpp:118-119): RGBA8, row 0 = top,
  * width x height texels, `stride_bytes` between rows.  Host pointer.  Like the reference's texture the image
@@ -122,7 +125,8 @@ int tp_shift(tp_context* ctx, float rate);
 void tp_default_params(int flavour, tp_params* p);
 /* n_iters x { tp_accumulate(image_slot); tp_energy(flavour); tp_shift(rate) } with no host
  * round trip (the reference reads back four buffers every frame, triangulate/main.cpp:201-204).
- * Asynchronous: returns after enqueueing; tp_retrieve / tp_synchronize wait. */
+ * Asynchronous: returns after enqueueing; tp_retrieve / tp_synchronize wait.  From 4 grad-iters on, all but the last
+ * run inside persistent launches (tp_set_option); the last one writes the buffers tp_retrieve reads. */
 int tp_iterate(tp_context* ctx, const tp_params* p, int n_iters);
 /* Optional: build the launch graph tp_iterate replays for these parameters now (it is otherwise built by the
  * first tp_iterate of >= 16 iterations after an upload), so that no later call pays for it.  Runs nothing.
@@ -163,8 +167,10 @@ enum { TP_RENDER_AVERAGE = 0, TP_RENDER_STORED = 1 };
 int tp_render(tp_context* ctx, int source, const float* points, uint8_t* dst_rgba, size_t stride);
 
 /* introspection for tests/benchmarks: 0 = records per row of the prefix table, 1 = chunks per line of k_lines for the
- * current triangulation (rows of a line are shared by that many lanes); 2..6 = 0 (work-list statistics of earlier
- * rounds) */
+ * current triangulation (rows of a line are shared by that many lanes); persistent path: 2 = patches (workgroups) of
+ * the current plan, 0 if none, 3 = its LDS bytes per workgroup, 4 = line sums crossing patch borders per grad-iter,
+ * 5 = persistent launches so far, 6 = grad-iters run inside them, 7 = census (1 a full grid is resident, -1 not,
+ * 0 not taken yet) */
 int tp_get_info(tp_context* ctx, int what, int64_t* value);
 
 /* device self-test of the exact span walker (tp_raster.h): for each (N0, step, d), the 32 values

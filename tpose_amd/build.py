@@ -11,8 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtpose_hip.so")
-SOURCES = ["tp_kernels.hip", "tp_context.hip"]
-HEADERS = ["tp_raster.h", "tp_kernels.h", os.path.join("..", "..", "include", "tpose_hip.h")]
+SOURCES = ["tp_kernels.hip", "tp_persist.hip", "tp_context.hip"]
+HEADERS = ["tp_raster.h", "tp_kernels.h", "tp_plan.h", "tp_persist.h", os.path.join("..", "..", "include", "tpose_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 

@@ -20,7 +20,7 @@ BUF_TENERGY, BUF_COLNUM, BUF_COLACC, BUF_POINTS, BUF_GRADIENT, BUF_PENERGY, BUF_
 # every symbol include/tpose_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "tp_abi_version", "tp_device_count", "tp_last_error", "tp_create", "tp_destroy", "tp_set_ratio",
-    "tp_get_ratio", "tp_set_dp", "tp_set_margin", "tp_set_image", "tp_set_image_device", "tp_upload", "tp_accumulate",
+    "tp_get_ratio", "tp_set_dp", "tp_set_option", "tp_set_image", "tp_set_image_device", "tp_upload", "tp_accumulate",
     "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_retrieve_many", "tp_synchronize",
     "tp_get_stream", "tp_profile_iterate", "tp_profile_accumulate", "tp_get_info", "tp_selftest_walker", "tp_render",
     "tp_prepare", "tp_selftest_line",
@@ -28,6 +28,9 @@ SYMBOLS = [
 
 
 RENDER_AVERAGE, RENDER_STORED = 0, 1
+OPT_PERSISTENT = 1
+PERSIST_OFF, PERSIST_AUTO = 0, 1
+INFO_PATCHES, INFO_PATCH_LDS, INFO_BORDER_LINES, INFO_PERSIST_LAUNCHES, INFO_PERSIST_ITERS, INFO_CENSUS = 2, 3, 4, 5, 6, 7
 
 
 class Params(C.Structure):
@@ -58,7 +61,7 @@ def load():
         lib.tp_set_ratio.argtypes = [C.c_void_p, C.c_float]
         lib.tp_get_ratio.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         lib.tp_set_dp.argtypes = [C.c_void_p, C.c_float]
-        lib.tp_set_margin.argtypes = [C.c_void_p, C.c_int]
+        lib.tp_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
         lib.tp_set_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         lib.tp_set_image_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         lib.tp_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -134,8 +137,11 @@ class Context:
     def set_dp(self, dp):
         self._ck(self.lib.tp_set_dp(self.h, dp))
 
-    def set_margin(self, margin_px):
-        self._ck(self.lib.tp_set_margin(self.h, margin_px))
+    def set_option(self, option, value):
+        self._ck(self.lib.tp_set_option(self.h, option, value))
+
+    def set_persistent(self, on):
+        self.set_option(OPT_PERSISTENT, PERSIST_AUTO if on else PERSIST_OFF)
 
     def set_image(self, slot, img):
         img = np.ascontiguousarray(img, np.uint8)

@@ -62,7 +62,6 @@ struct tp_context {
     // triangulation
     int NT = 0, NP = 0, capT = 0, capP = 0;
     float2* points = nullptr;
-    int margin_px = 0;  // tp_set_margin: accepted, no effect since round 2
     int4* tris = nullptr;
     int4* colors = nullptr;
     int* vtx_off = nullptr;
@@ -99,6 +98,25 @@ struct tp_context {
     size_t render_pts_cap = 0;
     uint8_t* up_pinned = nullptr;  // host-pinned staging for tp_upload (copies ride the stream, no wait at the end)
     size_t up_pinned_bytes = 0;
+    // persistent grad-iter kernel (tp_persist.hip): the plan of the current triangulation is built by the first
+    // tp_iterate long enough to use it (not by tp_upload: schedules upload after every topology change)
+    int persist_mode = TP_PERSIST_AUTO;
+    int num_cus = 0;
+    int census = 0;                 // 0 not taken, 1 every workgroup of a full grid is resident, -1 not: two-kernel path only
+    int lds_attr = 0;               // dynamic LDS the kernel is currently allowed
+    std::vector<float> h_points;    // host copies of the last upload (what the plan is cut from)
+    std::vector<int32_t> h_tris, h_edge_uv, h_he_edge;
+    pk_plan plan;
+    uint64_t plan_generation = 0;   // generation the plan (ok or refused) belongs to
+    pk_wg* d_wg = nullptr; int32_t* d_pool = nullptr;
+    size_t cap_wg = 0, cap_pool = 0;
+    unsigned long long* posbox = nullptr; unsigned long long* linebox = nullptr;
+    size_t cap_posbox = 0, cap_linebox = 0;   // (in vertices / edges)
+    float2* points_out = nullptr; size_t cap_points_out = 0;
+    unsigned* d_status = nullptr;   // [0] a lane of a persistent launch gave up waiting, [1] census counter
+    uint32_t epoch = 1;             // number of the next grad-iter of a persistent launch (mailbox tags)
+    bool persist_unchecked = false; // persistent launches were enqueued since the status word was last read
+    int64_t persist_launches = 0, persist_iters = 0;
     std::vector<uint64_t> hkeys;   // open-addressing table of tp_upload: undirected edge key -> id
     std::vector<int> hvals;
     std::vector<uint32_t> hstamp;
@@ -180,6 +198,139 @@ int check_slot(tp_context* c, int slot) {
     return TP_OK;
 }
 
+// ---- persistent grad-iter kernel: status, census, plan ------------------------------------------------------------
+#define PK_LDS_LIMIT (160 * 1024 - 512)  /* (the kernel has a few static bytes of its own) */
+#define PK_MIN_ITERS 4        /* shorter tp_iterate calls are not worth a plan (frame-by-frame schedules) */
+#define PK_MAX_EPOCH 32000u   /* mailbox tags carry 15 bits of the grad-iter's number */
+#define PK_MAX_LAUNCH 8192    /* grad-iters per launch */
+
+// after the stream was synchronised: did a lane of a persistent launch give up waiting?  (Never seen with every
+// workgroup resident; the state of the triangulation is undefined then.)
+int check_persist_status(tp_context* c) {
+    if (!c->persist_unchecked || !c->d_status) return TP_OK;
+    c->persist_unchecked = false;
+    unsigned st[2] = {0u, 0u};
+    HIP_TRY(c, hipMemcpy(st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
+    if (st[0] != 0u) {
+        hipMemset(c->d_status, 0, sizeof st);
+        c->census = -6;  // do not try again in this context
+        return fail(c, TP_ERR_HIP, "a persistent grad-iter launch timed out waiting for a neighbouring workgroup; vertex positions are undefined (re-upload)");
+    }
+    return TP_OK;
+}
+
+template <class T>
+int grow(tp_context* c, T** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return TP_OK;
+    hipFree(*p); *p = nullptr; *cap = 0;
+    const size_t n = need + need / 2 + 64;
+    HIP_TRY(c, dev_alloc(p, n));
+    *cap = n;
+    return TP_OK;
+}
+
+// once per context: launch a full grid of the persistent kernel in census mode -- every workgroup arrives at a counter and
+// waits for all the others.  If that times out, workgroups of such a grid are not resident together on this device
+// (CU masking, another process) and hand-overs inside a launch would never complete: the context keeps to two kernels.
+int take_census(tp_context* c) {
+    if (c->census != 0) return TP_OK;
+    c->census = -1;
+    if (c->num_cus < 1) return TP_OK;
+    if (!c->d_status) { HIP_TRY(c, dev_alloc(&c->d_status, 2)); }
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(unsigned), c->stream));
+    if (tp_persist_set_lds(PK_LDS_LIMIT) != 0) { (void)hipGetLastError(); c->census = -2; return TP_OK; }
+    c->lds_attr = PK_LDS_LIMIT;
+    std::vector<pk_wg> hw((size_t)c->num_cus, pk_wg());
+    if (int rc = grow(c, &c->d_wg, &c->cap_wg, hw.size())) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_wg, hw.data(), sizeof(pk_wg) * hw.size(), hipMemcpyHostToDevice, c->stream));
+    pk_args A{};
+    A.wg = c->d_wg; A.parts = c->num_cus; A.n_iters = -1; A.status = c->d_status;
+    tp_launch_persist(A, PK_LDS_LIMIT, c->stream);
+    if (hipGetLastError() != hipSuccess) { c->census = -3; return TP_OK; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned st[2] = {1u, 0u};
+    HIP_TRY(c, hipMemcpy(st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemset(c->d_status, 0, sizeof st));
+    if (st[0] == 0u && st[1] == (unsigned)c->num_cus) c->census = 1;
+    else c->census = -4 - (int)(st[0] != 0u);
+    return TP_OK;
+}
+
+// the plan of the current triangulation (built once per upload, on first use); *use = whether tp_iterate may take the
+// persistent path
+int ensure_plan(tp_context* c, float dp, bool* use) {
+    *use = false;
+    if (c->persist_mode == TP_PERSIST_OFF) return TP_OK;
+    if (int rc = take_census(c)) return rc;
+    if (c->census != 1) return TP_OK;
+    if (c->plan_generation != c->generation) {
+        c->plan_generation = c->generation;
+        pk_build_plan(c->NP, c->NT, c->h_tris.data(), c->h_points.data(), c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
+                      c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, c->num_cus, PK_LDS_LIMIT, c->plan);
+        if (c->plan.ok) {
+            // (the stream may still be running launches that read the previous plan: uploads synchronise, and a plan is only
+            // rebuilt after an upload)
+            if (int rc = grow(c, &c->d_wg, &c->cap_wg, c->plan.wg.size())) return rc;
+            if (int rc = grow(c, &c->d_pool, &c->cap_pool, c->plan.pool.size())) return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->d_wg, c->plan.wg.data(), sizeof(pk_wg) * c->plan.wg.size(), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->d_pool, c->plan.pool.data(), sizeof(int32_t) * c->plan.pool.size(), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));  // (pageable sources: the copies must not outlive the vectors' contents)
+            const size_t np = (size_t)c->NP, ne = (size_t)c->NE;
+            bool fresh = false;
+            if (np > c->cap_posbox || !c->posbox) {
+                hipFree(c->posbox); c->posbox = nullptr; c->cap_posbox = 0;
+                const size_t n = np + np / 2 + 64;
+                HIP_TRY(c, dev_alloc(&c->posbox, n * 4)); c->cap_posbox = n; fresh = true;
+            }
+            if (ne > c->cap_linebox || !c->linebox) {
+                hipFree(c->linebox); c->linebox = nullptr; c->cap_linebox = 0;
+                const size_t n = ne + ne / 2 + 64;
+                HIP_TRY(c, dev_alloc(&c->linebox, n * 2 * PK_NLINES * PK_GRANULES)); c->cap_linebox = n; fresh = true;
+            }
+            if (int rc = grow(c, &c->points_out, &c->cap_points_out, np)) return rc;
+            // slot numbering changed with the triangulation: stale granules of the previous one must not match a tag
+            (void)fresh;
+            HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 4 * sizeof(unsigned long long), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->linebox, 0, c->cap_linebox * 2 * PK_NLINES * PK_GRANULES * sizeof(unsigned long long), c->stream));
+            c->epoch = 1;
+        }
+    }
+    *use = c->plan.ok;
+    return TP_OK;
+}
+
+// n grad-iters of the persistent kernel (positions only), then `points_out` -> `points` / `epos`
+int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n) {
+    while (n > 0) {
+        const int k = n < PK_MAX_LAUNCH ? n : PK_MAX_LAUNCH;
+        if (c->epoch + (uint32_t)k > PK_MAX_EPOCH) {
+            HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 4 * sizeof(unsigned long long), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->linebox, 0, c->cap_linebox * 2 * PK_NLINES * PK_GRANULES * sizeof(unsigned long long), c->stream));
+            c->epoch = 1;
+        }
+        pk_args A{};
+        A.wg = c->d_wg; A.pool = c->d_pool; A.parts = c->plan.parts;
+        A.vw.dp = dp; A.vw.ratio = c->ratio; A.vw.halfW = 0.5f * (float)c->W; A.vw.halfH = 0.5f * (float)c->H; A.vw.W = c->W; A.vw.H = c->H;
+        A.prefix = c->prefix[p.image_slot]; A.prefix_pitch = c->prefix_pitch;
+        A.points = c->points; A.points_out = c->points_out; A.ca = c->ca;
+        A.NT = c->NT; A.NP = c->NP; A.NE = c->NE;
+        A.flavour = p.flavour; A.rate = p.rate;
+        A.posbox = c->posbox; A.linebox = c->linebox;
+        A.epoch = c->epoch; A.n_iters = k; A.status = c->d_status;
+#ifdef TPOSE_DEBUG
+        A.dbg = persist_dbg_buffer(c->plan.parts);
+#endif
+        tp_launch_persist(A, c->plan.lds_bytes, c->stream);
+        tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        c->epoch += (uint32_t)k;
+        c->persist_unchecked = true;
+        c->persist_launches++; c->persist_iters += k;
+        n -= k;
+    }
+    return TP_OK;
+}
+
 // enqueue one grad-iter on the context stream (no sync)
 void enqueue_iter(tp_context* c, const tp_params& p, float dp) {
     tp_launch L = make_launch(c, p.image_slot, dp);
@@ -222,6 +373,10 @@ int tp_create(int device, int width, int height, tp_context** out) {
     c->device = device; c->W = width; c->H = height;
     c->prefix_pitch = tp_prefix_pitch(width);
     c->ratio = (float)width / (float)height;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -243,6 +398,7 @@ int tp_destroy(tp_context* c) {
     free_triangulation(c);
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->prefix[0]); hipFree(c->prefix[1]);
     hipFree(c->render_pic); hipFree(c->render_pts);
+    hipFree(c->d_wg); hipFree(c->d_pool); hipFree(c->posbox); hipFree(c->linebox); hipFree(c->points_out); hipFree(c->d_status);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->up_pinned) hipHostFree(c->up_pinned);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -268,12 +424,16 @@ int tp_set_dp(tp_context* c, float dp) {
     return TP_OK;
 }
 
-int tp_set_margin(tp_context* c, int margin_px) {
+int tp_set_option(tp_context* c, int option, int64_t value) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
-    if (margin_px < 0 || margin_px > 1024) return fail(c, TP_ERR_INVALID, "margin %d outside 0..1024", margin_px);
-    c->margin_px = margin_px;
-    return TP_OK;
+    switch (option) {
+        case TP_OPT_PERSISTENT:
+            if (value != TP_PERSIST_OFF && value != TP_PERSIST_AUTO) return fail(c, TP_ERR_INVALID, "TP_OPT_PERSISTENT: bad value %lld", (long long)value);
+            c->persist_mode = (int)value;
+            return TP_OK;
+        default: return fail(c, TP_ERR_INVALID, "unknown option %d", option);
+    }
 }
 
 int tp_get_ratio(const tp_context* c, float* ratio) {
@@ -323,6 +483,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rc = check_persist_status(c)) return rc;
 
     if (NT > c->capT || NP > c->capP) {
         free_triangulation(c);
@@ -445,6 +606,9 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         }
     }
     c->NT = NT; c->NP = NP;
+    c->h_points.assign(points, points + 2 * (size_t)NP);
+    c->h_tris.assign(tris, tris + 4 * (size_t)NT);
+    c->h_edge_uv.swap(edge_uv); c->h_he_edge.swap(he_edge);
     c->have_colors = colors != nullptr;
     {   // reference tables of the fused update (device side: reads the arrays just copied)
         tp_launch L = make_launch(c, 0, 0.0f);
@@ -566,6 +730,16 @@ int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
     const float dp = resolve_dp(c, p->flavour, p->dp);
 
     int left = n_iters;
+    if (left >= PK_MIN_ITERS) {
+        // all but the last grad-iter inside persistent launches (positions only); the last one through k_lines + k_update,
+        // which write the buffers the reference reads back (`tenergy`, `colnum`, `colacc`, `gradient`)
+        bool use = false;
+        if (int rc = ensure_plan(c, dp, &use)) return rc;
+        if (use) {
+            if (int rc = enqueue_persistent(c, *p, dp, left - 1)) return rc;
+            left = 1;
+        }
+    }
     if (left >= CHUNK) {
         graph_entry* g = nullptr;
         if (int rc = chunk_graph(c, p, dp, &g)) return rc;
@@ -599,6 +773,9 @@ int tp_prepare(tp_context* c, const tp_params* p) {
     if (!c) return TP_ERR_INVALID;
     if (int rc = validate_params(c, p, 0)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
+    bool use = false;
+    if (int rc = ensure_plan(c, resolve_dp(c, p->flavour, p->dp), &use)) return rc;
+    if (use) return TP_OK;
     graph_entry* g = nullptr;
     return chunk_graph(c, p, resolve_dp(c, p->flavour, p->dp), &g);
 }
@@ -664,7 +841,7 @@ int tp_synchronize(tp_context* c) {
     if (!c) return TP_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return TP_OK;
+    return check_persist_status(c);
 }
 
 namespace {
@@ -721,6 +898,7 @@ int tp_retrieve_many(tp_context* c, int n, const int* what, void* const* dst, co
     for (int k = 0; k < n; k++)
         if (bytes[k]) HIP_TRY(c, hipMemcpyAsync(c->pinned + off[k], src[k], bytes[k], hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rc = check_persist_status(c)) return rc;
     for (int k = 0; k < n; k++) {
         if (bytes[k]) memcpy(dst[k], c->pinned + off[k], bytes[k]);
         else if (what[k] == TP_BUF_PENERGY) memset(dst[k], 0, count[k] * 4);
@@ -822,7 +1000,12 @@ int tp_get_info(tp_context* c, int what, int64_t* value) {
     switch (what) {
         case 0: *value = c->prefix_pitch; return TP_OK;
         case 1: *value = c->lanes_per_line; return TP_OK;
-        case 2: case 3: case 4: case 5: case 6: *value = 0; return TP_OK;  // (work-list statistics of earlier rounds)
+        case 2: *value = (c->plan_generation == c->generation && c->plan.ok) ? c->plan.parts : 0; return TP_OK;
+        case 3: *value = (c->plan_generation == c->generation && c->plan.ok) ? c->plan.lds_bytes : 0; return TP_OK;
+        case 4: *value = (c->plan_generation == c->generation && c->plan.ok) ? c->plan.imp_total : 0; return TP_OK;
+        case 5: *value = c->persist_launches; return TP_OK;
+        case 6: *value = c->persist_iters; return TP_OK;
+        case 7: *value = c->census; return TP_OK;
         default: return fail(c, TP_ERR_INVALID, "unknown info %d", what);
     }
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "tp_raster.h"
+#include "tp_plan.h"
 
 #define TP_NLINES 9        /* lines per undirected edge: base + 4 moves of either endpoint */
 #define TP_W_WORDS 6       /* values per line sum: sum x, n_odd, sum r, sum g, sum b, q */
@@ -51,3 +52,31 @@ void tp_launch_prefix_table(const uint8_t* img, int pitch, int W, int H, int pre
 void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s);
 void tp_launch_selftest_line(const int4* ends, const int* H, int n, int rows, int32_t* out, hipStream_t s);
 void tp_launch_render(const tp_launch& L, const float2* pts, int source, void* out, int out_pitch_px, hipStream_t s);
+
+// ---- persistent grad-iter kernel (tp_persist.hip): K grad-iters per launch, one workgroup per patch of the mesh
+#define PK_DBG_ITERS 64
+struct pk_args {
+    const pk_wg* wg;            // [parts] per-patch headers (tp_plan.h)
+    const int32_t* pool;        // the patches' tables
+    int parts;
+    tp_view vw;
+    const uint4* prefix;        // row prefix table of the swept image
+    int prefix_pitch;
+    const float2* points;       // positions at the start of the launch
+    float2* points_out;         // positions after n_iters grad-iters (vertices of at least one triangle only)
+    const int4* ca;             // warp flavour: the stored colours, replicated x13 by upload
+    int NT, NP, NE;
+    int flavour;
+    float rate;
+    unsigned long long* posbox;   // [2][NP][2] position mailbox
+    unsigned long long* linebox;  // [2][9 NE][5] line-sum mailbox
+    unsigned epoch;               // number of the launch's first grad-iter (tags; 1 .. 32767 between mailbox resets)
+    int n_iters;                  // < 0: census of resident workgroups instead
+    unsigned* status;             // [0] raised by a lane that gave up waiting, [1] census counter
+#ifdef TPOSE_DEBUG
+    unsigned long long* dbg;      // [parts][PK_DBG_ITERS][8] phase timestamps
+#endif
+};
+int tp_persist_set_lds(int bytes);  // hipFuncSetAttribute(max dynamic LDS); returns the hipError_t
+void tp_launch_persist(const pk_args& A, int lds_bytes, hipStream_t s);
+void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, hipStream_t s);

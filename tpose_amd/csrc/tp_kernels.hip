@@ -619,6 +619,20 @@ void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s
     hipLaunchKernelGGL(k_update, dim3((unsigned)nblocks), dim3(UPD_THREADS), 0, s, L, flavour, rate);
 }
 
+// after a persistent launch (tp_persist.hip): the positions it left in `points_out` become `points` (vertices no triangle
+// uses are not owned by any patch and keep theirs), and every vertex files its position with its edges (k_lines reads
+// endpoints by edge)
+__global__ void k_persist_finish(tp_launch L, const float2* points_out) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= L.NP) return;
+    float2 p = L.points[v];
+    if (L.vtx_off[v + 1] > L.vtx_off[v]) { p = points_out[v]; L.points[v] = p; }
+    publish_position(L, v, p, 0, 1);
+}
+void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_persist_finish, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L, points_out);
+}
+
 // tpose::upload colour replication (source/triangulation.hpp:633-641): col[i*NT + k] = colors[k]
 __global__ void k_replicate_colors(tp_launch L) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,235 @@
+// tp_persist.hip -- K grad-iters in ONE launch: the persistent form of the reference's frame
+// (software/triangulate/main.cpp:132-155: doenergy -> gradient.cs -> shift.cs; software/warp/main.cpp:153-178).
+//
+// One workgroup per patch of the mesh (tp_plan.h), all resident at once (at most one per CU).  What a lane does in
+// each phase is in tp_persist.h; this file is the choreography: the phases of a grad-iter, the workgroup barriers
+// between them and the two hand-overs between workgroups,
+//   positions  owner of a vertex  ->  the patches that use it      two 8-byte granules {tag : 32, float : 32}
+//   line sums  owner of an edge   ->  the patches whose corners use them   five granules {tag : 16, payload : 48}
+// Every granule is written by ONE agent-scope (sc1, write-through) store and read by agent-scope loads that bypass
+// the reader's L1; the tag is the grad-iter's number, so a granule is valid on its own: no flags, no fences, no order
+// between granules (MI355X guide, "R2: the data IS the flag").  Mailboxes are double-buffered by the parity of the
+// grad-iter: a producer cannot be two grad-iters ahead of any consumer of the same slot, because its own next position
+// needs a line sum that needs the consumer's next position (tp_plan.h: every consumer of a vertex's position or of an
+// edge's line sums owns a neighbour of that vertex / a vertex of a triangle on that edge).
+// Nothing here is placement-dependent: workgroup b -> patch is a permutation chosen for L2 locality only.
+//
+// Every wait is bounded: a lane that polls longer than PK_TIMEOUT_TICKS raises the launch's status word and the whole
+// grid drains; the host sees it at its next synchronisation (tp_context.hip) and reports an error.
+#include "tp_kernels.h"
+#include "tp_persist.h"
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+#define PK_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define PK_TIMEOUT_TICKS 30000000ull  // 0.3 s of the 100 MHz wall clock
+
+#ifdef TPOSE_DEBUG
+#define PK_STAMP(k) do { if (threadIdx.x == 0 && A.dbg && it < PK_DBG_ITERS) A.dbg[((size_t)blockIdx.x * PK_DBG_ITERS + it) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PK_STAMP(k) do { } while (0)
+#endif
+
+namespace {
+
+struct spin_state { unsigned spins; unsigned long long t0; };
+
+// one more turn of a polling loop; true: give up (somebody raised the status word, or this lane waited too long)
+__device__ __forceinline__ bool spin_fail(spin_state& st, gu32* status) {
+    if ((++st.spins & 63u) == 0u) {
+        if (__hip_atomic_load(status, PK_RLX_AGENT) != 0u) return true;
+        const unsigned long long now = wall_clock64();
+        if (st.t0 == 0ull) st.t0 = now;
+        else if (now - st.t0 > PK_TIMEOUT_TICKS) { __hip_atomic_store(status, 1u, PK_RLX_AGENT); return true; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+    return false;
+}
+
+__device__ __forceinline__ int patch_of_block(int b, int parts) {
+    // workgroup b runs on XCD b mod 8 (observed, never relied on): give every XCD one run of neighbouring patches
+    return (parts & 7) == 0 ? (b & 7) * (parts >> 3) + (b >> 3) : b;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int part = patch_of_block((int)blockIdx.x, A.parts);
+    const pk_wg w = A.wg[part];
+    pk_view V;
+    pk_carve(smem, w, V);
+    gu32* status = (gu32*)A.status;
+
+    if (A.n_iters < 0) {
+        // census (once per context): are all workgroups of this grid resident together?  Everyone arrives at one counter
+        // and waits for the others; a launch whose last workgroups only start when earlier ones exit times out.
+        if (tid == 0) {
+            gu32* cnt = status + 1;
+            __hip_atomic_fetch_add(cnt, 1u, PK_RLX_AGENT);
+            spin_state st = {0u, 0ull};
+            while (__hip_atomic_load(cnt, PK_RLX_AGENT) < (unsigned)A.parts)
+                if (spin_fail(st, status)) break;
+        }
+        return;
+    }
+
+    // ---- prologue: the patch's tables and positions into LDS
+    {
+        const int32_t* pool = A.pool;
+        for (int i = tid; i < w.n_slots; i += PK_THREADS) V.vid[i] = pool[w.off_vid + i];
+        for (int i = tid; i < 2 * w.n_own_e; i += PK_THREADS) ((int32_t*)V.edges)[i] = pool[w.off_edges + i];
+        for (int i = tid; i < 2 * w.n_items; i += PK_THREADS) ((int32_t*)V.items)[i] = pool[w.off_items + i];
+        for (int i = tid; i < 4 * w.n_corners; i += PK_THREADS) ((int32_t*)V.corners)[i] = pool[w.off_corners + i];
+        for (int i = tid; i < w.n_imp; i += PK_THREADS) V.imp[i] = pool[w.off_imp + i];
+        for (int i = tid; i < w.n_exp; i += PK_THREADS) V.exp_[i] = pool[w.off_exp + i];
+        for (int i = tid; i < w.n_slots; i += PK_THREADS) {
+            const float2 p = A.points[pool[w.off_vid + i]];
+            V.pos[i].x = p.x; V.pos[i].y = p.y;
+        }
+        for (int i = tid; i < w.n_own_e; i += PK_THREADS) { V.band[i].x = 0x3fffffff; V.band[i].y = -1; }
+        for (int i = tid; i < 6 * PK_NLINES * w.n_own_e; i += PK_THREADS) V.sums[i] = 0ull;
+        if (tid == 0) V.flags[0] = 0;
+    }
+    // the stored colour of this lane's variant (warp flavour: `colacc` as uploaded, triangle.fs:49-50) never changes
+    // during a launch; the first pass of the corner lanes keeps it in registers
+    pk_i4 col0 = {0, 0, 0, 0};
+    if (A.flavour == 1 && tid < 4 * w.n_corners) {
+        const int k = tid >> 2, m = (tid & 3) + 1;
+        const int t = A.pool[w.off_corners + 4 * k], s = A.pool[w.off_corners + 4 * k + 1] & 3;
+        const int4 c = A.ca[(size_t)(4 * s + m) * A.NT + t];
+        col0.x = c.x; col0.y = c.y; col0.z = c.z; col0.w = c.w;
+    }
+    const char* table = reinterpret_cast<const char*>(A.prefix);
+    gu64* posbox = (gu64*)A.posbox;
+    gu64* linebox = (gu64*)A.linebox;
+    const size_t NLT = (size_t)A.NE * PK_NLINES;
+    int failed = 0;
+    __syncthreads();
+
+    for (int it = 0; it < A.n_iters; it++) {
+        const uint32_t epoch = A.epoch + (uint32_t)it, tag = pk_tag(epoch), par = epoch & 1u;
+        PK_STAMP(0);
+        // ---- P0: positions of the foreign vertices this patch uses (the first grad-iter of a launch read `points`)
+        if (it > 0) {
+            for (int s = w.n_own_v + tid; s < w.n_slots; s += PK_THREADS) {
+                gu64* g = posbox + ((size_t)par * A.NP + V.vid[s]) * 2;
+                spin_state st = {0u, 0ull};
+                unsigned long long a, b;
+                for (;;) {
+                    a = __hip_atomic_load(g, PK_RLX_AGENT); b = __hip_atomic_load(g + 1, PK_RLX_AGENT);
+                    if ((uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag) break;
+                    if (spin_fail(st, status)) { failed = 1; break; }
+                }
+                V.pos[s].x = __uint_as_float((uint32_t)a); V.pos[s].y = __uint_as_float((uint32_t)b);
+            }
+        }
+        if (__syncthreads_or(failed)) return;
+        PK_STAMP(1);
+        // ---- P1: line set-up (low threads), snapped positions (high threads), gradient reset
+        for (int l = tid; l < PK_NLINES * w.n_own_e; l += PK_THREADS) {
+            pk_walker wk;
+            pk_setup_lane(V, A.vw, l, wk);
+            V.wk[l] = wk;
+            if (wk.ra <= wk.rb) { atomicMin(&V.band[l / PK_NLINES].x, wk.ra); atomicMax(&V.band[l / PK_NLINES].y, wk.rb); }
+        }
+        {
+            const int nsnap = 5 * w.n_own_v + (w.n_slots - w.n_own_v);
+            for (int j = PK_THREADS - 1 - tid; j < nsnap; j += PK_THREADS) pk_snap_lane(w, V, A.vw, j);
+            for (int k = tid; k < w.n_own_v; k += PK_THREADS) { V.grad[k].x = 0; V.grad[k].y = 0; }
+        }
+        __syncthreads();
+        PK_STAMP(2);
+        // ---- P3: walk -- one table record per (line, row); chunks of a line meet in LDS
+        for (int j = tid; j < PK_NLINES * w.n_items; j += PK_THREADS) {
+            pk_acc a;
+            const int l = pk_walk_lane<PK_ROWS_PER_LANE>(V, table, A.prefix_pitch, A.vw.W, j, a);
+            if (a.xs | a.nodd | a.r | a.q) {
+                unsigned long long* s = V.sums + (size_t)l * 6;
+                atomicAdd(&s[0], (unsigned long long)a.xs); atomicAdd(&s[1], (unsigned long long)a.nodd);
+                atomicAdd(&s[2], (unsigned long long)a.r); atomicAdd(&s[3], (unsigned long long)a.g);
+                atomicAdd(&s[4], (unsigned long long)a.b); atomicAdd(&s[5], (unsigned long long)a.q);
+            }
+        }
+        __syncthreads();
+        PK_STAMP(3);
+        // ---- P4: post the line sums other patches use (low threads) ...
+        for (int k = tid; k < w.n_exp; k += PK_THREADS) {
+            const int ls = V.exp_[k], le = ls / PK_NLINES;
+            const size_t gl = (size_t)V.edges[le].y * PK_NLINES + (ls - le * PK_NLINES);
+            unsigned long long g[PK_GRANULES];
+            pk_pack_line(V.sums + (size_t)ls * 6, tag, g);
+            gu64* dst = linebox + ((size_t)par * NLT + gl) * PK_GRANULES;
+#pragma unroll
+            for (int i = 0; i < PK_GRANULES; i++) __hip_atomic_store(dst + i, g[i], PK_RLX_AGENT);
+        }
+        // ---- P5: ... and collect the ones this patch uses (high threads)
+        for (int k = PK_THREADS - 1 - tid; k < w.n_imp; k += PK_THREADS) {
+            gu64* src = linebox + ((size_t)par * NLT + V.imp[k]) * PK_GRANULES;
+            unsigned long long g[PK_GRANULES];
+            spin_state st = {0u, 0ull};
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < PK_GRANULES; i++) { g[i] = __hip_atomic_load(src + i, PK_RLX_AGENT); ok &= pk_granule_ok(g[i], tag); }
+                if (ok) break;
+                if (spin_fail(st, status)) { failed = 1; break; }
+            }
+            unsigned long long s6[6];
+            pk_unpack_line(g, s6);
+            unsigned long long* s = V.sums + (size_t)(PK_NLINES * w.n_own_e + k) * 6;
+#pragma unroll
+            for (int i = 0; i < 6; i++) s[i] = s6[i];
+        }
+        if (__syncthreads_or(failed)) return;
+        PK_STAMP(4);
+        // ---- P6: corners -- four displaced variants each, central differences into the vertex's gradient (int32 wrapping
+        // sums, like the reference's atomics: gradient.cs:24-35)
+        for (int j = tid; j < 4 * w.n_corners; j += PK_THREADS) {
+            const int k = j >> 2, m = (j & 3) + 1;
+            pk_i4 col = col0;
+            if (A.flavour == 1 && j >= PK_THREADS) {
+                const pk_i4 cr = V.corners[k];
+                const int4 c = A.ca[(size_t)(4 * (cr.y & 3) + m) * A.NT + cr.x];
+                col.x = c.x; col.y = c.y; col.z = c.z;
+            }
+            const int32_t e = pk_corner_lane(w, V, k, m, A.flavour, col);
+            const uint32_t d = (uint32_t)e - (uint32_t)__shfl_xor(e, 1);   // lanes 4k+0/1: E(+dx), E(-dx); 4k+2/3: E(+dy), E(-dy)
+            const int own = (V.corners[k].y >> 2) & 0x3ff;
+            if ((j & 3) == 0) atomicAdd(&V.grad[own].x, (int)d);
+            if ((j & 3) == 2) atomicAdd(&V.grad[own].y, (int)d);
+        }
+        __syncthreads();
+        PK_STAMP(5);
+        // ---- P7: the step of the patch's own vertices; the new positions go to the mailbox of the next grad-iter (or, after
+        // the last one, to `points_out`); the other threads clear the line sums and bands for the next grad-iter
+        const bool last = it + 1 == A.n_iters;
+        for (int k = tid; k < w.n_own_v; k += PK_THREADS) {
+            const int v = V.vid[k];
+            const pk_f2 p = pk_vertex_lane(V.pos[k], V.grad[k].x, V.grad[k].y, v, A.vw.ratio, A.rate);
+            V.pos[k] = p;
+            if (last) A.points_out[v] = make_float2(p.x, p.y);
+            else {
+                const unsigned long long T = (unsigned long long)pk_tag(epoch + 1u) << 32;
+                gu64* g = posbox + ((size_t)((epoch + 1u) & 1u) * A.NP + v) * 2;
+                __hip_atomic_store(g, T | __float_as_uint(p.x), PK_RLX_AGENT);
+                __hip_atomic_store(g + 1, T | __float_as_uint(p.y), PK_RLX_AGENT);
+            }
+        }
+        if (!last) {
+            for (int i = PK_THREADS - 1 - tid; i < 6 * PK_NLINES * w.n_own_e; i += PK_THREADS) V.sums[i] = 0ull;
+            for (int i = PK_THREADS - 1 - tid; i < w.n_own_e; i += PK_THREADS) { V.band[i].x = 0x3fffffff; V.band[i].y = -1; }
+        }
+        PK_STAMP(6);
+        // (no barrier here: P0 of the next grad-iter touches foreign position slots only, and its barrier orders the rest)
+    }
+}
+
+int tp_persist_set_lds(int bytes) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+void tp_launch_persist(const pk_args& A, int lds_bytes, hipStream_t s) {
+    hipLaunchKernelGGL(k_persist, dim3((unsigned)A.parts), dim3(PK_THREADS), (size_t)lds_bytes, s, A);
+}
+
