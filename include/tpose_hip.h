@@ -168,7 +168,7 @@ int tp_render(tp_context* ctx, int source, const float* points, uint8_t* dst_rgb
 
 /* introspection for tests/benchmarks: 0 = records per row of the prefix table, 1 = chunks per line of k_lines for the
  * current triangulation (rows of a line are shared by that many lanes); persistent path: 2 = patches (workgroups) of
- * the current plan, 0 if none, 3 = its LDS bytes per workgroup, 4 = line sums crossing patch borders per grad-iter,
+ * the current plan, 0 if none, 3 = its LDS bytes per workgroup, 4 = lines all patches walk per grad-iter (9 per edge if none were walked twice),
  * 5 = persistent launches so far, 6 = grad-iters run inside them, 7 = census (1 a full grid is resident, -1 not,
  * 0 not taken yet) */
 int tp_get_info(tp_context* ctx, int what, int64_t* value);

@@ -252,3 +252,46 @@ extern "C" int emul_line_check(int32_t Xa, int32_t Ya, int32_t Xb, int32_t Yb, i
     }
     return bad;
 }
+
+
+// the pixel records (16 bytes per pixel column, fields with headroom) against plain sums: every column c = 0..W of every
+// row on its own, and sums of up to 16 records at pseudo-random columns; returns the mismatches
+extern "C" int emul_px_check(const uint8_t* img, size_t stride, int W, int H) {
+    int bad = 0;
+    std::vector<uint64_t> recs(2 * (size_t)(W + 1));
+    std::vector<uint64_t> ref(5 * (size_t)(W + 1));
+    uint32_t seed = 12345u + (uint32_t)W * 31u + (uint32_t)H;
+    for (int r = 0; r < H; r++) {
+        uint32_t run[5] = {0, 0, 0, 0, 0};
+        for (int c = 0; c <= W; c++) {
+            tp_px_pack(run, &recs[2 * (size_t)c]);
+            for (int k = 0; k < 5; k++) ref[5 * (size_t)c + k] = run[k];
+            if (c < W) {
+                uint32_t px;
+                memcpy(&px, img + (size_t)r * stride + 4 * (size_t)c, 4);
+                const uint32_t R = px & 0xffu, G = (px >> 8) & 0xffu, B = (px >> 16) & 0xffu;
+                run[0] += (R + G + B) & 1u; run[1] += R; run[2] += G; run[3] += B; run[4] += R * R + G * G + B * B;
+            }
+        }
+        for (int c = 0; c <= W; c++) {
+            uint32_t nodd, R, G, B; uint64_t Q;
+            tp_px_unpack(recs[2 * (size_t)c], recs[2 * (size_t)c + 1], nodd, R, G, B, Q);
+            const uint64_t* e = &ref[5 * (size_t)c];
+            if (nodd != e[0] || R != e[1] || G != e[2] || B != e[3] || Q != e[4]) bad++;
+        }
+        for (int trial = 0; trial < 8; trial++) {   // sums of 1..16 records, the widest columns included
+            uint64_t lo = 0, hi = 0, e[5] = {0, 0, 0, 0, 0};
+            const int n = 1 + (trial * 5) % TP_PX_MAXSUM;
+            for (int k = 0; k < n; k++) {
+                seed = seed * 1664525u + 1013904223u;
+                const int c = (trial & 1) ? W - (int)((seed >> 8) % (uint32_t)(W < 4 ? W + 1 : 4)) : (int)((seed >> 8) % (uint32_t)(W + 1));
+                lo += recs[2 * (size_t)c]; hi += recs[2 * (size_t)c + 1];
+                for (int q = 0; q < 5; q++) e[q] += ref[5 * (size_t)c + q];
+            }
+            uint32_t nodd, R, G, B; uint64_t Q;
+            tp_px_unpack(lo, hi, nodd, R, G, B, Q);
+            if (nodd != e[0] || R != e[1] || G != e[2] || B != e[3] || Q != e[4]) bad++;
+        }
+    }
+    return bad;
+}

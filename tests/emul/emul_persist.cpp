@@ -14,28 +14,28 @@ namespace {
 struct part_state {
     std::vector<char> lds;
     pk_view V;
+    std::vector<pk_lane_cache<PK_ROWS_PER_LANE>> cache;   // one per cached lane-item, like the kernel's registers
 };
 }  // namespace
 
-// returns 0, or a negative code: -1 plan refused, -2 a position granule had the wrong tag, -3 a line granule had
-// the wrong tag, -4 pack / unpack of a line sum is not the identity
+// returns 0, or a negative code: -1 plan refused, -2 a position granule had the wrong tag
 extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, float* points, int NP, const int32_t* tris,
                             int NT, const int32_t* ca, int flavour, float dp, float ratio, float rate, int iters,
                             int max_parts, int lds_limit, int64_t* stats) {
     tp_view vw;
     vw.dp = dp; vw.ratio = ratio; vw.halfW = 0.5f * (float)W; vw.halfH = 0.5f * (float)H; vw.W = W; vw.H = H;
-    // the per-image table, as k_prefix builds it
-    const int NG = tp_prefix_groups(W), pitch = tp_prefix_pitch(W);
-    std::vector<uint32_t> T((size_t)H * pitch * TP_PFX_WORDS, 0);
+    // the per-image table in pixel records, as k_prefix_px builds it
+    if (W > TP_PX_MAXW) return -1;
+    const int pitch = tp_px_pitch(W);
+    std::vector<uint64_t> T((size_t)H * pitch * 2, 0);
     for (int r = 0; r < H; r++) {
         uint32_t run[5] = {0, 0, 0, 0, 0};
-        for (int g = 0; g < NG; g++) {
-            uint32_t px[4] = {0, 0, 0, 0};
-            const int npx = tp_min(4, W - 4 * g) < 0 ? 0 : tp_min(4, W - 4 * g);
-            for (int i = 0; i < npx; i++) memcpy(&px[i], img + (size_t)r * stride + 4 * (size_t)(4 * g + i), 4);
-            tp_prefix_pack(run, px, npx, &T[((size_t)r * pitch + g) * TP_PFX_WORDS]);
-            for (int i = 0; i < npx; i++) {
-                const uint32_t R = px[i] & 0xffu, G = (px[i] >> 8) & 0xffu, B = (px[i] >> 16) & 0xffu;
+        for (int c = 0; c <= W; c++) {
+            tp_px_pack(run, &T[((size_t)r * pitch + c) * 2]);
+            if (c < W) {
+                uint32_t px;
+                memcpy(&px, img + (size_t)r * stride + 4 * (size_t)c, 4);
+                const uint32_t R = px & 0xffu, G = (px >> 8) & 0xffu, B = (px >> 16) & 0xffu;
                 run[0] += (R + G + B) & 1u; run[1] += R; run[2] += G; run[3] += B; run[4] += R * R + G * G + B * B;
             }
         }
@@ -54,7 +54,7 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
     const int NE = (int)(edge_uv.size() / 2);
     pk_plan P;
     pk_build_plan(NP, NT, tris, points, NE, edge_uv.data(), he_edge.data(), W, H, ratio, dp * 0.5f * (float)H, max_parts, lds_limit, P);
-    if (stats) { stats[0] = P.ok; stats[1] = P.parts; stats[2] = P.lds_bytes; stats[3] = P.imp_total; stats[4] = P.exp_total; stats[5] = NE; }
+    if (stats) { stats[0] = P.ok; stats[1] = P.parts; stats[2] = P.lds_bytes; stats[3] = P.lines_total; stats[4] = P.foreign_total; stats[5] = NE; }
     if (!P.ok) return -1;
 
     std::vector<part_state> S((size_t)P.parts);
@@ -64,14 +64,15 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
         pk_view& V = S[p].V;
         pk_carve(S[p].lds.data(), w, V);
         memcpy(V.vid, &P.pool[w.off_vid], sizeof(int32_t) * w.n_slots);
-        memcpy(V.edges, &P.pool[w.off_edges], sizeof(int32_t) * 2 * w.n_own_e);
-        memcpy(V.items, &P.pool[w.off_items], sizeof(int32_t) * 2 * w.n_items);
+        memcpy(V.edges, &P.pool[w.off_edges], sizeof(int32_t) * w.n_edges);
+        memcpy(V.lines, &P.pool[w.off_lines], sizeof(int32_t) * w.n_lines);
+        memcpy(V.li, &P.pool[w.off_li], sizeof(int32_t) * 3 * w.n_li);
         memcpy(V.corners, &P.pool[w.off_corners], sizeof(int32_t) * 4 * w.n_corners);
-        memcpy(V.imp, &P.pool[w.off_imp], sizeof(int32_t) * w.n_imp);
-        memcpy(V.exp_, &P.pool[w.off_exp], sizeof(int32_t) * w.n_exp);
         for (int s = 0; s < w.n_slots; s++) { V.pos[s].x = points[2 * V.vid[s]]; V.pos[s].y = points[2 * V.vid[s] + 1]; }
+        S[p].cache.resize(PK_CACHED);
+        for (int j = 0; j < PK_CACHED; j++) pk_cache_init(S[p].cache[j], V, j, j < w.n_li);
     }
-    std::vector<unsigned long long> posbox((size_t)2 * NP * 2, 0), linebox((size_t)2 * NE * PK_NLINES * PK_GRANULES, 0);
+    std::vector<unsigned long long> posbox((size_t)2 * NP * 2, 0);
     const char* table = reinterpret_cast<const char*>(T.data());
     for (int it = 0; it < iters; it++) {
         const uint32_t e = 1 + it, tag = pk_tag(e), par = e & 1;
@@ -87,41 +88,28 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
                 }
             // P1
             for (int j = 0; j < 5 * w.n_own_v + (w.n_slots - w.n_own_v); j++) pk_snap_lane(w, V, vw, j);
-            for (int le = 0; le < w.n_own_e; le++) { V.band[le].x = 0x3fffffff; V.band[le].y = -1; }
-            for (int l = 0; l < PK_NLINES * w.n_own_e; l++) {
+            for (int le = 0; le < w.n_edges; le++) { V.band[le].x = 0x3fffffff; V.band[le].y = -1; }
+            for (int l = 0; l < w.n_lines; l++) {
                 pk_walker wkr;
-                pk_setup_lane(V, vw, l, wkr);
+                const int le = pk_setup_lane(V, vw, l, wkr);
                 V.wk[l] = wkr;
-                if (wkr.ra <= wkr.rb) { pk_i2& b = V.band[l / PK_NLINES]; b.x = tp_min(b.x, wkr.ra); b.y = tp_max(b.y, wkr.rb); }
+                if (wkr.ra <= wkr.rb) { pk_i2& b = V.band[le]; b.x = tp_min(b.x, wkr.ra); b.y = tp_max(b.y, wkr.rb); }
             }
-            memset(V.sums, 0, sizeof(unsigned long long) * 6 * (size_t)w.n_sums);
+            memset(V.sums, 0, sizeof(unsigned long long) * 6 * (size_t)w.n_lines);
             for (int k = 0; k < w.n_own_v; k++) { V.grad[k].x = 0; V.grad[k].y = 0; }
             // P3
-            for (int j = 0; j < PK_NLINES * w.n_items; j++) {
+            for (int j = 0; j < w.n_li; j++) {
                 pk_acc a;
-                const int l = pk_walk_lane<PK_ROWS_PER_LANE>(V, table, pitch, W, j, a);
+                int l;
+                if (j < PK_CACHED) {
+                    if (w.rows <= 8) pk_walk_cached<8>(S[p].cache[j], V, table, pitch, W, a);
+                    else if (w.rows <= 10) pk_walk_cached<10>(S[p].cache[j], V, table, pitch, W, a);
+                    else pk_walk_cached<PK_ROWS_PER_LANE>(S[p].cache[j], V, table, pitch, W, a);
+                    l = S[p].cache[j].l;
+                }
+                else l = pk_walk_lane(V, table, pitch, W, j, a);
                 unsigned long long* s = V.sums + (size_t)l * 6;
                 s[0] += a.xs; s[1] += a.nodd; s[2] += a.r; s[3] += a.g; s[4] += a.b; s[5] += a.q;
-            }
-            // P4
-            for (int k = 0; k < w.n_exp; k++) {
-                const int ls = V.exp_[k], le = ls / PK_NLINES, q = ls - le * PK_NLINES;
-                const int gl = V.edges[le].y * PK_NLINES + q;
-                unsigned long long g[PK_GRANULES], back[6];
-                pk_pack_line(V.sums + (size_t)ls * 6, tag, g);
-                pk_unpack_line(g, back);
-                if (memcmp(back, V.sums + (size_t)ls * 6, sizeof back)) return -4;
-                memcpy(&linebox[((size_t)par * NE * PK_NLINES + gl) * PK_GRANULES], g, sizeof g);
-            }
-        }
-        for (int p = 0; p < P.parts; p++) {
-            const pk_wg& w = P.wg[p];
-            pk_view& V = S[p].V;
-            // P5
-            for (int k = 0; k < w.n_imp; k++) {
-                const unsigned long long* g = &linebox[((size_t)par * NE * PK_NLINES + V.imp[k]) * PK_GRANULES];
-                for (int i = 0; i < PK_GRANULES; i++) if (!pk_granule_ok(g[i], tag)) return -3;
-                pk_unpack_line(g, V.sums + (size_t)(PK_NLINES * w.n_own_e + k) * 6);
             }
             // P6
             for (int k = 0; k < w.n_corners; k++) {
@@ -136,7 +124,8 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
                 V.grad[own].x = (int32_t)((uint32_t)V.grad[own].x + ((uint32_t)en[1] - (uint32_t)en[2]));
                 V.grad[own].y = (int32_t)((uint32_t)V.grad[own].y + ((uint32_t)en[3] - (uint32_t)en[4]));
             }
-            // P7
+            // P7: posts go to the OTHER parity of the mailbox, so workgroups replayed later in this sweep still read this
+            // grad-iter's positions
             for (int k = 0; k < w.n_own_v; k++) {
                 const pk_f2 np_ = pk_vertex_lane(V.pos[k], V.grad[k].x, V.grad[k].y, V.vid[k], ratio, rate);
                 V.pos[k] = np_;
@@ -172,14 +161,38 @@ extern "C" int emul_plan(const float* points, int NP, const int32_t* tris, int N
     pk_plan P;
     pk_build_plan(NP, NT, tris, points, NE, edge_uv.data(), he_edge.data(), W, H, ratio, dp_px, max_parts, lds_limit, P);
     if (stats) {
-        stats[0] = P.ok; stats[1] = P.parts; stats[2] = P.lds_bytes; stats[3] = P.imp_total; stats[4] = P.exp_total; stats[5] = NE;
+        stats[0] = P.ok; stats[1] = P.parts; stats[2] = P.lds_bytes; stats[3] = P.lines_total; stats[4] = P.foreign_total; stats[5] = NE;
         stats[6] = (int64_t)P.work_max; stats[7] = (int64_t)P.work_mean;
-        int mi = 0, mc = 0, ms = 0, mit = 0;
-        for (auto& w : P.wg) { mi = tp_max(mi, w.n_imp); mc = tp_max(mc, w.n_corners); ms = tp_max(ms, w.n_slots); mit = tp_max(mit, w.n_items); }
-        stats[8] = mi; stats[9] = mc; stats[10] = ms; stats[11] = mit;
+        int ml = 0, mc = 0, ms = 0, mit = 0;
+        for (auto& w : P.wg) { ml = tp_max(ml, w.n_lines); mc = tp_max(mc, w.n_corners); ms = tp_max(ms, w.n_slots); mit = tp_max(mit, w.n_li); }
+        stats[8] = ml; stats[9] = mc; stats[10] = ms; stats[11] = mit;
     }
     if (!P.ok) return -1;
     if (owner_v) memcpy(owner_v, P.owner_v.data(), sizeof(int32_t) * NP);
-    if (owner_e) memcpy(owner_e, P.owner_e.data(), sizeof(int32_t) * NE);
+    (void)owner_e;
     return 0;
+}
+
+// per-patch figures of a plan (tools/plan_stats.py): {own vertices, slots, edges, lines, lane-items, corners, rows per lane}
+extern "C" int emul_plan_patches(const float* points, int NP, const int32_t* tris, int NT, int W, int H, float ratio, float dp_px,
+                                 int max_parts, int lds_limit, int32_t* out, int cap) {
+    std::map<std::pair<int, int>, int> eid;
+    std::vector<int32_t> edge_uv, he_edge(3 * (size_t)NT);
+    for (int t = 0; t < NT; t++)
+        for (int k = 0; k < 3; k++) {
+            const int o = tris[4 * t + k], d = tris[4 * t + (k + 1) % 3];
+            const std::pair<int, int> key(o < d ? o : d, o < d ? d : o);
+            auto it = eid.find(key);
+            if (it == eid.end()) { it = eid.emplace(key, (int)(edge_uv.size() / 2)).first; edge_uv.push_back(key.first); edge_uv.push_back(key.second); }
+            he_edge[3 * t + k] = it->second * 2 + (o != key.first ? 1 : 0);
+        }
+    pk_plan P;
+    pk_build_plan(NP, NT, tris, points, (int)(edge_uv.size() / 2), edge_uv.data(), he_edge.data(), W, H, ratio, dp_px, max_parts, lds_limit, P);
+    if (!P.ok) return -1;
+    for (int p = 0; p < P.parts && p < cap; p++) {
+        const pk_wg& w = P.wg[p];
+        int32_t* o = out + 8 * p;
+        o[0] = w.n_own_v; o[1] = w.n_slots; o[2] = w.n_edges; o[3] = w.n_lines; o[4] = w.n_li; o[5] = w.n_corners; o[6] = w.rows; o[7] = w.lds_bytes;
+    }
+    return P.parts;
 }

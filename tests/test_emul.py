@@ -212,3 +212,122 @@ def test_whole_line_walker_is_exact(em):
             assert r == 0, (Xa, Ya, Xb, Yb, H, tl, bad.value)
             n += 1
     assert n == 6000
+
+
+# ------------------------------------------------------------------------------------------------
+# Persistent grad-iter kernel (tpose_amd/csrc/tp_plan.h + tp_persist.h): the plan and the lane functions replayed on
+# the CPU, workgroup by workgroup, with the position mailbox as a plain array -- everything but the device-side waiting.
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emp():
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    so = os.path.join(HERE, "_build", "libtp_emul_persist.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so,
+                           os.path.join(HERE, "emul", "emul_persist.cpp")])
+    return C.CDLL(so)
+
+
+def emul_persist(emp, sweep, pts, tris, flavour, ratio, rate, iters, colors=None, dp=None, max_parts=256, lds=160 * 1024):
+    NT, NP = tris.shape[0], pts.shape[0]
+    H, W = sweep.shape[:2]
+    d = O.dp(flavour, NT) if dp is None else dp
+    p = np.ascontiguousarray(pts.copy())
+    ca = np.ascontiguousarray(np.tile(colors, (13, 1)).astype(np.int32)) if colors is not None else None
+    stats = np.zeros(16, np.int64)
+    rc = emp.emul_persist(sweep.ctypes.data_as(C.c_void_p), C.c_size_t(sweep.strides[0]), W, H, p.ctypes.data_as(C.c_void_p), NP,
+                          tris.ctypes.data_as(C.c_void_p), NT, ca.ctypes.data_as(C.c_void_p) if ca is not None else None,
+                          flavour, C.c_float(d), C.c_float(ratio), C.c_float(rate), iters, max_parts, lds,
+                          stats.ctypes.data_as(C.c_void_p))
+    return rc, p, stats
+
+
+@pytest.mark.parametrize("W,H,grid", [(64, 48, (6, 4)), (300, 200, (15, 5)), (257, 131, (6, 4)), (128, 32, None)])
+@pytest.mark.parametrize("flavour", [0, 1])
+@pytest.mark.parametrize("max_parts", [1, 5, 256])
+def test_persistent_plan_and_lanes_match_oracle(emp, W, H, grid, flavour, max_parts):
+    img, imgB, pts, tris, ratio, colors = case(W, H, grid)
+    sweep = imgB if flavour else img
+    rate = 0.00003 if flavour else 0.00005
+    rc, p, stats = emul_persist(emp, sweep, pts, tris, flavour, ratio, rate, 6, colors=colors if flavour else None,
+                                max_parts=max_parts, lds=1 << 20)
+    assert rc == 0, (rc, stats)
+    ref = O.iterate(sweep, pts, tris, flavour, ratio, rate, 6, colors=colors if flavour else None, literal=False)
+    assert np.array_equal(p.view(np.uint32), ref["points"].view(np.uint32))
+    assert 1 <= stats[1] <= max_parts
+
+
+def test_persistent_record_cache_over_many_grad_iters(emp):
+    """the records a lane keeps from one grad-iter to the next: fast-moving vertices (stale records, lines that outgrow
+    the rows a lane keeps) over 60 grad-iters"""
+    W, H, grid = 300, 200, (15, 5)
+    img, _, pts, tris, ratio, _ = case(W, H, grid)
+    for rate in (0.00005, 0.0004):
+        rc, p, stats = emul_persist(emp, img, pts, tris, 0, ratio, rate, 60, max_parts=7)
+        assert rc == 0
+        ref = O.iterate(img, pts, tris, 0, ratio, rate, 60, literal=False)
+        assert np.array_equal(p.view(np.uint32), ref["points"].view(np.uint32)), rate
+
+
+def test_persistent_plan_on_soups_and_bad_vertices(emp):
+    """triangle soups (edges shared by many triangles, duplicated triangles, vertices outside the domain, NaN): the plan
+    either refuses (an edge naming one vertex twice) or replays to the oracle's bits"""
+    W, H = 200, 150
+    img = synth.voronoi_raster(W, H, seed=3, sites=10)
+    ratio = float(np.float32(W) / np.float32(H))
+    rng = np.random.default_rng(5)
+    ran = 0
+    for trial in range(24):
+        NP = 30
+        pts = (rng.random((NP, 2)).astype(np.float32) * 2 - 1) * np.float32(1.3)
+        pts[:, 0] *= np.float32(ratio)
+        if trial % 5 == 0:
+            pts[10:14] *= np.float32(1e6)
+        if trial % 7 == 0:
+            pts[3, 0] = np.float32("nan")
+        tris = np.zeros((40, 4), np.int32)
+        tris[:, :3] = rng.integers(0, NP, (40, 3))
+        if trial % 2 == 0:   # no degenerate triangles: the plan must accept
+            for t in range(40):
+                while len(set(tris[t, :3].tolist())) < 3:
+                    tris[t, :3] = rng.integers(0, NP, 3)
+        rc, p, stats = emul_persist(emp, img, pts, tris, 0, ratio, 0.00005, 4, dp=[0.05, 0.3][trial % 2], max_parts=1 + trial % 6, lds=1 << 20)
+        if trial % 2 == 0:
+            assert rc == 0
+        if rc == 0:
+            ran += 1
+            ref = O.iterate(img, pts, tris, 0, ratio, 0.00005, 4, dp_=[0.05, 0.3][trial % 2], literal=False)
+            used = np.zeros(NP, bool)
+            used[tris[:, :3].ravel()] = True   # (vertices no triangle uses are left to the last grad-iter's k_update, which clamps them)
+            assert np.array_equal(p.view(np.uint32)[used], ref["points"].view(np.uint32)[used]), trial
+            assert np.array_equal(p.view(np.uint32)[~used], pts.view(np.uint32)[~used])
+        else:
+            assert rc == -1 and stats[0] == 0
+    assert ran >= 12
+
+
+def test_persistent_plan_statistics(emp):
+    """the cut at the metric size: every CU gets a patch, patches are balanced, few lines are walked twice"""
+    W = H = 2048
+    img, pts, tris, he, ratio = synth.workload(W, H, 3000)
+    NP, NT = pts.shape[0], tris.shape[0]
+    stats = np.zeros(16, np.int64)
+    owner = np.zeros(NP, np.int32)
+    rc = emp.emul_plan(pts.ctypes.data_as(C.c_void_p), NP, tris.ctypes.data_as(C.c_void_p), NT, W, H, C.c_float(ratio),
+                       C.c_float(10.0), 256, 160 * 1024, owner.ctypes.data_as(C.c_void_p), None, stats.ctypes.data_as(C.c_void_p))
+    assert rc == 0 and stats[0] == 1 and stats[1] == 256
+    assert stats[3] <= 1.15 * 9 * stats[5]          # lines walked vs 9 per edge
+    assert stats[6] <= 1.3 * stats[7]               # heaviest patch vs the mean
+    assert stats[2] <= 64 * 1024                    # LDS per workgroup
+    assert (np.bincount(owner[owner >= 0], minlength=256) > 0).all()
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (2, 1), (3, 2), (5, 2), (97, 5), (256, 2), (1011, 3), (4096, 3)])
+def test_pixel_records_are_exact(em, W, H):
+    """every column 0..W of every row from the 16-byte pixel records, and sums of up to 16 of them unpacked once -- at the
+    packing limits too (4096 pixels of 255s: 20-bit channel sums, 30-bit squares, 13-bit parity count, 16 records added)"""
+    rng = np.random.default_rng(W * 31 + H)
+    for kind in range(3):
+        img = rng.integers(0, 256, (H, W, 4), dtype=np.uint8) if kind == 0 else \
+            np.full((H, W, 4), 255, np.uint8) if kind == 1 else (rng.integers(0, 2, (H, W, 4), dtype=np.uint8) * 255)
+        img = np.ascontiguousarray(img)
+        assert em.emul_px_check(img.ctypes.data_as(C.c_void_p), C.c_size_t(img.strides[0]), W, H) == 0

@@ -193,14 +193,15 @@ def test_device_whole_line_walker_is_exact():
     assert np.array_equal(got[idx, 2:][ok], exact[ok].astype(np.int64))
 
 
-@pytest.mark.parametrize("margin", [0, 2, 6, 40])
-def test_work_list_reuse_never_changes_results(margin):
-    """tp_set_margin is a tuning hint (round 1 kept work lists while vertices stayed inside a margin; round 2 rebuilds
-    them every iteration): any value must give the oracle's bits.  A high step rate makes vertices travel many pixels."""
+@pytest.mark.parametrize("persistent", [0, 1])
+def test_fast_moving_vertices_match_oracle(persistent):
+    """A high step rate makes vertices travel many pixels per grad-iter: the persistent kernel's lanes find their cached
+    table records stale almost every time (and lines outgrow the rows a lane keeps); the two-kernel path sees lines far
+    longer than at upload.  Either way the oracle's bits."""
     W, H, grid = 300, 200, (15, 5)
     img, imgB, pts, tris, ratio, colors = case(W, H, grid)
     ctx = capi.Context(0, W, H)
-    ctx.set_margin(margin)
+    ctx.set_persistent(persistent)
     ctx.set_image(capi.IMAGE_A, img)
     ctx.upload(pts, tris)
     rate = 0.0004
@@ -347,10 +348,9 @@ def test_wide_raster_many_tile_columns():
 
 
 @pytest.mark.parametrize("kind", ["nan", "inf", "huge", "allsame", "concentrated"])
-def test_work_lists_grow_instead_of_failing(kind):
-    """Vertex sets that blow the initial work-list capacities at the metric size (far-away, coincident
-    or crowded vertices; NaN / inf) must neither fault nor fail: the library grows the lists and
-    replays the iterations, and the results still match the oracle bit for bit."""
+def test_hostile_vertex_sets_match_oracle(kind):
+    """Far-away, coincident or crowded vertices, NaN / inf at the metric size must neither fault nor fail, and the results
+    still match the oracle bit for bit."""
     W = H = 2048
     img, pts, tris, he, ratio = synth.workload(W, H, 3000)
     bad = pts.copy()

@@ -37,8 +37,8 @@ def parity(W, H, grid, flavour, iters):
     return okp and oke
 
 
-def timing(W, H, NT, steps, flavour=0):
-    img, pts, tris, he, ratio = synth.workload(W, H, NT)
+def timing(W, H, NT, steps, flavour=0, contrast=0.1):
+    img, pts, tris, he, ratio = synth.workload(W, H, NT, contrast=contrast)
     res = {}
     for mode in (1, 0):
         ctx = capi.Context(0, W, H)
@@ -57,11 +57,11 @@ def timing(W, H, NT, steps, flavour=0):
             ctx.iterate(p, steps)
             ctx.synchronize()
             ts.append((time.perf_counter() - t0) / steps * 1e6)
-        res[mode] = (min(ts), ctx.retrieve(capi.BUF_POINTS), ctx.info(capi.INFO_PATCHES), ctx.info(capi.INFO_PATCH_LDS), ctx.info(capi.INFO_BORDER_LINES))
+        res[mode] = (min(ts), ctx.retrieve(capi.BUF_POINTS), ctx.info(capi.INFO_PATCHES), ctx.info(capi.INFO_PATCH_LDS), ctx.info(capi.INFO_PATCH_LINES))
         ctx.close()
     same = np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
-    print("timing %dx%d / %d triangles flavour %d, %d steps: persistent %.2f us/iter (patches %d, LDS %d B, border lines %d) | "
-          "two-kernel %.2f us/iter | same positions after %d iters: %s" % (W, H, tris.shape[0], flavour, steps, res[1][0], res[1][2], res[1][3], res[1][4],
+    print("timing %dx%d / %d triangles contrast %g flavour %d, %d steps: persistent %.2f us/iter (patches %d, LDS %d B, lines walked %d) | "
+          "two-kernel %.2f us/iter | same positions after %d iters: %s" % (W, H, tris.shape[0], contrast, flavour, steps, res[1][0], res[1][2], res[1][3], res[1][4],
                                                                     res[0][0], 64 + 3 * steps, same), flush=True)
     return same
 
@@ -73,7 +73,9 @@ if __name__ == "__main__":
         for fl in (0, 1):
             ok &= parity(W, H, grid, fl, 6)
     ok &= parity(300, 200, (15, 5), 0, 200)
+    ok &= timing(2048, 2048, 3000, 128)
     ok &= timing(2048, 2048, 3000, 512)
+    ok &= timing(2048, 2048, 3000, 2048)
     if not quick:
         ok &= timing(2048, 2048, 3000, 2048, flavour=1)
         ok &= timing(4096, 4096, 12000, 512)

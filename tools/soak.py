@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised parity soak (needs an MI355X; the oracle is the checker): random raster sizes, random triangle
-soups and jittered grids, both flavours, random dp and margins, piecewise moments and fused iterations, all
+soups and jittered grids, both flavours, random dp, persistent launches on and off, piecewise moments and fused iterations, all
 compared bit for bit.  `python tools/soak.py [cases] [seed]`."""
 import os
 import sys
@@ -56,11 +56,11 @@ for case in range(cases):
     ctx.accumulate(flavour, capi.IMAGE_B if flavour else capi.IMAGE_A)
     ctx.energy(flavour)
     ok = np.array_equal(ctx.retrieve(capi.BUF_MOMENTS), O.moments(sweep, pts, tris, dpe, ratio))
-    # fused iterations (optionally with work-list reuse)
-    iters = int(rng.integers(1, 5))
-    margin = int(rng.choice([0, 0, 3, 20]))
+    # fused iterations (persistent launches or the two-kernel path)
+    iters = int(rng.integers(1, 9))
+    margin = int(rng.choice([0, 0, 1, 1]))  # persistent launches on / off
     ctx.upload(pts, tris, colors)
-    ctx.set_margin(margin)
+    ctx.set_persistent(margin)
     params = capi.default_params(flavour)
     params.dp = dp
     rate = float(np.float32(rng.choice([params.rate, 1e-5, 2e-4])))
@@ -72,7 +72,7 @@ for case in range(cases):
     ok &= np.array_equal(ctx.retrieve(capi.BUF_GRADIENT), ref["gr"].reshape(-1, 2))
     # the piecewise calls in the reference's order give the same state
     ctx.upload(pts, tris, colors)
-    ctx.set_margin(0)
+    ctx.set_persistent(1)
     for k in range(iters):
         ctx.accumulate(flavour, capi.IMAGE_B if flavour else capi.IMAGE_A)
         ctx.energy(flavour)
@@ -82,6 +82,6 @@ for case in range(cases):
     ctx.close()
     if not ok:
         bad += 1
-        print("MISMATCH case %d: %dx%d kind %d flavour %d dp %g iters %d margin %d NT %d" % (case, W, H, kind, flavour, dp, iters, margin, tris.shape[0]), flush=True)
+        print("MISMATCH case %d: %dx%d kind %d flavour %d dp %g iters %d persistent %d NT %d" % (case, W, H, kind, flavour, dp, iters, margin, tris.shape[0]), flush=True)
 print("soak: %d cases, %d mismatches" % (cases, bad))
 sys.exit(1 if bad else 0)

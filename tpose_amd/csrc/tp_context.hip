@@ -77,6 +77,8 @@ struct tp_context {
     int lanes_per_line = 1;        // k_lines: lanes per line, from the mean number of rows of an edge at upload
     uint4* prefix[2] = {nullptr, nullptr};   // per-image row prefix tables
     int prefix_pitch = 0;
+    uint4* px[2] = {nullptr, nullptr};     // the same in pixel records (rasters up to TP_PX_MAXW columns): persistent kernel
+    int px_pitch = 0;
     // outputs
     int32_t* ten = nullptr;
     int32_t* cn = nullptr;
@@ -110,8 +112,8 @@ struct tp_context {
     uint64_t plan_generation = 0;   // generation the plan (ok or refused) belongs to
     pk_wg* d_wg = nullptr; int32_t* d_pool = nullptr;
     size_t cap_wg = 0, cap_pool = 0;
-    unsigned long long* posbox = nullptr; unsigned long long* linebox = nullptr;
-    size_t cap_posbox = 0, cap_linebox = 0;   // (in vertices / edges)
+    unsigned long long* posbox = nullptr;
+    size_t cap_posbox = 0;   // (in vertices)
     float2* points_out = nullptr; size_t cap_points_out = 0;
     unsigned* d_status = nullptr;   // [0] a lane of a persistent launch gave up waiting, [1] census counter
     uint32_t epoch = 1;             // number of the next grad-iter of a persistent launch (mailbox tags)
@@ -199,6 +201,15 @@ int check_slot(tp_context* c, int slot) {
 }
 
 // ---- persistent grad-iter kernel: status, census, plan ------------------------------------------------------------
+#ifdef TPOSE_DEBUG  // debug flavour of the library (tools/persist_timeline.py): per-workgroup phase timestamps
+static unsigned long long* g_persist_dbg = nullptr;
+static const size_t PERSIST_DBG_WORDS = (size_t)512 * PK_DBG_ITERS * 16;
+unsigned long long* persist_dbg_buffer(int parts, hipStream_t s) {
+    if (!g_persist_dbg) { hipMalloc((void**)&g_persist_dbg, PERSIST_DBG_WORDS * 8); }
+    hipMemsetAsync(g_persist_dbg, 0, PERSIST_DBG_WORDS * 8, s);
+    return parts <= 512 ? g_persist_dbg : nullptr;
+}
+#endif
 #define PK_LDS_LIMIT (160 * 1024 - 512)  /* (the kernel has a few static bytes of its own) */
 #define PK_MIN_ITERS 4        /* shorter tp_iterate calls are not worth a plan (frame-by-frame schedules) */
 #define PK_MAX_EPOCH 32000u   /* mailbox tags carry 15 bits of the grad-iter's number */
@@ -260,7 +271,7 @@ int take_census(tp_context* c) {
 // persistent path
 int ensure_plan(tp_context* c, float dp, bool* use) {
     *use = false;
-    if (c->persist_mode == TP_PERSIST_OFF) return TP_OK;
+    if (c->persist_mode == TP_PERSIST_OFF || !c->px_pitch) return TP_OK;  // (rasters wider than 4096 columns have no pixel-record table)
     if (int rc = take_census(c)) return rc;
     if (c->census != 1) return TP_OK;
     if (c->plan_generation != c->generation) {
@@ -275,23 +286,15 @@ int ensure_plan(tp_context* c, float dp, bool* use) {
             HIP_TRY(c, hipMemcpyAsync(c->d_wg, c->plan.wg.data(), sizeof(pk_wg) * c->plan.wg.size(), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipMemcpyAsync(c->d_pool, c->plan.pool.data(), sizeof(int32_t) * c->plan.pool.size(), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));  // (pageable sources: the copies must not outlive the vectors' contents)
-            const size_t np = (size_t)c->NP, ne = (size_t)c->NE;
-            bool fresh = false;
+            const size_t np = (size_t)c->NP;
             if (np > c->cap_posbox || !c->posbox) {
                 hipFree(c->posbox); c->posbox = nullptr; c->cap_posbox = 0;
                 const size_t n = np + np / 2 + 64;
-                HIP_TRY(c, dev_alloc(&c->posbox, n * 4)); c->cap_posbox = n; fresh = true;
-            }
-            if (ne > c->cap_linebox || !c->linebox) {
-                hipFree(c->linebox); c->linebox = nullptr; c->cap_linebox = 0;
-                const size_t n = ne + ne / 2 + 64;
-                HIP_TRY(c, dev_alloc(&c->linebox, n * 2 * PK_NLINES * PK_GRANULES)); c->cap_linebox = n; fresh = true;
+                HIP_TRY(c, dev_alloc(&c->posbox, n * 4)); c->cap_posbox = n;
             }
             if (int rc = grow(c, &c->points_out, &c->cap_points_out, np)) return rc;
-            // slot numbering changed with the triangulation: stale granules of the previous one must not match a tag
-            (void)fresh;
+            // vertex numbering changed with the triangulation: stale granules of the previous one must not match a tag
             HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 4 * sizeof(unsigned long long), c->stream));
-            HIP_TRY(c, hipMemsetAsync(c->linebox, 0, c->cap_linebox * 2 * PK_NLINES * PK_GRANULES * sizeof(unsigned long long), c->stream));
             c->epoch = 1;
         }
     }
@@ -305,20 +308,20 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n) {
         const int k = n < PK_MAX_LAUNCH ? n : PK_MAX_LAUNCH;
         if (c->epoch + (uint32_t)k > PK_MAX_EPOCH) {
             HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 4 * sizeof(unsigned long long), c->stream));
-            HIP_TRY(c, hipMemsetAsync(c->linebox, 0, c->cap_linebox * 2 * PK_NLINES * PK_GRANULES * sizeof(unsigned long long), c->stream));
             c->epoch = 1;
         }
         pk_args A{};
         A.wg = c->d_wg; A.pool = c->d_pool; A.parts = c->plan.parts;
         A.vw.dp = dp; A.vw.ratio = c->ratio; A.vw.halfW = 0.5f * (float)c->W; A.vw.halfH = 0.5f * (float)c->H; A.vw.W = c->W; A.vw.H = c->H;
-        A.prefix = c->prefix[p.image_slot]; A.prefix_pitch = c->prefix_pitch;
+        A.px = c->px[p.image_slot]; A.px_pitch = c->px_pitch;
         A.points = c->points; A.points_out = c->points_out; A.ca = c->ca;
         A.NT = c->NT; A.NP = c->NP; A.NE = c->NE;
         A.flavour = p.flavour; A.rate = p.rate;
-        A.posbox = c->posbox; A.linebox = c->linebox;
+        A.posbox = c->posbox;
         A.epoch = c->epoch; A.n_iters = k; A.status = c->d_status;
 #ifdef TPOSE_DEBUG
-        A.dbg = persist_dbg_buffer(c->plan.parts);
+        A.dbg = persist_dbg_buffer(c->plan.parts, c->stream);
+        { const char* f = getenv("TPOSE_DBG_FIRST"); A.dbg_first = f ? atoi(f) : 0; }
 #endif
         tp_launch_persist(A, c->plan.lds_bytes, c->stream);
         tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->stream);
@@ -372,6 +375,7 @@ int tp_create(int device, int width, int height, tp_context** out) {
     tp_context* c = new tp_context();
     c->device = device; c->W = width; c->H = height;
     c->prefix_pitch = tp_prefix_pitch(width);
+    c->px_pitch = width <= TP_PX_MAXW ? tp_px_pitch(width) : 0;
     c->ratio = (float)width / (float)height;
     {
         hipDeviceProp_t prop;
@@ -396,9 +400,9 @@ int tp_destroy(tp_context* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     drop_graphs(c);
     free_triangulation(c);
-    hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->prefix[0]); hipFree(c->prefix[1]);
+    hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->prefix[0]); hipFree(c->prefix[1]); hipFree(c->px[0]); hipFree(c->px[1]);
     hipFree(c->render_pic); hipFree(c->render_pts);
-    hipFree(c->d_wg); hipFree(c->d_pool); hipFree(c->posbox); hipFree(c->linebox); hipFree(c->points_out); hipFree(c->d_status);
+    hipFree(c->d_wg); hipFree(c->d_pool); hipFree(c->posbox); hipFree(c->points_out); hipFree(c->d_status);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->up_pinned) hipHostFree(c->up_pinned);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -453,6 +457,10 @@ static int set_image_common(tp_context* c, int slot, const void* src, size_t str
     // row prefix table of this image (16 bytes per pixel): what the line sums read, iteration after iteration
     if (!c->prefix[slot]) HIP_TRY(c, dev_alloc(&c->prefix[slot], (size_t)c->H * c->prefix_pitch * 2));
     tp_launch_prefix_table(c->img[slot], c->W * 4, c->W, c->H, c->prefix_pitch, c->prefix[slot], c->stream);
+    if (c->px_pitch) {  // pixel records of the same sums: what the persistent grad-iter kernel reads
+        if (!c->px[slot]) HIP_TRY(c, dev_alloc(&c->px[slot], (size_t)c->H * c->px_pitch));
+        tp_launch_px_table(c->img[slot], c->W * 4, c->W, c->H, c->px_pitch, c->px[slot], c->stream);
+    }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_img[slot] = true;
@@ -994,6 +1002,17 @@ int tp_debug_dump(tp_context* c, unsigned long long* out, int n) {
 }
 #endif
 
+#ifdef TPOSE_DEBUG
+// debug flavour only (tools/persist_timeline.py): [workgroup][grad-iter < 64][8] phase timestamps of the last persistent launch
+int tp_debug_dump_persist(tp_context* c, unsigned long long* out, int n) {
+    api_guard api_lock;
+    if (!g_persist_dbg) return TP_ERR_STATE;
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(out, g_persist_dbg, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost);
+    return TP_OK;
+}
+#endif
+
 int tp_get_info(tp_context* c, int what, int64_t* value) {
     api_guard api_lock;
     if (!c || !value) return TP_ERR_INVALID;
@@ -1002,7 +1021,7 @@ int tp_get_info(tp_context* c, int what, int64_t* value) {
         case 1: *value = c->lanes_per_line; return TP_OK;
         case 2: *value = (c->plan_generation == c->generation && c->plan.ok) ? c->plan.parts : 0; return TP_OK;
         case 3: *value = (c->plan_generation == c->generation && c->plan.ok) ? c->plan.lds_bytes : 0; return TP_OK;
-        case 4: *value = (c->plan_generation == c->generation && c->plan.ok) ? c->plan.imp_total : 0; return TP_OK;
+        case 4: *value = (c->plan_generation == c->generation && c->plan.ok) ? c->plan.lines_total : 0; return TP_OK;
         case 5: *value = c->persist_launches; return TP_OK;
         case 6: *value = c->persist_iters; return TP_OK;
         case 7: *value = c->census; return TP_OK;

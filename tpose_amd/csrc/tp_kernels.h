@@ -49,6 +49,7 @@ void tp_launch_vertex_refs(const tp_launch& L, int* vref, int* vvar, hipStream_t
 void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s);
 // per-image row prefix table (tp_raster.h, "Per-image row prefix table")
 void tp_launch_prefix_table(const uint8_t* img, int pitch, int W, int H, int prefix_pitch, uint4* P, hipStream_t s);
+void tp_launch_px_table(const uint8_t* img, int pitch, int W, int H, int px_pitch, uint4* P, hipStream_t s);  // rasters up to TP_PX_MAXW columns
 void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s);
 void tp_launch_selftest_line(const int4* ends, const int* H, int n, int rows, int32_t* out, hipStream_t s);
 void tp_launch_render(const tp_launch& L, const float2* pts, int source, void* out, int out_pitch_px, hipStream_t s);
@@ -60,8 +61,8 @@ struct pk_args {
     const int32_t* pool;        // the patches' tables
     int parts;
     tp_view vw;
-    const uint4* prefix;        // row prefix table of the swept image
-    int prefix_pitch;
+    const uint4* px;            // row prefix table of the swept image in pixel records (tp_raster.h): [H][px_pitch] 16 bytes
+    int px_pitch;
     const float2* points;       // positions at the start of the launch
     float2* points_out;         // positions after n_iters grad-iters (vertices of at least one triangle only)
     const int4* ca;             // warp flavour: the stored colours, replicated x13 by upload
@@ -69,12 +70,12 @@ struct pk_args {
     int flavour;
     float rate;
     unsigned long long* posbox;   // [2][NP][2] position mailbox
-    unsigned long long* linebox;  // [2][9 NE][5] line-sum mailbox
     unsigned epoch;               // number of the launch's first grad-iter (tags; 1 .. 32767 between mailbox resets)
     int n_iters;                  // < 0: census of resident workgroups instead
     unsigned* status;             // [0] raised by a lane that gave up waiting, [1] census counter
 #ifdef TPOSE_DEBUG
-    unsigned long long* dbg;      // [parts][PK_DBG_ITERS][8] phase timestamps
+    unsigned long long* dbg;      // [parts][PK_DBG_ITERS][16] phase timestamps of the grad-iters dbg_first ...
+    int dbg_first;
 #endif
 };
 int tp_persist_set_lds(int bytes);  // hipFuncSetAttribute(max dynamic LDS); returns the hipError_t

@@ -84,6 +84,49 @@ void tp_launch_prefix_table(const uint8_t* img, int pitch, int W, int H, int pre
     hipLaunchKernelGGL(k_prefix, dim3((unsigned)H), dim3(256), 0, s, img, pitch, W, prefix_pitch, P);
 }
 
+// the same sums in pixel records (tp_raster.h, "Pixel records": 16 bytes per pixel column; rasters up to 4096 columns) --
+// what the persistent kernel reads.  One 256-thread workgroup per row; thread t owns the columns [t C, (t + 1) C)
+__global__ __launch_bounds__(256) void k_prefix_px(const uint8_t* img, int pitch, int W, int px_pitch, uint4* P) {
+    __shared__ uint32_t wave_total[4][5];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NC = W + 1;   // columns c = 0..W
+    const int C = (NC + 255) / 256;
+    const int c0 = min(NC, tid * C), c1 = min(NC, c0 + C);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(img + (size_t)row * pitch);
+    uint32_t own[5] = {0, 0, 0, 0, 0};
+    for (int c = c0; c < min(W, c1); c++) px_moments5(src[c], own);
+    uint32_t inc[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        uint32_t v = own[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)v, o);
+            if (lane >= o) v += up;
+        }
+        inc[k] = v;
+        if (lane == 63) wave_total[wave][k] = v;
+    }
+    __syncthreads();
+    uint32_t run[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        uint32_t before = 0;
+        for (int w = 0; w < wave; w++) before += wave_total[w][k];
+        run[k] = before + inc[k] - own[k];
+    }
+    uint4* dst = P + (size_t)row * px_pitch;
+    for (int c = c0; c < c1; c++) {
+        uint64_t rec[2];
+        tp_px_pack(run, rec);
+        dst[c] = make_uint4((uint32_t)rec[0], (uint32_t)(rec[0] >> 32), (uint32_t)rec[1], (uint32_t)(rec[1] >> 32));
+        if (c < W) px_moments5(src[c], run);
+    }
+}
+void tp_launch_px_table(const uint8_t* img, int pitch, int W, int H, int px_pitch, uint4* P, hipStream_t s) {
+    hipLaunchKernelGGL(k_prefix_px, dim3((unsigned)H), dim3(256), 0, s, img, pitch, W, px_pitch, P);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Line sums.  W(line) = sum over the line's rows of the row prefix at the crossing column: six values
 // {sum x, n_odd, sum r, sum g, sum b, q}.
@@ -357,8 +400,8 @@ __global__ __launch_bounds__(256) void k_shift(tp_launch L, float rate) {
     if (p.x <= -R) { p.x = -R; tgx = 0.0f; } else if (p.x >= R) { p.x = R; tgx = 0.0f; }
     if (p.y <= -1.0f) { p.y = -1.0f; tgy = 0.0f; } else if (p.y >= 1.0f) { p.y = 1.0f; tgy = 0.0f; }
     // p -= rate * tgr / 256 / 256  (shift.cs:45), one rounding per operation
-    p.x = tp_fsub(p.x, tp_fdiv(tp_fdiv(tp_fmul(rate, tgx), 256.0f), 256.0f));
-    p.y = tp_fsub(p.y, tp_fdiv(tp_fdiv(tp_fmul(rate, tgy), 256.0f), 256.0f));
+    p.x = tp_fsub(p.x, tp_shift_scale(tp_fmul(rate, tgx)));
+    p.y = tp_fsub(p.y, tp_shift_scale(tp_fmul(rate, tgy)));
     L.points[gid] = p;
     publish_position(L, gid, p, 0, 1);
 }
@@ -594,8 +637,8 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
                 if (x <= -R) { x = -R; tgx = 0.0f; } else if (x >= R) { x = R; tgx = 0.0f; }
                 if (y <= -1.0f) { y = -1.0f; tgy = 0.0f; } else if (y >= 1.0f) { y = 1.0f; tgy = 0.0f; }
                 if (deg > 0) {  // (unused vertices are only clamped: shift.cs:25-43 runs for every i in [4, NPoints))
-                    x = tp_fsub(x, tp_fdiv(tp_fdiv(tp_fmul(rate, tgx), 256.0f), 256.0f));
-                    y = tp_fsub(y, tp_fdiv(tp_fdiv(tp_fmul(rate, tgy), 256.0f), 256.0f));
+                    x = tp_fsub(x, tp_shift_scale(tp_fmul(rate, tgx)));
+                    y = tp_fsub(y, tp_shift_scale(tp_fmul(rate, tgy)));
                 }
                 L.points[v] = make_float2(x, y);
                 newp = make_float2(x, y); moved = 1;

@@ -2,11 +2,10 @@
 //
 // K grad-iters of the reference's frame -- doenergy (mode-1 draw of 13 NT triangles), gradient.cs, shift.cs
 // (software/triangulate/main.cpp:132-155, shader/gradient.cs:19-36, shader/shift.cs:16-47; the warp program likewise) --
-// run inside one launch.  A workgroup owns a patch of the mesh (tp_plan.h) and per grad-iter
-//   P0  reads the positions of the foreign vertices it uses from the position mailbox (tagged granules),
-//   P1  snaps positions (vertex stage, triangle.vs:59-84) and sets its own edges' nine lines up (tp_setup_line),
-//   P3  walks the lines over the per-image row prefix table: line sums into LDS,
-//   P4  writes the line sums other patches use to the line mailbox,  P5 reads the ones it uses,
+// run inside one launch.  A workgroup owns a patch of the mesh (tp_plan.h: some vertices) and per grad-iter
+//   P0  reads the positions of the neighbouring vertices it uses from the position mailbox (tagged granules),
+//   P1  snaps positions (vertex stage, triangle.vs:59-84) and sets up every line its corners use (tp_setup_line),
+//   P3  walks the lines over the per-image row prefix table (pixel records): line sums into LDS,
 //   P6  forms the four displaced variants of every corner (own vertex, incident triangle): moments = signed sum of
 //       three line sums, energy (triangle.fs:37-43), central differences (gradient.cs) into the vertex's gradient,
 //   P7  takes the shift.cs step of its own vertices and posts the new positions.
@@ -28,35 +27,33 @@ struct pk_walker { int64_t x, s; int32_t ra, rb; };  // tp_line
 
 // the workgroup's LDS, carved in the order of pk_lds_bytes (tp_plan.h)
 struct pk_view {
-    unsigned long long* sums;  // [n_sums][6] line sums {sum x, n_odd, sum r, sum g, sum b, q}
-    pk_walker* wk;             // [9 n_own_e]
+    unsigned long long* sums;  // [n_lines][6] line sums {sum x, n_odd, sum r, sum g, sum b, q}
+    pk_walker* wk;             // [n_lines]
     pk_f2* pos;                // [n_slots]
-    pk_i2* snap;               // own slot k: [5 k + move]; foreign slot s: [5 n_own_v + s - n_own_v] (unmoved)
-    pk_i2* band;               // [n_own_e] first and last row of an edge's nine lines
+    pk_i2* snap;               // own slot k: [5 k + move]; neighbour slot s: [5 n_own_v + s - n_own_v] (unmoved)
+    pk_i2* band;               // [n_edges] first and last row of an edge's lines
     pk_i2* grad;               // [n_own_v]
     int32_t* vid;              // static tables, copied from the plan's pool at the start of the launch
-    pk_i2* edges;
-    pk_i2* items;
+    int32_t* edges;
+    int32_t* lines;
+    int32_t* li;
     pk_i4* corners;
-    int32_t* imp;
-    int32_t* exp_;
     int32_t* flags;
 };
 
 TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     char* p = base;
-    V.sums = (unsigned long long*)p; p += pk_align16(w.n_sums * 48);
-    V.wk = (pk_walker*)p; p += pk_align16(9 * w.n_own_e * 24);
+    V.sums = (unsigned long long*)p; p += pk_align16(w.n_lines * 48);
+    V.wk = (pk_walker*)p; p += pk_align16(w.n_lines * 24);
     V.pos = (pk_f2*)p; p += pk_align16(w.n_slots * 8);
     V.snap = (pk_i2*)p; p += pk_align16((4 * w.n_own_v + w.n_slots) * 8);
-    V.band = (pk_i2*)p; p += pk_align16(w.n_own_e * 8);
+    V.band = (pk_i2*)p; p += pk_align16(w.n_edges * 8);
     V.grad = (pk_i2*)p; p += pk_align16(w.n_own_v * 8);
     V.vid = (int32_t*)p; p += pk_align16(w.n_slots * 4);
-    V.edges = (pk_i2*)p; p += pk_align16(w.n_own_e * 8);
-    V.items = (pk_i2*)p; p += pk_align16(w.n_items * 8);
+    V.edges = (int32_t*)p; p += pk_align16(w.n_edges * 4);
+    V.lines = (int32_t*)p; p += pk_align16(w.n_lines * 4);
+    V.li = (int32_t*)p; p += pk_align16(w.n_li * 12);
     V.corners = (pk_i4*)p; p += pk_align16(w.n_corners * 16);
-    V.imp = (int32_t*)p; p += pk_align16(w.n_imp * 4);
-    V.exp_ = (int32_t*)p; p += pk_align16(w.n_exp * 4);
     V.flags = (int32_t*)p;
 }
 
@@ -74,11 +71,11 @@ TP_HD void pk_snap_lane(const pk_wg& w, const pk_view& V, const tp_view& vw, int
     V.snap[j].x = X; V.snap[j].y = Y;
 }
 
-// P1b, lane l < 9 n_own_e: line l = (own edge l / 9, version l % 9) -- the walker of the whole line.  The caller
-// folds ra / rb into the edge's band (LDS atomics on the device).
-TP_HD void pk_setup_lane(const pk_view& V, const tp_view& vw, int l, pk_walker& out) {
-    const int le = l / PK_NLINES, q = l - le * PK_NLINES;
-    const int su = V.edges[le].x & 0xffff, sv = (V.edges[le].x >> 16) & 0xffff;
+// P1b, lane l < n_lines: line l = (local edge, version) -- the walker of the whole line.  Returns the local edge: the
+// caller folds ra / rb into that edge's band (LDS atomics on the device).
+TP_HD int pk_setup_lane(const pk_view& V, const tp_view& vw, int l, pk_walker& out) {
+    const int le = V.lines[l] & 0xffff, q = V.lines[l] >> 16;
+    const int su = V.edges[le] & 0xffff, sv = (V.edges[le] >> 16) & 0xffff;
     const pk_f2 pu = V.pos[su], pv = V.pos[sv];
     // line q: endpoint u displaced by move mu, endpoint v by move mv (tp_kernels.hip: k_lines)
     const int mu = (q >= 1 && q <= 4) ? q : 0, mv = q >= 5 ? q - 4 : 0;
@@ -88,6 +85,7 @@ TP_HD void pk_setup_lane(const pk_view& V, const tp_view& vw, int l, pk_walker& 
     tp_line ln;
     tp_setup_line(Xa, Ya, Xb, Yb, vw.H, ln);
     out.x = ln.x; out.s = ln.s; out.ra = ln.ra; out.rb = ln.rb;
+    return le;
 }
 
 // x / d for the item's chunk count d (magic = floor(2^32 / d) + 1, exact for x d < 2^32; d == 1: magic 0)
@@ -104,82 +102,152 @@ struct pk_acc {
     uint64_t r, g, b, q;
 };
 
-// P3, lane-item j < 9 n_items: item j / 9 = (own edge, chunk c of TL), version j % 9.  The lane takes the rows
-// first, first + TL, ... of its line, where first is the first row >= ra on the residue (rmin + c) mod TL of the
-// edge's band: the nine lines of an edge sit in adjacent lanes ON THE SAME ROWS, and their crossing columns lie within
-// a few pixels of each other, so their table records share a cache line or two.  `table`: the image's row prefix
-// table (tp_raster.h), `pitch` records per row.  Returns the line-sum slot, the partial sums in `a`.
-template <int BATCH>
-TP_HD int pk_walk_lane(const pk_view& V, const char* table, int pitch, int W, int j, pk_acc& a) {
-    const int item = j / PK_NLINES, q = j - item * PK_NLINES;
-    const pk_i2 it = V.items[item];
-    const int le = it.x & 0xff, c = (it.x >> 8) & 0xfff, TL = (it.x >> 20) & 0xfff;
-    const uint32_t magic = (uint32_t)it.y;
-    const int l = le * PK_NLINES + q;
-    const pk_walker ln = V.wk[l];
-    a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
-    if (ln.ra > ln.rb) return l;
-    const int base = V.band[le].x + c;                                            // ra >= rmin: ra - base > -TL
+struct pk_rec { uint64_t lo, hi; };   // one pixel record (tp_raster.h, "Pixel records")
+
+// the sum of up to TP_PX_MAXSUM records into the partial sums of a lane
+TP_HD void pk_add_unpacked(uint64_t lo, uint64_t hi, pk_acc& a) {
+    uint32_t no, r, g, b; uint64_t q;
+    tp_px_unpack(lo, hi, no, r, g, b, q);
+    a.nodd += no; a.r += r; a.g += g; a.b += b; a.q += q;
+}
+
+// The rows of one lane: first, first + TL, ... (n of them) of line `ln`, where first is the first row >= ra on the residue
+// (rmin + c) mod TL of the edge's band -- the lines of an edge sit in adjacent lanes ON THE SAME ROWS, and their crossing
+// columns lie within a few pixels of each other, so their table records share a cache line.
+struct pk_rows { int n; int64_t x, xs; uint32_t row, rs; };
+TP_HD pk_rows pk_lane_rows(const pk_walker& ln, int rmin, int c, int TL, uint32_t magic, int pitch) {
+    pk_rows r; r.n = 0; r.x = 0; r.xs = 0; r.row = 0; r.rs = 0;
+    if (ln.ra > ln.rb) return r;
+    const int base = rmin + c;                                                    // ra >= rmin: ra - base > -TL
     const int first = base + (int)pk_div((uint32_t)(ln.ra - base + TL - 1), magic) * TL;
-    int n = ln.rb >= first ? (int)pk_div((uint32_t)(ln.rb - first), magic) + 1 : 0;
-    int64_t x = ln.x + (int64_t)(first - ln.ra) * ln.s;
-    const int64_t xs = (int64_t)((uint64_t)ln.s * (uint64_t)TL);                  // (unsigned: a steep two-row line may wrap, unused then)
-    // (byte offsets into the table fit 32 bits: 16384 rows x 4100 records x 32 bytes < 2^32)
-    uint32_t row = (uint32_t)(n > 0 ? first : 0) * (uint32_t)pitch * 32u;
-    const uint32_t rs = (uint32_t)TL * (uint32_t)pitch * 32u;
-    for (; n > 0; n -= BATCH) {
-        pk_u4 d0[BATCH], d1[BATCH];
-        int col[BATCH];
+    if (ln.rb < first) return r;
+    r.n = (int)pk_div((uint32_t)(ln.rb - first), magic) + 1;
+    r.x = ln.x + (int64_t)(first - ln.ra) * ln.s;
+    r.xs = (int64_t)((uint64_t)ln.s * (uint64_t)TL);                              // (unsigned: a steep two-row line may wrap, unused then)
+    // (byte offsets into the table fit 32 bits: 4096 rows x 4104 records x 16 bytes < 2^29)
+    r.row = (uint32_t)first * (uint32_t)pitch * 16u;
+    r.rs = (uint32_t)TL * (uint32_t)pitch * 16u;
+    return r;
+}
+// crossing column of the current row, clamped to [0, W]; then one row on
+TP_HD int pk_next_col(pk_rows& r, int W) {
+    const int xc = (int32_t)((uint64_t)r.x >> 32) >> (TP_LINE_FRAC - 32);   // x >> 40: the high word, shifted arithmetically
+    r.x = (int64_t)((uint64_t)r.x + (uint64_t)r.xs);
+    return tp_clamp0(xc, W);
+}
+
+// rows [0, n) of a lane without a register cache, B records requested together
+template <int B>
+TP_HD void pk_walk_rows(pk_rows& r, const char* table, int W, pk_acc& a) {
+    static_assert(B <= TP_PX_MAXSUM, "records added before unpacking");
+    for (; r.n > 0; r.n -= B) {
+        pk_rec d[B];
+        uint32_t sx = 0;
 #pragma unroll
-        for (int u = 0; u < BATCH; u++) {
-            d0[u].x = d0[u].y = d0[u].z = d0[u].w = 0; d1[u] = d0[u]; col[u] = 0;
-            if (u < n) {
-                const int xc = (int)(x >> TP_LINE_FRAC);
-                col[u] = xc < 0 ? 0 : (xc > W ? W : xc);
-                const pk_u4* rec = reinterpret_cast<const pk_u4*>(table + (row + (((uint32_t)col[u] & ~3u) << 3)));
-                d0[u] = rec[0]; d1[u] = rec[1];
-                x = (int64_t)((uint64_t)x + (uint64_t)xs); row += rs;
+        for (int u = 0; u < B; u++) {
+            d[u].lo = 0; d[u].hi = 0;
+            if (u < r.n) {
+                const uint32_t col = (uint32_t)pk_next_col(r, W);
+                sx += col;
+                d[u] = *reinterpret_cast<const pk_rec*>(table + (r.row + (col << 4)));
+                r.row += r.rs;
             }
         }
-        uint32_t sx = 0, so = 0, sr = 0, sg = 0, sb = 0;
+        uint64_t lo = 0, hi = 0;
 #pragma unroll
-        for (int u = 0; u < BATCH; u++) {
-            const uint32_t rec[TP_PFX_WORDS] = {d0[u].x, d0[u].y, d0[u].z, d0[u].w, d1[u].x, d1[u].y, d1[u].z, d1[u].w};
-            uint32_t no, ru, gu, bu, qu;
-            tp_prefix_eval(rec, col[u], no, ru, gu, bu, qu);   // (an all-zero record at column 0 adds nothing)
-            sx += (uint32_t)col[u]; so += no; sr += ru; sg += gu; sb += bu;   // BATCH <= 8 records: 8 x 2^22 fits
-            a.q += qu;
-        }
-        a.xs += sx; a.nodd += so; a.r += sr; a.g += sg; a.b += sb;
+        for (int u = 0; u < B; u++) { lo += d[u].lo; hi += d[u].hi; }
+        a.xs += sx;
+        pk_add_unpacked(lo, hi, a);
     }
+}
+
+// P3, lane-item j >= PK_CACHED (a patch with more lane-items than its threads keep records for): (line l, chunk c of TL), nothing kept between
+// grad-iters.  Returns the line-sum slot, the partial sums in `a`.
+TP_HD int pk_walk_lane(const pk_view& V, const char* table, int pitch, int W, int j, pk_acc& a) {
+    const int l = V.li[3 * j] & 0xffff, c = V.li[3 * j] >> 16, TL = V.li[3 * j + 1];
+    const uint32_t magic = (uint32_t)V.li[3 * j + 2];
+    a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
+    pk_rows r = pk_lane_rows(V.wk[l], V.band[V.lines[l] & 0xffff].x, c, TL, magic, pitch);
+    pk_walk_rows<4>(r, table, W, a);
     return l;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Line mailbox.  A line sum travels as five 8-byte granules {tag : 16, payload : 48}, each written by ONE store and
-// valid on its own (the tag names the grad-iter): xs, n_odd <= 16384 * 16384 = 2^28 (29 bits), r, g, b < 2^36,
-// q < 2^46.
-//   g0 = q                       g1 = r | xs[0:12] << 36        g2 = g | xs[12:24] << 36
-//   g3 = b | nodd[0:12] << 36    g4 = xs[24:29] | nodd[12:29] << 5
-// ---------------------------------------------------------------------------------------------------------------
-TP_HD void pk_pack_line(const unsigned long long s[6], uint32_t tag, unsigned long long g[PK_GRANULES]) {
-    const unsigned long long T = (unsigned long long)(tag & 0xffffu) << 48;
-    const unsigned long long xs = s[0], no = s[1];
-    g[0] = T | s[5];
-    g[1] = T | s[2] | ((xs & 0xfffull) << 36);
-    g[2] = T | s[3] | (((xs >> 12) & 0xfffull) << 36);
-    g[3] = T | s[4] | ((no & 0xfffull) << 36);
-    g[4] = T | ((xs >> 24) & 0x1full) | ((no >> 12) << 5);
+// P3, lane-item j < PK_CACHED: one of thread (j mod PK_THREADS)'s own lane-items for the whole launch.  A lane walks the
+// same rows of the same line every grad-iter and vertices move by a fraction of a pixel, so the record it needs for a row
+// is usually the one it used a grad-iter ago: the records of its first R rows stay in registers (`rec`, with the crossing
+// column they belong to in `col`; `row0` is the table offset of the first row -- when the line's first row changes,
+// everything is fetched again) and a row is only loaded again when its crossing column has changed.  What is summed is
+// always the record of the current crossing column -- the cache changes the traffic, never the values.
+// Rows beyond the line's end count as column 0, whose record holds the moments of no pixels and adds nothing: no
+// lane-dependent branches in either loop.
+template <int R>
+struct pk_lane_cache {
+    int l, c, TL, le;       // the lane-item: line-sum slot, chunk, chunks, local edge (never change during a launch)
+    uint32_t magic;
+    uint32_t row0;          // table offset of the first row the cached records belong to; ~0: nothing cached
+    int32_t col[R];         // crossing column of rec[u]; -1: nothing cached
+    pk_rec rec[R];
+};
+template <int R>
+TP_HD void pk_cache_init(pk_lane_cache<R>& C, const pk_view& V, int j, bool live) {
+    C.l = live ? V.li[3 * j] & 0xffff : 0; C.c = live ? V.li[3 * j] >> 16 : 0; C.TL = live ? V.li[3 * j + 1] : 1;
+    C.magic = live ? (uint32_t)V.li[3 * j + 2] : 0u;
+    C.le = live ? V.lines[C.l] & 0xffff : 0;
+    C.row0 = 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < R; u++) { C.col[u] = -1; C.rec[u].lo = 0; C.rec[u].hi = 0; }
 }
-TP_HD bool pk_granule_ok(unsigned long long g, uint32_t tag) { return (uint32_t)(g >> 48) == (tag & 0xffffu); }
-TP_HD void pk_unpack_line(const unsigned long long g[PK_GRANULES], unsigned long long s[6]) {
-    const unsigned long long M36 = (1ull << 36) - 1ull;
-    s[5] = g[0] & ((1ull << 48) - 1ull);
-    s[2] = g[1] & M36; s[3] = g[2] & M36; s[4] = g[3] & M36;
-    s[0] = ((g[1] >> 36) & 0xfffull) | (((g[2] >> 36) & 0xfffull) << 12) | ((g[4] & 0x1full) << 24);
-    s[1] = ((g[3] >> 36) & 0xfffull) | (((g[4] >> 5) & 0x1ffffull) << 12);
+// RR <= R: how many of the R cached rows the lanes of this workgroup use (the plan's rows per lane, rounded up to one of the
+// instantiated values: the loops are straight-line code, rows a lane does not have cost what the others cost)
+template <int RR, int R>
+TP_HD void pk_walk_cached(pk_lane_cache<R>& C, const pk_view& V, const char* table, int pitch, int W, pk_acc& a) {
+    static_assert(RR <= R && RR <= TP_PX_MAXSUM, "records added before unpacking");
+    const int rows = RR;
+    a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
+    pk_rows r = pk_lane_rows(V.wk[C.l], V.band[C.le].x, C.c, C.TL, C.magic, pitch);
+    const uint32_t live = r.n >= 32 ? 0xffffffffu : ((1u << r.n) - 1u);   // bit u: row u exists
+    // pass 1, straight-line: this grad-iter's crossing columns; has any of them left its cached record?
+    uint32_t sx = 0, stale = r.row ^ C.row0;   // (another first row: every record is another row's)
+    {
+        pk_rows t = r;
+#pragma unroll
+        for (int u = 0; u < RR; u++) {
+            const int32_t col = pk_next_col(t, W) & (int32_t)(0u - ((live >> u) & 1u));
+            sx += (uint32_t)col;
+            stale |= (uint32_t)(col ^ C.col[u]);
+        }
+    }
+    // pass 1b, only when some lane of the wave needs a record: walk again and fetch what changed
+    if (stale != 0u) {
+        const bool all = r.row != C.row0;
+        C.row0 = r.row;
+        pk_rows t = r;
+#pragma unroll
+        for (int u = 0; u < RR; u++) {
+            const uint32_t on = 0u - ((live >> u) & 1u);
+            const int32_t col = pk_next_col(t, W) & (int32_t)on;
+            if (all || col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
+#if !defined(PK_EXP_NOLOAD)   // timing experiments only (tools/build_variants.py); never defined in the product
+                C.rec[u] = *reinterpret_cast<const pk_rec*>(table + (((r.row + (uint32_t)u * r.rs) & on) + ((uint32_t)col << 4)));
+#endif
+#if !defined(PK_EXP_NOCACHE)
+                C.col[u] = col;
+#endif
+            }
+        }
+    }
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int u = 0; u < RR; u++) { lo += C.rec[u].lo; hi += C.rec[u].hi; }
+    a.xs = sx;
+    pk_add_unpacked(lo, hi, a);
+    if (r.n > rows) {   // the line has grown beyond the rows this workgroup's lanes keep
+        r.n -= rows; r.x = (int64_t)((uint64_t)r.x + (uint64_t)rows * (uint64_t)r.xs); r.row += (uint32_t)rows * r.rs;
+        pk_walk_rows<4>(r, table, W, a);
+    }
 }
-// tag of grad-iter `epoch` (1 .. 32767 between two resets of the mailboxes): never 0, differs between e and e - 2
+
+// tag of grad-iter `epoch` (1 .. 32767 between two resets of the mailbox): never 0, differs between e and e - 2
 TP_HD uint32_t pk_tag(uint32_t epoch) { return 0x8000u | (epoch & 0x7fffu); }
 
 // P6, lane (corner k, move m = 1..4): the energy of variant (t, 4 s + m) of the corner's triangle -- the corner's vertex
@@ -215,8 +283,8 @@ TP_HD pk_f2 pk_vertex_lane(pk_f2 p, int32_t gx, int32_t gy, int vid, float ratio
     float x = p.x, y = p.y;
     if (x <= -ratio) { x = -ratio; tgx = 0.0f; } else if (x >= ratio) { x = ratio; tgx = 0.0f; }
     if (y <= -1.0f) { y = -1.0f; tgy = 0.0f; } else if (y >= 1.0f) { y = 1.0f; tgy = 0.0f; }
-    x = tp_fsub(x, tp_fdiv(tp_fdiv(tp_fmul(rate, tgx), 256.0f), 256.0f));
-    y = tp_fsub(y, tp_fdiv(tp_fdiv(tp_fmul(rate, tgy), 256.0f), 256.0f));
+    x = tp_fsub(x, tp_shift_scale(tp_fmul(rate, tgx)));
+    y = tp_fsub(y, tp_shift_scale(tp_fmul(rate, tgy)));
     pk_f2 r; r.x = x; r.y = y;
     return r;
 }

@@ -3,15 +3,15 @@
 //
 // One workgroup per patch of the mesh (tp_plan.h), all resident at once (at most one per CU).  What a lane does in
 // each phase is in tp_persist.h; this file is the choreography: the phases of a grad-iter, the workgroup barriers
-// between them and the two hand-overs between workgroups,
-//   positions  owner of a vertex  ->  the patches that use it      two 8-byte granules {tag : 32, float : 32}
-//   line sums  owner of an edge   ->  the patches whose corners use them   five granules {tag : 16, payload : 48}
+// between them and the ONE hand-over between workgroups,
+//   positions  owner of a vertex  ->  the owners of its neighbours     two 8-byte granules {tag : 32, float : 32}
 // Every granule is written by ONE agent-scope (sc1, write-through) store and read by agent-scope loads that bypass
 // the reader's L1; the tag is the grad-iter's number, so a granule is valid on its own: no flags, no fences, no order
-// between granules (MI355X guide, "R2: the data IS the flag").  Mailboxes are double-buffered by the parity of the
-// grad-iter: a producer cannot be two grad-iters ahead of any consumer of the same slot, because its own next position
-// needs a line sum that needs the consumer's next position (tp_plan.h: every consumer of a vertex's position or of an
-// edge's line sums owns a neighbour of that vertex / a vertex of a triangle on that edge).
+// between granules (MI355X guide, "R2: the data IS the flag").  The mailbox is double-buffered by the parity of the
+// grad-iter: a vertex's owner cannot post the position of grad-iter e + 2 before every reader has taken that of e,
+// because its own grad-iter e + 1 needs the positions e + 1 of all the vertex's neighbours, and their owners -- the
+// readers -- post those only after a grad-iter e that read the vertex (every vertex of a triangle is posted every
+// grad-iter, the four fixed corners included, so this holds for all of them).
 // Nothing here is placement-dependent: workgroup b -> patch is a permutation chosen for L2 locality only.
 //
 // Every wait is bounded: a lane that polls longer than PK_TIMEOUT_TICKS raises the launch's status word and the whole
@@ -25,7 +25,7 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 #define PK_TIMEOUT_TICKS 30000000ull  // 0.3 s of the 100 MHz wall clock
 
 #ifdef TPOSE_DEBUG
-#define PK_STAMP(k) do { if (threadIdx.x == 0 && A.dbg && it < PK_DBG_ITERS) A.dbg[((size_t)blockIdx.x * PK_DBG_ITERS + it) * 8 + (k)] = wall_clock64(); } while (0)
+#define PK_STAMP(k) do { if (threadIdx.x == 0 && A.dbg && it >= A.dbg_first && it < A.dbg_first + PK_DBG_ITERS) A.dbg[((size_t)blockIdx.x * PK_DBG_ITERS + (it - A.dbg_first)) * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define PK_STAMP(k) do { } while (0)
 #endif
@@ -79,17 +79,16 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
     {
         const int32_t* pool = A.pool;
         for (int i = tid; i < w.n_slots; i += PK_THREADS) V.vid[i] = pool[w.off_vid + i];
-        for (int i = tid; i < 2 * w.n_own_e; i += PK_THREADS) ((int32_t*)V.edges)[i] = pool[w.off_edges + i];
-        for (int i = tid; i < 2 * w.n_items; i += PK_THREADS) ((int32_t*)V.items)[i] = pool[w.off_items + i];
+        for (int i = tid; i < w.n_edges; i += PK_THREADS) V.edges[i] = pool[w.off_edges + i];
+        for (int i = tid; i < w.n_lines; i += PK_THREADS) V.lines[i] = pool[w.off_lines + i];
+        for (int i = tid; i < 3 * w.n_li; i += PK_THREADS) V.li[i] = pool[w.off_li + i];
         for (int i = tid; i < 4 * w.n_corners; i += PK_THREADS) ((int32_t*)V.corners)[i] = pool[w.off_corners + i];
-        for (int i = tid; i < w.n_imp; i += PK_THREADS) V.imp[i] = pool[w.off_imp + i];
-        for (int i = tid; i < w.n_exp; i += PK_THREADS) V.exp_[i] = pool[w.off_exp + i];
         for (int i = tid; i < w.n_slots; i += PK_THREADS) {
             const float2 p = A.points[pool[w.off_vid + i]];
             V.pos[i].x = p.x; V.pos[i].y = p.y;
         }
-        for (int i = tid; i < w.n_own_e; i += PK_THREADS) { V.band[i].x = 0x3fffffff; V.band[i].y = -1; }
-        for (int i = tid; i < 6 * PK_NLINES * w.n_own_e; i += PK_THREADS) V.sums[i] = 0ull;
+        for (int i = tid; i < w.n_edges; i += PK_THREADS) { V.band[i].x = 0x3fffffff; V.band[i].y = -1; }
+        for (int i = tid; i < 6 * w.n_lines; i += PK_THREADS) V.sums[i] = 0ull;
         if (tid == 0) V.flags[0] = 0;
     }
     // the stored colour of this lane's variant (warp flavour: `colacc` as uploaded, triangle.fs:49-50) never changes
@@ -101,17 +100,19 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         const int4 c = A.ca[(size_t)(4 * s + m) * A.NT + t];
         col0.x = c.x; col0.y = c.y; col0.z = c.z; col0.w = c.w;
     }
-    const char* table = reinterpret_cast<const char*>(A.prefix);
+    const char* table = reinterpret_cast<const char*>(A.px);
+    // this thread's lane-item of the walk and the table records of its rows: in registers for the whole launch
+    pk_lane_cache<PK_ROWS_PER_LANE> cache[PK_NI];
     gu64* posbox = (gu64*)A.posbox;
-    gu64* linebox = (gu64*)A.linebox;
-    const size_t NLT = (size_t)A.NE * PK_NLINES;
     int failed = 0;
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PK_NI; i++) pk_cache_init(cache[i], V, tid + i * PK_THREADS, tid + i * PK_THREADS < w.n_li);
 
     for (int it = 0; it < A.n_iters; it++) {
         const uint32_t epoch = A.epoch + (uint32_t)it, tag = pk_tag(epoch), par = epoch & 1u;
         PK_STAMP(0);
-        // ---- P0: positions of the foreign vertices this patch uses (the first grad-iter of a launch read `points`)
+        // ---- P0: positions of the neighbouring vertices this patch uses (the first grad-iter of a launch read `points`)
         if (it > 0) {
             for (int s = w.n_own_v + tid; s < w.n_slots; s += PK_THREADS) {
                 gu64* g = posbox + ((size_t)par * A.NP + V.vid[s]) * 2;
@@ -128,11 +129,11 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         if (__syncthreads_or(failed)) return;
         PK_STAMP(1);
         // ---- P1: line set-up (low threads), snapped positions (high threads), gradient reset
-        for (int l = tid; l < PK_NLINES * w.n_own_e; l += PK_THREADS) {
+        for (int l = tid; l < w.n_lines; l += PK_THREADS) {
             pk_walker wk;
-            pk_setup_lane(V, A.vw, l, wk);
+            const int le = pk_setup_lane(V, A.vw, l, wk);
             V.wk[l] = wk;
-            if (wk.ra <= wk.rb) { atomicMin(&V.band[l / PK_NLINES].x, wk.ra); atomicMax(&V.band[l / PK_NLINES].y, wk.rb); }
+            if (wk.ra <= wk.rb) { atomicMin(&V.band[le].x, wk.ra); atomicMax(&V.band[le].y, wk.rb); }
         }
         {
             const int nsnap = 5 * w.n_own_v + (w.n_slots - w.n_own_v);
@@ -142,48 +143,32 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         __syncthreads();
         PK_STAMP(2);
         // ---- P3: walk -- one table record per (line, row); chunks of a line meet in LDS
-        for (int j = tid; j < PK_NLINES * w.n_items; j += PK_THREADS) {
-            pk_acc a;
-            const int l = pk_walk_lane<PK_ROWS_PER_LANE>(V, table, A.prefix_pitch, A.vw.W, j, a);
+        auto fold = [&](int l, const pk_acc& a) {
             if (a.xs | a.nodd | a.r | a.q) {
                 unsigned long long* s = V.sums + (size_t)l * 6;
                 atomicAdd(&s[0], (unsigned long long)a.xs); atomicAdd(&s[1], (unsigned long long)a.nodd);
                 atomicAdd(&s[2], (unsigned long long)a.r); atomicAdd(&s[3], (unsigned long long)a.g);
                 atomicAdd(&s[4], (unsigned long long)a.b); atomicAdd(&s[5], (unsigned long long)a.q);
             }
+        };
+#pragma unroll
+        for (int i = 0; i < PK_NI; i++)
+            if (tid + i * PK_THREADS < w.n_li) {
+                pk_acc a;
+                if (w.rows <= 8) pk_walk_cached<8>(cache[i], V, table, A.px_pitch, A.vw.W, a);
+                else if (w.rows <= 10) pk_walk_cached<10>(cache[i], V, table, A.px_pitch, A.vw.W, a);
+                else pk_walk_cached<PK_ROWS_PER_LANE>(cache[i], V, table, A.px_pitch, A.vw.W, a);
+                PK_STAMP(8 + 2 * i);
+                fold(cache[i].l, a);
+                PK_STAMP(9 + 2 * i);
+            }
+        for (int j = PK_CACHED + tid; j < w.n_li; j += PK_THREADS) {
+            pk_acc a;
+            const int l = pk_walk_lane(V, table, A.px_pitch, A.vw.W, j, a);
+            fold(l, a);
         }
         __syncthreads();
         PK_STAMP(3);
-        // ---- P4: post the line sums other patches use (low threads) ...
-        for (int k = tid; k < w.n_exp; k += PK_THREADS) {
-            const int ls = V.exp_[k], le = ls / PK_NLINES;
-            const size_t gl = (size_t)V.edges[le].y * PK_NLINES + (ls - le * PK_NLINES);
-            unsigned long long g[PK_GRANULES];
-            pk_pack_line(V.sums + (size_t)ls * 6, tag, g);
-            gu64* dst = linebox + ((size_t)par * NLT + gl) * PK_GRANULES;
-#pragma unroll
-            for (int i = 0; i < PK_GRANULES; i++) __hip_atomic_store(dst + i, g[i], PK_RLX_AGENT);
-        }
-        // ---- P5: ... and collect the ones this patch uses (high threads)
-        for (int k = PK_THREADS - 1 - tid; k < w.n_imp; k += PK_THREADS) {
-            gu64* src = linebox + ((size_t)par * NLT + V.imp[k]) * PK_GRANULES;
-            unsigned long long g[PK_GRANULES];
-            spin_state st = {0u, 0ull};
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int i = 0; i < PK_GRANULES; i++) { g[i] = __hip_atomic_load(src + i, PK_RLX_AGENT); ok &= pk_granule_ok(g[i], tag); }
-                if (ok) break;
-                if (spin_fail(st, status)) { failed = 1; break; }
-            }
-            unsigned long long s6[6];
-            pk_unpack_line(g, s6);
-            unsigned long long* s = V.sums + (size_t)(PK_NLINES * w.n_own_e + k) * 6;
-#pragma unroll
-            for (int i = 0; i < 6; i++) s[i] = s6[i];
-        }
-        if (__syncthreads_or(failed)) return;
-        PK_STAMP(4);
         // ---- P6: corners -- four displaced variants each, central differences into the vertex's gradient (int32 wrapping
         // sums, like the reference's atomics: gradient.cs:24-35)
         for (int j = tid; j < 4 * w.n_corners; j += PK_THREADS) {
@@ -201,13 +186,17 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
             if ((j & 3) == 2) atomicAdd(&V.grad[own].y, (int)d);
         }
         __syncthreads();
-        PK_STAMP(5);
+        PK_STAMP(4);
         // ---- P7: the step of the patch's own vertices; the new positions go to the mailbox of the next grad-iter (or, after
         // the last one, to `points_out`); the other threads clear the line sums and bands for the next grad-iter
         const bool last = it + 1 == A.n_iters;
         for (int k = tid; k < w.n_own_v; k += PK_THREADS) {
             const int v = V.vid[k];
+#if defined(PK_EXP_FREEZE)  // timing experiments only: the mesh stands still
+            const pk_f2 p = pk_vertex_lane(V.pos[k], V.grad[k].x, V.grad[k].y, v, A.vw.ratio, 0.0f);
+#else
             const pk_f2 p = pk_vertex_lane(V.pos[k], V.grad[k].x, V.grad[k].y, v, A.vw.ratio, A.rate);
+#endif
             V.pos[k] = p;
             if (last) A.points_out[v] = make_float2(p.x, p.y);
             else {
@@ -218,10 +207,10 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
             }
         }
         if (!last) {
-            for (int i = PK_THREADS - 1 - tid; i < 6 * PK_NLINES * w.n_own_e; i += PK_THREADS) V.sums[i] = 0ull;
-            for (int i = PK_THREADS - 1 - tid; i < w.n_own_e; i += PK_THREADS) { V.band[i].x = 0x3fffffff; V.band[i].y = -1; }
+            for (int i = PK_THREADS - 1 - tid; i < 6 * w.n_lines; i += PK_THREADS) V.sums[i] = 0ull;
+            for (int i = PK_THREADS - 1 - tid; i < w.n_edges; i += PK_THREADS) { V.band[i].x = 0x3fffffff; V.band[i].y = -1; }
         }
-        PK_STAMP(6);
+        PK_STAMP(5);
         // (no barrier here: P0 of the next grad-iter touches foreign position slots only, and its barrier orders the rest)
     }
 }

@@ -3,11 +3,13 @@
 //
 // What it replaces in the reference: nothing -- the reference issues two instanced draws and two dispatches per frame
 // (software/triangulate/main.cpp:132-155) and lets the GL driver schedule them.  Here K grad-iters run inside ONE
-// launch; a workgroup owns a compact patch of the mesh (some vertices, some undirected edges) for the whole launch and
-// only what crosses a patch border travels between workgroups:
-//   * vertex positions, from the vertex's owner to the owners of its edges and of its neighbours;
-//   * line sums (tp_raster.h, "Edge-centric form") of border edges, from the edge's owner to the owners of the vertices
-//     whose gradient they enter.
+// launch; a workgroup owns a compact patch of the mesh -- some VERTICES -- for the whole launch and computes everything
+// their gradients need itself: for every corner (own vertex, incident triangle) the four displaced lines of the two edges
+// at the vertex and the base line of the opposite edge (tp_raster.h, "Edge-centric form").  Only vertex positions travel
+// between workgroups, from a vertex's owner to the owners of its neighbours: 16 bytes per vertex and grad-iter.  Line sums
+// never leave a workgroup (a first version handed the sums of border edges over instead of recomputing them: each hop cost
+// 2.4 us or more against 0.7 us for positions -- profiles/r03_*); the price is that the base line of a border edge is
+// walked by up to three workgroups (+10 % lines at 3000 triangles) and its band of the table is read by each of them.
 // Ownership is decided ONCE per upload from the topology and the upload-time positions (recursive coordinate
 // bisection balanced by table look-ups), never by where a vertex has drifted to: there is nothing to re-bin while
 // the descent runs, and results cannot depend on the cut (integer sums commute; every float operation is per vertex).
@@ -24,30 +26,29 @@
 #include <vector>
 
 #define PK_NLINES 9
-#define PK_GRANULES 5      /* 8-byte granules of a line sum in the mailbox (tp_persist.h) */
-#define PK_THREADS 1024
-#define PK_ROWS_PER_LANE 8   /* table records a lane of the walk requests together */
+#define PK_THREADS 512
+#define PK_NI 2                /* lane-items of the walk a thread keeps table records for, in registers */
+#define PK_CACHED (PK_THREADS * PK_NI)
+#ifndef PK_ROWS_PER_LANE
+#define PK_ROWS_PER_LANE 12  /* table records a lane of the walk keeps in registers: the most rows per lane */
+#endif
 #define PK_MAX_SLOTS 1023    /* position slots of a workgroup (10-bit fields of the corner records) */
-#define PK_MAX_SUMS 65535    /* line-sum slots of a workgroup (16-bit fields) */
-#define PK_MAX_OWN_EDGES 255 /* 8-bit field of the item records */
 #define PK_MAX_TL 4095       /* chunks per line (12-bit field) */
 
 // per-workgroup header; every `off_*` indexes pk_plan::pool (int32 units)
 struct pk_wg {
-    int32_t n_own_v, n_slots;  // position slots: the patch's own vertices first, then the foreign ones it reads
-    int32_t n_own_e;           // own undirected edges: nine lines each, line-sum slots [0, 9 n_own_e)
-    int32_t n_items;           // walk items (edge, chunk): nine lanes each
+    int32_t n_own_v, n_slots;  // position slots: the patch's own vertices first, then the neighbours it reads
+    int32_t n_edges;           // local edges: every edge one of the patch's corners uses
+    int32_t n_lines;           // lines the patch walks = line-sum slots (per local edge: its needed versions, ascending)
+    int32_t n_li;              // lane-items of the walk: (line, chunk)
     int32_t n_corners;         // (own vertex, incident triangle): four lanes each, one per move
-    int32_t n_imp, n_exp;      // line sums read from / written to the mailbox
-    int32_t n_sums;            // 9 n_own_e + n_imp
+    int32_t rows;              // rows a lane of the walk takes: chunks per line = the line's rows / this (<= PK_ROWS_PER_LANE)
     int32_t off_vid;           // [n_slots] global vertex id
-    int32_t off_edges;         // [n_own_e] {slot_u | slot_v << 16, global edge id}
-    int32_t off_items;         // [n_items] {own edge | chunk << 8 | chunks << 20, magic = floor(2^32 / chunks) + 1}
-    int32_t off_corners;       // [n_corners] {t, s | slot_a << 12 | slot_b << 22 | own << 2, out | in << 16, opp}
-    int32_t off_imp;           // [n_imp] global line id (edge * 9 + version); destination slot 9 n_own_e + k
-    int32_t off_exp;           // [n_exp] own line-sum slot (edge_local * 9 + version)
+    int32_t off_edges;         // [n_edges] slot_u | slot_v << 16
+    int32_t off_lines;         // [n_lines] local edge | version << 16
+    int32_t off_li;            // [n_li] {line | chunk << 16, chunks, magic = floor(2^32 / chunks) + 1 (0: one chunk)}
+    int32_t off_corners;       // [n_corners] {t, s | own << 2 | slot_a << 12 | slot_b << 22, out | in << 16, opp}
     int32_t lds_bytes;         // dynamic LDS of this workgroup (pk_lds_bytes)
-    int32_t pad;
 };
 
 struct pk_plan {
@@ -57,9 +58,9 @@ struct pk_plan {
     int lds_bytes = 0;         // max over workgroups
     std::vector<pk_wg> wg;
     std::vector<int32_t> pool;
-    std::vector<int32_t> owner_v, owner_e;  // (kept for tests and statistics)
+    std::vector<int32_t> owner_v;           // (kept for tests and statistics)
     double work_max = 0.0, work_mean = 0.0; // table look-ups per workgroup at upload
-    int64_t imp_total = 0, exp_total = 0;
+    int64_t lines_total = 0, foreign_total = 0;  // lines walked by all patches (9 NE if nothing were walked twice); foreign position slots
 };
 
 // dynamic LDS carve (bytes), identical on the device (tp_persist.h: pk_carve)
@@ -71,18 +72,17 @@ struct pk_plan {
 PK_HD int pk_align16(int v) { return (v + 15) & ~15; }
 inline int pk_lds_bytes(const pk_wg& w) {
     int b = 0;
-    b += pk_align16(w.n_sums * 48);                 // line sums: six 64-bit words
-    b += pk_align16(9 * w.n_own_e * 24);            // walkers
+    b += pk_align16(w.n_lines * 48);                // line sums: six 64-bit words
+    b += pk_align16(w.n_lines * 24);                // walkers
     b += pk_align16(w.n_slots * 8);                 // positions
-    b += pk_align16((4 * w.n_own_v + w.n_slots) * 8);  // snapped positions: foreign slots unmoved only, own slots + 4 moves
-    b += pk_align16(w.n_own_e * 8);                 // row band of an edge's nine lines
+    b += pk_align16((4 * w.n_own_v + w.n_slots) * 8);  // snapped positions: neighbours unmoved only, own slots + 4 moves
+    b += pk_align16(w.n_edges * 8);                 // row band of an edge's lines
     b += pk_align16(w.n_own_v * 8);                 // gradient
     b += pk_align16(w.n_slots * 4);                 // vid
-    b += pk_align16(w.n_own_e * 8);                 // edges
-    b += pk_align16(w.n_items * 8);                 // items
+    b += pk_align16(w.n_edges * 4);                 // edges
+    b += pk_align16(w.n_lines * 4);                 // lines
+    b += pk_align16(w.n_li * 12);                   // lane-items
     b += pk_align16(w.n_corners * 16);              // corners
-    b += pk_align16(w.n_imp * 4);                   // imports
-    b += pk_align16(w.n_exp * 4);                   // exports
     return b + 64;                                  // flags
 }
 
@@ -134,30 +134,36 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
 
     // rows of every edge at upload: table look-ups per line
     std::vector<float> rows((size_t)NE);
-    std::vector<double> wv((size_t)NP, 0.0);
-    std::vector<int> deg((size_t)NP, 0);
-    double total = 0.0;
     for (int e = 0; e < NE; e++) {
         const float ya = points[2 * (size_t)EU(e) + 1], yb = points[2 * (size_t)EV(e) + 1];
         float r = fabsf(ya - yb) * 0.5f * (float)H;
         if (!(r >= 0.0f)) r = 0.0f;                   // NaN positions: no rows
-        r = std::min(r, (float)H) + 1.0f;
-        rows[e] = r;
-        const double w = (double)PK_NLINES * r;
-        wv[EU(e)] += 0.5 * w; wv[EV(e)] += 0.5 * w;
-        total += w;
+        rows[e] = std::min(r, (float)H) + 1.0f;
     }
+    // a vertex's work: per corner the four moves of its two edges (each edge at the vertex is shared by two corners) and the
+    // opposite base line (shared with the corner across the edge, if that one is in the same patch), plus the corner itself
+    std::vector<double> wv((size_t)NP, 0.0);
+    std::vector<int> deg((size_t)NP, 0);
+    double total = 0.0;
     for (int t = 0; t < NT; t++)
-        for (int s = 0; s < 3; s++) { const int v = tris[4 * (size_t)t + s]; deg[v]++; wv[v] += 40.0; total += 40.0; }
+        for (int s = 0; s < 3; s++) {
+            const int v = tris[4 * (size_t)t + s];
+            const int sn = s == 2 ? 0 : s + 1, sp = s == 0 ? 2 : s - 1;
+            const double w = 2.0 * (rows[he_edge[3 * (size_t)t + s] >> 1] + rows[he_edge[3 * (size_t)t + sp] >> 1]) +
+                             0.75 * rows[he_edge[3 * (size_t)t + sn] >> 1] + 40.0;
+            deg[v]++; wv[v] += w; total += w;
+        }
 
-    // workgroups: about PK_THREADS * PK_ROWS_PER_LANE look-ups each, at most one per edge
-    int parts = (int)std::min<double>((double)max_parts, std::ceil(total / (double)(PK_THREADS * PK_ROWS_PER_LANE)));
-    parts = std::max(1, std::min(parts, NE));
+    // workgroups: at least ~4 look-ups per lane each, at most one per used vertex
+    int used = 0;
+    for (int v = 0; v < NP; v++) used += deg[v] > 0;
+    int parts = (int)std::min<double>((double)max_parts, std::ceil(total / (double)(PK_CACHED * 4)));
+    parts = std::max(1, std::min(parts, used));
     if (parts >= 16) parts &= ~7;  // whole runs of patches per XCD (tp_persist.hip maps workgroup b to XCD b mod 8)
 
     // 1. vertices -> patches
     std::vector<pk_detail::rcb_vertex> a;
-    a.reserve((size_t)NP);
+    a.reserve((size_t)used);
     for (int v = 0; v < NP; v++) {
         if (!deg[v]) continue;
         float x = points[2 * (size_t)v] / ratio * 0.5f * (float)W, y = points[2 * (size_t)v + 1] * 0.5f * (float)H;
@@ -167,28 +173,30 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
     }
     P.owner_v.assign((size_t)NP, -1);
     pk_detail::rcb(a, 0, (int)a.size(), 0, parts, P.owner_v);
-
-    // 2. edges -> the lighter of the two patches at their ends
-    std::vector<double> load((size_t)parts, 0.0);
-    for (int v = 0; v < NP; v++) if (deg[v]) load[P.owner_v[v]] += 40.0 * deg[v];
-    P.owner_e.assign((size_t)NE, 0);
-    for (int e = 0; e < NE; e++) {
-        const int pu = P.owner_v[EU(e)], pv = P.owner_v[EV(e)];
-        const int p = load[pu] <= load[pv] ? pu : pv;
-        P.owner_e[e] = p;
-        load[p] += (double)PK_NLINES * rows[e];
+    // 1b. even the patches out: a vertex on a patch border moves to the neighbouring patch whenever that narrows the gap
+    // between the two (the heaviest patch sets the pace of every grad-iter; bisection alone leaves it ~15 % above the mean)
+    if (parts > 1) {
+        std::vector<double> load((size_t)parts, 0.0);
+        std::vector<int> count((size_t)parts, 0);
+        for (auto& q : a) { load[P.owner_v[q.v]] += q.w; count[P.owner_v[q.v]]++; }
+        for (int pass = 0; pass < 12; pass++) {
+            int moved = 0;
+            for (int e = 0; e < NE; e++) {
+                int u = EU(e), v = EV(e);
+                int A = P.owner_v[u], B = P.owner_v[v];
+                if (A == B) continue;
+                if (load[A] < load[B]) { std::swap(u, v); std::swap(A, B); }   // u sits in the heavier patch A
+                if (count[A] <= 1 || load[A] - load[B] <= wv[u]) continue;      // (moving u must leave A above B: no ping-pong)
+                P.owner_v[u] = B;
+                load[A] -= wv[u]; load[B] += wv[u]; count[A]--; count[B]++;
+                moved++;
+            }
+            if (!moved) break;
+        }
     }
-    for (int p = 0; p < parts; p++) { P.work_max = std::max(P.work_max, load[p]); P.work_mean += load[p] / parts; }
 
-    // 3. per-patch lists
-    std::vector<std::vector<int>> own_v((size_t)parts), own_e((size_t)parts);
+    std::vector<std::vector<int>> own_v((size_t)parts);
     for (auto& q : a) own_v[P.owner_v[q.v]].push_back(q.v);   // (a is in bisection order: neighbours stay neighbours)
-    for (int e = 0; e < NE; e++) own_e[P.owner_e[e]].push_back(e);
-    std::vector<int> elocal((size_t)NE);
-    for (int p = 0; p < parts; p++) {
-        if ((int)own_e[p].size() > PK_MAX_OWN_EDGES) { P.why = "a patch owns more than 255 edges"; return; }
-        for (size_t k = 0; k < own_e[p].size(); k++) elocal[own_e[p][k]] = (int)k;
-    }
     // vertex -> corners (t, s), in triangle order
     std::vector<int> voff((size_t)NP + 1, 0), vadj((size_t)3 * NT);
     for (int t = 0; t < NT; t++) for (int s = 0; s < 3; s++) voff[tris[4 * (size_t)t + s] + 1]++;
@@ -196,59 +204,81 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
     { std::vector<int> cur(voff.begin(), voff.end() - 1);
       for (int t = 0; t < NT; t++) for (int s = 0; s < 3; s++) vadj[cur[tris[4 * (size_t)t + s]]++] = 3 * t + s; }
 
+    // 2. per-patch tables.  Scratch indexed by global ids is stamped with the patch number instead of being cleared.
     P.parts = parts;
     P.wg.assign((size_t)parts, pk_wg());
-    std::vector<std::vector<int32_t>> exports((size_t)parts);   // own line-sum slots other patches read
-    std::vector<std::vector<char>> exported((size_t)parts);
-    for (int p = 0; p < parts; p++) exported[p].assign(own_e[p].size() * PK_NLINES, 0);
-
-    struct built { std::vector<int32_t> vid, edges, items, corners, imp; };
-    std::vector<built> B((size_t)parts);
+    std::vector<int> vslot((size_t)NP, 0), vstamp((size_t)NP, -1), eloc((size_t)NE, 0), estamp((size_t)NE, -1);
+    std::vector<int32_t> vid, edges, emask, eglob, lines, li, corners, first;
     for (int p = 0; p < parts; p++) {
         pk_wg& w = P.wg[p];
-        built& b = B[p];
-        std::unordered_map<int, int> slot_of;  // vertex -> position slot
+        vid.clear(); edges.clear(); emask.clear(); eglob.clear(); lines.clear(); li.clear(); corners.clear();
         auto slot = [&](int v) {
-            auto it = slot_of.find(v);
-            if (it != slot_of.end()) return it->second;
-            const int s = (int)b.vid.size();
-            slot_of.emplace(v, s); b.vid.push_back(v);
-            return s;
+            if (vstamp[v] != p) { vstamp[v] = p; vslot[v] = (int)vid.size(); vid.push_back(v); }
+            return vslot[v];
+        };
+        // which versions of edge e the patch needs: bit 0 the base line, bit 1 versions 1..4 (first endpoint displaced),
+        // bit 2 versions 5..8 (second endpoint displaced)
+        auto need = [&](int e, int bits) {
+            if (estamp[e] != p) {
+                estamp[e] = p; eloc[e] = (int)eglob.size();
+                eglob.push_back(e); emask.push_back(0);
+            }
+            emask[eloc[e]] |= bits;
         };
         for (int v : own_v[p]) slot(v);
         w.n_own_v = (int)own_v[p].size();
-        // own edges and their walk items
-        w.n_own_e = (int)own_e[p].size();
-        for (int e : own_e[p]) {
-            const int su = slot(EU(e)), sv = slot(EV(e));
-            b.edges.push_back(su | (sv << 16)); b.edges.push_back(e);
-        }
-        for (int le = 0; le < w.n_own_e; le++) {
-            const float r = rows[own_e[p][le]] + dp_px;
-            int tl = (int)std::ceil(r / (float)PK_ROWS_PER_LANE);
+        for (int v : own_v[p])
+            for (int j = voff[v]; j < voff[v + 1]; j++) {
+                const int h = vadj[j], t = h / 3, s = h - 3 * t;
+                const int sn = s == 2 ? 0 : s + 1, sp = s == 0 ? 2 : s - 1;
+                const int he_out = he_edge[3 * (size_t)t + s], he_in = he_edge[3 * (size_t)t + sp], he_opp = he_edge[3 * (size_t)t + sn];
+                // edge leaving the vertex: the vertex is its origin -- the edge's second endpoint when the half-edge is flipped
+                // (tp_edge_version: flipped ? 4 + m : m); edge arriving: the vertex is its destination (flipped ? m : 4 + m)
+                need(he_out >> 1, (he_out & 1) ? 4 : 2);
+                need(he_in >> 1, (he_in & 1) ? 2 : 4);
+                need(he_opp >> 1, 1);
+            }
+        // local edges in order of first use; their lines (needed versions, ascending) and lane-items
+        w.n_edges = (int)eglob.size();
+        if (w.n_edges > 65535) { P.why = "a patch uses more than 65535 edges"; return; }
+        first.assign((size_t)w.n_edges * PK_NLINES, -1);
+        // rows per lane: the fewest (down to 4) that still give every lane-item its own thread, so that lanes can keep their
+        // table records in registers from one grad-iter to the next (tp_persist.h)
+        auto lane_items = [&](int rpl) {
+            long n = 0;
+            for (int le = 0; le < w.n_edges; le++) {
+                int nl = 0;
+                for (int q = 0; q < PK_NLINES; q++) nl += (emask[le] & (q == 0 ? 1 : q <= 4 ? 2 : 4)) != 0;
+                const int tl = std::max(1, std::min((int)std::ceil((rows[eglob[le]] + dp_px) / (float)rpl), PK_MAX_TL));
+                n += (long)nl * tl;
+            }
+            return n;
+        };
+        int rpl = 4;
+        while (rpl < PK_ROWS_PER_LANE && lane_items(rpl) > PK_CACHED) rpl++;
+        w.rows = rpl;
+        for (int le = 0; le < w.n_edges; le++) {
+            const int e = eglob[le];
+            edges.push_back(slot(EU(e)) | (slot(EV(e)) << 16));
+            const float r = rows[e] + dp_px;
+            int tl = (int)std::ceil(r / (float)rpl);
             tl = std::max(1, std::min(tl, PK_MAX_TL));
             const uint32_t magic = tl == 1 ? 0u : (uint32_t)(0x100000000ull / (uint64_t)tl) + 1u;
-            for (int c = 0; c < tl; c++) { b.items.push_back(le | (c << 8) | (tl << 20)); b.items.push_back((int32_t)magic); }
-        }
-        w.n_items = (int)(b.items.size() / 2);
-        // corners of own vertices; line sums they need
-        std::unordered_map<int, int> imp_slot;  // global line id -> line-sum slot
-        // slot of line `ver` of edge e, followed by the slots of the next n - 1 versions (a foreign edge's lines are
-        // imported in the groups the corners use: the base line alone, the four moves of one endpoint together)
-        auto line_slot = [&](int e, int ver, int n) {
-            const int q = P.owner_e[e];
-            if (q == p) return elocal[e] * PK_NLINES + ver;
-            const int gl = e * PK_NLINES + ver;
-            auto it = imp_slot.find(gl);
-            if (it != imp_slot.end()) return it->second;
-            const int s = w.n_own_e * PK_NLINES + (int)b.imp.size();
-            for (int k = 0; k < n; k++) {
-                imp_slot.emplace(gl + k, s + k); b.imp.push_back(gl + k);
-                const int ls = elocal[e] * PK_NLINES + ver + k;
-                if (!exported[q][ls]) { exported[q][ls] = 1; exports[q].push_back(ls); }
+            const int l0 = (int)lines.size();
+            for (int q = 0; q < PK_NLINES; q++) {
+                const int bit = q == 0 ? 1 : q <= 4 ? 2 : 4;
+                if (!(emask[le] & bit)) continue;
+                first[(size_t)le * PK_NLINES + q] = (int)lines.size();
+                lines.push_back(le | (q << 16));
             }
-            return s;
-        };
+            const int nl = (int)lines.size() - l0;
+            // the lines of an edge take the same rows in adjacent lanes: their table records share cache lines
+            for (int c = 0; c < tl; c++)
+                for (int k = 0; k < nl; k++) { li.push_back((l0 + k) | (c << 16)); li.push_back(tl); li.push_back((int32_t)magic); }
+        }
+        w.n_lines = (int)lines.size();
+        w.n_li = (int)(li.size() / 3);
+        if (w.n_lines > 65535) { P.why = "a patch walks more than 65535 lines"; return; }
         for (int k = 0; k < w.n_own_v; k++) {
             const int v = own_v[p][k];
             for (int j = voff[v]; j < voff[v + 1]; j++) {
@@ -256,40 +286,31 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
                 const int sn = s == 2 ? 0 : s + 1, sp = s == 0 ? 2 : s - 1;
                 const int va = tris[4 * (size_t)t + sn], vb = tris[4 * (size_t)t + sp];
                 const int he_out = he_edge[3 * (size_t)t + s], he_in = he_edge[3 * (size_t)t + sp], he_opp = he_edge[3 * (size_t)t + sn];
-                // edge leaving the vertex: the vertex is its origin (tp_edge_version: flipped ? 4 + m : m);
-                // edge arriving: the vertex is its destination (flipped ? m : 4 + m); four consecutive slots, moves 1..4
-                const int vo = (he_out & 1) ? 4 : 0, vi = (he_in & 1) ? 0 : 4;
-                const int so = line_slot(he_out >> 1, vo + 1, 4), si = line_slot(he_in >> 1, vi + 1, 4);
-                const int sopp = line_slot(he_opp >> 1, 0, 1);
-                b.corners.push_back(t);
-                b.corners.push_back(s | (k << 2) | (slot(va) << 12) | (slot(vb) << 22));
-                b.corners.push_back(so | (si << 16));
-                b.corners.push_back(sopp);
+                const int so = first[(size_t)eloc[he_out >> 1] * PK_NLINES + ((he_out & 1) ? 5 : 1)];
+                const int si = first[(size_t)eloc[he_in >> 1] * PK_NLINES + ((he_in & 1) ? 1 : 5)];
+                const int sopp = first[(size_t)eloc[he_opp >> 1] * PK_NLINES];
+                corners.push_back(t);
+                corners.push_back(s | (k << 2) | (slot(va) << 12) | (slot(vb) << 22));
+                corners.push_back(so | (si << 16));
+                corners.push_back(sopp);
             }
         }
-        w.n_corners = (int)(b.corners.size() / 4);
-        w.n_slots = (int)b.vid.size();
-        w.n_imp = (int)b.imp.size();
-        w.n_sums = w.n_own_e * PK_NLINES + w.n_imp;
+        w.n_corners = (int)(corners.size() / 4);
+        w.n_slots = (int)vid.size();
         if (w.n_slots > PK_MAX_SLOTS || w.n_own_v > 1023) { P.why = "a patch reads more than 1023 vertices"; return; }
-        if (w.n_sums > PK_MAX_SUMS) { P.why = "a patch needs more than 65535 line sums"; return; }
-    }
-    // 4. lay the pool out
-    for (int p = 0; p < parts; p++) {
-        pk_wg& w = P.wg[p];
-        built& b = B[p];
-        w.n_exp = (int)exports[p].size();
         auto put = [&](const std::vector<int32_t>& src) {
             const int off = (int)P.pool.size();
             P.pool.insert(P.pool.end(), src.begin(), src.end());
             while (P.pool.size() & 3) P.pool.push_back(0);  // 16-byte aligned tables
             return off;
         };
-        w.off_vid = put(b.vid); w.off_edges = put(b.edges); w.off_items = put(b.items);
-        w.off_corners = put(b.corners); w.off_imp = put(b.imp); w.off_exp = put(exports[p]);
+        w.off_vid = put(vid); w.off_edges = put(edges); w.off_lines = put(lines); w.off_li = put(li); w.off_corners = put(corners);
         w.lds_bytes = pk_lds_bytes(w);
         P.lds_bytes = std::max(P.lds_bytes, w.lds_bytes);
-        P.imp_total += w.n_imp; P.exp_total += w.n_exp;
+        P.lines_total += w.n_lines; P.foreign_total += w.n_slots - w.n_own_v;
+        double work = 40.0 * w.n_corners;
+        for (int l = 0; l < w.n_lines; l++) work += rows[eglob[lines[l] & 0xffff]];
+        P.work_max = std::max(P.work_max, work); P.work_mean += work / parts;
     }
     if (P.lds_bytes > lds_limit) { P.why = "a patch does not fit the LDS"; return; }
     P.ok = true;

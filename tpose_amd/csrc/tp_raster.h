@@ -66,6 +66,10 @@ TP_HD float tp_fdiv(float a, float b) {
 #endif
 }
 
+// shift.cs:45  `/ 256 / 256`: two divisions by a power of two are one multiplication by 2^-16 -- exact, unless the result
+// were subnormal, which rate * gradient / 65536 never is for a non-zero integer gradient (>= 1e-5 * 2^-16)
+TP_HD float tp_shift_scale(float v) { return tp_fmul(v, 1.52587890625e-05f); }
+
 // dp law, triangle.vs:60-62 (triangulate: 4, 3000) / warp triangle.vs:63-65 (9, 1000)
 inline float tp_reference_dp(int flavour, int NT) {
     volatile float k = flavour ? 9.0f : 4.0f, m = flavour ? 1000.0f : 3000.0f;
@@ -78,6 +82,16 @@ inline float tp_reference_dp(int flavour, int NT) {
 
 TP_HD int32_t tp_min(int32_t a, int32_t b) { return a < b ? a : b; }
 TP_HD int32_t tp_max(int32_t a, int32_t b) { return a > b ? a : b; }
+// v clamped to [0, hi] (hi >= 0, the same for every lane): v_med3_i32 with an inline constant and a scalar operand
+TP_HD int32_t tp_clamp0(int32_t v, int32_t hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t d;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(d) : "v"(v), "s"(hi));
+    return d;
+#else
+    return v < 0 ? 0 : (v > hi ? hi : v);
+#endif
+}
 
 TP_HD int32_t tp_snap256(float f) {
     float v = tp_fadd(tp_fmul(f, 256.0f), 0.5f);
@@ -102,7 +116,7 @@ TP_HD void tp_vertex_stage(float px, float py, int i, int slot, const tp_view& v
     }
     float tx = tp_fadd(px, Dx);
     float ty = tp_fadd(py, Dy);
-    float nx = tp_fdiv(tx, vw.ratio);
+    float nx = vw.ratio == 1.0f ? tx : tp_fdiv(tx, vw.ratio);  // (x / 1 is x: square rasters skip the division)
     float fx = tp_fmul(tp_fadd(nx, 1.0f), vw.halfW);
     float fy = tp_fmul(tp_fsub(1.0f, ty), vw.halfH);
     X = tp_snap256(fx);
@@ -439,4 +453,35 @@ TP_HD void tp_prefix_eval(const uint32_t rec[TP_PFX_WORDS], int32_t c, uint32_t&
     g = tp_udot4(G, 0x01010101u, rec[1]);
     b = tp_udot4(B, 0x01010101u, rec[2]);
     q = tp_udot4(R, R, tp_udot4(G, G, tp_udot4(B, B, rec[3])));
+}
+
+
+// =============================================================================================
+// Pixel records (round 3): the row prefix sums in 16 bytes per PIXEL COLUMN, for rasters up to TP_PX_MAXW columns -- what
+// the persistent kernel (tp_persist.hip) reads.  Record c of a row holds the moments of the pixels x < c in fields
+// with FOUR BITS OF HEADROOM each, so that up to 16 records can be added as two 64-bit integers without a carry from
+// one field into the next, and unpacked once:
+//   low  64 bits   sum r (20 bits: 255 * 4096 < 2^20) in a 24-bit slot | sum g << 24 | n_odd bits 0..11 << 48 (16-bit slot)
+//   high 64 bits   sum b in a 24-bit slot | sum (r^2 + g^2 + b^2) (30 bits: 195075 * 4096 < 2^30) << 24 (34-bit slot)
+//                  | n_odd bit 12 << 58 (6-bit slot)
+// One look-up is one 16-byte load and two 64-bit additions; a lane of the walk unpacks its six sums once per grad-iter.
+// (The 32-byte records per four pixels above cost ~14 instructions per look-up to evaluate and two loads; on this part
+// a wave64 integer instruction takes four cycles of its SIMD, and the walk was bound by exactly that.)
+// =============================================================================================
+#define TP_PX_MAXW 4096
+#define TP_PX_MAXSUM 16   /* records that may be added before unpacking */
+TP_HD int32_t tp_px_pitch(int32_t W) { return (W + 1 + 7) & ~7; }   // records per row (c = 0..W): whole 128-byte lines
+
+// running moments m = {n_odd, r, g, b, q} of the pixels before column c -> record {low, high}
+TP_HD void tp_px_pack(const uint32_t m[5], uint64_t rec[2]) {
+    rec[0] = (uint64_t)m[1] | ((uint64_t)m[2] << 24) | ((uint64_t)(m[0] & 0xfffu) << 48);
+    rec[1] = (uint64_t)m[3] | ((uint64_t)m[4] << 24) | ((uint64_t)(m[0] >> 12) << 58);
+}
+// the sum of up to TP_PX_MAXSUM records -> the sums of their moments
+TP_HD void tp_px_unpack(uint64_t lo, uint64_t hi, uint32_t& nodd, uint32_t& r, uint32_t& g, uint32_t& b, uint64_t& q) {
+    r = (uint32_t)lo & 0xffffffu;
+    g = (uint32_t)(lo >> 24) & 0xffffffu;
+    nodd = (uint32_t)(lo >> 48) + ((uint32_t)(hi >> 58) << 12);
+    b = (uint32_t)hi & 0xffffffu;
+    q = (hi >> 24) & 0x3ffffffffull;
 }

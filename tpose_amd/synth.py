@@ -143,10 +143,22 @@ def mean_colors(img, pts, tris, ratio):
 GRID_FOR_NT = {3000: (50, 30), 12000: (100, 60), 150: (15, 5), 48: (6, 4), 2: None}
 
 
-def workload(W, H, NT, seed=1234):
-    """(imgA, points, triangles, halfedges, ratio) for a named synthetic workload."""
+def photo_contrast(img, contrast):
+    """the raster with its RGB contrast about mid-grey scaled by `contrast` (rounded to nearest)"""
+    out = img.copy()
+    rgb = img[:, :, :3].astype(np.float32)
+    out[:, :, :3] = np.clip(128.0 + (rgb - 128.0) * np.float32(contrast) + 0.5, 0, 255).astype(np.uint8)
+    return out
+
+
+def workload(W, H, NT, seed=1234, contrast=1.0):
+    """(imgA, points, triangles, halfedges, ratio) for a named synthetic workload.  contrast < 1: the same Voronoi +
+    noise raster with photograph-like contrast between neighbouring regions (the reference's fixed-step descent,
+    shift.cs:45, is only stable on such rasters: a full-contrast one throws vertices hundreds of pixels)."""
     ratio = float(np.float32(W) / np.float32(H))
     img = voronoi_raster(W, H, seed=seed)
+    if contrast != 1.0:
+        img = photo_contrast(img, contrast)
     if NT == 2:
         pts, tris, he = two_triangle(ratio)
     else:
