@@ -88,12 +88,10 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
                 }
             // P1
             for (int j = 0; j < 5 * w.n_own_v + (w.n_slots - w.n_own_v); j++) pk_snap_lane(w, V, vw, j);
-            for (int le = 0; le < w.n_edges; le++) { V.band[le].x = 0x3fffffff; V.band[le].y = -1; }
             for (int l = 0; l < w.n_lines; l++) {
                 pk_walker wkr;
-                const int le = pk_setup_lane(V, vw, l, wkr);
+                pk_setup_lane(V, vw, l, wkr);
                 V.wk[l] = wkr;
-                if (wkr.ra <= wkr.rb) { pk_i2& b = V.band[le]; b.x = tp_min(b.x, wkr.ra); b.y = tp_max(b.y, wkr.rb); }
             }
             memset(V.sums, 0, sizeof(unsigned long long) * 6 * (size_t)w.n_lines);
             for (int k = 0; k < w.n_own_v; k++) { V.grad[k].x = 0; V.grad[k].y = 0; }
@@ -102,9 +100,7 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
                 pk_acc a;
                 int l;
                 if (j < PK_CACHED) {
-                    if (w.rows <= 8) pk_walk_cached<8>(S[p].cache[j], V, table, pitch, W, a);
-                    else if (w.rows <= 10) pk_walk_cached<10>(S[p].cache[j], V, table, pitch, W, a);
-                    else pk_walk_cached<PK_ROWS_PER_LANE>(S[p].cache[j], V, table, pitch, W, a);
+                    pk_walk_cached<PK_ROWS_PER_LANE>(S[p].cache[j], V, table, pitch, W, a);
                     l = S[p].cache[j].l;
                 }
                 else l = pk_walk_lane(V, table, pitch, W, j, a);

@@ -47,8 +47,8 @@ sel = st[:, 8:IT]
 for k, lab in enumerate(labels):
     d = (sel[:, :, k + 1] - sel[:, :, k]) / 100.0
     out[lab] = {str(q): round(float(np.percentile(d, q)), 2) for q in (1, 50, 90, 100)}
-# inside P3, thread 0: first lane-item walked / folded into LDS, second walked / folded
-sub = [("P3a item 0 walk", 2, 8), ("P3b item 0 atomics", 8, 9), ("P3c item 1 walk", 9, 10), ("P3d item 1 atomics", 10, 11), ("P3e barrier", 11, 3)]
+# inside P3, thread 0: columns scanned and stale records requested for both lane-items; records summed and folded into LDS
+sub = [("P3a scan + fetch", 2, 8), ("P3b sums + atomics", 8, 9), ("P3e barrier", 9, 3)]
 for lab, a, b in sub:
     d = (sel[:, :, b] - sel[:, :, a]) / 100.0
     ok = (sel[:, :, a] > 0) & (sel[:, :, b] > 0)

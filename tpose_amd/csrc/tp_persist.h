@@ -13,7 +13,8 @@
 // grad-iter of a tp_iterate call runs through k_lines + k_update (tp_kernels.hip), which write them.
 //
 // Everything here is __host__ __device__: tests/emul replays the phases on the CPU, workgroup by workgroup, with the
-// mailboxes replaced by plain copies, and compares with the oracle.  The shipped library never runs it on the host.
+// mailboxes replaced by plain copies, and tests/test_emul.py compares the result with the CPU restatement of the reference.
+// The shipped library never runs it on the host.
 #pragma once
 
 #include "tp_raster.h"
@@ -31,7 +32,6 @@ struct pk_view {
     pk_walker* wk;             // [n_lines]
     pk_f2* pos;                // [n_slots]
     pk_i2* snap;               // own slot k: [5 k + move]; neighbour slot s: [5 n_own_v + s - n_own_v] (unmoved)
-    pk_i2* band;               // [n_edges] first and last row of an edge's lines
     pk_i2* grad;               // [n_own_v]
     int32_t* vid;              // static tables, copied from the plan's pool at the start of the launch
     int32_t* edges;
@@ -47,7 +47,6 @@ TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     V.wk = (pk_walker*)p; p += pk_align16(w.n_lines * 24);
     V.pos = (pk_f2*)p; p += pk_align16(w.n_slots * 8);
     V.snap = (pk_i2*)p; p += pk_align16((4 * w.n_own_v + w.n_slots) * 8);
-    V.band = (pk_i2*)p; p += pk_align16(w.n_edges * 8);
     V.grad = (pk_i2*)p; p += pk_align16(w.n_own_v * 8);
     V.vid = (int32_t*)p; p += pk_align16(w.n_slots * 4);
     V.edges = (int32_t*)p; p += pk_align16(w.n_edges * 4);
@@ -71,9 +70,8 @@ TP_HD void pk_snap_lane(const pk_wg& w, const pk_view& V, const tp_view& vw, int
     V.snap[j].x = X; V.snap[j].y = Y;
 }
 
-// P1b, lane l < n_lines: line l = (local edge, version) -- the walker of the whole line.  Returns the local edge: the
-// caller folds ra / rb into that edge's band (LDS atomics on the device).
-TP_HD int pk_setup_lane(const pk_view& V, const tp_view& vw, int l, pk_walker& out) {
+// P1b, lane l < n_lines: line l = (local edge, version) -- the walker of the whole line
+TP_HD void pk_setup_lane(const pk_view& V, const tp_view& vw, int l, pk_walker& out) {
     const int le = V.lines[l] & 0xffff, q = V.lines[l] >> 16;
     const int su = V.edges[le] & 0xffff, sv = (V.edges[le] >> 16) & 0xffff;
     const pk_f2 pu = V.pos[su], pv = V.pos[sv];
@@ -85,7 +83,6 @@ TP_HD int pk_setup_lane(const pk_view& V, const tp_view& vw, int l, pk_walker& o
     tp_line ln;
     tp_setup_line(Xa, Ya, Xb, Yb, vw.H, ln);
     out.x = ln.x; out.s = ln.s; out.ra = ln.ra; out.rb = ln.rb;
-    return le;
 }
 
 // x / d for the item's chunk count d (magic = floor(2^32 / d) + 1, exact for x d < 2^32; d == 1: magic 0)
@@ -111,18 +108,20 @@ TP_HD void pk_add_unpacked(uint64_t lo, uint64_t hi, pk_acc& a) {
     a.nodd += no; a.r += r; a.g += g; a.b += b; a.q += q;
 }
 
-// The rows of one lane: first, first + TL, ... (n of them) of line `ln`, where first is the first row >= ra on the residue
-// (rmin + c) mod TL of the edge's band -- the lines of an edge sit in adjacent lanes ON THE SAME ROWS, and their crossing
-// columns lie within a few pixels of each other, so their table records share a cache line.
+// The rows of one lane: chunk c of TL takes the rows r = c (mod TL) of its line -- first, first + TL, ... (n of them).  The
+// lines of an edge have the same chunks: adjacent lanes work ON THE SAME ROWS, and their crossing columns lie within a few
+// pixels of each other, so what they fetch shares cache lines.  Residues are absolute (not counted from the line's first
+// row): when an endpoint crosses a pixel row, one lane of the line gains or loses a row and the others keep theirs.
 struct pk_rows { int n; int64_t x, xs; uint32_t row, rs; };
-TP_HD pk_rows pk_lane_rows(const pk_walker& ln, int rmin, int c, int TL, uint32_t magic, int pitch) {
+TP_HD pk_rows pk_lane_rows(const pk_walker& ln, int c, int TL, uint32_t magic, int pitch) {
     pk_rows r; r.n = 0; r.x = 0; r.xs = 0; r.row = 0; r.rs = 0;
     if (ln.ra > ln.rb) return r;
-    const int base = rmin + c;                                                    // ra >= rmin: ra - base > -TL
-    const int first = base + (int)pk_div((uint32_t)(ln.ra - base + TL - 1), magic) * TL;
+    int d = c - (ln.ra - (int)pk_div((uint32_t)ln.ra, magic) * TL);   // c - ra mod TL
+    d += d < 0 ? TL : 0;
+    const int first = ln.ra + d;
     if (ln.rb < first) return r;
     r.n = (int)pk_div((uint32_t)(ln.rb - first), magic) + 1;
-    r.x = ln.x + (int64_t)(first - ln.ra) * ln.s;
+    r.x = ln.x + (int64_t)d * ln.s;
     r.xs = (int64_t)((uint64_t)ln.s * (uint64_t)TL);                              // (unsigned: a steep two-row line may wrap, unused then)
     // (byte offsets into the table fit 32 bits: 4096 rows x 4104 records x 16 bytes < 2^29)
     r.row = (uint32_t)first * (uint32_t)pitch * 16u;
@@ -167,7 +166,7 @@ TP_HD int pk_walk_lane(const pk_view& V, const char* table, int pitch, int W, in
     const int l = V.li[3 * j] & 0xffff, c = V.li[3 * j] >> 16, TL = V.li[3 * j + 1];
     const uint32_t magic = (uint32_t)V.li[3 * j + 2];
     a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
-    pk_rows r = pk_lane_rows(V.wk[l], V.band[V.lines[l] & 0xffff].x, c, TL, magic, pitch);
+    pk_rows r = pk_lane_rows(V.wk[l], c, TL, magic, pitch);
     pk_walk_rows<4>(r, table, W, a);
     return l;
 }
@@ -182,7 +181,7 @@ TP_HD int pk_walk_lane(const pk_view& V, const char* table, int pitch, int W, in
 // lane-dependent branches in either loop.
 template <int R>
 struct pk_lane_cache {
-    int l, c, TL, le;       // the lane-item: line-sum slot, chunk, chunks, local edge (never change during a launch)
+    int l, c, TL;           // the lane-item: line-sum slot, chunk, chunks (never change during a launch)
     uint32_t magic;
     uint32_t row0;          // table offset of the first row the cached records belong to; ~0: nothing cached
     int32_t col[R];         // crossing column of rec[u]; -1: nothing cached
@@ -190,61 +189,75 @@ struct pk_lane_cache {
 };
 template <int R>
 TP_HD void pk_cache_init(pk_lane_cache<R>& C, const pk_view& V, int j, bool live) {
-    C.l = live ? V.li[3 * j] & 0xffff : 0; C.c = live ? V.li[3 * j] >> 16 : 0; C.TL = live ? V.li[3 * j + 1] : 1;
+    C.l = live ? V.li[3 * j] & 0xffff : 0; C.c = live ? V.li[3 * j] >> 16 : 0;
+    C.TL = live ? V.li[3 * j + 1] : 0;     // (0 chunks: a thread without a lane-item -- no rows, ever)
     C.magic = live ? (uint32_t)V.li[3 * j + 2] : 0u;
-    C.le = live ? V.lines[C.l] & 0xffff : 0;
-    C.row0 = 0xffffffffu;
+    C.row0 = live ? 0xffffffffu : 0u;
 #pragma unroll
-    for (int u = 0; u < R; u++) { C.col[u] = -1; C.rec[u].lo = 0; C.rec[u].hi = 0; }
+    for (int u = 0; u < R; u++) { C.col[u] = live ? -1 : 0; C.rec[u].lo = 0; C.rec[u].hi = 0; }
 }
-// RR <= R: how many of the R cached rows the lanes of this workgroup use (the plan's rows per lane, rounded up to one of the
-// instantiated values: the loops are straight-line code, rows a lane does not have cost what the others cost)
+// The walk of a cached lane-item in three steps, so that a thread can run each step for all its lane-items before the next
+// (the fetches of both are in flight together).  RR <= R: how many of the R cached rows the lanes of this workgroup use
+// (the plan's rows per lane, rounded up to one of the instantiated values: the loops are straight-line code, rows a lane
+// does not have cost what the others cost).
+struct pk_scan { pk_rows r; uint32_t live, sx, stale; };
+// step 1, straight-line: this grad-iter's rows and crossing columns; has any column left its cached record?
 template <int RR, int R>
-TP_HD void pk_walk_cached(pk_lane_cache<R>& C, const pk_view& V, const char* table, int pitch, int W, pk_acc& a) {
+TP_HD pk_scan pk_walk_scan(const pk_lane_cache<R>& C, const pk_view& V, int pitch, int W) {
     static_assert(RR <= R && RR <= TP_PX_MAXSUM, "records added before unpacking");
-    const int rows = RR;
-    a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
-    pk_rows r = pk_lane_rows(V.wk[C.l], V.band[C.le].x, C.c, C.TL, C.magic, pitch);
-    const uint32_t live = r.n >= 32 ? 0xffffffffu : ((1u << r.n) - 1u);   // bit u: row u exists
-    // pass 1, straight-line: this grad-iter's crossing columns; has any of them left its cached record?
-    uint32_t sx = 0, stale = r.row ^ C.row0;   // (another first row: every record is another row's)
-    {
-        pk_rows t = r;
+    pk_scan S;
+    if (C.TL == 0) { S.r.n = 0; S.r.x = 0; S.r.xs = 0; S.r.row = 0; S.r.rs = 0; }
+    else S.r = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
+    S.live = S.r.n >= 32 ? 0xffffffffu : ((1u << S.r.n) - 1u);   // bit u: row u exists
+    S.sx = 0; S.stale = S.r.row ^ C.row0;                          // (another first row: every record is another row's)
+    pk_rows t = S.r;
 #pragma unroll
-        for (int u = 0; u < RR; u++) {
-            const int32_t col = pk_next_col(t, W) & (int32_t)(0u - ((live >> u) & 1u));
-            sx += (uint32_t)col;
-            stale |= (uint32_t)(col ^ C.col[u]);
-        }
+    for (int u = 0; u < RR; u++) {
+        const int32_t col = pk_next_col(t, W) & (int32_t)(0u - ((S.live >> u) & 1u));
+        S.sx += (uint32_t)col;
+        S.stale |= (uint32_t)(col ^ C.col[u]);
     }
-    // pass 1b, only when some lane of the wave needs a record: walk again and fetch what changed
-    if (stale != 0u) {
-        const bool all = r.row != C.row0;
-        C.row0 = r.row;
-        pk_rows t = r;
+    return S;
+}
+// step 2, only when S.stale: walk again and fetch what changed (loads are issued, not waited for)
+template <int RR, int R>
+TP_HD void pk_walk_fetch(pk_lane_cache<R>& C, const pk_scan& S, const char* table, int W) {
+    const bool all = S.r.row != C.row0;
+    C.row0 = S.r.row;
+    pk_rows t = S.r;
 #pragma unroll
-        for (int u = 0; u < RR; u++) {
-            const uint32_t on = 0u - ((live >> u) & 1u);
-            const int32_t col = pk_next_col(t, W) & (int32_t)on;
-            if (all || col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
+    for (int u = 0; u < RR; u++) {
+        const uint32_t on = 0u - ((S.live >> u) & 1u);
+        const int32_t col = pk_next_col(t, W) & (int32_t)on;
+        if (all || col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
 #if !defined(PK_EXP_NOLOAD)   // timing experiments only (tools/build_variants.py); never defined in the product
-                C.rec[u] = *reinterpret_cast<const pk_rec*>(table + (((r.row + (uint32_t)u * r.rs) & on) + ((uint32_t)col << 4)));
+            C.rec[u] = *reinterpret_cast<const pk_rec*>(table + (((S.r.row + (uint32_t)u * S.r.rs) & on) + ((uint32_t)col << 4)));
 #endif
 #if !defined(PK_EXP_NOCACHE)
-                C.col[u] = col;
+            C.col[u] = col;
 #endif
-            }
         }
     }
+}
+// step 3: the line's partial sums of this lane
+template <int RR, int R>
+TP_HD void pk_walk_sum(const pk_lane_cache<R>& C, const pk_scan& S, const char* table, int W, pk_acc& a) {
+    a.xs = S.sx; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
     uint64_t lo = 0, hi = 0;
 #pragma unroll
     for (int u = 0; u < RR; u++) { lo += C.rec[u].lo; hi += C.rec[u].hi; }
-    a.xs = sx;
     pk_add_unpacked(lo, hi, a);
-    if (r.n > rows) {   // the line has grown beyond the rows this workgroup's lanes keep
-        r.n -= rows; r.x = (int64_t)((uint64_t)r.x + (uint64_t)rows * (uint64_t)r.xs); r.row += (uint32_t)rows * r.rs;
+    if (S.r.n > RR) {   // the line has grown beyond the rows this workgroup's lanes keep
+        pk_rows r = S.r;
+        r.n -= RR; r.x = (int64_t)((uint64_t)r.x + (uint64_t)RR * (uint64_t)r.xs); r.row += (uint32_t)RR * r.rs;
         pk_walk_rows<4>(r, table, W, a);
     }
+}
+template <int RR, int R>
+TP_HD void pk_walk_cached(pk_lane_cache<R>& C, const pk_view& V, const char* table, int pitch, int W, pk_acc& a) {
+    const pk_scan S = pk_walk_scan<RR>(C, V, pitch, W);
+    if (S.stale != 0u) pk_walk_fetch<RR>(C, S, table, W);
+    pk_walk_sum<RR>(C, S, table, W, a);
 }
 
 // tag of grad-iter `epoch` (1 .. 32767 between two resets of the mailbox): never 0, differs between e and e - 2

@@ -18,6 +18,7 @@
 // grid drains; the host sees it at its next synchronisation (tp_context.hip) and reports an error.
 #include "tp_kernels.h"
 #include "tp_persist.h"
+#include <type_traits>
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
@@ -87,7 +88,6 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
             const float2 p = A.points[pool[w.off_vid + i]];
             V.pos[i].x = p.x; V.pos[i].y = p.y;
         }
-        for (int i = tid; i < w.n_edges; i += PK_THREADS) { V.band[i].x = 0x3fffffff; V.band[i].y = -1; }
         for (int i = tid; i < 6 * w.n_lines; i += PK_THREADS) V.sums[i] = 0ull;
         if (tid == 0) V.flags[0] = 0;
     }
@@ -131,9 +131,8 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         // ---- P1: line set-up (low threads), snapped positions (high threads), gradient reset
         for (int l = tid; l < w.n_lines; l += PK_THREADS) {
             pk_walker wk;
-            const int le = pk_setup_lane(V, A.vw, l, wk);
+            pk_setup_lane(V, A.vw, l, wk);
             V.wk[l] = wk;
-            if (wk.ra <= wk.rb) { atomicMin(&V.band[le].x, wk.ra); atomicMax(&V.band[le].y, wk.rb); }
         }
         {
             const int nsnap = 5 * w.n_own_v + (w.n_slots - w.n_own_v);
@@ -151,17 +150,25 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
                 atomicAdd(&s[4], (unsigned long long)a.b); atomicAdd(&s[5], (unsigned long long)a.q);
             }
         };
+        // (each step for both lane-items of the thread before the next step: their fetches are in flight together)
+        auto walk = [&](auto rr) {
+            constexpr int RR = decltype(rr)::value;
+            pk_scan S[PK_NI];
 #pragma unroll
-        for (int i = 0; i < PK_NI; i++)
-            if (tid + i * PK_THREADS < w.n_li) {
+            for (int i = 0; i < PK_NI; i++) S[i] = pk_walk_scan<RR>(cache[i], V, A.px_pitch, A.vw.W);
+#pragma unroll
+            for (int i = 0; i < PK_NI; i++)
+                if (S[i].stale != 0u) pk_walk_fetch<RR>(cache[i], S[i], table, A.vw.W);
+            PK_STAMP(8);
+#pragma unroll
+            for (int i = 0; i < PK_NI; i++) {
                 pk_acc a;
-                if (w.rows <= 8) pk_walk_cached<8>(cache[i], V, table, A.px_pitch, A.vw.W, a);
-                else if (w.rows <= 10) pk_walk_cached<10>(cache[i], V, table, A.px_pitch, A.vw.W, a);
-                else pk_walk_cached<PK_ROWS_PER_LANE>(cache[i], V, table, A.px_pitch, A.vw.W, a);
-                PK_STAMP(8 + 2 * i);
+                pk_walk_sum<RR>(cache[i], S[i], table, A.vw.W, a);
                 fold(cache[i].l, a);
-                PK_STAMP(9 + 2 * i);
             }
+            PK_STAMP(9);
+        };
+        walk(std::integral_constant<int, PK_ROWS_PER_LANE>());   // (variants for patches of fewer rows per lane made the compiler spill)
         for (int j = PK_CACHED + tid; j < w.n_li; j += PK_THREADS) {
             pk_acc a;
             const int l = pk_walk_lane(V, table, A.px_pitch, A.vw.W, j, a);
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         __syncthreads();
         PK_STAMP(4);
         // ---- P7: the step of the patch's own vertices; the new positions go to the mailbox of the next grad-iter (or, after
-        // the last one, to `points_out`); the other threads clear the line sums and bands for the next grad-iter
+        // the last one, to `points_out`); the other threads clear the line sums for the next grad-iter
         const bool last = it + 1 == A.n_iters;
         for (int k = tid; k < w.n_own_v; k += PK_THREADS) {
             const int v = V.vid[k];
@@ -208,7 +215,6 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         }
         if (!last) {
             for (int i = PK_THREADS - 1 - tid; i < 6 * w.n_lines; i += PK_THREADS) V.sums[i] = 0ull;
-            for (int i = PK_THREADS - 1 - tid; i < w.n_edges; i += PK_THREADS) { V.band[i].x = 0x3fffffff; V.band[i].y = -1; }
         }
         PK_STAMP(5);
         // (no barrier here: P0 of the next grad-iter touches foreign position slots only, and its barrier orders the rest)

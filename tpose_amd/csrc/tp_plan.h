@@ -15,7 +15,7 @@
 // the descent runs, and results cannot depend on the cut (integer sums commute; every float operation is per vertex).
 //
 // Plain C++ (no HIP): tests/emul compiles this header with g++ and replays the kernel's lane functions
-// (tp_persist.h) phase by phase on the CPU against the oracle.
+// (tp_persist.h) phase by phase on the CPU.
 #pragma once
 
 #include <stdint.h>
@@ -76,7 +76,6 @@ inline int pk_lds_bytes(const pk_wg& w) {
     b += pk_align16(w.n_lines * 24);                // walkers
     b += pk_align16(w.n_slots * 8);                 // positions
     b += pk_align16((4 * w.n_own_v + w.n_slots) * 8);  // snapped positions: neighbours unmoved only, own slots + 4 moves
-    b += pk_align16(w.n_edges * 8);                 // row band of an edge's lines
     b += pk_align16(w.n_own_v * 8);                 // gradient
     b += pk_align16(w.n_slots * 4);                 // vid
     b += pk_align16(w.n_edges * 4);                 // edges
