@@ -90,7 +90,7 @@ int tp_get_ratio(const tp_context* ctx, float* ratio);
 int tp_set_dp(tp_context* ctx, float dp);
 
 /* Execution options (no counterpart in the reference, whose frame loop is fixed).  Results never depend on them.
- * TP_OPT_PERSISTENT: TP_PERSIST_AUTO (default) lets tp_iterate run all but the last of >= 4 grad-iters inside
+ * TP_OPT_PERSISTENT: TP_PERSIST_AUTO (default) lets tp_iterate run calls of >= 4 grad-iters inside
  * persistent launches (one workgroup per patch of the mesh, K grad-iters per launch) when the device keeps a full grid
  * resident; TP_PERSIST_OFF keeps every grad-iter on the two-kernel path (k_lines + k_update). */
 enum tp_option { TP_OPT_PERSISTENT = 1 };
@@ -125,8 +125,8 @@ int tp_shift(tp_context* ctx, float rate);
 void tp_default_params(int flavour, tp_params* p);
 /* n_iters x { tp_accumulate(image_slot); tp_energy(flavour); tp_shift(rate) } with no host
  * round trip (the reference reads back four buffers every frame, triangulate/main.cpp:201-204).
- * Asynchronous: returns after enqueueing; tp_retrieve / tp_synchronize wait.  From 4 grad-iters on, all but the last
- * run inside persistent launches (tp_set_option); the last one writes the buffers tp_retrieve reads. */
+ * Asynchronous: returns after enqueueing; tp_retrieve / tp_synchronize wait.  From 4 grad-iters on they run inside
+ * persistent launches (tp_set_option); the last one writes the buffers tp_retrieve reads. */
 int tp_iterate(tp_context* ctx, const tp_params* p, int n_iters);
 /* Optional: build the launch graph tp_iterate replays for these parameters now (it is otherwise built by the
  * first tp_iterate of >= 16 iterations after an upload), so that no later call pays for it.  Runs nothing.

@@ -21,7 +21,7 @@ struct part_state {
 // returns 0, or a negative code: -1 plan refused, -2 a position granule had the wrong tag
 extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, float* points, int NP, const int32_t* tris,
                             int NT, const int32_t* ca, int flavour, float dp, float ratio, float rate, int iters,
-                            int max_parts, int lds_limit, int64_t* stats) {
+                            int max_parts, int lds_limit, int64_t* stats, int32_t* ten, int32_t* cn, int32_t* ca_out, int32_t* gr) {
     tp_view vw;
     vw.dp = dp; vw.ratio = ratio; vw.halfW = 0.5f * (float)W; vw.halfH = 0.5f * (float)H; vw.W = W; vw.H = H;
     // the per-image table in pixel records, as k_prefix_px builds it
@@ -65,9 +65,10 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
         pk_carve(S[p].lds.data(), w, V);
         memcpy(V.vid, &P.pool[w.off_vid], sizeof(int32_t) * w.n_slots);
         memcpy(V.edges, &P.pool[w.off_edges], sizeof(int32_t) * w.n_edges);
-        memcpy(V.lines, &P.pool[w.off_lines], sizeof(int32_t) * w.n_lines);
-        memcpy(V.li, &P.pool[w.off_li], sizeof(int32_t) * 3 * w.n_li);
+        memcpy(V.lines, &P.pool[w.off_lines], sizeof(int32_t) * w.n_lines_all);
+        memcpy(V.li, &P.pool[w.off_li], sizeof(int32_t) * 3 * w.n_li_all);
         memcpy(V.corners, &P.pool[w.off_corners], sizeof(int32_t) * 4 * w.n_corners);
+        memcpy(V.base, &P.pool[w.off_base], sizeof(int32_t) * 4 * w.n_base);
         for (int s = 0; s < w.n_slots; s++) { V.pos[s].x = points[2 * V.vid[s]]; V.pos[s].y = points[2 * V.vid[s] + 1]; }
         S[p].cache.resize(PK_CACHED);
         for (int j = 0; j < PK_CACHED; j++) pk_cache_init(S[p].cache[j], V, j, j < w.n_li);
@@ -76,9 +77,11 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
     const char* table = reinterpret_cast<const char*>(T.data());
     for (int it = 0; it < iters; it++) {
         const uint32_t e = 1 + it, tag = pk_tag(e), par = e & 1;
+        const bool emit = it + 1 == iters && ten != nullptr;   // the last grad-iter writes the reference's buffers
         for (int p = 0; p < P.parts; p++) {
             const pk_wg& w = P.wg[p];
             pk_view& V = S[p].V;
+            const int n_lines = emit ? w.n_lines_all : w.n_lines, n_li = emit ? w.n_li_all : w.n_li;
             if (it > 0)  // P0
                 for (int s = w.n_own_v; s < w.n_slots; s++) {
                     const unsigned long long* g = &posbox[((size_t)par * NP + V.vid[s]) * 2];
@@ -88,18 +91,18 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
                 }
             // P1
             for (int j = 0; j < 5 * w.n_own_v + (w.n_slots - w.n_own_v); j++) pk_snap_lane(w, V, vw, j);
-            for (int l = 0; l < w.n_lines; l++) {
+            for (int l = 0; l < n_lines; l++) {
                 pk_walker wkr;
                 pk_setup_lane(V, vw, l, wkr);
                 V.wk[l] = wkr;
             }
-            memset(V.sums, 0, sizeof(unsigned long long) * 6 * (size_t)w.n_lines);
+            memset(V.sums, 0, sizeof(unsigned long long) * 6 * (size_t)w.n_lines_all);
             for (int k = 0; k < w.n_own_v; k++) { V.grad[k].x = 0; V.grad[k].y = 0; }
             // P3
-            for (int j = 0; j < w.n_li; j++) {
+            for (int j = 0; j < n_li; j++) {
                 pk_acc a;
                 int l;
-                if (j < PK_CACHED) {
+                if (j < PK_CACHED && j < w.n_li) {
                     pk_walk_cached<PK_ROWS_PER_LANE>(S[p].cache[j], V, table, pitch, W, a);
                     l = S[p].cache[j].l;
                 }
@@ -115,14 +118,30 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
                 for (int m = 1; m <= 4; m++) {
                     pk_i4 col = {0, 0, 0, 0};
                     if (flavour == 1 && ca) { const int32_t* c4 = ca + 4 * ((size_t)(4 * s + m) * NT + t); col.x = c4[0]; col.y = c4[1]; col.z = c4[2]; }
-                    en[m] = pk_corner_lane(w, V, k, m, flavour, col);
+                    const tp_moments mm = pk_corner_moments(w, V, k, m);
+                    en[m] = pk_energy(mm, flavour, col);
+                    if (emit) {
+                        const size_t id = (size_t)(4 * s + m) * NT + t;
+                        if (flavour == 0) { ca_out[4 * id] = tp_wrap32(mm.sr); ca_out[4 * id + 1] = tp_wrap32(mm.sg); ca_out[4 * id + 2] = tp_wrap32(mm.sb); ca_out[4 * id + 3] = 0; }
+                        ten[id] = en[m]; cn[id] = tp_wrap32(mm.n);
+                    }
                 }
                 V.grad[own].x = (int32_t)((uint32_t)V.grad[own].x + ((uint32_t)en[1] - (uint32_t)en[2]));
                 V.grad[own].y = (int32_t)((uint32_t)V.grad[own].y + ((uint32_t)en[3] - (uint32_t)en[4]));
             }
+            if (emit)
+                for (int k = 0; k < w.n_base; k++) {
+                    int t;
+                    const tp_moments mm = pk_base_moments(w, V, k, t);
+                    pk_i4 col = {0, 0, 0, 0};
+                    if (flavour == 1 && ca) { col.x = ca[4 * t]; col.y = ca[4 * t + 1]; col.z = ca[4 * t + 2]; }
+                    if (flavour == 0) { ca_out[4 * t] = tp_wrap32(mm.sr); ca_out[4 * t + 1] = tp_wrap32(mm.sg); ca_out[4 * t + 2] = tp_wrap32(mm.sb); ca_out[4 * t + 3] = 0; }
+                    ten[t] = pk_energy(mm, flavour, col); cn[t] = tp_wrap32(mm.n);
+                }
             // P7: posts go to the OTHER parity of the mailbox, so workgroups replayed later in this sweep still read this
             // grad-iter's positions
             for (int k = 0; k < w.n_own_v; k++) {
+                if (emit && gr) { gr[2 * V.vid[k]] = V.grad[k].x; gr[2 * V.vid[k] + 1] = V.grad[k].y; }
                 const pk_f2 np_ = pk_vertex_lane(V.pos[k], V.grad[k].x, V.grad[k].y, V.vid[k], ratio, rate);
                 V.pos[k] = np_;
                 uint32_t bx, by;

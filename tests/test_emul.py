@@ -234,11 +234,17 @@ def emul_persist(emp, sweep, pts, tris, flavour, ratio, rate, iters, colors=None
     p = np.ascontiguousarray(pts.copy())
     ca = np.ascontiguousarray(np.tile(colors, (13, 1)).astype(np.int32)) if colors is not None else None
     stats = np.zeros(16, np.int64)
+    out = dict(ten=np.zeros(13 * NT, np.int32), cn=np.zeros(13 * NT, np.int32), ca=np.zeros((13 * NT, 4), np.int32), gr=np.zeros((NP, 2), np.int32))
     rc = emp.emul_persist(sweep.ctypes.data_as(C.c_void_p), C.c_size_t(sweep.strides[0]), W, H, p.ctypes.data_as(C.c_void_p), NP,
                           tris.ctypes.data_as(C.c_void_p), NT, ca.ctypes.data_as(C.c_void_p) if ca is not None else None,
                           flavour, C.c_float(d), C.c_float(ratio), C.c_float(rate), iters, max_parts, lds,
-                          stats.ctypes.data_as(C.c_void_p))
+                          stats.ctypes.data_as(C.c_void_p), out["ten"].ctypes.data_as(C.c_void_p), out["cn"].ctypes.data_as(C.c_void_p),
+                          out["ca"].ctypes.data_as(C.c_void_p), out["gr"].ctypes.data_as(C.c_void_p))
+    stats_out.clear(); stats_out.update(out)
     return rc, p, stats
+
+
+stats_out = {}
 
 
 @pytest.mark.parametrize("W,H,grid", [(64, 48, (6, 4)), (300, 200, (15, 5)), (257, 131, (6, 4)), (128, 32, None)])
@@ -254,6 +260,11 @@ def test_persistent_plan_and_lanes_match_oracle(emp, W, H, grid, flavour, max_pa
     ref = O.iterate(sweep, pts, tris, flavour, ratio, rate, 6, colors=colors if flavour else None, literal=False)
     assert np.array_equal(p.view(np.uint32), ref["points"].view(np.uint32))
     assert 1 <= stats[1] <= max_parts
+    # the last grad-iter's outputs in the reference's layout: all 13 variants of every triangle, and the gradient
+    assert np.array_equal(stats_out["ten"], ref["ten"]) and np.array_equal(stats_out["cn"], ref["cn"])
+    assert np.array_equal(stats_out["gr"], ref["gr"].reshape(-1, 2))
+    if flavour == 0:
+        assert np.array_equal(stats_out["ca"], ref["ca"].reshape(-1, 4))
 
 
 def test_persistent_record_cache_over_many_grad_iters(emp):

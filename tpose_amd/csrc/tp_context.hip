@@ -302,7 +302,8 @@ int ensure_plan(tp_context* c, float dp, bool* use) {
     return TP_OK;
 }
 
-// n grad-iters of the persistent kernel (positions only), then `points_out` -> `points` / `epos`
+// n grad-iters of the persistent kernel -- the last one writes `tenergy`, `colnum`, `colacc`, `gradient` --, then
+// `points_out` -> `points` / `epos`
 int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n) {
     while (n > 0) {
         const int k = n < PK_MAX_LAUNCH ? n : PK_MAX_LAUNCH;
@@ -319,6 +320,7 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n) {
         A.flavour = p.flavour; A.rate = p.rate;
         A.posbox = c->posbox;
         A.epoch = c->epoch; A.n_iters = k; A.status = c->d_status;
+        A.emit = n == k; A.ten = c->ten; A.cn = c->cn; A.ca_out = c->ca; A.gr = c->gr;
 #ifdef TPOSE_DEBUG
         A.dbg = persist_dbg_buffer(c->plan.parts, c->stream);
         { const char* f = getenv("TPOSE_DBG_FIRST"); A.dbg_first = f ? atoi(f) : 0; }
@@ -739,13 +741,12 @@ int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
 
     int left = n_iters;
     if (left >= PK_MIN_ITERS) {
-        // all but the last grad-iter inside persistent launches (positions only); the last one through k_lines + k_update,
-        // which write the buffers the reference reads back (`tenergy`, `colnum`, `colacc`, `gradient`)
+        // inside persistent launches; the last grad-iter also writes the buffers the reference reads back
         bool use = false;
         if (int rc = ensure_plan(c, dp, &use)) return rc;
         if (use) {
-            if (int rc = enqueue_persistent(c, *p, dp, left - 1)) return rc;
-            left = 1;
+            if (int rc = enqueue_persistent(c, *p, dp, left)) return rc;
+            left = 0;
         }
     }
     if (left >= CHUNK) {

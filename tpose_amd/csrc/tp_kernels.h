@@ -65,7 +65,9 @@ struct pk_args {
     int px_pitch;
     const float2* points;       // positions at the start of the launch
     float2* points_out;         // positions after n_iters grad-iters (vertices of at least one triangle only)
-    const int4* ca;             // warp flavour: the stored colours, replicated x13 by upload
+    const int4* ca;             // warp flavour: the stored colours, replicated x13 by upload (`colacc` as it stands)
+    int emit;                   // the last grad-iter of this launch writes the reference's buffers:
+    int32_t* ten; int32_t* cn; int4* ca_out; int2* gr;   // `tenergy`, `colnum`, `colacc` (triangulate), `gradient`
     int NT, NP, NE;
     int flavour;
     float rate;

@@ -669,7 +669,13 @@ __global__ void k_persist_finish(tp_launch L, const float2* points_out) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= L.NP) return;
     float2 p = L.points[v];
-    if (L.vtx_off[v + 1] > L.vtx_off[v]) { p = points_out[v]; L.points[v] = p; }
+    if (L.vtx_off[v + 1] > L.vtx_off[v]) p = points_out[v];
+    else if (v >= 4) {   // shift.cs:25-43 runs for every i in [4, NPoints): a vertex no triangle uses is still clamped
+        const float R = L.vw.ratio;
+        p.x = p.x <= -R ? -R : (p.x >= R ? R : p.x);
+        p.y = p.y <= -1.0f ? -1.0f : (p.y >= 1.0f ? 1.0f : p.y);
+    }
+    L.points[v] = p;
     publish_position(L, v, p, 0, 1);
 }
 void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, hipStream_t s) {

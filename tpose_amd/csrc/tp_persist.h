@@ -9,8 +9,9 @@
 //   P6  forms the four displaced variants of every corner (own vertex, incident triangle): moments = signed sum of
 //       three line sums, energy (triangle.fs:37-43), central differences (gradient.cs) into the vertex's gradient,
 //   P7  takes the shift.cs step of its own vertices and posts the new positions.
-// The buffers the reference reads back (`tenergy`, `colnum`, `colacc`, `gradient`) are not produced here: the LAST
-// grad-iter of a tp_iterate call runs through k_lines + k_update (tp_kernels.hip), which write them.
+// The buffers the reference reads back (`tenergy`, `colnum`, `colacc`, `gradient`) are written by the LAST grad-iter of a
+// tp_iterate call only: that one also walks the base lines the base variants need (tp_plan.h) and stores every
+// variant's outputs in the reference's layout.
 //
 // Everything here is __host__ __device__: tests/emul replays the phases on the CPU, workgroup by workgroup, with the
 // mailboxes replaced by plain copies, and tests/test_emul.py compares the result with the CPU restatement of the reference.
@@ -28,8 +29,8 @@ struct pk_walker { int64_t x, s; int32_t ra, rb; };  // tp_line
 
 // the workgroup's LDS, carved in the order of pk_lds_bytes (tp_plan.h)
 struct pk_view {
-    unsigned long long* sums;  // [n_lines][6] line sums {sum x, n_odd, sum r, sum g, sum b, q}
-    pk_walker* wk;             // [n_lines]
+    unsigned long long* sums;  // [n_lines_all][6] line sums {sum x, n_odd, sum r, sum g, sum b, q}
+    pk_walker* wk;             // [n_lines_all]
     pk_f2* pos;                // [n_slots]
     pk_i2* snap;               // own slot k: [5 k + move]; neighbour slot s: [5 n_own_v + s - n_own_v] (unmoved)
     pk_i2* grad;               // [n_own_v]
@@ -38,21 +39,23 @@ struct pk_view {
     int32_t* lines;
     int32_t* li;
     pk_i4* corners;
+    pk_i4* base;
     int32_t* flags;
 };
 
 TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     char* p = base;
-    V.sums = (unsigned long long*)p; p += pk_align16(w.n_lines * 48);
-    V.wk = (pk_walker*)p; p += pk_align16(w.n_lines * 24);
+    V.sums = (unsigned long long*)p; p += pk_align16(w.n_lines_all * 48);
+    V.wk = (pk_walker*)p; p += pk_align16(w.n_lines_all * 24);
     V.pos = (pk_f2*)p; p += pk_align16(w.n_slots * 8);
     V.snap = (pk_i2*)p; p += pk_align16((4 * w.n_own_v + w.n_slots) * 8);
     V.grad = (pk_i2*)p; p += pk_align16(w.n_own_v * 8);
     V.vid = (int32_t*)p; p += pk_align16(w.n_slots * 4);
     V.edges = (int32_t*)p; p += pk_align16(w.n_edges * 4);
-    V.lines = (int32_t*)p; p += pk_align16(w.n_lines * 4);
-    V.li = (int32_t*)p; p += pk_align16(w.n_li * 12);
+    V.lines = (int32_t*)p; p += pk_align16(w.n_lines_all * 4);
+    V.li = (int32_t*)p; p += pk_align16(w.n_li_all * 12);
     V.corners = (pk_i4*)p; p += pk_align16(w.n_corners * 16);
+    V.base = (pk_i4*)p; p += pk_align16(w.n_base * 16);
     V.flags = (int32_t*)p;
 }
 
@@ -263,10 +266,17 @@ TP_HD void pk_walk_cached(pk_lane_cache<R>& C, const pk_view& V, const char* tab
 // tag of grad-iter `epoch` (1 .. 32767 between two resets of the mailbox): never 0, differs between e and e - 2
 TP_HD uint32_t pk_tag(uint32_t epoch) { return 0x8000u | (epoch & 0x7fffu); }
 
-// P6, lane (corner k, move m = 1..4): the energy of variant (t, 4 s + m) of the corner's triangle -- the corner's vertex
-// displaced by move m.  Moments = signed sum of three line sums (tp_raster.h, "Edge-centric form"); energy as
-// k_update's emit_variant.  col: the stored colour of the variant (warp flavour; triangle.fs:49-50).
-TP_HD int32_t pk_corner_lane(const pk_wg& w, const pk_view& V, int k, int m, int flavour, pk_i4 col) {
+// signed sum of three line sums: the exact pixel moments of a variant (tp_raster.h, "Edge-centric form")
+TP_HD tp_moments pk_moments3(int c0, const unsigned long long* S0, int c1, const unsigned long long* S1, int c2, const unsigned long long* S2) {
+    int64_t mo[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) mo[q] = (int64_t)c0 * (int64_t)S0[q] + (int64_t)c1 * (int64_t)S1[q] + (int64_t)c2 * (int64_t)S2[q];
+    const tp_moments mm = {mo[0], mo[1], mo[2], mo[3], mo[4], mo[5]};
+    return mm;
+}
+// P6, lane (corner k, move m = 1..4): the moments of variant (t, 4 s + m) of the corner's triangle -- the corner's vertex
+// displaced by move m
+TP_HD tp_moments pk_corner_moments(const pk_wg& w, const pk_view& V, int k, int m) {
     const pk_i4 cr = V.corners[k];
     const int s = cr.y & 3, own = (cr.y >> 2) & 0x3ff, sa = (cr.y >> 12) & 0x3ff, sb = (cr.y >> 22) & 0x3ff;
     const int sn = s == 2 ? 0 : s + 1, sp = s == 0 ? 2 : s - 1;
@@ -278,15 +288,24 @@ TP_HD int32_t pk_corner_lane(const pk_wg& w, const pk_view& V, int k, int m, int
     const int cs = s == 0 ? c[0] : s == 1 ? c[1] : c[2];
     const int cn = sn == 0 ? c[0] : sn == 1 ? c[1] : c[2];
     const int cp = sp == 0 ? c[0] : sp == 1 ? c[1] : c[2];
-    const unsigned long long* Sout = V.sums + (size_t)((cr.z & 0xffff) + m - 1) * 6;
-    const unsigned long long* Sin = V.sums + (size_t)(((cr.z >> 16) & 0xffff) + m - 1) * 6;
-    const unsigned long long* Sopp = V.sums + (size_t)(cr.w & 0xffff) * 6;
-    int64_t mo[6];
-#pragma unroll
-    for (int q = 0; q < 6; q++) mo[q] = (int64_t)cs * (int64_t)Sout[q] + (int64_t)cp * (int64_t)Sin[q] + (int64_t)cn * (int64_t)Sopp[q];
-    const tp_moments mm = {mo[0], mo[1], mo[2], mo[3], mo[4], mo[5]};
-    const int64_t E = flavour == 0 ? tp_energy_triangulate(mm) : tp_energy64(mm, col.x, col.y, col.z);
-    return tp_wrap32(E);
+    return pk_moments3(cs, V.sums + (size_t)((cr.z & 0xffff) + m - 1) * 6, cp, V.sums + (size_t)(((cr.z >> 16) & 0xffff) + m - 1) * 6,
+                       cn, V.sums + (size_t)(cr.w & 0xffff) * 6);
+}
+// energy of a variant as k_update's emit_variant forms it (triangle.fs:37-43; warp: against the stored colour, :46-53)
+TP_HD int32_t pk_energy(const tp_moments& mm, int flavour, pk_i4 col) {
+    return tp_wrap32(flavour == 0 ? tp_energy_triangulate(mm) : tp_energy64(mm, col.x, col.y, col.z));
+}
+// last grad-iter of a call, base variant k of the patch (a triangle whose first vertex it owns): moments from the three base lines
+TP_HD tp_moments pk_base_moments(const pk_wg& w, const pk_view& V, int k, int& t) {
+    const pk_i4 b = V.base[k];
+    t = b.x;
+    const int own = b.y & 0x3ff, s1 = (b.y >> 10) & 0x3ff, s2 = (b.y >> 20) & 0x3ff;
+    int32_t X[3], Y[3], c[3];
+    const pk_i2 p0 = V.snap[pk_snap_index(w, own, 0)], p1 = V.snap[pk_snap_index(w, s1, 0)], p2 = V.snap[pk_snap_index(w, s2, 0)];
+    X[0] = p0.x; Y[0] = p0.y; X[1] = p1.x; Y[1] = p1.y; X[2] = p2.x; Y[2] = p2.y;
+    tp_variant_coeffs(X, Y, c);
+    return pk_moments3(c[0], V.sums + (size_t)(b.z & 0xffff) * 6, c[1], V.sums + (size_t)((b.z >> 16) & 0xffff) * 6,
+                       c[2], V.sums + (size_t)(b.w & 0xffff) * 6);
 }
 
 // P7, own vertex k with gradient (gx, gy): the shift.cs step (shift.cs:16-47).  Vertices 0..3 never move.

@@ -81,14 +81,15 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         const int32_t* pool = A.pool;
         for (int i = tid; i < w.n_slots; i += PK_THREADS) V.vid[i] = pool[w.off_vid + i];
         for (int i = tid; i < w.n_edges; i += PK_THREADS) V.edges[i] = pool[w.off_edges + i];
-        for (int i = tid; i < w.n_lines; i += PK_THREADS) V.lines[i] = pool[w.off_lines + i];
-        for (int i = tid; i < 3 * w.n_li; i += PK_THREADS) V.li[i] = pool[w.off_li + i];
+        for (int i = tid; i < w.n_lines_all; i += PK_THREADS) V.lines[i] = pool[w.off_lines + i];
+        for (int i = tid; i < 3 * w.n_li_all; i += PK_THREADS) V.li[i] = pool[w.off_li + i];
         for (int i = tid; i < 4 * w.n_corners; i += PK_THREADS) ((int32_t*)V.corners)[i] = pool[w.off_corners + i];
+        for (int i = tid; i < 4 * w.n_base; i += PK_THREADS) ((int32_t*)V.base)[i] = pool[w.off_base + i];
         for (int i = tid; i < w.n_slots; i += PK_THREADS) {
             const float2 p = A.points[pool[w.off_vid + i]];
             V.pos[i].x = p.x; V.pos[i].y = p.y;
         }
-        for (int i = tid; i < 6 * w.n_lines; i += PK_THREADS) V.sums[i] = 0ull;
+        for (int i = tid; i < 6 * w.n_lines_all; i += PK_THREADS) V.sums[i] = 0ull;
         if (tid == 0) V.flags[0] = 0;
     }
     // the stored colour of this lane's variant (warp flavour: `colacc` as uploaded, triangle.fs:49-50) never changes
@@ -111,6 +112,9 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
 
     for (int it = 0; it < A.n_iters; it++) {
         const uint32_t epoch = A.epoch + (uint32_t)it, tag = pk_tag(epoch), par = epoch & 1u;
+        // the last grad-iter of a call that wants the reference's buffers also walks the base lines of the base variants
+        const bool last = it + 1 == A.n_iters, emit = last && A.emit;
+        const int n_lines = emit ? w.n_lines_all : w.n_lines, n_li = emit ? w.n_li_all : w.n_li;
         PK_STAMP(0);
         // ---- P0: positions of the neighbouring vertices this patch uses (the first grad-iter of a launch read `points`)
         if (it > 0) {
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         if (__syncthreads_or(failed)) return;
         PK_STAMP(1);
         // ---- P1: line set-up (low threads), snapped positions (high threads), gradient reset
-        for (int l = tid; l < w.n_lines; l += PK_THREADS) {
+        for (int l = tid; l < n_lines; l += PK_THREADS) {
             pk_walker wk;
             pk_setup_lane(V, A.vw, l, wk);
             V.wk[l] = wk;
@@ -169,7 +173,8 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
             PK_STAMP(9);
         };
         walk(std::integral_constant<int, PK_ROWS_PER_LANE>());   // (variants for patches of fewer rows per lane made the compiler spill)
-        for (int j = PK_CACHED + tid; j < w.n_li; j += PK_THREADS) {
+        // (lane-items beyond the cached ones: a patch with more than PK_CACHED, and the base lines of the last grad-iter)
+        for (int j = (w.n_li < PK_CACHED ? w.n_li : PK_CACHED) + tid; j < n_li; j += PK_THREADS) {
             pk_acc a;
             const int l = pk_walk_lane(V, table, A.px_pitch, A.vw.W, j, a);
             fold(l, a);
@@ -182,23 +187,40 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
             const int k = j >> 2, m = (j & 3) + 1;
             pk_i4 col = col0;
             if (A.flavour == 1 && j >= PK_THREADS) {
-                const pk_i4 cr = V.corners[k];
-                const int4 c = A.ca[(size_t)(4 * (cr.y & 3) + m) * A.NT + cr.x];
+                const pk_i4 cq = V.corners[k];
+                const int4 c = A.ca[(size_t)(4 * (cq.y & 3) + m) * A.NT + cq.x];
                 col.x = c.x; col.y = c.y; col.z = c.z;
             }
-            const int32_t e = pk_corner_lane(w, V, k, m, A.flavour, col);
+            const pk_i4 cr = V.corners[k];
+            const tp_moments mm = pk_corner_moments(w, V, k, m);
+            const int32_t e = pk_energy(mm, A.flavour, col);
             const uint32_t d = (uint32_t)e - (uint32_t)__shfl_xor(e, 1);   // lanes 4k+0/1: E(+dx), E(-dx); 4k+2/3: E(+dy), E(-dy)
-            const int own = (V.corners[k].y >> 2) & 0x3ff;
+            const int own = (cr.y >> 2) & 0x3ff;
             if ((j & 3) == 0) atomicAdd(&V.grad[own].x, (int)d);
             if ((j & 3) == 2) atomicAdd(&V.grad[own].y, (int)d);
+            if (emit) {   // the variant's outputs in the reference's layout, id = i NT + t (triangle.vs:47-48)
+                const size_t id = (size_t)(4 * (cr.y & 3) + m) * A.NT + cr.x;
+                if (A.flavour == 0) A.ca_out[id] = make_int4(tp_wrap32(mm.sr), tp_wrap32(mm.sg), tp_wrap32(mm.sb), 0);
+                A.ten[id] = e; A.cn[id] = tp_wrap32(mm.n);
+            }
+        }
+        if (emit) {   // base variants (i = 0) of the triangles whose first vertex this patch owns
+            for (int k = tid; k < w.n_base; k += PK_THREADS) {
+                int t;
+                const tp_moments mm = pk_base_moments(w, V, k, t);
+                pk_i4 col = {0, 0, 0, 0};
+                if (A.flavour == 1) { const int4 c = A.ca[t]; col.x = c.x; col.y = c.y; col.z = c.z; }
+                if (A.flavour == 0) A.ca_out[t] = make_int4(tp_wrap32(mm.sr), tp_wrap32(mm.sg), tp_wrap32(mm.sb), 0);
+                A.ten[t] = pk_energy(mm, A.flavour, col); A.cn[t] = tp_wrap32(mm.n);
+            }
         }
         __syncthreads();
         PK_STAMP(4);
         // ---- P7: the step of the patch's own vertices; the new positions go to the mailbox of the next grad-iter (or, after
         // the last one, to `points_out`); the other threads clear the line sums for the next grad-iter
-        const bool last = it + 1 == A.n_iters;
         for (int k = tid; k < w.n_own_v; k += PK_THREADS) {
             const int v = V.vid[k];
+            if (emit) A.gr[v] = make_int2(V.grad[k].x, V.grad[k].y);
 #if defined(PK_EXP_FREEZE)  // timing experiments only: the mesh stands still
             const pk_f2 p = pk_vertex_lane(V.pos[k], V.grad[k].x, V.grad[k].y, v, A.vw.ratio, 0.0f);
 #else

@@ -39,15 +39,18 @@
 struct pk_wg {
     int32_t n_own_v, n_slots;  // position slots: the patch's own vertices first, then the neighbours it reads
     int32_t n_edges;           // local edges: every edge one of the patch's corners uses
-    int32_t n_lines;           // lines the patch walks = line-sum slots (per local edge: its needed versions, ascending)
-    int32_t n_li;              // lane-items of the walk: (line, chunk)
+    int32_t n_lines;           // lines the patch walks every grad-iter = line-sum slots (per local edge: its needed versions, ascending)
+    int32_t n_lines_all;       // ... plus the base lines only the LAST grad-iter of a call walks (outputs of the base variants)
+    int32_t n_li, n_li_all;    // lane-items of the walk: (line, chunk); likewise
     int32_t n_corners;         // (own vertex, incident triangle): four lanes each, one per move
+    int32_t n_base;            // triangles whose first vertex the patch owns: it writes their base variant's outputs
     int32_t rows;              // rows a lane of the walk takes: chunks per line = the line's rows / this (<= PK_ROWS_PER_LANE)
     int32_t off_vid;           // [n_slots] global vertex id
     int32_t off_edges;         // [n_edges] slot_u | slot_v << 16
     int32_t off_lines;         // [n_lines] local edge | version << 16
     int32_t off_li;            // [n_li] {line | chunk << 16, chunks, magic = floor(2^32 / chunks) + 1 (0: one chunk)}
     int32_t off_corners;       // [n_corners] {t, s | own << 2 | slot_a << 12 | slot_b << 22, out | in << 16, opp}
+    int32_t off_base;          // [n_base] {t, own | slot_1 << 10 | slot_2 << 20, line of edge 0 | edge 1 << 16, line of edge 2}
     int32_t lds_bytes;         // dynamic LDS of this workgroup (pk_lds_bytes)
 };
 
@@ -72,16 +75,17 @@ struct pk_plan {
 PK_HD int pk_align16(int v) { return (v + 15) & ~15; }
 inline int pk_lds_bytes(const pk_wg& w) {
     int b = 0;
-    b += pk_align16(w.n_lines * 48);                // line sums: six 64-bit words
-    b += pk_align16(w.n_lines * 24);                // walkers
+    b += pk_align16(w.n_lines_all * 48);            // line sums: six 64-bit words
+    b += pk_align16(w.n_lines_all * 24);            // walkers
     b += pk_align16(w.n_slots * 8);                 // positions
     b += pk_align16((4 * w.n_own_v + w.n_slots) * 8);  // snapped positions: neighbours unmoved only, own slots + 4 moves
     b += pk_align16(w.n_own_v * 8);                 // gradient
     b += pk_align16(w.n_slots * 4);                 // vid
     b += pk_align16(w.n_edges * 4);                 // edges
-    b += pk_align16(w.n_lines * 4);                 // lines
-    b += pk_align16(w.n_li * 12);                   // lane-items
+    b += pk_align16(w.n_lines_all * 4);             // lines
+    b += pk_align16(w.n_li_all * 12);               // lane-items
     b += pk_align16(w.n_corners * 16);              // corners
+    b += pk_align16(w.n_base * 16);                 // base variants
     return b + 64;                                  // flags
 }
 
@@ -207,16 +211,16 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
     P.parts = parts;
     P.wg.assign((size_t)parts, pk_wg());
     std::vector<int> vslot((size_t)NP, 0), vstamp((size_t)NP, -1), eloc((size_t)NE, 0), estamp((size_t)NE, -1);
-    std::vector<int32_t> vid, edges, emask, eglob, lines, li, corners, first;
+    std::vector<int32_t> vid, edges, emask, eglob, lines, li, corners, first, base;
     for (int p = 0; p < parts; p++) {
         pk_wg& w = P.wg[p];
-        vid.clear(); edges.clear(); emask.clear(); eglob.clear(); lines.clear(); li.clear(); corners.clear();
+        vid.clear(); edges.clear(); emask.clear(); eglob.clear(); lines.clear(); li.clear(); corners.clear(); base.clear();
         auto slot = [&](int v) {
             if (vstamp[v] != p) { vstamp[v] = p; vslot[v] = (int)vid.size(); vid.push_back(v); }
             return vslot[v];
         };
         // which versions of edge e the patch needs: bit 0 the base line, bit 1 versions 1..4 (first endpoint displaced),
-        // bit 2 versions 5..8 (second endpoint displaced)
+        // bit 2 versions 5..8 (second endpoint displaced); bit 3: the base line, for the outputs of a base variant only
         auto need = [&](int e, int bits) {
             if (estamp[e] != p) {
                 estamp[e] = p; eloc[e] = (int)eglob.size();
@@ -236,6 +240,7 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
                 need(he_out >> 1, (he_out & 1) ? 4 : 2);
                 need(he_in >> 1, (he_in & 1) ? 2 : 4);
                 need(he_opp >> 1, 1);
+                if (s == 0) { need(he_out >> 1, 8); need(he_in >> 1, 8); }   // the triangle's base variant is this patch's to write
             }
         // local edges in order of first use; their lines (needed versions, ascending) and lane-items
         w.n_edges = (int)eglob.size();
@@ -247,7 +252,7 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
             long n = 0;
             for (int le = 0; le < w.n_edges; le++) {
                 int nl = 0;
-                for (int q = 0; q < PK_NLINES; q++) nl += (emask[le] & (q == 0 ? 1 : q <= 4 ? 2 : 4)) != 0;
+                for (int q = 0; q < PK_NLINES; q++) nl += (emask[le] & (q == 0 ? 1 : q <= 4 ? 2 : 4)) != 0;   // (the lines of every grad-iter)
                 const int tl = std::max(1, std::min((int)std::ceil((rows[eglob[le]] + dp_px) / (float)rpl), PK_MAX_TL));
                 n += (long)nl * tl;
             }
@@ -277,7 +282,19 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
         }
         w.n_lines = (int)lines.size();
         w.n_li = (int)(li.size() / 3);
-        if (w.n_lines > 65535) { P.why = "a patch walks more than 65535 lines"; return; }
+        // base lines only the outputs of base variants need: walked by the last grad-iter of a call, after the others
+        for (int le = 0; le < w.n_edges; le++) {
+            if ((emask[le] & 9) != 8) continue;
+            const float r = rows[eglob[le]] + dp_px;
+            const int tl = std::max(1, std::min((int)std::ceil(r / (float)rpl), PK_MAX_TL));
+            const uint32_t magic = tl == 1 ? 0u : (uint32_t)(0x100000000ull / (uint64_t)tl) + 1u;
+            first[(size_t)le * PK_NLINES] = (int)lines.size();
+            for (int c = 0; c < tl; c++) { li.push_back((int)lines.size() | (c << 16)); li.push_back(tl); li.push_back((int32_t)magic); }
+            lines.push_back(le);
+        }
+        w.n_lines_all = (int)lines.size();
+        w.n_li_all = (int)(li.size() / 3);
+        if (w.n_lines_all > 65535) { P.why = "a patch walks more than 65535 lines"; return; }
         for (int k = 0; k < w.n_own_v; k++) {
             const int v = own_v[p][k];
             for (int j = voff[v]; j < voff[v + 1]; j++) {
@@ -292,9 +309,16 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
                 corners.push_back(s | (k << 2) | (slot(va) << 12) | (slot(vb) << 22));
                 corners.push_back(so | (si << 16));
                 corners.push_back(sopp);
+                if (s == 0) {
+                    base.push_back(t);
+                    base.push_back(k | (slot(va) << 10) | (slot(vb) << 20));
+                    base.push_back(first[(size_t)eloc[he_out >> 1] * PK_NLINES] | (sopp << 16));
+                    base.push_back(first[(size_t)eloc[he_in >> 1] * PK_NLINES]);
+                }
             }
         }
         w.n_corners = (int)(corners.size() / 4);
+        w.n_base = (int)(base.size() / 4);
         w.n_slots = (int)vid.size();
         if (w.n_slots > PK_MAX_SLOTS || w.n_own_v > 1023) { P.why = "a patch reads more than 1023 vertices"; return; }
         auto put = [&](const std::vector<int32_t>& src) {
@@ -304,6 +328,7 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
             return off;
         };
         w.off_vid = put(vid); w.off_edges = put(edges); w.off_lines = put(lines); w.off_li = put(li); w.off_corners = put(corners);
+        w.off_base = put(base);
         w.lds_bytes = pk_lds_bytes(w);
         P.lds_bytes = std::max(P.lds_bytes, w.lds_bytes);
         P.lines_total += w.n_lines; P.foreign_total += w.n_slots - w.n_own_v;
