@@ -2,8 +2,8 @@
 """bench.py -- headline benchmark of the t-pose hot path on MI355X.
 
 Metric (BASELINE.json): triangles*grad-iters / second at a 2048x2048 RGBA8 raster, 3000 triangles,
-plus the achieved fraction of the HBM roofline of the dominant kernel (k_lines: the pixel sums of every edge line,
-read from the per-image row prefix table).
+plus the achieved fraction of the HBM roofline of the dominant kernel (k_persist: K grad-iters per launch, one workgroup
+per patch of the mesh; the line sums read the per-image row prefix table).
 
   python bench.py --gpus N --steps K --warmup W
 
@@ -26,7 +26,9 @@ import numpy as np  # noqa: E402
 
 W = H = 2048
 NT = 3000
-DOMINANT = "k_lines"  # the kernel the roofline figure is about
+DOMINANT = "k_persist"  # the kernel the roofline figure is about: K grad-iters per launch
+CONTRAST = 0.1          # photograph-like contrast of the synthetic raster (tpose_amd/synth.py: workload)
+CHILD_ITERS = 256       # grad-iters per k_persist launch in the profiler passes
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -85,9 +87,9 @@ def cpu_baseline(img, pts, tris, ratio, budget_s=14.0):
 
 
 def live_pmc_traffic(timeout_s=150):
-    """HBM-side bytes per k_lines launch, collected NOW: two separate rocprofv3 --pmc passes (FETCH_SIZE,
-    WRITE_SIZE; counters only, no trace domains) over a child run of this script (64 fused grad-iters of the same
-    workload), corrected as the MI355X guide prescribes for gfx950 (2 x FETCH_SIZE + WRITE_SIZE, units KB).
+    """HBM-side bytes per k_persist launch (CHILD_ITERS grad-iters), collected NOW: two separate rocprofv3 --pmc passes
+    (FETCH_SIZE, WRITE_SIZE; counters only, no trace domains) over a child run of this script (the same workload),
+    corrected as the MI355X guide prescribes for gfx950 (2 x FETCH_SIZE + WRITE_SIZE, units KB).
     Returns (bytes, note) or (None, reason)."""
     import csv
     import glob
@@ -120,12 +122,12 @@ def live_pmc_traffic(timeout_s=150):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return int((2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]) * 1024), \
-        "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 80 launches each), 2 x FETCH + WRITE, KB"
+        "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 4 launches of %d grad-iters each), 2 x FETCH + WRITE, KB" % CHILD_ITERS
 
 
 def live_kernel_trace(timeout_s=150):
-    """Average duration of the kernels of a grad-iter as rocprofv3 sees them: `rocprofv3 --kernel-trace --stats` over a
-    child run of this script (256 fused grad-iters of the same workload).  Returns ({kernel: avg_us}, note) or (None, reason)."""
+    """Average duration of the kernels as rocprofv3 sees them: `rocprofv3 --kernel-trace --stats` over a child run of this
+    script (4 launches of CHILD_ITERS grad-iters of the same workload).  Returns ({kernel: avg_us}, note) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -146,8 +148,12 @@ def live_kernel_trace(timeout_s=150):
         for row in csv.DictReader(open(files[0])):
             name = row["Name"].split("(")[0].replace("void ", "")
             if name.startswith("k_"):
-                out[name] = {"avg_us": float(row["AverageNs"]) / 1e3, "calls": int(row["Calls"])}
-        return out, "live: rocprofv3 --kernel-trace --stats over 256 fused grad-iters (child run)"
+                avg, calls = float(row["AverageNs"]) / 1e3, int(row["Calls"])
+                if name == DOMINANT and calls > 1 and "MinNs" in row:
+                    # one of the launches is the census of resident workgroups (the same kernel, a few microseconds): leave it out
+                    avg, calls = (avg * calls - float(row["MinNs"]) / 1e3) / (calls - 1), calls - 1
+                out[name] = {"avg_us": avg, "calls": calls}
+        return out, "live: rocprofv3 --kernel-trace --stats over 4 launches of %d grad-iters (child run)" % CHILD_ITERS
     except Exception as e:  # noqa: BLE001 -- measurement is best effort, the bench line must still appear
         return None, "kernel trace: %s" % e
     finally:
@@ -192,7 +198,7 @@ def main():
         local_rank = 0
 
     # independent replica per rank: its own image (seeded by rank) and triangulation
-    img, pts, tris, he, ratio = synth.workload(W, H, NT, seed=dist_util.replica_seed(rank))
+    img, pts, tris, he, ratio = synth.workload(W, H, NT, seed=dist_util.replica_seed(rank), contrast=CONTRAST)
     NP = pts.shape[0]
     ctx = capi.Context(local_rank, W, H)
     ctx.set_image(capi.IMAGE_A, img)
@@ -214,20 +220,24 @@ def main():
 
     if args.pmc_child or args.trace_child:  # what the profiler passes sample: fused grad-iters, nothing else
         ctx.prepare(params)
-        ctx.iterate(params, 256 if args.trace_child else 80)
+        for _ in range(4):
+            ctx.iterate(params, CHILD_ITERS)
         ctx.synchronize()
         ctx.close()
         return
-    ctx.prepare(params)  # the launch graph of the fused iteration is built here, whatever --warmup and --steps are
+    ctx.prepare(params)  # the plan of the persistent launches (and the census of resident workgroups) is built here
     ctx.iterate(params, args.warmup)
     sync_all()
     # the timed region: exactly K steps, barrier + synchronize on both sides, max over ranks; repeated REPEATS times
-    # (each repeat continues the descent from where the last one stopped), the MEDIAN is reported
-    times = []
+    # (each repeat continues the descent from where the last one stopped), the MEDIAN is reported.  HIP events on the
+    # library's own stream bracket the same region (what the device spent, without the host's launch and wait).
+    times, dev_us = [], []
     for rep in range(args.repeats):
         sync_all()
         t0 = time.perf_counter()
+        ctx.timer_start()
         ctx.iterate(params, args.steps)
+        dev_us.append(ctx.timer_stop())
         ctx.synchronize()
         torch.cuda.synchronize()
         dt_rep = time.perf_counter() - t0
@@ -237,48 +247,53 @@ def main():
     dt = sorted(times)[len(times) // 2]
     if dist is not None:
         dist.barrier()
+    patches, persist_iters = ctx.info(capi.INFO_PATCHES), ctx.info(capi.INFO_PERSIST_ITERS)
 
-    # dominant kernel: average k_lines launch duration, HIP events on the library's own stream, right
-    # after the timed region, same workload and state: 4 x 64 back-to-back launches replayed as a graph (the
-    # way the kernel runs in the fused path); the eager per-dispatch figure is kept beside it
-    acc_samples = sorted(ctx.profile_accumulate(params, 64) for _ in range(5))
-    acc_us = acc_samples[len(acc_samples) // 2]
-    acc_us_eager = ctx.profile_iterate(params, 256)
+    # dominant kernel: k_persist, CHILD_ITERS grad-iters per launch, HIP events on the library's stream right after the timed
+    # region, same workload and state (the events also cover the small kernel that files the positions: < 3 us per launch)
+    ev_samples = []
+    for _ in range(5):
+        ctx.timer_start()
+        ctx.iterate(params, CHILD_ITERS)
+        ev_samples.append(ctx.timer_stop())
+    ev_samples.sort()
+    kern_us_events = ev_samples[len(ev_samples) // 2]
+    # the two-kernel path (k_lines + k_update per grad-iter: what every call ran through before round 3, and what calls
+    # of fewer than 4 grad-iters and rasters wider than 4096 columns still use), same state, for comparison
+    ctx.set_persistent(False)
+    ctx.prepare(params)
+    ctx.iterate(params, 64)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.iterate(params, 512)
+    ctx.synchronize()
+    two_kernel_ms = (time.perf_counter() - t0) / 512 * 1e3
     # the reference's frame (software/triangulate/main.cpp:196-204): one grad-iter, then terr, perr, cn and the points
     # read back -- reported beside the fused figure, never as `value`
-    ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(256):
         ctx.iterate(params, 1)
         ctx.retrieve_many([capi.BUF_TENERGY, capi.BUF_PENERGY, capi.BUF_COLNUM, capi.BUF_POINTS])
     readback_ms = (time.perf_counter() - t0) / 256 * 1e3
+    ctx.set_persistent(True)
     bytes_iter = algorithmic_bytes(W, H, NT, NP)
-    # the same kernel as rocprofv3 sees it inside the fused path (what profiles/ holds): the roofline figure uses THIS
-    # duration when it is available, so that it can be reproduced from a kernel trace; the HIP-event figure stays beside it
+    # the same kernel as rocprofv3 sees it (what profiles/ holds): the roofline figure uses THIS duration when it is
+    # available, so that it can be reproduced from a kernel trace; the HIP-event figure stays beside it
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     trace, trace_note = (None, "skipped")
     if rank == 0 and world == 1 and not args.no_pmc and not under_profiler:
         ctx.synchronize()
         trace, trace_note = live_kernel_trace()
-    acc_us_events = acc_us
+    kern_us = kern_us_events
     if trace and DOMINANT in trace:
-        acc_us = trace[DOMINANT]["avg_us"]
-    achieved = bytes_iter / (acc_us * 1e-6) / 1e9
+        kern_us = trace[DOMINANT]["avg_us"]
+    achieved = bytes_iter * CHILD_ITERS / (kern_us * 1e-6) / 1e9
     # HBM-side traffic of the same kernel: 2 x FETCH_SIZE + WRITE_SIZE per launch (the gfx950 correction of the
-    # guide), from two live counter passes over a child run; the committed passes are the fall-back
+    # guide), from two live counter passes over a child run
     traffic, traffic_source = None, None
     if rank == 0 and world == 1 and not args.no_pmc and not under_profiler:  # never nest profilers
         ctx.synchronize()
         traffic, traffic_source = live_pmc_traffic()
-    if traffic is None:
-        why = traffic_source
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")))
-            traffic = pmc[DOMINANT]["hbm_bytes_per_launch_corrected"]
-            traffic_source = "profiles/r02_pmc_hbm.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" + \
-                (" -- live passes unavailable: %s" % why if why else "")
-        except Exception:
-            traffic_source = why
 
     if rank == 0:
         line = {
@@ -289,29 +304,40 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "timing": "median of %d timed regions of %d steps; ms_per_step of each: %s" % (
                 len(times), args.steps, ", ".join("%.5f" % (t / args.steps * 1e3) for t in times)),
+            "ms_per_step_device": sorted(dev_us)[len(dev_us) // 2] / args.steps / 1e3,
+            "ms_per_step_device_note": "HIP events on the library's stream around the same timed regions (median): what the "
+                                       "device spent, without the host's launch and wait",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step_two_kernel_path": two_kernel_ms,
             "ms_per_step_readback_every_iter": readback_ms,
             "dtype": "int64", "data": "synthetic",
             "config": {
-                "workload": "2048x2048 RGBA8 synthetic Voronoi+noise raster, 3000-triangle jittered grid "
-                            "(50x30x2), %s flavour, one replica per GPU" % ("warp" if args.flavour else "triangulate"),
+                "workload": "2048x2048 RGBA8 synthetic Voronoi+noise raster at photograph-like contrast (x%.2f about mid-grey: "
+                            "the reference's fixed-step descent is stable on it), 3000-triangle jittered grid (50x30x2), %s "
+                            "flavour, one replica per GPU" % (CONTRAST, "warp" if args.flavour else "triangulate"),
                 "raster": [W, H], "triangles": NT, "points": NP, "variants": 13 * NT,
                 "parallelism": "replicas x%d (no data-path collective)" % world,
+                "path": "persistent launches: %d patches (workgroups), %d grad-iters ran inside them" % (patches, persist_iters),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_source,
-                "kernel": DOMINANT, "kernel_us": acc_us, "algorithmic_bytes": bytes_iter,
-                "kernel_timing": ("average duration in a rocprofv3 --kernel-trace --stats pass over a child run (256 fused "
-                                  "grad-iters), collected by this command" if trace and DOMINANT in trace else
+                "observed_bound": "latency, not bandwidth: VALU issue inside a workgroup (the walk of the edge lines) plus one "
+                                  "position hand-over between workgroups per grad-iter; the table records a lane needs stay in "
+                                  "its registers from one grad-iter to the next, so HBM-side traffic is far below the algorithmic bytes",
+                "hbm_side_GBs": (traffic / (kern_us * 1e-6) / 1e9) if traffic else None,
+                "kernel": DOMINANT, "kernel_us": kern_us, "grad_iters_per_launch": CHILD_ITERS,
+                "us_per_grad_iter": kern_us / CHILD_ITERS,
+                "algorithmic_bytes": bytes_iter * CHILD_ITERS, "algorithmic_bytes_per_grad_iter": bytes_iter,
+                "kernel_timing": ("average duration in a rocprofv3 --kernel-trace --stats pass over a child run (4 launches of "
+                                  "%d grad-iters), collected by this command" % CHILD_ITERS if trace and DOMINANT in trace else
                                   "HIP events (kernel trace unavailable: %s)" % trace_note),
                 "kernel_trace_us": trace,
-                "kernel_us_hip_events": acc_us_events,
-                "kernel_us_hip_events_note": "HIP events around graph replays of 64 back-to-back launches on the library's "
-                                             "stream (median of 5 replays), after the timed region, same state",
-                "kernel_us_samples": acc_samples,
-                "kernel_us_eager_dispatch_timestamps": acc_us_eager,
+                "kernel_us_hip_events": kern_us_events,
+                "kernel_us_hip_events_note": "HIP events on the library's stream around one launch of %d grad-iters (median of 5), "
+                                             "after the timed region, same state" % CHILD_ITERS,
+                "kernel_us_samples": ev_samples,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -142,9 +142,11 @@ int tp_retrieve(tp_context* ctx, int what, void* dst, size_t count);
 int tp_retrieve_many(tp_context* ctx, int n, const int* what, void* const* dst, const size_t* count);
 int tp_synchronize(tp_context* ctx);
 
-/* measurement hooks (bench.py): the HIP stream the kernels run on, and HIP-event timing of the
- * dominant kernel (k_lines: the pixel sums of every edge line). */
+/* measurement hooks (bench.py): the HIP stream the kernels run on; a pair of HIP events on that stream around whatever is
+ * enqueued between the two calls (tp_timer_stop waits for the second event and returns the time between them) */
 int tp_get_stream(tp_context* ctx, void** hip_stream);
+int tp_timer_start(tp_context* ctx);
+int tp_timer_stop(tp_context* ctx, double* elapsed_us);
 /* runs n_iters grad-iters eagerly with the dispatch's own timestamps around every k_lines launch; returns the
  * average duration of that kernel in microseconds */
 int tp_profile_iterate(tp_context* ctx, const tp_params* p, int n_iters, double* accumulate_us);

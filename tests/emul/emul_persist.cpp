@@ -65,8 +65,7 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
         pk_carve(S[p].lds.data(), w, V);
         memcpy(V.vid, &P.pool[w.off_vid], sizeof(int32_t) * w.n_slots);
         memcpy(V.edges, &P.pool[w.off_edges], sizeof(int32_t) * w.n_edges);
-        memcpy(V.lines, &P.pool[w.off_lines], sizeof(int32_t) * w.n_lines_all);
-        memcpy(V.li, &P.pool[w.off_li], sizeof(int32_t) * 3 * w.n_li_all);
+        for (int l = 0; l < w.n_lines_all; l++) pk_expand_line(V, &P.pool[w.off_lines], l);
         memcpy(V.corners, &P.pool[w.off_corners], sizeof(int32_t) * 4 * w.n_corners);
         memcpy(V.base, &P.pool[w.off_base], sizeof(int32_t) * 4 * w.n_base);
         for (int s = 0; s < w.n_slots; s++) { V.pos[s].x = points[2 * V.vid[s]]; V.pos[s].y = points[2 * V.vid[s] + 1]; }

@@ -23,7 +23,7 @@ SYMBOLS = [
     "tp_get_ratio", "tp_set_dp", "tp_set_option", "tp_set_image", "tp_set_image_device", "tp_upload", "tp_accumulate",
     "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_retrieve_many", "tp_synchronize",
     "tp_get_stream", "tp_profile_iterate", "tp_profile_accumulate", "tp_get_info", "tp_selftest_walker", "tp_render",
-    "tp_prepare", "tp_selftest_line",
+    "tp_prepare", "tp_selftest_line", "tp_timer_start", "tp_timer_stop",
 ]
 
 
@@ -78,6 +78,8 @@ def load():
         lib.tp_profile_iterate.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_double)]
         lib.tp_profile_accumulate.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_double)]
         lib.tp_get_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        lib.tp_timer_start.argtypes = [C.c_void_p]
+        lib.tp_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         lib.tp_device_count.argtypes = [C.POINTER(C.c_int)]
         lib.tp_selftest_walker.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.tp_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -253,6 +255,15 @@ class Context:
         self._ck(self.lib.tp_selftest_walker(self.h, N0.ctypes.data, step.ctypes.data, d.ctypes.data,
                                              N0.shape[0], out.ctypes.data))
         return out
+
+    def timer_start(self):
+        self._ck(self.lib.tp_timer_start(self.h))
+
+    def timer_stop(self):
+        """microseconds between timer_start and now on the library's stream (HIP events); waits for the stream"""
+        us = C.c_double(0.0)
+        self._ck(self.lib.tp_timer_stop(self.h, C.byref(us)))
+        return us.value
 
     def stream(self):
         s = C.c_void_p()

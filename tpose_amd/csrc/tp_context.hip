@@ -845,6 +845,26 @@ int tp_profile_accumulate(tp_context* c, const tp_params* p, int launches, doubl
     return TP_OK;
 }
 
+int tp_timer_start(tp_context* c) {
+    api_guard api_lock;
+    if (!c) return TP_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    return TP_OK;
+}
+
+int tp_timer_stop(tp_context* c, double* elapsed_us) {
+    api_guard api_lock;
+    if (!c || !elapsed_us) return TP_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    float ms = 0.0f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *elapsed_us = (double)ms * 1000.0;
+    return check_persist_status(c);
+}
+
 int tp_synchronize(tp_context* c) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;

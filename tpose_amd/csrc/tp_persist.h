@@ -59,6 +59,17 @@ TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     V.flags = (int32_t*)p;
 }
 
+// prologue, lane l < n_lines_all: the line's entry of the plan -> V.lines[l] and the lane-items of its chunks
+TP_HD void pk_expand_line(const pk_view& V, const int32_t* plan_lines, int l) {
+    const int32_t w0 = plan_lines[4 * l], w1 = plan_lines[4 * l + 1], magic = plan_lines[4 * l + 2], li0 = plan_lines[4 * l + 3];
+    const int TL = w1 & 0xffff, nl = w1 >> 16;
+    V.lines[l] = w0;
+    for (int c = 0; c < TL; c++) {
+        int32_t* e = V.li + 3 * (size_t)(li0 + c * nl);
+        e[0] = l | (c << 16); e[1] = TL; e[2] = magic;
+    }
+}
+
 TP_HD int pk_snap_index(const pk_wg& w, int slot, int move) {
     return slot < w.n_own_v ? 5 * slot + move : 5 * w.n_own_v + (slot - w.n_own_v);
 }

@@ -81,8 +81,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         const int32_t* pool = A.pool;
         for (int i = tid; i < w.n_slots; i += PK_THREADS) V.vid[i] = pool[w.off_vid + i];
         for (int i = tid; i < w.n_edges; i += PK_THREADS) V.edges[i] = pool[w.off_edges + i];
-        for (int i = tid; i < w.n_lines_all; i += PK_THREADS) V.lines[i] = pool[w.off_lines + i];
-        for (int i = tid; i < 3 * w.n_li_all; i += PK_THREADS) V.li[i] = pool[w.off_li + i];
+        for (int i = tid; i < w.n_lines_all; i += PK_THREADS) pk_expand_line(V, pool + w.off_lines, i);
         for (int i = tid; i < 4 * w.n_corners; i += PK_THREADS) ((int32_t*)V.corners)[i] = pool[w.off_corners + i];
         for (int i = tid; i < 4 * w.n_base; i += PK_THREADS) ((int32_t*)V.base)[i] = pool[w.off_base + i];
         for (int i = tid; i < w.n_slots; i += PK_THREADS) {

@@ -47,8 +47,9 @@ struct pk_wg {
     int32_t rows;              // rows a lane of the walk takes: chunks per line = the line's rows / this (<= PK_ROWS_PER_LANE)
     int32_t off_vid;           // [n_slots] global vertex id
     int32_t off_edges;         // [n_edges] slot_u | slot_v << 16
-    int32_t off_lines;         // [n_lines] local edge | version << 16
-    int32_t off_li;            // [n_li] {line | chunk << 16, chunks, magic = floor(2^32 / chunks) + 1 (0: one chunk)}
+    int32_t off_lines;         // [n_lines_all] {local edge | version << 16, chunks | lines of the edge << 16, magic = floor(2^32 / chunks) + 1
+                               // (0: one chunk), lane-item of chunk 0}: chunk c of the line is lane-item [3] + c * lines of the edge --
+                               // the lane-item table {line | chunk << 16, chunks, magic} is expanded from this on the device
     int32_t off_corners;       // [n_corners] {t, s | own << 2 | slot_a << 12 | slot_b << 22, out | in << 16, opp}
     int32_t off_base;          // [n_base] {t, own | slot_1 << 10 | slot_2 << 20, line of edge 0 | edge 1 << 16, line of edge 2}
     int32_t lds_bytes;         // dynamic LDS of this workgroup (pk_lds_bytes)
@@ -211,10 +212,12 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
     P.parts = parts;
     P.wg.assign((size_t)parts, pk_wg());
     std::vector<int> vslot((size_t)NP, 0), vstamp((size_t)NP, -1), eloc((size_t)NE, 0), estamp((size_t)NE, -1);
-    std::vector<int32_t> vid, edges, emask, eglob, lines, li, corners, first, base;
+    std::vector<int32_t> vid, edges, emask, eglob, lines, corners, first, base;
+    std::vector<int> enl_scratch;
+    P.pool.reserve((size_t)NT * 128 + 8192);
     for (int p = 0; p < parts; p++) {
         pk_wg& w = P.wg[p];
-        vid.clear(); edges.clear(); emask.clear(); eglob.clear(); lines.clear(); li.clear(); corners.clear(); base.clear();
+        vid.clear(); edges.clear(); emask.clear(); eglob.clear(); lines.clear(); corners.clear(); base.clear();
         auto slot = [&](int v) {
             if (vstamp[v] != p) { vstamp[v] = p; vslot[v] = (int)vid.size(); vid.push_back(v); }
             return vslot[v];
@@ -248,52 +251,50 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
         first.assign((size_t)w.n_edges * PK_NLINES, -1);
         // rows per lane: the fewest (down to 4) that still give every lane-item its own thread, so that lanes can keep their
         // table records in registers from one grad-iter to the next (tp_persist.h)
-        auto lane_items = [&](int rpl) {
-            long n = 0;
-            for (int le = 0; le < w.n_edges; le++) {
-                int nl = 0;
-                for (int q = 0; q < PK_NLINES; q++) nl += (emask[le] & (q == 0 ? 1 : q <= 4 ? 2 : 4)) != 0;   // (the lines of every grad-iter)
-                const int tl = std::max(1, std::min((int)std::ceil((rows[eglob[le]] + dp_px) / (float)rpl), PK_MAX_TL));
-                n += (long)nl * tl;
-            }
-            return n;
+        std::vector<int>& enl = enl_scratch;   // lines of every grad-iter per local edge
+        enl.assign((size_t)w.n_edges, 0);
+        for (int le = 0; le < w.n_edges; le++) enl[le] = ((emask[le] & 1) ? 1 : 0) + ((emask[le] & 2) ? 4 : 0) + ((emask[le] & 4) ? 4 : 0);
+        auto chunks = [&](int le, int rpl) {   // ceil((rows + dp) / rpl), 1 .. PK_MAX_TL
+            const int r = (int)std::ceil(rows[eglob[le]] + dp_px);
+            return std::max(1, std::min((r + rpl - 1) / rpl, PK_MAX_TL));
         };
         int rpl = 4;
-        while (rpl < PK_ROWS_PER_LANE && lane_items(rpl) > PK_CACHED) rpl++;
+        for (; rpl < PK_ROWS_PER_LANE; rpl++) {
+            long n = 0;
+            for (int le = 0; le < w.n_edges; le++) n += (long)enl[le] * chunks(le, rpl);
+            if (n <= PK_CACHED) break;
+        }
         w.rows = rpl;
+        int n_li = 0;
         for (int le = 0; le < w.n_edges; le++) {
             const int e = eglob[le];
             edges.push_back(slot(EU(e)) | (slot(EV(e)) << 16));
-            const float r = rows[e] + dp_px;
-            int tl = (int)std::ceil(r / (float)rpl);
-            tl = std::max(1, std::min(tl, PK_MAX_TL));
+            const int tl = chunks(le, rpl), nl = enl[le];
             const uint32_t magic = tl == 1 ? 0u : (uint32_t)(0x100000000ull / (uint64_t)tl) + 1u;
-            const int l0 = (int)lines.size();
+            int k = 0;
             for (int q = 0; q < PK_NLINES; q++) {
                 const int bit = q == 0 ? 1 : q <= 4 ? 2 : 4;
                 if (!(emask[le] & bit)) continue;
-                first[(size_t)le * PK_NLINES + q] = (int)lines.size();
-                lines.push_back(le | (q << 16));
+                first[(size_t)le * PK_NLINES + q] = (int)(lines.size() / 4);
+                // the lines of an edge take the same rows in adjacent lanes
+                lines.push_back(le | (q << 16)); lines.push_back(tl | (nl << 16)); lines.push_back((int32_t)magic); lines.push_back(n_li + k);
+                k++;
             }
-            const int nl = (int)lines.size() - l0;
-            // the lines of an edge take the same rows in adjacent lanes: their table records share cache lines
-            for (int c = 0; c < tl; c++)
-                for (int k = 0; k < nl; k++) { li.push_back((l0 + k) | (c << 16)); li.push_back(tl); li.push_back((int32_t)magic); }
+            n_li += nl * tl;
         }
-        w.n_lines = (int)lines.size();
-        w.n_li = (int)(li.size() / 3);
+        w.n_lines = (int)(lines.size() / 4);
+        w.n_li = n_li;
         // base lines only the outputs of base variants need: walked by the last grad-iter of a call, after the others
         for (int le = 0; le < w.n_edges; le++) {
             if ((emask[le] & 9) != 8) continue;
-            const float r = rows[eglob[le]] + dp_px;
-            const int tl = std::max(1, std::min((int)std::ceil(r / (float)rpl), PK_MAX_TL));
+            const int tl = chunks(le, rpl);
             const uint32_t magic = tl == 1 ? 0u : (uint32_t)(0x100000000ull / (uint64_t)tl) + 1u;
-            first[(size_t)le * PK_NLINES] = (int)lines.size();
-            for (int c = 0; c < tl; c++) { li.push_back((int)lines.size() | (c << 16)); li.push_back(tl); li.push_back((int32_t)magic); }
-            lines.push_back(le);
+            first[(size_t)le * PK_NLINES] = (int)(lines.size() / 4);
+            lines.push_back(le); lines.push_back(tl | (1 << 16)); lines.push_back((int32_t)magic); lines.push_back(n_li);
+            n_li += tl;
         }
-        w.n_lines_all = (int)lines.size();
-        w.n_li_all = (int)(li.size() / 3);
+        w.n_lines_all = (int)(lines.size() / 4);
+        w.n_li_all = n_li;
         if (w.n_lines_all > 65535) { P.why = "a patch walks more than 65535 lines"; return; }
         for (int k = 0; k < w.n_own_v; k++) {
             const int v = own_v[p][k];
@@ -327,13 +328,13 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
             while (P.pool.size() & 3) P.pool.push_back(0);  // 16-byte aligned tables
             return off;
         };
-        w.off_vid = put(vid); w.off_edges = put(edges); w.off_lines = put(lines); w.off_li = put(li); w.off_corners = put(corners);
+        w.off_vid = put(vid); w.off_edges = put(edges); w.off_lines = put(lines); w.off_corners = put(corners);
         w.off_base = put(base);
         w.lds_bytes = pk_lds_bytes(w);
         P.lds_bytes = std::max(P.lds_bytes, w.lds_bytes);
         P.lines_total += w.n_lines; P.foreign_total += w.n_slots - w.n_own_v;
         double work = 40.0 * w.n_corners;
-        for (int l = 0; l < w.n_lines; l++) work += rows[eglob[lines[l] & 0xffff]];
+        for (int l = 0; l < w.n_lines; l++) work += rows[eglob[lines[4 * (size_t)l] & 0xffff]];
         P.work_max = std::max(P.work_max, work); P.work_mean += work / parts;
     }
     if (P.lds_bytes > lds_limit) { P.why = "a patch does not fit the LDS"; return; }
