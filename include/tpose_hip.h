@@ -172,7 +172,7 @@ int tp_render(tp_context* ctx, int source, const float* points, uint8_t* dst_rgb
  * current triangulation (rows of a line are shared by that many lanes); persistent path: 2 = patches (workgroups) of
  * the current plan, 0 if none, 3 = its LDS bytes per workgroup, 4 = lines all patches walk per grad-iter (9 per edge if none were walked twice),
  * 5 = persistent launches so far, 6 = grad-iters run inside them, 7 = census (1 a full grid is resident, -1 not,
- * 0 not taken yet) */
+ * 0 not taken yet), 8 = plans cut again during long descents (vertices had drifted from where the plan saw them) */
 int tp_get_info(tp_context* ctx, int what, int64_t* value);
 
 /* device self-test of the exact span walker (tp_raster.h): for each (N0, step, d), the 32 values

@@ -30,7 +30,7 @@ SYMBOLS = [
 RENDER_AVERAGE, RENDER_STORED = 0, 1
 OPT_PERSISTENT = 1
 PERSIST_OFF, PERSIST_AUTO = 0, 1
-INFO_PATCHES, INFO_PATCH_LDS, INFO_PATCH_LINES, INFO_PERSIST_LAUNCHES, INFO_PERSIST_ITERS, INFO_CENSUS = 2, 3, 4, 5, 6, 7
+INFO_PATCHES, INFO_PATCH_LDS, INFO_PATCH_LINES, INFO_PERSIST_LAUNCHES, INFO_PERSIST_ITERS, INFO_CENSUS, INFO_REPLANS = 2, 3, 4, 5, 6, 7, 8
 
 
 class Params(C.Structure):

@@ -110,8 +110,24 @@ struct tp_context {
     std::vector<int32_t> h_tris, h_edge_uv, h_he_edge;
     pk_plan plan;
     uint64_t plan_generation = 0;   // generation the plan (ok or refused) belongs to
-    pk_wg* d_wg = nullptr; int32_t* d_pool = nullptr;
-    size_t cap_wg = 0, cap_pool = 0;
+    pk_wg* d_wg = nullptr; int32_t* d_pool = nullptr;   // the plan the next launch reads (= plan_dev[plan_slot])
+    size_t cap_wg = 0, cap_pool = 0;                    // (census only)
+    // Re-planning while a long descent runs: vertices drift, lines grow, and the patches of the upload-time plan go out of
+    // balance.  After every chunk of grad-iters the positions ride the stream into a pinned snapshot; before launching a
+    // chunk the host waits for the snapshot of two chunks ago (never more than two chunks are in flight), and if a vertex
+    // has moved more than PK_REPLAN_PX pixels since the current plan was cut, cuts a new one from it -- while the GPU runs
+    // the chunk in between -- and uploads it into the other of two plan buffers.  Results do not depend on the cut.
+    struct plan_buf { pk_wg* wg = nullptr; int32_t* pool = nullptr; size_t cap_wg = 0, cap_pool = 0; uint8_t* stage = nullptr; size_t cap_stage = 0; };
+    plan_buf plan_dev[2];
+    int plan_slot = 0;
+    std::vector<float> plan_points;           // positions the current plan was cut from
+    float* snap_host[2] = {nullptr, nullptr};  // pinned: positions after a chunk
+    size_t snap_cap = 0;
+    hipEvent_t snap_ev[2] = {nullptr, nullptr};
+    bool snap_pending[2] = {false, false};
+    int snap_next = 0;
+    int iters_since_snap = 0;
+    int64_t replans = 0;
     unsigned long long* posbox = nullptr;
     size_t cap_posbox = 0;   // (in vertices)
     float2* points_out = nullptr; size_t cap_points_out = 0;
@@ -213,7 +229,6 @@ unsigned long long* persist_dbg_buffer(int parts, hipStream_t s) {
 #define PK_LDS_LIMIT (160 * 1024 - 512)  /* (the kernel has a few static bytes of its own) */
 #define PK_MIN_ITERS 4        /* shorter tp_iterate calls are not worth a plan (frame-by-frame schedules) */
 #define PK_MAX_EPOCH 32000u   /* mailbox tags carry 15 bits of the grad-iter's number */
-#define PK_MAX_LAUNCH 8192    /* grad-iters per launch */
 
 // after the stream was synchronised: did a lane of a persistent launch give up waiting?  (Never seen with every
 // workgroup resident; the state of the triangulation is undefined then.)
@@ -267,7 +282,41 @@ int take_census(tp_context* c) {
     return TP_OK;
 }
 
-// the plan of the current triangulation (built once per upload, on first use); *use = whether tp_iterate may take the
+#define PK_CHUNK 1024         /* grad-iters per launch of a long call: the granule of re-planning */
+#define PK_REPLAN_PX 3.0f     /* a vertex this far from where the plan saw it: cut a new plan */
+
+// cut a plan from `points` and send it to plan buffer `slot` (through that buffer's pinned staging area: the copy rides
+// the stream and the host does not wait for it).  c->plan is replaced only when the new plan is usable.
+int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok) {
+    pk_plan np;
+    pk_build_plan(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
+                  c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, c->num_cus, PK_LDS_LIMIT, np);
+    *ok = np.ok;
+    if (!np.ok) { if (!c->plan.ok) c->plan = np; return TP_OK; }
+    tp_context::plan_buf& B = c->plan_dev[slot];
+    if (int rc = grow(c, &B.wg, &B.cap_wg, np.wg.size())) return rc;
+    if (int rc = grow(c, &B.pool, &B.cap_pool, np.pool.size())) return rc;
+    const size_t b_wg = sizeof(pk_wg) * np.wg.size(), b_pool = sizeof(int32_t) * np.pool.size();
+    if (b_wg + b_pool > B.cap_stage) {
+        // (the staging area may still feed a copy enqueued for an earlier plan in this buffer: wait before dropping it)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (B.stage) hipHostFree(B.stage);
+        B.stage = nullptr; B.cap_stage = 0;
+        const size_t n = (b_wg + b_pool) * 3 / 2 + 4096;
+        HIP_TRY(c, hipHostMalloc((void**)&B.stage, n, hipHostMallocDefault));
+        B.cap_stage = n;
+    }
+    memcpy(B.stage, np.wg.data(), b_wg);
+    memcpy(B.stage + b_wg, np.pool.data(), b_pool);
+    HIP_TRY(c, hipMemcpyAsync(B.wg, B.stage, b_wg, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(B.pool, B.stage + b_wg, b_pool, hipMemcpyHostToDevice, c->stream));
+    c->plan = std::move(np);
+    c->plan_slot = slot;
+    c->plan_points.assign(points, points + 2 * (size_t)c->NP);
+    return TP_OK;
+}
+
+// the plan of the current triangulation (built on first use after an upload); *use = whether tp_iterate may take the
 // persistent path
 int ensure_plan(tp_context* c, float dp, bool* use) {
     *use = false;
@@ -276,16 +325,11 @@ int ensure_plan(tp_context* c, float dp, bool* use) {
     if (c->census != 1) return TP_OK;
     if (c->plan_generation != c->generation) {
         c->plan_generation = c->generation;
-        pk_build_plan(c->NP, c->NT, c->h_tris.data(), c->h_points.data(), c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
-                      c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, c->num_cus, PK_LDS_LIMIT, c->plan);
-        if (c->plan.ok) {
-            // (the stream may still be running launches that read the previous plan: uploads synchronise, and a plan is only
-            // rebuilt after an upload)
-            if (int rc = grow(c, &c->d_wg, &c->cap_wg, c->plan.wg.size())) return rc;
-            if (int rc = grow(c, &c->d_pool, &c->cap_pool, c->plan.pool.size())) return rc;
-            HIP_TRY(c, hipMemcpyAsync(c->d_wg, c->plan.wg.data(), sizeof(pk_wg) * c->plan.wg.size(), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(c->d_pool, c->plan.pool.data(), sizeof(int32_t) * c->plan.pool.size(), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));  // (pageable sources: the copies must not outlive the vectors' contents)
+        c->plan = pk_plan();
+        c->snap_pending[0] = c->snap_pending[1] = false;   // (uploads synchronise the stream: nothing is in flight)
+        bool ok = false;
+        if (int rc = build_plan(c, c->h_points.data(), dp, 0, &ok)) return rc;
+        if (ok) {
             const size_t np = (size_t)c->NP;
             if (np > c->cap_posbox || !c->posbox) {
                 hipFree(c->posbox); c->posbox = nullptr; c->cap_posbox = 0;
@@ -293,6 +337,14 @@ int ensure_plan(tp_context* c, float dp, bool* use) {
                 HIP_TRY(c, dev_alloc(&c->posbox, n * 4)); c->cap_posbox = n;
             }
             if (int rc = grow(c, &c->points_out, &c->cap_points_out, np)) return rc;
+            if (np > c->snap_cap) {
+                for (int k = 0; k < 2; k++) { if (c->snap_host[k]) hipHostFree(c->snap_host[k]); c->snap_host[k] = nullptr; }
+                c->snap_cap = 0;
+                const size_t n = np + np / 2 + 64;
+                for (int k = 0; k < 2; k++) HIP_TRY(c, hipHostMalloc((void**)&c->snap_host[k], n * 2 * sizeof(float), hipHostMallocDefault));
+                c->snap_cap = n;
+            }
+            for (int k = 0; k < 2; k++) if (!c->snap_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->snap_ev[k], hipEventDisableTiming));
             // vertex numbering changed with the triangulation: stale granules of the previous one must not match a tag
             HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 4 * sizeof(unsigned long long), c->stream));
             c->epoch = 1;
@@ -302,17 +354,41 @@ int ensure_plan(tp_context* c, float dp, bool* use) {
     return TP_OK;
 }
 
+// before a chunk: the snapshot of two chunks ago, if there is one -- a new plan when the mesh has drifted
+int maybe_replan(tp_context* c, float dp) {
+    const int k = c->snap_next;   // the older of the two snapshot slots: the one the coming chunk's snapshot will overwrite
+    if (!c->snap_pending[k]) return TP_OK;
+    HIP_TRY(c, hipEventSynchronize(c->snap_ev[k]));
+    c->snap_pending[k] = false;
+    const float* q = c->snap_host[k];
+    const float* o = c->plan_points.data();
+    const float sx = 0.5f * (float)c->W / c->ratio, sy = 0.5f * (float)c->H;
+    float worst = 0.0f;
+    for (size_t i = 0, n = 2 * (size_t)c->NP; i < n; i += 2) {
+        const float dx = (q[i] - o[i]) * sx, dy = (q[i + 1] - o[i + 1]) * sy;
+        const float d = (dx < 0 ? -dx : dx) > (dy < 0 ? -dy : dy) ? (dx < 0 ? -dx : dx) : (dy < 0 ? -dy : dy);
+        if (d > worst) worst = d;   // (NaN never compares greater: a vertex gone to NaN does not trigger)
+    }
+    if (worst <= PK_REPLAN_PX) return TP_OK;
+    bool ok = false;
+    if (int rc = build_plan(c, q, dp, c->plan_slot ^ 1, &ok)) return rc;
+    if (ok) c->replans++;
+    return TP_OK;
+}
+
 // n grad-iters of the persistent kernel -- the last one writes `tenergy`, `colnum`, `colacc`, `gradient` --, then
 // `points_out` -> `points` / `epos`
 int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n) {
     while (n > 0) {
-        const int k = n < PK_MAX_LAUNCH ? n : PK_MAX_LAUNCH;
+        // long calls go chunk by chunk (a chunk and a half rather than a short tail)
+        const int k = n <= PK_CHUNK + PK_CHUNK / 2 ? n : PK_CHUNK;
+        if (int rc = maybe_replan(c, dp)) return rc;
         if (c->epoch + (uint32_t)k > PK_MAX_EPOCH) {
             HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 4 * sizeof(unsigned long long), c->stream));
             c->epoch = 1;
         }
         pk_args A{};
-        A.wg = c->d_wg; A.pool = c->d_pool; A.parts = c->plan.parts;
+        A.wg = c->plan_dev[c->plan_slot].wg; A.pool = c->plan_dev[c->plan_slot].pool; A.parts = c->plan.parts;
         A.vw.dp = dp; A.vw.ratio = c->ratio; A.vw.halfW = 0.5f * (float)c->W; A.vw.halfH = 0.5f * (float)c->H; A.vw.W = c->W; A.vw.H = c->H;
         A.px = c->px[p.image_slot]; A.px_pitch = c->px_pitch;
         A.points = c->points; A.points_out = c->points_out; A.ca = c->ca;
@@ -331,7 +407,16 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n) {
         c->epoch += (uint32_t)k;
         c->persist_unchecked = true;
         c->persist_launches++; c->persist_iters += k;
+        c->iters_since_snap += k;
         n -= k;
+        if (c->iters_since_snap >= PK_CHUNK / 2) {   // the positions after this chunk, for a later maybe_replan
+            const int sl = c->snap_next;
+            HIP_TRY(c, hipMemcpyAsync(c->snap_host[sl], c->points, sizeof(float) * 2 * (size_t)c->NP, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipEventRecord(c->snap_ev[sl], c->stream));
+            c->snap_pending[sl] = true;
+            c->snap_next = sl ^ 1;
+            c->iters_since_snap = 0;
+        }
     }
     return TP_OK;
 }
@@ -405,6 +490,12 @@ int tp_destroy(tp_context* c) {
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->prefix[0]); hipFree(c->prefix[1]); hipFree(c->px[0]); hipFree(c->px[1]);
     hipFree(c->render_pic); hipFree(c->render_pts);
     hipFree(c->d_wg); hipFree(c->d_pool); hipFree(c->posbox); hipFree(c->points_out); hipFree(c->d_status);
+    for (int k = 0; k < 2; k++) {
+        hipFree(c->plan_dev[k].wg); hipFree(c->plan_dev[k].pool);
+        if (c->plan_dev[k].stage) hipHostFree(c->plan_dev[k].stage);
+        if (c->snap_host[k]) hipHostFree(c->snap_host[k]);
+        if (c->snap_ev[k]) hipEventDestroy(c->snap_ev[k]);
+    }
     if (c->pinned) hipHostFree(c->pinned);
     if (c->up_pinned) hipHostFree(c->up_pinned);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -1046,6 +1137,7 @@ int tp_get_info(tp_context* c, int what, int64_t* value) {
         case 5: *value = c->persist_launches; return TP_OK;
         case 6: *value = c->persist_iters; return TP_OK;
         case 7: *value = c->census; return TP_OK;
+        case 8: *value = c->replans; return TP_OK;
         default: return fail(c, TP_ERR_INVALID, "unknown info %d", what);
     }
 }
