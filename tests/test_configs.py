@@ -177,8 +177,22 @@ def test_config5_fundamental_matrix_from_config3_warp(config3):
     run(gpu, "-ia", str(config3 / "a.ppm"), "-ib", str(config3 / "b.ppm"), "-ta", ta, "-tb", tb, "-schedule", "two_way",
         "-levelframes", "200", "-quiet")
     subprocess.check_call(["make", "-s", "-C", HOST, "fundamental"])
-    out = run(os.path.join(HOST, "fundamental"), ta, ta + ".warp", tb, tb + ".warp")
+    dump = str(config3 / "matches.txt")
+    out = run(os.path.join(HOST, "fundamental"), ta, ta + ".warp", tb, tb + ".warp", "-dumpmatches", dump)
     vals = [float(l.split(":")[1]) for l in out.splitlines() if "mean squared Sampson distance" in l]
     assert len(vals) == 3 and all(np.isfinite(v) for v in vals)
     ma = int(out.split("Found A Matches: ")[1].split()[0]); mb = int(out.split("Found B Matches: ")[1].split()[0])
     assert ma > 20 and mb > 20
+    # "Sampson error vs reference" (BASELINE config 5): the NumPy restatement of source/multiview.hpp:187-242 (tests/
+    # test_multiview.py) on the very matches the harness used.  Tolerances as in the CPU test of the same comparison: 1 % of
+    # the mean squared Sampson distance (float32 storage between the 100 re-weighting rounds), entries up to scale 5e-3.
+    from test_multiview import np_fsampson, np_mean_sampson, same_up_to_scale
+    M = np.loadtxt(dump, dtype=np.float64)
+    A, B = M[:, 0:2].astype(np.float32), M[:, 2:4].astype(np.float32)
+    assert A.shape[0] == ma + mb
+    FS = np.loadtxt(dump + ".F", dtype=np.float64)
+    Fn = np_fsampson(A, B)
+    s_mine, s_np = np_mean_sampson(FS, A, B), np_mean_sampson(Fn, A, B)
+    assert abs(s_mine - vals[0]) <= 1e-4 * s_mine + 1e-15        # what the harness printed is this F on these matches
+    assert s_mine <= s_np * 1.01 + 1e-14
+    assert same_up_to_scale(FS.astype(np.float32), Fn, 5e-3)

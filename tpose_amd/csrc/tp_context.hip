@@ -547,7 +547,7 @@ static int set_image_common(tp_context* c, int slot, const void* src, size_t str
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->img[slot]) HIP_TRY(c, dev_alloc(&c->img[slot], (size_t)c->W * c->H * 4));
     HIP_TRY(c, hipMemcpy2DAsync(c->img[slot], (size_t)c->W * 4, src, stride, (size_t)c->W * 4, c->H, kind, c->stream));
-    // row prefix table of this image (16 bytes per pixel): what the line sums read, iteration after iteration
+    // row prefix table of this image (32-byte records per four pixels: 8 bytes per pixel): what k_lines reads, grad-iter after grad-iter
     if (!c->prefix[slot]) HIP_TRY(c, dev_alloc(&c->prefix[slot], (size_t)c->H * c->prefix_pitch * 2));
     tp_launch_prefix_table(c->img[slot], c->W * 4, c->W, c->H, c->prefix_pitch, c->prefix[slot], c->stream);
     if (c->px_pitch) {  // pixel records of the same sums: what the persistent grad-iter kernel reads
@@ -1070,15 +1070,20 @@ int tp_selftest_walker(tp_context* c, const int64_t* N0, const int32_t* step, co
     if (!c || !N0 || !step || !d || !out || n < 0) return TP_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     int64_t* dN = nullptr; int32_t *ds = nullptr, *dd = nullptr, *dout = nullptr;
-    HIP_TRY(c, dev_alloc(&dN, n)); HIP_TRY(c, dev_alloc(&ds, n)); HIP_TRY(c, dev_alloc(&dd, n));
-    HIP_TRY(c, dev_alloc(&dout, (size_t)n * 32));
-    HIP_TRY(c, hipMemcpy(dN, N0, sizeof(int64_t) * n, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(ds, step, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(dd, d, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    tp_launch_selftest_walker(dN, ds, dd, n, dout, c->stream);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(out, dout, sizeof(int32_t) * 32 * (size_t)n, hipMemcpyDeviceToHost));
+    hipError_t e = dev_alloc(&dN, n);   // (one exit: the four buffers are freed on every path)
+    if (e == hipSuccess) e = dev_alloc(&ds, n);
+    if (e == hipSuccess) e = dev_alloc(&dd, n);
+    if (e == hipSuccess) e = dev_alloc(&dout, (size_t)n * 32);
+    if (e == hipSuccess) e = hipMemcpy(dN, N0, sizeof(int64_t) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ds, step, sizeof(int32_t) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dd, d, sizeof(int32_t) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        tp_launch_selftest_walker(dN, ds, dd, n, dout, c->stream);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(int32_t) * 32 * (size_t)n, hipMemcpyDeviceToHost);
     hipFree(dN); hipFree(ds); hipFree(dd); hipFree(dout);
+    if (e != hipSuccess) return fail(c, TP_ERR_HIP, "selftest_walker: %s", hipGetErrorString(e));
     return TP_OK;
 }
 

@@ -32,7 +32,7 @@ static void report(const char* name, const mview::Matrix3f& F, const std::vector
 
 int main(int argc, char** argv) {
     std::vector<std::string> files;
-    std::string matches, points_out, select;
+    std::string matches, points_out, select, dump;
     int level = 0, imw = 0, imh = 0;
     for (int a = 1; a < argc; a++) {
         const std::string k = argv[a];
@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
         else if (k == "-select") select = val();
         else if (k == "-all") select.clear();
         else if (k == "-points") points_out = val();
+        else if (k == "-dumpmatches") dump = val();   // the matches the estimators get, "xA yA xB yB" per line, and F_Sampson
         else files.push_back(k);
     }
     io::verbose = false;
@@ -89,6 +90,16 @@ int main(int argc, char** argv) {
     if (matchX.size() < 8) { std::cout << "Insufficient Matches..." << std::endl; return 0; }
     const mview::Matrix3f FS = mview::F_Sampson(matchX, matchY);
     report("F_Sampson", FS, matchX, matchY);
+    if (!dump.empty()) {
+        FILE* f = std::fopen(dump.c_str(), "w");
+        if (!f) return 1;
+        for (size_t i = 0; i < matchX.size(); i++) std::fprintf(f, "%.9g %.9g %.9g %.9g\n", matchX[i].x, matchX[i].y, matchY[i].x, matchY[i].y);
+        std::fclose(f);
+        f = std::fopen((dump + ".F").c_str(), "w");
+        if (!f) return 1;
+        for (int r = 0; r < 3; r++) std::fprintf(f, "%.9g %.9g %.9g\n", FS(r, 0), FS(r, 1), FS(r, 2));
+        std::fclose(f);
+    }
     report("F_LMEDS", mview::F_LMEDS(matchX, matchY), matchX, matchY);
     report("F_RANSAC", mview::F_RANSAC(matchX, matchY), matchX, matchY);
     if (!points_out.empty()) {  // optimal correction + structure with the tool's intrinsics
