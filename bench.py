@@ -237,8 +237,7 @@ def main():
         t0 = time.perf_counter()
         ctx.timer_start()
         ctx.iterate(params, args.steps)
-        dev_us.append(ctx.timer_stop())
-        ctx.synchronize()
+        dev_us.append(ctx.timer_stop())   # (waits for the end of the region on the library's stream)
         torch.cuda.synchronize()
         dt_rep = time.perf_counter() - t0
         if dist is not None:

@@ -216,6 +216,27 @@ int check_slot(tp_context* c, int slot) {
     return TP_OK;
 }
 
+// Waiting for the stream: calls of a few grad-iters finish in tens of microseconds, less than it takes a blocked host
+// thread to be woken (~20-30 us).  Poll for up to a quarter of a millisecond first, then block.
+hipError_t wait_stream(hipStream_t s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(250)) break;
+    }
+    return hipStreamSynchronize(s);
+}
+hipError_t wait_event(hipEvent_t ev) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(250)) break;
+    }
+    return hipEventSynchronize(ev);
+}
+
 // ---- persistent grad-iter kernel: status, census, plan ------------------------------------------------------------
 #ifdef TPOSE_DEBUG  // debug flavour of the library (tools/persist_timeline.py): per-workgroup phase timestamps
 static unsigned long long* g_persist_dbg = nullptr;
@@ -949,7 +970,7 @@ int tp_timer_stop(tp_context* c, double* elapsed_us) {
     if (!c || !elapsed_us) return TP_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, wait_event(c->ev1));
     float ms = 0.0f;
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *elapsed_us = (double)ms * 1000.0;
@@ -960,7 +981,7 @@ int tp_synchronize(tp_context* c) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, wait_stream(c->stream));
     return check_persist_status(c);
 }
 
@@ -1017,7 +1038,7 @@ int tp_retrieve_many(tp_context* c, int n, const int* what, void* const* dst, co
     // all copies ride the context's stream behind the enqueued work: ONE wait for the whole batch
     for (int k = 0; k < n; k++)
         if (bytes[k]) HIP_TRY(c, hipMemcpyAsync(c->pinned + off[k], src[k], bytes[k], hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, wait_stream(c->stream));
     if (int rc = check_persist_status(c)) return rc;
     for (int k = 0; k < n; k++) {
         if (bytes[k]) memcpy(dst[k], c->pinned + off[k], bytes[k]);
