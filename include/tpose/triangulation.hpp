@@ -319,6 +319,11 @@ inline void doframe() {
     p.image_slot = swept_slot();
     check(tp_iterate(ctx, &p, 1), "doframe");
 }
+// frames until geterr < threshold (or maxframes of them), the test applied on the library's side of the boundary
+// (tp_iterate_until: no read-back per frame); afterwards everything stands as after the reference's loop
+//     do { doframe(); retrieve(tr); } while (geterr(tr) >= threshold)
+// -- the buffers of the last frame in terr / perr / cn, its points in tr, toterr / newerr / relerr as geterr left them.
+
 // the four Buffer::retrieve calls of every frame
 inline void retrieve(triangulation* tr) {
     const int what[4] = {TP_BUF_TENERGY, TP_BUF_PENERGY, TP_BUF_COLNUM, TP_BUF_POINTS};
@@ -369,6 +374,17 @@ inline void sum_energy(triangulation* tr) {
     toterr = newerr;
 }
 inline float geterr(triangulation* tr) { sum_energy(tr); return std::fabs(relerr); }
+inline long descend(triangulation* tr, double threshold, long maxframes) {
+    tp_params p;
+    tp_default_params(flavour, &p);
+    p.image_slot = swept_slot();
+    int frames = 0;
+    float rel = 0.0f;
+    check(tp_iterate_until(ctx, &p, (int)(maxframes > 0x3fffffff ? 0x3fffffff : maxframes), threshold, &toterr, &frames, &rel), "descend");
+    newerr = toterr; relerr = rel;
+    retrieve(tr);
+    return frames;
+}
 inline float gettoterr(triangulation* tr) { sum_energy(tr); return std::fabs(toterr); }
 inline int maxerrid(triangulation* tr) {
     maxerr = 0;

@@ -128,6 +128,19 @@ void tp_default_params(int flavour, tp_params* p);
  * Asynchronous: returns after enqueueing; tp_retrieve / tp_synchronize wait.  From 4 grad-iters on they run inside
  * persistent launches (tp_set_option); the last one writes the buffers tp_retrieve reads. */
 int tp_iterate(tp_context* ctx, const tp_params* p, int n_iters);
+/* The reference's frame loop up to its convergence test, without a read-back per frame: frames of { accumulate; energy;
+ * shift } run until |relerr| < threshold, relerr = (toterr - newerr) / toterr with newerr = sum over t < NT of
+ * float(tenergy[t]) in float32, ascending t, and toterr <- newerr after every frame -- tpose::geterr
+ * (source/triangulation.hpp:653-674) as software/triangulate/main.cpp:201-210 (threshold 1e-4) and software/warp/main.cpp:
+ * 226-231 (1e-6) apply it -- or until max_frames frames have run.  *toterr is the caller's running total (the reference's
+ * global, initially 1.0), updated frame by frame.  On return the context is in the state after the LAST frame run
+ * (*frames of them; its buffers readable with tp_retrieve, positions after its step), exactly as if the frames had
+ * been issued one by one with a test in between.  Frames run in chunks inside persistent launches that keep each
+ * frame's base energies and starting positions on the device; the host applies the test to a chunk at a time and the
+ * converged frame is then re-run to leave its buffers.  The threshold is a double because the reference compares its float
+ * against a double literal (`geterr(&tr) < 1E-4`).  Synchronous. */
+int tp_iterate_until(tp_context* ctx, const tp_params* p, int max_frames, double threshold, float* toterr, int* frames,
+                     float* relerr /* may be NULL */);
 /* Optional: build the launch graph tp_iterate replays for these parameters now (it is otherwise built by the
  * first tp_iterate of >= 16 iterations after an upload), so that no later call pays for it.  Runs nothing.
  * The reference has no counterpart -- its frame loop issues GL calls one by one (triangulate/main.cpp:190-204). */

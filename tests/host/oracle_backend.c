@@ -3,6 +3,7 @@
  * Linking a harness against this instead of libtpose_hip.so gives a schedule-level reference run:
  * tests compare the .tri files the two builds write, byte for byte.  Never shipped, never linked by
  * the product. */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -151,5 +152,23 @@ int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
         tp_energy(c, p->flavour);
         tp_shift(c, p->rate);
     }
+    return TP_OK;
+}
+
+/* the reference's loop up to its convergence test, frame by frame (software/warp/main.cpp:220-231) */
+int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double threshold, float* toterr, int* frames, float* relerr) {
+    float tot = *toterr, rel = 0.0f;
+    int done = 0;
+    while (done < max_frames) {
+        tp_iterate(c, p, 1);
+        done++;
+        float newerr = 0.0f;
+        for (int i = 0; i < c->NT; i++) { float err = 0.0f; err += (float)c->ten[i]; newerr += err; }
+        rel = (tot - newerr) / tot;
+        tot = newerr;
+        if ((double)fabsf(rel) < threshold) break;
+    }
+    *toterr = tot; *frames = done;
+    if (relerr) *relerr = rel;
     return TP_OK;
 }

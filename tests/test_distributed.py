@@ -89,7 +89,7 @@ def _torchrun(args, nproc, timeout=600):
 @pytest.mark.gpu
 def test_bench_line_contract_one_gpu():
     """`python bench.py` with the driver's flags: ONE JSON line with the metric of BASELINE.json, the roofline object of
-    the dominant kernel (k_lines) and the CPU baseline; the kernel trace and the counter passes are collected live"""
+    the dominant kernel (k_persist: K grad-iters per launch) and the CPU baseline; the kernel trace and the counter passes are collected live"""
     import sys
     r = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5"], capture_output=True, text=True,
                        timeout=900, cwd=ROOT)
@@ -102,10 +102,12 @@ def test_bench_line_contract_one_gpu():
     assert abs(line["value"] - 3000 * 20 / (line["ms_per_step"] * 20e-3)) < 1e-6 * line["value"]
     assert line["config"]["raster"] == [2048, 2048] and line["config"]["triangles"] == 3000 and "workload" in line["config"]
     rf = line["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "k_lines"
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "k_persist"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
     assert abs(rf["achieved"] - rf["algorithmic_bytes"] / (rf["kernel_us"] * 1e-6) / 1e9) < 1e-6 * rf["achieved"]
-    assert rf["traffic"] is None or rf["traffic"] > rf["algorithmic_bytes"] // 2
+    assert rf["algorithmic_bytes"] == rf["algorithmic_bytes_per_grad_iter"] * rf["grad_iters_per_launch"]
+    assert rf["traffic"] is None or rf["traffic"] > 0   # (far below the algorithmic bytes: the records a lane needs stay in registers)
+    assert rf["observed_bound"] and line["ms_per_step_two_kernel_path"] > 0 and "persistent launches" in line["config"]["path"]
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["single_thread_value"] > 0 and cb["cpu_model"]
     assert line["ms_per_step_readback_every_iter"] > line["ms_per_step"]

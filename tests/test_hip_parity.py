@@ -558,3 +558,71 @@ def test_two_host_threads_two_contexts():
         (ten, points), (img, pts, tris, ratio) = results[k]
         ref = O.iterate(img, pts, tris, 0, ratio, RATE[0], 340, literal=False)
         assert np.array_equal(ten, ref["ten"]) and np.array_equal(points.view(np.uint32), ref["points"].view(np.uint32))
+
+
+def _reference_loop(ctx, params, NT, threshold, max_frames, toterr=1.0):
+    """the reference's loop: one frame, read tenergy back, tpose::geterr in float32 ascending t (triangulation.hpp:653-674)"""
+    tot = np.float32(toterr)
+    frames = 0
+    rel = np.float32(0)
+    while frames < max_frames:
+        ctx.iterate(params, 1)
+        frames += 1
+        ten = ctx.retrieve(capi.BUF_TENERGY)[:NT]
+        newerr = np.float32(0)
+        for v in ten.astype(np.float32):
+            newerr = np.float32(newerr + v)
+        with np.errstate(all="ignore"):
+            rel = np.float32(np.float32(tot - newerr) / tot)
+        tot = newerr
+        if float(abs(rel)) < threshold:
+            break
+    return frames, float(tot), float(rel)
+
+
+@pytest.mark.parametrize("flavour,threshold,cap", [(0, 1e-4, 400), (1, 1e-6, 300), (0, 1e-9, 70), (0, 1e-4, 3)])
+@pytest.mark.parametrize("persistent", [1, 0])
+def test_iterate_until_is_the_reference_loop(flavour, threshold, cap, persistent):
+    """tp_iterate_until against the reference's frame loop with a read-back and geterr after every frame: the same number
+    of frames, the same running total, and the same buffers and positions afterwards -- bit for bit"""
+    W, H, grid = 300, 200, (15, 5)
+    img = synth.photo_contrast(synth.voronoi_raster(W, H, seed=7, sites=12), 0.3)
+    imgB = synth.displaced_raster(img, amp=6.0)
+    ratio = float(np.float32(W) / np.float32(H))
+    pts, tris, _ = synth.grid_triangulation(grid[0], grid[1], ratio=ratio)
+    colors = synth.mean_colors(img, pts, tris, ratio)
+    NT = tris.shape[0]
+    res = []
+    for mode in ("loop", "until"):
+        ctx = capi.Context(0, W, H)
+        ctx.set_persistent(persistent)
+        ctx.set_image(capi.IMAGE_A, img)
+        ctx.set_image(capi.IMAGE_B, imgB)
+        ctx.upload(pts, tris, colors if flavour else None)
+        p = capi.default_params(flavour)
+        out = []
+        tot = 1.0
+        for leg in range(2):   # two legs: the running total carries over
+            if mode == "loop":
+                ctx.set_persistent(0)
+                n, tot, rel = _reference_loop(ctx, p, NT, threshold, cap, tot)
+            else:
+                n, tot, rel = ctx.iterate_until(p, cap, threshold, tot)
+            out.append((n, np.float32(tot).view(np.uint32), np.float32(rel).view(np.uint32)))
+        res.append((out, ctx.retrieve(capi.BUF_POINTS), ctx.retrieve(capi.BUF_TENERGY), ctx.retrieve(capi.BUF_COLNUM),
+                    ctx.retrieve(capi.BUF_GRADIENT)))
+        ctx.close()
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+    for k in (2, 3, 4):
+        assert np.array_equal(res[0][k], res[1][k])
+
+
+def test_two_contexts_iterate_concurrently_on_one_gpu():
+    """two contexts driven from two threads: their persistent launches compete for the same CUs (a launch whose
+    workgroups are not all resident gives up and its grad-iters are run again on the two-kernel path) -- results exact"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "two_contexts.py")], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

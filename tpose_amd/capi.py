@@ -23,7 +23,7 @@ SYMBOLS = [
     "tp_get_ratio", "tp_set_dp", "tp_set_option", "tp_set_image", "tp_set_image_device", "tp_upload", "tp_accumulate",
     "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_retrieve_many", "tp_synchronize",
     "tp_get_stream", "tp_profile_iterate", "tp_profile_accumulate", "tp_get_info", "tp_selftest_walker", "tp_render",
-    "tp_prepare", "tp_selftest_line", "tp_timer_start", "tp_timer_stop",
+    "tp_prepare", "tp_selftest_line", "tp_timer_start", "tp_timer_stop", "tp_iterate_until",
 ]
 
 
@@ -78,6 +78,7 @@ def load():
         lib.tp_profile_iterate.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_double)]
         lib.tp_profile_accumulate.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_double)]
         lib.tp_get_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        lib.tp_iterate_until.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float)]
         lib.tp_timer_start.argtypes = [C.c_void_p]
         lib.tp_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         lib.tp_device_count.argtypes = [C.POINTER(C.c_int)]
@@ -255,6 +256,12 @@ class Context:
         self._ck(self.lib.tp_selftest_walker(self.h, N0.ctypes.data, step.ctypes.data, d.ctypes.data,
                                              N0.shape[0], out.ctypes.data))
         return out
+
+    def iterate_until(self, params, max_frames, threshold, toterr=1.0):
+        """frames until tpose::geterr < threshold (or max_frames); returns (frames run, toterr, relerr of the last frame)"""
+        tot, n, rel = C.c_float(toterr), C.c_int(0), C.c_float(0.0)
+        self._ck(self.lib.tp_iterate_until(self.h, C.byref(params), max_frames, C.c_double(threshold), C.byref(tot), C.byref(n), C.byref(rel)))
+        return n.value, tot.value, rel.value
 
     def timer_start(self):
         self._ck(self.lib.tp_timer_start(self.h))

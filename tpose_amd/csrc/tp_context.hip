@@ -128,12 +128,20 @@ struct tp_context {
     int snap_next = 0;
     int iters_since_snap = 0;
     int64_t replans = 0;
+    bool plan_base_every = false;   // the current plan walks every triangle's base lines in every grad-iter (tp_iterate_until)
+    int32_t* ering = nullptr; float2* pring = nullptr;   // tp_iterate_until: per-frame base energies / positions of a chunk
+    size_t cap_ering = 0, cap_pring = 0;
+    int32_t* ering_host = nullptr; size_t cap_ering_host = 0;   // pinned
     unsigned long long* posbox = nullptr;
     size_t cap_posbox = 0;   // (in vertices)
     float2* points_out = nullptr; size_t cap_points_out = 0;
     unsigned* d_status = nullptr;   // [0] a lane of a persistent launch gave up waiting, [1] census counter
     uint32_t epoch = 1;             // number of the next grad-iter of a persistent launch (mailbox tags)
     bool persist_unchecked = false; // persistent launches were enqueued since the status word was last read
+    struct journal_entry { tp_params p; int iters; };
+    std::vector<journal_entry> journal;   // ... which ones (tp_iterate): replayed on the two-kernel path if a launch gave up
+    unsigned done_base = 0;               // the device's count of completed persistent launches when the journal was last empty
+    int64_t persist_failures = 0;
     int64_t persist_launches = 0, persist_iters = 0;
     std::vector<uint64_t> hkeys;   // open-addressing table of tp_upload: undirected edge key -> id
     std::vector<int> hvals;
@@ -251,18 +259,32 @@ unsigned long long* persist_dbg_buffer(int parts, hipStream_t s) {
 #define PK_MIN_ITERS 4        /* shorter tp_iterate calls are not worth a plan (frame-by-frame schedules) */
 #define PK_MAX_EPOCH 32000u   /* mailbox tags carry 15 bits of the grad-iter's number */
 
-// after the stream was synchronised: did a lane of a persistent launch give up waiting?  (Never seen with every
-// workgroup resident; the state of the triangulation is undefined then.)
+int enqueue_two_kernel(tp_context* c, const tp_params* p, float dp, int n);
+
+// After the stream was synchronised: did a lane of a persistent launch give up waiting?  That happens when the launch's
+// workgroups were not all resident together -- another process or another context had a persistent launch of its own on
+// the same GPU at that moment (the census only shows that a full grid fits an otherwise idle device).  A launch that
+// gives up changes nothing: `points` is only written by the small kernel behind it, which does nothing once the status
+// word is raised, and so do all later persistent launches.  So the grad-iters of the launches that did not complete are
+// run again here, on the two-kernel path, and the context stops using persistent launches.
 int check_persist_status(tp_context* c) {
     if (!c->persist_unchecked || !c->d_status) return TP_OK;
     c->persist_unchecked = false;
-    unsigned st[2] = {0u, 0u};
+    unsigned st[3] = {0u, 0u, 0u};
     HIP_TRY(c, hipMemcpy(st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
-    if (st[0] != 0u) {
-        hipMemset(c->d_status, 0, sizeof st);
-        c->census = -6;  // do not try again in this context
-        return fail(c, TP_ERR_HIP, "a persistent grad-iter launch timed out waiting for a neighbouring workgroup; vertex positions are undefined (re-upload)");
+    const size_t completed = (size_t)(st[2] - c->done_base);
+    c->done_base = st[2];
+    if (st[0] == 0u) { c->journal.clear(); return TP_OK; }
+    HIP_TRY(c, hipMemset(c->d_status, 0, sizeof(unsigned)));
+    c->census = -6;  // two kernels per grad-iter from now on in this context
+    c->persist_failures++;
+    std::vector<tp_context::journal_entry> todo(c->journal.begin() + (completed < c->journal.size() ? completed : c->journal.size()), c->journal.end());
+    c->journal.clear();
+    for (auto& e : todo) {
+        if (e.iters <= 0) continue;
+        if (int rc = enqueue_two_kernel(c, &e.p, resolve_dp(c, e.p.flavour, e.p.dp), e.iters)) return rc;
     }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return TP_OK;
 }
 
@@ -283,8 +305,8 @@ int take_census(tp_context* c) {
     if (c->census != 0) return TP_OK;
     c->census = -1;
     if (c->num_cus < 1) return TP_OK;
-    if (!c->d_status) { HIP_TRY(c, dev_alloc(&c->d_status, 2)); }
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(unsigned), c->stream));
+    if (!c->d_status) { HIP_TRY(c, dev_alloc(&c->d_status, 4)); }
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 4 * sizeof(unsigned), c->stream));
     if (tp_persist_set_lds(PK_LDS_LIMIT) != 0) { (void)hipGetLastError(); c->census = -2; return TP_OK; }
     c->lds_attr = PK_LDS_LIMIT;
     std::vector<pk_wg> hw((size_t)c->num_cus, pk_wg());
@@ -297,7 +319,8 @@ int take_census(tp_context* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     unsigned st[2] = {1u, 0u};
     HIP_TRY(c, hipMemcpy(st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemset(c->d_status, 0, sizeof st));
+    HIP_TRY(c, hipMemset(c->d_status, 0, 4 * sizeof(unsigned)));
+    c->done_base = 0;
     if (st[0] == 0u && st[1] == (unsigned)c->num_cus) c->census = 1;
     else c->census = -4 - (int)(st[0] != 0u);
     return TP_OK;
@@ -311,7 +334,7 @@ int take_census(tp_context* c) {
 int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok) {
     pk_plan np;
     pk_build_plan(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
-                  c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, c->num_cus, PK_LDS_LIMIT, np);
+                  c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, c->num_cus, PK_LDS_LIMIT, np, c->plan_base_every);
     *ok = np.ok;
     if (!np.ok) { if (!c->plan.ok) c->plan = np; return TP_OK; }
     tp_context::plan_buf& B = c->plan_dev[slot];
@@ -339,14 +362,21 @@ int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok)
 
 // the plan of the current triangulation (built on first use after an upload); *use = whether tp_iterate may take the
 // persistent path
-int ensure_plan(tp_context* c, float dp, bool* use) {
+int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false) {
     *use = false;
     if (c->persist_mode == TP_PERSIST_OFF || !c->px_pitch) return TP_OK;  // (rasters wider than 4096 columns have no pixel-record table)
     if (int rc = take_census(c)) return rc;
     if (c->census != 1) return TP_OK;
+    if (c->plan_generation == c->generation && base_every && !c->plan_base_every) {
+        // the plan of this triangulation does not walk the base lines in every grad-iter yet: cut it again (from the
+        // upload-time positions; a later re-plan follows the mesh) -- nothing in flight reads the plan buffers by then
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->plan_generation = 0;
+    }
     if (c->plan_generation != c->generation) {
         c->plan_generation = c->generation;
         c->plan = pk_plan();
+        c->plan_base_every = base_every;
         c->snap_pending[0] = c->snap_pending[1] = false;   // (uploads synchronise the stream: nothing is in flight)
         bool ok = false;
         if (int rc = build_plan(c, c->h_points.data(), dp, 0, &ok)) return rc;
@@ -399,10 +429,10 @@ int maybe_replan(tp_context* c, float dp) {
 
 // n grad-iters of the persistent kernel -- the last one writes `tenergy`, `colnum`, `colacc`, `gradient` --, then
 // `points_out` -> `points` / `epos`
-int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n) {
+int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings = false) {
     while (n > 0) {
         // long calls go chunk by chunk (a chunk and a half rather than a short tail)
-        const int k = n <= PK_CHUNK + PK_CHUNK / 2 ? n : PK_CHUNK;
+        const int k = n <= PK_CHUNK + PK_CHUNK / 2 ? n : PK_CHUNK;   // (rings: the caller's chunks are shorter than this)
         if (int rc = maybe_replan(c, dp)) return rc;
         if (c->epoch + (uint32_t)k > PK_MAX_EPOCH) {
             HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 4 * sizeof(unsigned long long), c->stream));
@@ -417,13 +447,15 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n) {
         A.flavour = p.flavour; A.rate = p.rate;
         A.posbox = c->posbox;
         A.epoch = c->epoch; A.n_iters = k; A.status = c->d_status;
-        A.emit = n == k; A.ten = c->ten; A.cn = c->cn; A.ca_out = c->ca; A.gr = c->gr;
+        A.emit = n == k && !rings; A.ten = c->ten; A.cn = c->cn; A.ca_out = c->ca; A.gr = c->gr;
+        if (rings) { A.ering = c->ering; A.pring = c->pring; }
 #ifdef TPOSE_DEBUG
         A.dbg = persist_dbg_buffer(c->plan.parts, c->stream);
         { const char* f = getenv("TPOSE_DBG_FIRST"); A.dbg_first = f ? atoi(f) : 0; }
 #endif
         tp_launch_persist(A, c->plan.lds_bytes, c->stream);
-        tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->stream);
+        tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->stream);
+        c->journal.push_back({p, rings ? 0 : k});   // (a chunk of tp_iterate_until is checked by its caller: nothing to replay)
         HIP_TRY(c, hipGetLastError());
         c->epoch += (uint32_t)k;
         c->persist_unchecked = true;
@@ -511,6 +543,8 @@ int tp_destroy(tp_context* c) {
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->prefix[0]); hipFree(c->prefix[1]); hipFree(c->px[0]); hipFree(c->px[1]);
     hipFree(c->render_pic); hipFree(c->render_pts);
     hipFree(c->d_wg); hipFree(c->d_pool); hipFree(c->posbox); hipFree(c->points_out); hipFree(c->d_status);
+    hipFree(c->ering); hipFree(c->pring);
+    if (c->ering_host) hipHostFree(c->ering_host);
     for (int k = 0; k < 2; k++) {
         hipFree(c->plan_dev[k].wg); hipFree(c->plan_dev[k].pool);
         if (c->plan_dev[k].stage) hipHostFree(c->plan_dev[k].stage);
@@ -861,6 +895,14 @@ int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
             left = 0;
         }
     }
+    if (int rc = enqueue_two_kernel(c, p, dp, left)) return rc;
+    c->acc_slot = p->image_slot; c->last_flavour = p->flavour;
+    c->accumulated = c->energized = false;
+    return TP_OK;
+}
+
+// n grad-iters as k_lines + k_update each: whole chunks as graph replays, the rest eagerly
+int enqueue_two_kernel(tp_context* c, const tp_params* p, float dp, int left) {
     if (left >= CHUNK) {
         graph_entry* g = nullptr;
         if (int rc = chunk_graph(c, p, dp, &g)) return rc;
@@ -871,8 +913,6 @@ int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
     }
     for (int k = 0; k < left; k++) enqueue_iter(c, *p, dp);
     HIP_TRY(c, hipGetLastError());
-    c->acc_slot = p->image_slot; c->last_flavour = p->flavour;
-    c->accumulated = c->energized = false;
     return TP_OK;
 }
 }  // namespace
@@ -899,6 +939,88 @@ int tp_prepare(tp_context* c, const tp_params* p) {
     if (use) return TP_OK;
     graph_entry* g = nullptr;
     return chunk_graph(c, p, resolve_dp(c, p->flavour, p->dp), &g);
+}
+
+int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double threshold, float* toterr, int* frames, float* relerr) {
+    api_guard api_lock;
+    if (!c) return TP_ERR_INVALID;
+    if (int rc = validate_params(c, p, max_frames)) return rc;
+    if (!toterr || !frames) return fail(c, TP_ERR_INVALID, "iterate_until: toterr / frames is NULL");
+    *frames = 0;
+    if (relerr) *relerr = 0.0f;
+    if (max_frames == 0) return TP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const float dp = resolve_dp(c, p->flavour, p->dp);
+    const int NT = c->NT;
+    float tot = *toterr, rel = 0.0f;
+    // geterr (source/triangulation.hpp:653-674) on the base energies of one frame: float32, ascending t
+    auto frame_err = [&](const int32_t* terr) {
+        float newerr = 0.0f;
+        for (int i = 0; i < NT; i++) { float err = 0.0f; err += (float)terr[i]; newerr += err; }
+        rel = (tot - newerr) / tot;
+        tot = newerr;
+        return (double)std::fabs(rel);   // (the reference compares the float with a double literal)
+    };
+    auto host_ring = [&](size_t ints) -> int {
+        if (ints <= c->cap_ering_host && c->ering_host) return TP_OK;
+        if (c->ering_host) hipHostFree(c->ering_host);
+        c->ering_host = nullptr; c->cap_ering_host = 0;
+        HIP_TRY(c, hipHostMalloc((void**)&c->ering_host, ints * sizeof(int32_t), hipHostMallocDefault));
+        c->cap_ering_host = ints;
+        return TP_OK;
+    };
+    bool use = false;
+    if (max_frames >= PK_MIN_ITERS) { if (int rc = ensure_plan(c, dp, &use, true)) return rc; }
+    int done = 0, chunk = 32;
+    bool converged = false;
+    while (done < max_frames && !converged) {
+        const int left = max_frames - done;
+        if (!use || left < PK_MIN_ITERS) {
+            // frame by frame on the two-kernel path: one frame, then the base energies come back
+            if (int rc = host_ring((size_t)NT)) return rc;
+            enqueue_iter(c, *p, dp);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(c->ering_host, c->ten, sizeof(int32_t) * (size_t)NT, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, wait_stream(c->stream));
+            done++;
+            converged = frame_err(c->ering_host) < threshold;
+            continue;
+        }
+        // a chunk of frames inside one persistent launch: every frame leaves its base energies and its starting positions
+        const int C = left < chunk ? left : chunk;
+        if (int rc = grow(c, &c->ering, &c->cap_ering, (size_t)C * NT)) return rc;
+        if (int rc = grow(c, &c->pring, &c->cap_pring, (size_t)C * c->NP)) return rc;
+        if (int rc = host_ring((size_t)C * NT)) return rc;
+        if (int rc = enqueue_persistent(c, *p, dp, C, true)) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->ering_host, c->ering, sizeof(int32_t) * (size_t)C * NT, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, wait_stream(c->stream));
+        {
+            const int64_t fails = c->persist_failures;
+            if (int rc = check_persist_status(c)) return rc;
+            if (c->persist_failures != fails) { use = false; continue; }   // the chunk gave up (nothing changed): frame by frame from here
+        }
+        int j = 0;
+        for (; j < C; j++) {
+            done++;
+            if (frame_err(c->ering_host + (size_t)j * NT) < threshold) { converged = true; break; }
+        }
+        if (converged || done >= max_frames) {
+            // back to the start of the last frame that counts, and that frame once more on the two-kernel path: it writes the
+            // buffers the reference reads back (`tenergy`, `colnum`, `colacc`, `gradient`) and takes the step
+            const int last = converged ? j : C - 1;
+            tp_launch_persist_finish(make_launch(c, p->image_slot, dp), c->pring + (size_t)last * c->NP, nullptr, c->stream);
+            enqueue_iter(c, *p, dp);
+            HIP_TRY(c, hipGetLastError());
+            break;
+        }
+        if (chunk < 256) chunk *= 2;
+    }
+    if (!use || max_frames < PK_MIN_ITERS) { /* (the two-kernel frames left the buffers of the last frame in place) */ }
+    c->acc_slot = p->image_slot; c->last_flavour = p->flavour;
+    c->accumulated = c->energized = false;
+    *toterr = tot; *frames = done;
+    if (relerr) *relerr = rel;
+    return TP_OK;
 }
 
 int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* accumulate_us) {
@@ -1164,6 +1286,7 @@ int tp_get_info(tp_context* c, int what, int64_t* value) {
         case 6: *value = c->persist_iters; return TP_OK;
         case 7: *value = c->census; return TP_OK;
         case 8: *value = c->replans; return TP_OK;
+        case 9: *value = c->persist_failures; return TP_OK;
         default: return fail(c, TP_ERR_INVALID, "unknown info %d", what);
     }
 }

@@ -72,9 +72,11 @@ struct pk_args {
     int flavour;
     float rate;
     unsigned long long* posbox;   // [2][NP][2] position mailbox
+    int32_t* ering;               // tp_iterate_until: [n_iters][NT] energy of every triangle's base variant, frame by frame (or null)
+    float2* pring;                // tp_iterate_until: [n_iters][NP] positions at the START of every frame (vertices of triangles)
     unsigned epoch;               // number of the launch's first grad-iter (tags; 1 .. 32767 between mailbox resets)
     int n_iters;                  // < 0: census of resident workgroups instead
-    unsigned* status;             // [0] raised by a lane that gave up waiting, [1] census counter
+    unsigned* status;             // [0] raised by a lane that gave up waiting, [1] census counter, [2] completed launches (k_persist_finish)
 #ifdef TPOSE_DEBUG
     unsigned long long* dbg;      // [parts][PK_DBG_ITERS][16] phase timestamps of the grad-iters dbg_first ...
     int dbg_first;
@@ -82,4 +84,4 @@ struct pk_args {
 };
 int tp_persist_set_lds(int bytes);  // hipFuncSetAttribute(max dynamic LDS); returns the hipError_t
 void tp_launch_persist(const pk_args& A, int lds_bytes, hipStream_t s);
-void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, hipStream_t s);
+void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, hipStream_t s);  // status: of the launch before, or null

@@ -665,8 +665,13 @@ void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s
 // after a persistent launch (tp_persist.hip): the positions it left in `points_out` become `points` (vertices no triangle
 // uses are not owned by any patch and keep theirs), and every vertex files its position with its edges (k_lines reads
 // endpoints by edge)
-__global__ void k_persist_finish(tp_launch L, const float2* points_out) {
+// A launch that gave up (status[0] raised: its workgroups were not all resident, tp_context.hip) leaves everything as it was.
+__global__ void k_persist_finish(tp_launch L, const float2* points_out, unsigned* status) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (status) {
+        if (status[0] != 0u) return;
+        if (v == 0) status[2] += 1u;   // (launches complete one after the other: no atomic)
+    }
     if (v >= L.NP) return;
     float2 p = L.points[v];
     if (L.vtx_off[v + 1] > L.vtx_off[v]) p = points_out[v];
@@ -678,8 +683,8 @@ __global__ void k_persist_finish(tp_launch L, const float2* points_out) {
     L.points[v] = p;
     publish_position(L, v, p, 0, 1);
 }
-void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_persist_finish, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L, points_out);
+void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, hipStream_t s) {
+    hipLaunchKernelGGL(k_persist_finish, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L, points_out, status);
 }
 
 // tpose::upload colour replication (source/triangulation.hpp:633-641): col[i*NT + k] = colors[k]

@@ -15,7 +15,8 @@
 // Nothing here is placement-dependent: workgroup b -> patch is a permutation chosen for L2 locality only.
 //
 // Every wait is bounded: a lane that polls longer than PK_TIMEOUT_TICKS raises the launch's status word and the whole
-// grid drains; the host sees it at its next synchronisation (tp_context.hip) and reports an error.
+// grid drains without having changed anything the host can see; at its next synchronisation the host runs the grad-iters
+// of that launch (and of the launches behind it, which do nothing once the word is raised) on the two-kernel path.
 #include "tp_kernels.h"
 #include "tp_persist.h"
 #include <type_traits>
@@ -23,7 +24,7 @@
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 #define PK_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-#define PK_TIMEOUT_TICKS 30000000ull  // 0.3 s of the 100 MHz wall clock
+#define PK_TIMEOUT_TICKS 3000000ull  // 30 ms of the 100 MHz wall clock (a hand-over takes microseconds)
 
 #ifdef TPOSE_DEBUG
 #define PK_STAMP(k) do { if (threadIdx.x == 0 && A.dbg && it >= A.dbg_first && it < A.dbg_first + PK_DBG_ITERS) A.dbg[((size_t)blockIdx.x * PK_DBG_ITERS + (it - A.dbg_first)) * 16 + (k)] = wall_clock64(); } while (0)
@@ -75,6 +76,9 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         }
         return;
     }
+
+    // a launch behind one that gave up does nothing (tp_context.hip: the grad-iters are run again on the two-kernel path)
+    if (__hip_atomic_load(status, PK_RLX_AGENT) != 0u) return;
 
     // ---- prologue: the patch's tables and positions into LDS
     {
@@ -140,7 +144,10 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         {
             const int nsnap = 5 * w.n_own_v + (w.n_slots - w.n_own_v);
             for (int j = PK_THREADS - 1 - tid; j < nsnap; j += PK_THREADS) pk_snap_lane(w, V, A.vw, j);
-            for (int k = tid; k < w.n_own_v; k += PK_THREADS) { V.grad[k].x = 0; V.grad[k].y = 0; }
+            for (int k = tid; k < w.n_own_v; k += PK_THREADS) {
+                V.grad[k].x = 0; V.grad[k].y = 0;
+                if (A.pring) A.pring[(size_t)it * A.NP + V.vid[k]] = make_float2(V.pos[k].x, V.pos[k].y);   // (a frame can be returned to)
+            }
         }
         __syncthreads();
         PK_STAMP(2);
@@ -201,6 +208,15 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
                 const size_t id = (size_t)(4 * (cr.y & 3) + m) * A.NT + cr.x;
                 if (A.flavour == 0) A.ca_out[id] = make_int4(tp_wrap32(mm.sr), tp_wrap32(mm.sg), tp_wrap32(mm.sb), 0);
                 A.ten[id] = e; A.cn[id] = tp_wrap32(mm.n);
+            }
+        }
+        if (A.ering && !emit) {   // tp_iterate_until: the energy of the base variants, frame by frame (the plan walks their lines every grad-iter)
+            for (int k = tid; k < w.n_base; k += PK_THREADS) {
+                int t;
+                const tp_moments mm = pk_base_moments(w, V, k, t);
+                pk_i4 col = {0, 0, 0, 0};
+                if (A.flavour == 1) { const int4 c = A.ca[t]; col.x = c.x; col.y = c.y; col.z = c.z; }
+                A.ering[(size_t)it * A.NT + t] = pk_energy(mm, A.flavour, col);
             }
         }
         if (emit) {   // base variants (i = 0) of the triangles whose first vertex this patch owns

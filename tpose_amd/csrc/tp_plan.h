@@ -126,9 +126,10 @@ inline void rcb(std::vector<rcb_vertex>& a, int lo, int hi, int p0, int p1, std:
 // Build the plan.  tris: ivec4[NT]; points: vec2[NP] (upload-time positions); edge_uv: int[2 NE] endpoint ids (the low
 // 30 bits; tp_upload keeps flags above); he_edge: int[3 NT] edge * 2 + direction; W, H: raster; dp_px: a hint, the size
 // of the moves in pixels (lines get a few rows longer or shorter).  max_parts: workgroups that can be resident at once.
+// base_every: the base lines of every triangle are walked in every grad-iter (not only in the last one of a call).
 inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* points, int NE, const int32_t* edge_uv,
                           const int32_t* he_edge, int W, int H, float ratio, float dp_px, int max_parts, int lds_limit,
-                          pk_plan& P) {
+                          pk_plan& P, bool base_every = false) {
     P = pk_plan();
     if (NT < 1 || NE < 1 || max_parts < 1) { P.why = "empty triangulation"; return; }
     auto EU = [&](int e) { return edge_uv[2 * (size_t)e] & 0x3fffffff; };
@@ -243,7 +244,9 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
                 need(he_out >> 1, (he_out & 1) ? 4 : 2);
                 need(he_in >> 1, (he_in & 1) ? 2 : 4);
                 need(he_opp >> 1, 1);
-                if (s == 0) { need(he_out >> 1, 8); need(he_in >> 1, 8); }   // the triangle's base variant is this patch's to write
+                // the triangle's base variant is this patch's to write: in the last grad-iter of a call, or (tp_iterate_until: the
+                // energy of every frame is wanted) in every grad-iter
+                if (s == 0) { need(he_out >> 1, base_every ? 1 : 8); need(he_in >> 1, base_every ? 1 : 8); }
             }
         // local edges in order of first use; their lines (needed versions, ascending) and lane-items
         w.n_edges = (int)eglob.size();

@@ -36,13 +36,8 @@ inline long descend(direction& d, long levelframes) {
     tpose::warpA = d.warpA;
     tpose::toterr = d.toterr;
     tpose::upload(&d.tr);
-    long frames = 0;
-    while (frames < levelframes) {
-        frames++;
-        tpose::doframe();  // doreset + doenergy + doshift of the reference's frame, fused on the device
-        tpose::retrieve(&d.tr);
-        if (tpose::geterr(&d.tr) < 1E-6) break;
-    }
+    // doreset + doenergy + doshift of the reference's frame and its test, frame after frame on the library's side
+    const long frames = tpose::descend(&d.tr, 1E-6, levelframes);
     d.toterr = tpose::toterr;
     return frames;
 }
