@@ -15,8 +15,22 @@ struct part_state {
     std::vector<char> lds;
     pk_view V;
     std::vector<pk_lane_cache<PK_ROWS_PER_LANE>> cache;   // one per cached lane-item, like the kernel's registers
+    int n_li = 0, n_li_all = 0, rpl = 0;
 };
+int64_t* g_recuts = nullptr;   // optional: how often a patch cut its lines again
+// optional walk statistics (tools/drift_stats.py): per grad-iter {lanes with a stale record, most lane-items of a patch,
+// lanes with rows beyond the kept records, those rows, most such rows in one patch, most stale lanes in one patch}
+int64_t* g_walk_stats = nullptr;
+int g_walk_stats_iters = 0;
 }  // namespace
+
+extern "C" void emul_persist_walk_stats(int64_t* out, int iters, int64_t* recuts) { g_walk_stats = out; g_walk_stats_iters = iters; g_recuts = recuts; }
+// pk_magic against the integer division it stands for: mismatches over every chunk count
+extern "C" int emul_magic_check() {
+    int bad = 0;
+    for (int d = 1; d <= PK_MAX_TL; d++) bad += pk_magic(d) != (d == 1 ? 0u : (uint32_t)(0x100000000ull / (uint64_t)d) + 1u);
+    return bad;
+}
 
 // returns 0, or a negative code: -1 plan refused, -2 a position granule had the wrong tag
 extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, float* points, int NP, const int32_t* tris,
@@ -65,12 +79,11 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
         pk_carve(S[p].lds.data(), w, V);
         memcpy(V.vid, &P.pool[w.off_vid], sizeof(int32_t) * w.n_slots);
         memcpy(V.edges, &P.pool[w.off_edges], sizeof(int32_t) * w.n_edges);
-        for (int l = 0; l < w.n_lines_all; l++) pk_expand_line(V, &P.pool[w.off_lines], l);
+        memcpy(V.lines, &P.pool[w.off_lines], sizeof(int32_t) * w.n_lines_all);
         memcpy(V.corners, &P.pool[w.off_corners], sizeof(int32_t) * 4 * w.n_corners);
         memcpy(V.base, &P.pool[w.off_base], sizeof(int32_t) * 4 * w.n_base);
         for (int s = 0; s < w.n_slots; s++) { V.pos[s].x = points[2 * V.vid[s]]; V.pos[s].y = points[2 * V.vid[s] + 1]; }
         S[p].cache.resize(PK_CACHED);
-        for (int j = 0; j < PK_CACHED; j++) pk_cache_init(S[p].cache[j], V, j, j < w.n_li);
     }
     std::vector<unsigned long long> posbox((size_t)2 * NP * 2, 0);
     const char* table = reinterpret_cast<const char*>(T.data());
@@ -80,7 +93,8 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
         for (int p = 0; p < P.parts; p++) {
             const pk_wg& w = P.wg[p];
             pk_view& V = S[p].V;
-            const int n_lines = emit ? w.n_lines_all : w.n_lines, n_li = emit ? w.n_li_all : w.n_li;
+            const bool recut = (it & (PK_RECUT - 1)) == 0;
+            const int n_lines = emit ? w.n_lines_all : w.n_lines, n_setup = recut ? w.n_lines_all : n_lines;
             if (it > 0)  // P0
                 for (int s = w.n_own_v; s < w.n_slots; s++) {
                     const unsigned long long* g = &posbox[((size_t)par * NP + V.vid[s]) * 2];
@@ -90,22 +104,60 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
                 }
             // P1
             for (int j = 0; j < 5 * w.n_own_v + (w.n_slots - w.n_own_v); j++) pk_snap_lane(w, V, vw, j);
-            for (int l = 0; l < n_lines; l++) {
+            for (int l = 0; l < n_setup; l++) {
                 pk_walker wkr;
                 pk_setup_lane(V, vw, l, wkr);
                 V.wk[l] = wkr;
             }
             memset(V.sums, 0, sizeof(unsigned long long) * 6 * (size_t)w.n_lines_all);
+            if (recut) {   // the wave's lanes one after the other
+                const int RRk = P.rows_max <= 7 ? 8 : P.rows_max <= 9 ? 10 : P.rows_max <= 10 ? 11 : 12;   // tp_launch_persist's choice
+                int changed = 0, sum[64];
+                int rpl = it == 0 ? w.rows : S[p].rpl;
+                bool first = it == 0;
+                for (;;) {
+                    int every = 0, run = 0;
+                    for (int lane = 0; lane < 64; lane++) {
+                        int ev;
+                        sum[lane] = pk_recut_count(V, w.n_lines_all, w.n_lines, lane, 64, rpl, first, changed, ev);
+                        every += ev;
+                    }
+                    for (int lane = 0; lane < 64; lane++) { pk_recut_write(V, w.n_lines_all, lane, 64, run); run += sum[lane]; }
+                    if (every <= PK_CACHED || rpl >= RRk) break;
+                    rpl++; first = true;
+                }
+                S[p].rpl = rpl;
+                S[p].n_li = V.cut[w.n_lines]; S[p].n_li_all = V.cut[w.n_lines_all];
+                if (changed)
+                    for (int j = 0; j < PK_CACHED; j++)
+                        pk_cache_init(S[p].cache[j], V, j, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.n_lines_all, it == 0);
+                if (g_recuts) g_recuts[0] += changed;
+            }
+            const int n_li = emit ? S[p].n_li_all : S[p].n_li;
             for (int k = 0; k < w.n_own_v; k++) { V.grad[k].x = 0; V.grad[k].y = 0; }
             // P3
-            for (int j = 0; j < n_li; j++) {
-                pk_acc a;
-                int l;
-                if (j < PK_CACHED && j < w.n_li) {
-                    pk_walk_cached<PK_ROWS_PER_LANE>(S[p].cache[j], V, table, pitch, W, a);
-                    l = S[p].cache[j].l;
+            if (g_walk_stats && it < g_walk_stats_iters) {
+                int64_t* ws = g_walk_stats + 6 * (size_t)it;
+                const int RRk = P.rows_max <= 7 ? 8 : P.rows_max <= 9 ? 10 : P.rows_max <= 10 ? 11 : 12;   // tp_launch_persist's choice
+                int64_t over_rows = 0, stale = 0;
+                for (int j = 0; j < PK_CACHED; j++) {
+                    const pk_scan sc = pk_walk_scan<PK_ROWS_PER_LANE>(S[p].cache[j], V, pitch, W);
+                    if (sc.stale) { ws[0]++; stale++; }
+                    if (sc.r.n > RRk) { ws[2]++; ws[3] += sc.r.n - RRk; over_rows += sc.r.n - RRk; }
                 }
-                else l = pk_walk_lane(V, table, pitch, W, j, a);
+                if (over_rows > ws[4]) ws[4] = over_rows;
+                if (stale > ws[5]) ws[5] = stale;
+                if (S[p].n_li > ws[1]) ws[1] = S[p].n_li;
+            }
+            for (int j = 0; j < PK_CACHED; j++) {   // the cached slots (a slot without a lane-item walks nothing)
+                pk_acc a;
+                pk_walk_cached<PK_ROWS_PER_LANE>(S[p].cache[j], V, table, pitch, W, a);
+                unsigned long long* s = V.sums + (size_t)S[p].cache[j].l * 6;
+                s[0] += a.xs; s[1] += a.nodd; s[2] += a.r; s[3] += a.g; s[4] += a.b; s[5] += a.q;
+            }
+            for (int j = S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED; j < n_li; j++) {
+                pk_acc a;
+                const int l = pk_walk_lane(V, table, pitch, W, w.n_lines_all, j, a);
                 unsigned long long* s = V.sums + (size_t)l * 6;
                 s[0] += a.xs; s[1] += a.nodd; s[2] += a.r; s[3] += a.g; s[4] += a.b; s[5] += a.q;
             }

@@ -279,6 +279,26 @@ def test_persistent_record_cache_over_many_grad_iters(emp):
         assert np.array_equal(p.view(np.uint32), ref["points"].view(np.uint32)), rate
 
 
+def test_persistent_lines_are_cut_again_on_the_device(emp):
+    """every PK_RECUT grad-iters a patch counts the chunks of its lines again from the positions it has: 200 grad-iters of a
+    fast descent change the cut several times and never the result; the outputs of the last grad-iter come from base lines
+    cut long before"""
+    W, H, grid = 300, 200, (15, 5)
+    img, _, pts, tris, ratio, _ = case(W, H, grid)
+    recuts = np.zeros(1, np.int64)
+    emp.emul_persist_walk_stats(None, 0, recuts.ctypes.data_as(C.c_void_p))
+    try:
+        rc, p, stats = emul_persist(emp, img, pts, tris, 0, ratio, 0.0004, 200, max_parts=7)
+    finally:
+        emp.emul_persist_walk_stats(None, 0, None)
+    assert rc == 0
+    assert recuts[0] > stats[1], "no patch cut its lines again after the first grad-iter"
+    ref = O.iterate(img, pts, tris, 0, ratio, 0.0004, 200, literal=False)
+    assert np.array_equal(p.view(np.uint32), ref["points"].view(np.uint32))
+    assert np.array_equal(stats_out["ten"], ref["ten"]) and np.array_equal(stats_out["gr"], ref["gr"])
+    assert emp.emul_magic_check() == 0
+
+
 def test_persistent_plan_on_soups_and_bad_vertices(emp):
     """triangle soups (edges shared by many triangles, duplicated triangles, vertices outside the domain, NaN): the plan
     either refuses (an edge naming one vertex twice) or replays to the oracle's bits"""

@@ -314,7 +314,7 @@ int take_census(tp_context* c) {
     HIP_TRY(c, hipMemcpyAsync(c->d_wg, hw.data(), sizeof(pk_wg) * hw.size(), hipMemcpyHostToDevice, c->stream));
     pk_args A{};
     A.wg = c->d_wg; A.parts = c->num_cus; A.n_iters = -1; A.status = c->d_status;
-    tp_launch_persist(A, PK_LDS_LIMIT, c->stream);
+    tp_launch_persist(A, PK_ROWS_PER_LANE, PK_LDS_LIMIT, c->stream);
     if (hipGetLastError() != hipSuccess) { c->census = -3; return TP_OK; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     unsigned st[2] = {1u, 0u};
@@ -327,7 +327,7 @@ int take_census(tp_context* c) {
 }
 
 #define PK_CHUNK 1024         /* grad-iters per launch of a long call: the granule of re-planning */
-#define PK_REPLAN_PX 3.0f     /* a vertex this far from where the plan saw it: cut a new plan */
+#define PK_REPLAN_PX 2.0f     /* a vertex this far from where the plan saw it: cut a new plan */
 
 // cut a plan from `points` and send it to plan buffer `slot` (through that buffer's pinned staging area: the copy rides
 // the stream and the host does not wait for it).  c->plan is replaced only when the new plan is usable.
@@ -453,7 +453,7 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         A.dbg = persist_dbg_buffer(c->plan.parts, c->stream);
         { const char* f = getenv("TPOSE_DBG_FIRST"); A.dbg_first = f ? atoi(f) : 0; }
 #endif
-        tp_launch_persist(A, c->plan.lds_bytes, c->stream);
+        tp_launch_persist(A, c->plan.rows_max, c->plan.lds_bytes, c->stream);
         tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->stream);
         c->journal.push_back({p, rings ? 0 : k});   // (a chunk of tp_iterate_until is checked by its caller: nothing to replay)
         HIP_TRY(c, hipGetLastError());

@@ -83,5 +83,5 @@ struct pk_args {
 #endif
 };
 int tp_persist_set_lds(int bytes);  // hipFuncSetAttribute(max dynamic LDS); returns the hipError_t
-void tp_launch_persist(const pk_args& A, int lds_bytes, hipStream_t s);
+void tp_launch_persist(const pk_args& A, int rows, int lds_bytes, hipStream_t s);
 void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, hipStream_t s);  // status: of the launch before, or null

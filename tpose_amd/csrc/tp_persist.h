@@ -37,7 +37,7 @@ struct pk_view {
     int32_t* vid;              // static tables, copied from the plan's pool at the start of the launch
     int32_t* edges;
     int32_t* lines;
-    int32_t* li;
+    int32_t* cut;              // [n_lines_all + 1] first lane-item of every line; the last entry: how many there are
     pk_i4* corners;
     pk_i4* base;
     int32_t* flags;
@@ -53,21 +53,10 @@ TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     V.vid = (int32_t*)p; p += pk_align16(w.n_slots * 4);
     V.edges = (int32_t*)p; p += pk_align16(w.n_edges * 4);
     V.lines = (int32_t*)p; p += pk_align16(w.n_lines_all * 4);
-    V.li = (int32_t*)p; p += pk_align16(w.n_li_all * 12);
+    V.cut = (int32_t*)p; p += pk_align16((w.n_lines_all + 1) * 4);
     V.corners = (pk_i4*)p; p += pk_align16(w.n_corners * 16);
     V.base = (pk_i4*)p; p += pk_align16(w.n_base * 16);
     V.flags = (int32_t*)p;
-}
-
-// prologue, lane l < n_lines_all: the line's entry of the plan -> V.lines[l] and the lane-items of its chunks
-TP_HD void pk_expand_line(const pk_view& V, const int32_t* plan_lines, int l) {
-    const int32_t w0 = plan_lines[4 * l], w1 = plan_lines[4 * l + 1], magic = plan_lines[4 * l + 2], li0 = plan_lines[4 * l + 3];
-    const int TL = w1 & 0xffff, nl = w1 >> 16;
-    V.lines[l] = w0;
-    for (int c = 0; c < TL; c++) {
-        int32_t* e = V.li + 3 * (size_t)(li0 + c * nl);
-        e[0] = l | (c << 16); e[1] = TL; e[2] = magic;
-    }
 }
 
 TP_HD int pk_snap_index(const pk_wg& w, int slot, int move) {
@@ -106,6 +95,57 @@ TP_HD uint32_t pk_div(uint32_t x, uint32_t magic) {
 #else
     return magic ? (uint32_t)(((uint64_t)x * magic) >> 32) : x;
 #endif
+}
+
+TP_HD uint32_t pk_magic(int d) { return d == 1 ? 0u : (uint32_t)(4294967296.0 / (double)d) + 1u; }
+
+// ---- The chunks of a patch's lines.  A line of r rows is walked by ceil((r + slack) / rows-per-lane) lanes (its chunks,
+// consecutive lane-items); lines grow and shrink while the descent runs, so the workgroup counts again every PK_RECUT
+// grad-iters, from the walkers of the grad-iter at hand -- on the device, with nothing from the host.  A line keeps its
+// chunks while it still fits them and has not shrunk by a lane's worth (every change of one line moves the lane-items of
+// all the lines behind it, and every lane then fetches its records again).  How lines are cut never changes a sum.
+// A patch whose lines have grown into more lane-items than its threads keep records for takes a row more per lane.
+// One wave does it: lane i takes the lines [i B, (i + 1) B), B = ceil(n / lanes) -- pk_recut_count: chunks of each into
+// `tl` scratch (the lines' sum slots, zeroed again by pk_recut_write), their sum returned; the caller's prefix sum over
+// lanes gives `offset`; pk_recut_write: first lane-item of each.
+TP_HD int pk_recut_line(const pk_view& V, int l, int rpl, bool first) {
+    const pk_walker& k = V.wk[l];
+    const int rows = k.ra > k.rb ? 0 : k.rb - k.ra + 1;
+    const int fresh = pk_chunks(rows, rpl);
+    if (first) return fresh;
+    const int old = V.cut[l + 1] - V.cut[l];
+    return (rows + 1 <= old * rpl && old <= fresh + 1) ? old : fresh;
+}
+TP_HD int pk_recut_count(const pk_view& V, int n, int n_every, int lane, int lanes, int rpl, bool first, int& changed, int& sum_every) {
+    const int B = (n + lanes - 1) / lanes;
+    int sum = 0;
+    sum_every = 0;   // ... of the lines walked every grad-iter, [0, n_every)
+    for (int l = lane * B; l < n && l < (lane + 1) * B; l++) {
+        const int t = pk_recut_line(V, l, rpl, first);
+        changed |= first || t != V.cut[l + 1] - V.cut[l];
+        V.sums[6 * (size_t)l] = (unsigned long long)t;
+        sum += t;
+        sum_every += l < n_every ? t : 0;
+    }
+    return sum;
+}
+TP_HD void pk_recut_write(const pk_view& V, int n, int lane, int lanes, int offset) {
+    const int B = (n + lanes - 1) / lanes;
+    for (int l = lane * B; l < n && l < (lane + 1) * B; l++) {
+        V.cut[l] = offset;
+        offset += (int)V.sums[6 * (size_t)l];
+        V.sums[6 * (size_t)l] = 0ull;
+    }
+    if (lane == lanes - 1) V.cut[n] = offset;   // (the last lane's lines are the last ones, or it has none and its offset is the total)
+}
+// lane-item j -> (line l, chunk c of TL): the line whose run of lane-items holds j
+TP_HD void pk_find_item(const pk_view& V, int n_lines_all, int j, int& l, int& c, int& TL) {
+    int lo = 0, hi = n_lines_all;   // cut[lo] <= j < cut[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (V.cut[mid] <= j) lo = mid; else hi = mid;
+    }
+    l = lo; c = j - V.cut[lo]; TL = V.cut[lo + 1] - V.cut[lo];
 }
 
 struct pk_acc {
@@ -176,9 +216,10 @@ TP_HD void pk_walk_rows(pk_rows& r, const char* table, int W, pk_acc& a) {
 
 // P3, lane-item j >= PK_CACHED (a patch with more lane-items than its threads keep records for): (line l, chunk c of TL), nothing kept between
 // grad-iters.  Returns the line-sum slot, the partial sums in `a`.
-TP_HD int pk_walk_lane(const pk_view& V, const char* table, int pitch, int W, int j, pk_acc& a) {
-    const int l = V.li[3 * j] & 0xffff, c = V.li[3 * j] >> 16, TL = V.li[3 * j + 1];
-    const uint32_t magic = (uint32_t)V.li[3 * j + 2];
+TP_HD int pk_walk_lane(const pk_view& V, const char* table, int pitch, int W, int n_lines_all, int j, pk_acc& a) {
+    int l, c, TL;
+    pk_find_item(V, n_lines_all, j, l, c, TL);
+    const uint32_t magic = pk_magic(TL);
     a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
     pk_rows r = pk_lane_rows(V.wk[l], c, TL, magic, pitch);
     pk_walk_rows<4>(r, table, W, a);
@@ -195,17 +236,24 @@ TP_HD int pk_walk_lane(const pk_view& V, const char* table, int pitch, int W, in
 // lane-dependent branches in either loop.
 template <int R>
 struct pk_lane_cache {
-    int l, c, TL;           // the lane-item: line-sum slot, chunk, chunks (never change during a launch)
+    int l, c, TL;           // the lane-item: line-sum slot, chunk, chunks (until the patch's lines are cut again)
     uint32_t magic;
     uint32_t row0;          // table offset of the first row the cached records belong to; ~0: nothing cached
     int32_t col[R];         // crossing column of rec[u]; -1: nothing cached
     pk_rec rec[R];
 };
+// Which lane-item cached slot j (thread j mod PK_THREADS, its item j / PK_THREADS) takes: the chunks of a line are
+// consecutive lane-items, and consecutive lanes of a wave take lane-items 16 apart, so that the lanes of one LDS atomic
+// fold different lines (the same line from adjacent lanes serialises the instruction)
+TP_HD int pk_item_of_slot(int j) { return (j & 63) * (PK_CACHED / 64) + (j >> 6); }
 template <int R>
-TP_HD void pk_cache_init(pk_lane_cache<R>& C, const pk_view& V, int j, bool live) {
-    C.l = live ? V.li[3 * j] & 0xffff : 0; C.c = live ? V.li[3 * j] >> 16 : 0;
-    C.TL = live ? V.li[3 * j + 1] : 0;     // (0 chunks: a thread without a lane-item -- no rows, ever)
-    C.magic = live ? (uint32_t)V.li[3 * j + 2] : 0u;
+TP_HD void pk_cache_init(pk_lane_cache<R>& C, const pk_view& V, int slot, int n_li, int n_lines_all, bool fresh) {
+    const int j = pk_item_of_slot(slot);
+    const bool live = j < n_li;
+    int l = 0, c = 0, TL = 0;   // (0 chunks: a thread without a lane-item -- no rows, ever)
+    if (live) pk_find_item(V, n_lines_all, j, l, c, TL);
+    if (!fresh && l == C.l && c == C.c && TL == C.TL) return;   // the same rows of the same line as before: its records stay
+    C.l = l; C.c = c; C.TL = TL; C.magic = live ? pk_magic(TL) : 0u;
     C.row0 = live ? 0xffffffffu : 0u;
 #pragma unroll
     for (int u = 0; u < R; u++) { C.col[u] = live ? -1 : 0; C.rec[u].lo = 0; C.rec[u].hi = 0; }

@@ -55,6 +55,9 @@ __device__ __forceinline__ int patch_of_block(int b, int parts) {
 
 }  // namespace
 
+// RR: table records a lane keeps per lane-item = the most rows per lane of any patch of the plan (the launcher picks the
+// smallest instantiation that covers the plan: fewer rows, fewer registers and less straight-line code)
+template <int RR>
 __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         const int32_t* pool = A.pool;
         for (int i = tid; i < w.n_slots; i += PK_THREADS) V.vid[i] = pool[w.off_vid + i];
         for (int i = tid; i < w.n_edges; i += PK_THREADS) V.edges[i] = pool[w.off_edges + i];
-        for (int i = tid; i < w.n_lines_all; i += PK_THREADS) pk_expand_line(V, pool + w.off_lines, i);
+        for (int i = tid; i < w.n_lines_all; i += PK_THREADS) V.lines[i] = pool[w.off_lines + i];
         for (int i = tid; i < 4 * w.n_corners; i += PK_THREADS) ((int32_t*)V.corners)[i] = pool[w.off_corners + i];
         for (int i = tid; i < 4 * w.n_base; i += PK_THREADS) ((int32_t*)V.base)[i] = pool[w.off_base + i];
         for (int i = tid; i < w.n_slots; i += PK_THREADS) {
@@ -106,18 +109,19 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
     }
     const char* table = reinterpret_cast<const char*>(A.px);
     // this thread's lane-item of the walk and the table records of its rows: in registers for the whole launch
-    pk_lane_cache<PK_ROWS_PER_LANE> cache[PK_NI];
+    pk_lane_cache<RR> cache[PK_NI];
     gu64* posbox = (gu64*)A.posbox;
     int failed = 0;
+    int n_li_now = 0, n_li_all_now = 0;   // lane-items of the lines walked every grad-iter / with the last one's base lines
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PK_NI; i++) pk_cache_init(cache[i], V, tid + i * PK_THREADS, tid + i * PK_THREADS < w.n_li);
 
     for (int it = 0; it < A.n_iters; it++) {
         const uint32_t epoch = A.epoch + (uint32_t)it, tag = pk_tag(epoch), par = epoch & 1u;
         // the last grad-iter of a call that wants the reference's buffers also walks the base lines of the base variants
         const bool last = it + 1 == A.n_iters, emit = last && A.emit;
-        const int n_lines = emit ? w.n_lines_all : w.n_lines, n_li = emit ? w.n_li_all : w.n_li;
+        // every PK_RECUT grad-iters the patch looks at the chunks of its lines again (tp_persist.h, pk_recut_line)
+        const bool recut = (it & (PK_RECUT - 1)) == 0;
+        const int n_lines = emit ? w.n_lines_all : w.n_lines, n_setup = recut ? w.n_lines_all : n_lines;
         PK_STAMP(0);
         // ---- P0: positions of the neighbouring vertices this patch uses (the first grad-iter of a launch read `points`)
         if (it > 0) {
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         if (__syncthreads_or(failed)) return;
         PK_STAMP(1);
         // ---- P1: line set-up (low threads), snapped positions (high threads), gradient reset
-        for (int l = tid; l < n_lines; l += PK_THREADS) {
+        for (int l = tid; l < n_setup; l += PK_THREADS) {
             pk_walker wk;
             pk_setup_lane(V, A.vw, l, wk);
             V.wk[l] = wk;
@@ -150,6 +154,34 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
             }
         }
         __syncthreads();
+        if (recut) {
+            if (tid < 64) {
+                int changed = 0, rpl = it == 0 ? w.rows : V.flags[2];
+                bool first = it == 0;
+                for (;;) {
+                    int every;
+                    const int sum = pk_recut_count(V, w.n_lines_all, w.n_lines, tid, 64, rpl, first, changed, every);
+                    int incl = sum;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); incl += tid >= d ? o : 0; }
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) every += __shfl_xor(every, d);
+                    pk_recut_write(V, w.n_lines_all, tid, 64, incl - sum);
+                    if (every <= PK_CACHED || rpl >= RR) break;
+                    rpl++; first = true;   // (more lane-items than lanes keep records for: a row more per lane)
+                }
+                changed = __any(changed);
+                if (tid == 0) { V.flags[1] = changed; V.flags[2] = rpl; }
+            }
+            __syncthreads();
+            n_li_now = V.cut[w.n_lines]; n_li_all_now = V.cut[w.n_lines_all];
+            if (V.flags[1]) {
+#pragma unroll
+                for (int i = 0; i < PK_NI; i++)
+                    pk_cache_init(cache[i], V, tid + i * PK_THREADS, n_li_now < PK_CACHED ? n_li_now : PK_CACHED, w.n_lines_all, it == 0);
+            }
+        }
+        const int n_li = emit ? n_li_all_now : n_li_now;
         PK_STAMP(2);
         // ---- P3: walk -- one table record per (line, row); chunks of a line meet in LDS
         auto fold = [&](int l, const pk_acc& a) {
@@ -161,8 +193,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
             }
         };
         // (each step for both lane-items of the thread before the next step: their fetches are in flight together)
-        auto walk = [&](auto rr) {
-            constexpr int RR = decltype(rr)::value;
+        {
             pk_scan S[PK_NI];
 #pragma unroll
             for (int i = 0; i < PK_NI; i++) S[i] = pk_walk_scan<RR>(cache[i], V, A.px_pitch, A.vw.W);
@@ -177,12 +208,11 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
                 fold(cache[i].l, a);
             }
             PK_STAMP(9);
-        };
-        walk(std::integral_constant<int, PK_ROWS_PER_LANE>());   // (variants for patches of fewer rows per lane made the compiler spill)
+        }
         // (lane-items beyond the cached ones: a patch with more than PK_CACHED, and the base lines of the last grad-iter)
-        for (int j = (w.n_li < PK_CACHED ? w.n_li : PK_CACHED) + tid; j < n_li; j += PK_THREADS) {
+        for (int j = (n_li_now < PK_CACHED ? n_li_now : PK_CACHED) + tid; j < n_li; j += PK_THREADS) {
             pk_acc a;
-            const int l = pk_walk_lane(V, table, A.px_pitch, A.vw.W, j, a);
+            const int l = pk_walk_lane(V, table, A.px_pitch, A.vw.W, w.n_lines_all, j, a);
             fold(l, a);
         }
         __syncthreads();
@@ -259,9 +289,20 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
 }
 
 int tp_persist_set_lds(int bytes) {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<8>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<10>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<11>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<PK_ROWS_PER_LANE>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return rc;
 }
-void tp_launch_persist(const pk_args& A, int lds_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(k_persist, dim3((unsigned)A.parts), dim3(PK_THREADS), (size_t)lds_bytes, s, A);
+// rows: the most rows per lane of any patch of the plan (pk_plan::rows_max); the census passes PK_ROWS_PER_LANE
+void tp_launch_persist(const pk_args& A, int rows, int lds_bytes, hipStream_t s) {
+    const dim3 g((unsigned)A.parts), b(PK_THREADS);
+    // (one row more than the plan's rows per lane where there is an instantiation for it: a line that has grown by a chunk's
+    // worth of rows since the plan was cut still fits the records its lanes keep)
+    if (rows <= 7) hipLaunchKernelGGL(k_persist<8>, g, b, (size_t)lds_bytes, s, A);
+    else if (rows <= 9) hipLaunchKernelGGL(k_persist<10>, g, b, (size_t)lds_bytes, s, A);
+    else if (rows <= 10) hipLaunchKernelGGL(k_persist<11>, g, b, (size_t)lds_bytes, s, A);
+    else hipLaunchKernelGGL(k_persist<PK_ROWS_PER_LANE>, g, b, (size_t)lds_bytes, s, A);
 }
 

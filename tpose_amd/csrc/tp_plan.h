@@ -33,7 +33,9 @@
 #define PK_ROWS_PER_LANE 12  /* table records a lane of the walk keeps in registers: the most rows per lane */
 #endif
 #define PK_MAX_SLOTS 1023    /* position slots of a workgroup (10-bit fields of the corner records) */
-#define PK_MAX_TL 4095       /* chunks per line (12-bit field) */
+#define PK_MAX_TL 4095       /* chunks per line */
+#define PK_SLACK_ROWS 3      /* rows a line may grow before its chunks are cut again */
+#define PK_RECUT 64          /* grad-iters between two looks at the chunks of a patch's lines */
 
 // per-workgroup header; every `off_*` indexes pk_plan::pool (int32 units)
 struct pk_wg {
@@ -41,15 +43,14 @@ struct pk_wg {
     int32_t n_edges;           // local edges: every edge one of the patch's corners uses
     int32_t n_lines;           // lines the patch walks every grad-iter = line-sum slots (per local edge: its needed versions, ascending)
     int32_t n_lines_all;       // ... plus the base lines only the LAST grad-iter of a call walks (outputs of the base variants)
-    int32_t n_li, n_li_all;    // lane-items of the walk: (line, chunk); likewise
+    int32_t n_li, n_li_all;    // lane-items of the walk, (line, chunk), at the plan's positions; likewise (the workgroup cuts its
+                               // lines into chunks itself, from the positions it has: tp_persist.h, pk_recut_line)
     int32_t n_corners;         // (own vertex, incident triangle): four lanes each, one per move
     int32_t n_base;            // triangles whose first vertex the patch owns: it writes their base variant's outputs
     int32_t rows;              // rows a lane of the walk takes: chunks per line = the line's rows / this (<= PK_ROWS_PER_LANE)
     int32_t off_vid;           // [n_slots] global vertex id
     int32_t off_edges;         // [n_edges] slot_u | slot_v << 16
-    int32_t off_lines;         // [n_lines_all] {local edge | version << 16, chunks | lines of the edge << 16, magic = floor(2^32 / chunks) + 1
-                               // (0: one chunk), lane-item of chunk 0}: chunk c of the line is lane-item [3] + c * lines of the edge --
-                               // the lane-item table {line | chunk << 16, chunks, magic} is expanded from this on the device
+    int32_t off_lines;         // [n_lines_all] local edge | version << 16
     int32_t off_corners;       // [n_corners] {t, s | own << 2 | slot_a << 12 | slot_b << 22, out | in << 16, opp}
     int32_t off_base;          // [n_base] {t, own | slot_1 << 10 | slot_2 << 20, line of edge 0 | edge 1 << 16, line of edge 2}
     int32_t lds_bytes;         // dynamic LDS of this workgroup (pk_lds_bytes)
@@ -60,6 +61,7 @@ struct pk_plan {
     std::string why;           // when !ok: why the triangulation takes the two-kernel path instead
     int parts = 0;             // workgroups (grid size)
     int lds_bytes = 0;         // max over workgroups
+    int rows_max = 0;          // most rows per lane of any patch
     std::vector<pk_wg> wg;
     std::vector<int32_t> pool;
     std::vector<int32_t> owner_v;           // (kept for tests and statistics)
@@ -74,6 +76,11 @@ struct pk_plan {
 #define PK_HD inline
 #endif
 PK_HD int pk_align16(int v) { return (v + 15) & ~15; }
+// chunks of a line of `rows` pixel rows when a lane takes `rpl` of them
+PK_HD int pk_chunks(int rows, int rpl) {
+    const int t = (rows + PK_SLACK_ROWS + rpl - 1) / rpl;
+    return t < 1 ? 1 : t > PK_MAX_TL ? PK_MAX_TL : t;
+}
 inline int pk_lds_bytes(const pk_wg& w) {
     int b = 0;
     b += pk_align16(w.n_lines_all * 48);            // line sums: six 64-bit words
@@ -84,7 +91,7 @@ inline int pk_lds_bytes(const pk_wg& w) {
     b += pk_align16(w.n_slots * 4);                 // vid
     b += pk_align16(w.n_edges * 4);                 // edges
     b += pk_align16(w.n_lines_all * 4);             // lines
-    b += pk_align16(w.n_li_all * 12);               // lane-items
+    b += pk_align16((w.n_lines_all + 1) * 4);       // first lane-item of every line (and the total)
     b += pk_align16(w.n_corners * 16);              // corners
     b += pk_align16(w.n_base * 16);                 // base variants
     return b + 64;                                  // flags
@@ -214,7 +221,6 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
     P.wg.assign((size_t)parts, pk_wg());
     std::vector<int> vslot((size_t)NP, 0), vstamp((size_t)NP, -1), eloc((size_t)NE, 0), estamp((size_t)NE, -1);
     std::vector<int32_t> vid, edges, emask, eglob, lines, corners, first, base;
-    std::vector<int> enl_scratch;
     P.pool.reserve((size_t)NT * 128 + 8192);
     for (int p = 0; p < parts; p++) {
         pk_wg& w = P.wg[p];
@@ -254,49 +260,48 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
         first.assign((size_t)w.n_edges * PK_NLINES, -1);
         // rows per lane: the fewest (down to 4) that still give every lane-item its own thread, so that lanes can keep their
         // table records in registers from one grad-iter to the next (tp_persist.h)
-        std::vector<int>& enl = enl_scratch;   // lines of every grad-iter per local edge
-        enl.assign((size_t)w.n_edges, 0);
-        for (int le = 0; le < w.n_edges; le++) enl[le] = ((emask[le] & 1) ? 1 : 0) + ((emask[le] & 2) ? 4 : 0) + ((emask[le] & 4) ? 4 : 0);
-        auto chunks = [&](int le, int rpl) {   // ceil((rows + dp) / rpl), 1 .. PK_MAX_TL
-            const int r = (int)std::ceil(rows[eglob[le]] + dp_px);
-            return std::max(1, std::min((r + rpl - 1) / rpl, PK_MAX_TL));
+        // chunks of line q of a local edge: its own rows -- a move in y makes the line dp longer or shorter, a move in x
+        // leaves its rows alone -- over the rows per lane (an estimate for the choice of that number: the workgroup counts again)
+        auto chunks = [&](int le, int q, int rpl) {
+            const int e = eglob[le];
+            const int mu = (q >= 1 && q <= 4) ? q : 0, mv = q >= 5 ? q - 4 : 0;
+            float yu = points[2 * (size_t)EU(e) + 1] * 0.5f * (float)H, yv = points[2 * (size_t)EV(e) + 1] * 0.5f * (float)H;
+            yu += mu == 3 ? dp_px : mu == 4 ? -dp_px : 0.0f;
+            yv += mv == 3 ? dp_px : mv == 4 ? -dp_px : 0.0f;
+            float rr = fabsf(yu - yv);
+            if (!(rr >= 0.0f)) rr = 0.0f;   // NaN positions: no rows
+            return pk_chunks((int)std::ceil(std::min(rr, (float)H)) + 1, rpl);
         };
+        auto active = [&](int le, int q) { return (emask[le] & (q == 0 ? 1 : q <= 4 ? 2 : 4)) != 0; };
         int rpl = 4;
         for (; rpl < PK_ROWS_PER_LANE; rpl++) {
             long n = 0;
-            for (int le = 0; le < w.n_edges; le++) n += (long)enl[le] * chunks(le, rpl);
-            if (n <= PK_CACHED) break;
+            for (int le = 0; le < w.n_edges; le++)
+                for (int q = 0; q < PK_NLINES; q++) if (active(le, q)) n += chunks(le, q, rpl);
+            if (n <= PK_CACHED - PK_CACHED / 64) break;   // (a little room: lines grow and shrink while the descent runs)
         }
         w.rows = rpl;
         int n_li = 0;
         for (int le = 0; le < w.n_edges; le++) {
             const int e = eglob[le];
             edges.push_back(slot(EU(e)) | (slot(EV(e)) << 16));
-            const int tl = chunks(le, rpl), nl = enl[le];
-            const uint32_t magic = tl == 1 ? 0u : (uint32_t)(0x100000000ull / (uint64_t)tl) + 1u;
-            int k = 0;
             for (int q = 0; q < PK_NLINES; q++) {
-                const int bit = q == 0 ? 1 : q <= 4 ? 2 : 4;
-                if (!(emask[le] & bit)) continue;
-                first[(size_t)le * PK_NLINES + q] = (int)(lines.size() / 4);
-                // the lines of an edge take the same rows in adjacent lanes
-                lines.push_back(le | (q << 16)); lines.push_back(tl | (nl << 16)); lines.push_back((int32_t)magic); lines.push_back(n_li + k);
-                k++;
+                if (!active(le, q)) continue;
+                first[(size_t)le * PK_NLINES + q] = (int)lines.size();
+                lines.push_back(le | (q << 16));
+                n_li += chunks(le, q, rpl);   // (the chunks of a line are consecutive lane-items)
             }
-            n_li += nl * tl;
         }
-        w.n_lines = (int)(lines.size() / 4);
+        w.n_lines = (int)lines.size();
         w.n_li = n_li;
         // base lines only the outputs of base variants need: walked by the last grad-iter of a call, after the others
         for (int le = 0; le < w.n_edges; le++) {
             if ((emask[le] & 9) != 8) continue;
-            const int tl = chunks(le, rpl);
-            const uint32_t magic = tl == 1 ? 0u : (uint32_t)(0x100000000ull / (uint64_t)tl) + 1u;
-            first[(size_t)le * PK_NLINES] = (int)(lines.size() / 4);
-            lines.push_back(le); lines.push_back(tl | (1 << 16)); lines.push_back((int32_t)magic); lines.push_back(n_li);
-            n_li += tl;
+            first[(size_t)le * PK_NLINES] = (int)lines.size();
+            lines.push_back(le);
+            n_li += chunks(le, 0, rpl);
         }
-        w.n_lines_all = (int)(lines.size() / 4);
+        w.n_lines_all = (int)lines.size();
         w.n_li_all = n_li;
         if (w.n_lines_all > 65535) { P.why = "a patch walks more than 65535 lines"; return; }
         for (int k = 0; k < w.n_own_v; k++) {
@@ -335,9 +340,10 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
         w.off_base = put(base);
         w.lds_bytes = pk_lds_bytes(w);
         P.lds_bytes = std::max(P.lds_bytes, w.lds_bytes);
+        P.rows_max = std::max(P.rows_max, w.rows);
         P.lines_total += w.n_lines; P.foreign_total += w.n_slots - w.n_own_v;
         double work = 40.0 * w.n_corners;
-        for (int l = 0; l < w.n_lines; l++) work += rows[eglob[lines[4 * (size_t)l] & 0xffff]];
+        for (int l = 0; l < w.n_lines; l++) work += rows[eglob[lines[(size_t)l] & 0xffff]];
         P.work_max = std::max(P.work_max, work); P.work_mean += work / parts;
     }
     if (P.lds_bytes > lds_limit) { P.why = "a patch does not fit the LDS"; return; }
