@@ -326,8 +326,12 @@ int take_census(tp_context* c) {
     return TP_OK;
 }
 
-#define PK_CHUNK 1024         /* grad-iters per launch of a long call: the granule of re-planning */
+#ifndef PK_CHUNK
+#define PK_CHUNK 512          /* grad-iters per launch of a long call: the granule of re-planning */
+#endif
+#ifndef PK_REPLAN_PX
 #define PK_REPLAN_PX 2.0f     /* a vertex this far from where the plan saw it: cut a new plan */
+#endif
 
 // cut a plan from `points` and send it to plan buffer `slot` (through that buffer's pinned staging area: the copy rides
 // the stream and the host does not wait for it).  c->plan is replaced only when the new plan is usable.
@@ -405,9 +409,10 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false) {
     return TP_OK;
 }
 
-// before a chunk: the snapshot of two chunks ago, if there is one -- a new plan when the mesh has drifted
+// after a chunk has been enqueued: the snapshot taken after the chunk before it, if there is one -- a new plan for the
+// chunks to come when the mesh has drifted
 int maybe_replan(tp_context* c, float dp) {
-    const int k = c->snap_next;   // the older of the two snapshot slots: the one the coming chunk's snapshot will overwrite
+    const int k = c->snap_next;   // the older of the two snapshot slots: the one the next chunk's snapshot will overwrite
     if (!c->snap_pending[k]) return TP_OK;
     HIP_TRY(c, hipEventSynchronize(c->snap_ev[k]));
     c->snap_pending[k] = false;
@@ -433,7 +438,6 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
     while (n > 0) {
         // long calls go chunk by chunk (a chunk and a half rather than a short tail)
         const int k = n <= PK_CHUNK + PK_CHUNK / 2 ? n : PK_CHUNK;   // (rings: the caller's chunks are shorter than this)
-        if (int rc = maybe_replan(c, dp)) return rc;
         if (c->epoch + (uint32_t)k > PK_MAX_EPOCH) {
             HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 4 * sizeof(unsigned long long), c->stream));
             c->epoch = 1;
@@ -470,6 +474,8 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
             c->snap_next = sl ^ 1;
             c->iters_since_snap = 0;
         }
+        // with this chunk on the stream (the GPU has work while the host cuts): does the mesh want a new plan?
+        if (int rc = maybe_replan(c, dp)) return rc;
     }
     return TP_OK;
 }

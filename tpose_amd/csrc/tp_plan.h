@@ -34,8 +34,12 @@
 #endif
 #define PK_MAX_SLOTS 1023    /* position slots of a workgroup (10-bit fields of the corner records) */
 #define PK_MAX_TL 4095       /* chunks per line */
+#ifndef PK_SLACK_ROWS
 #define PK_SLACK_ROWS 3      /* rows a line may grow before its chunks are cut again */
-#define PK_RECUT 64          /* grad-iters between two looks at the chunks of a patch's lines */
+#endif
+#ifndef PK_RECUT
+#define PK_RECUT 64          /* grad-iters between two looks at the chunks of a patch's lines (a power of two) */
+#endif
 
 // per-workgroup header; every `off_*` indexes pk_plan::pool (int32 units)
 struct pk_wg {
