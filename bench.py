@@ -144,15 +144,22 @@ def live_kernel_trace(timeout_s=150):
         files = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
         if r.returncode != 0 or not files:
             return None, "rocprofv3 --kernel-trace failed (rc %d)" % r.returncode
-        out = {}
+        out, acc = {}, {}
         for row in csv.DictReader(open(files[0])):
-            name = row["Name"].split("(")[0].replace("void ", "")
+            # (the persistent kernel is a template over the rows a lane keeps: k_persist<11>, k_persist<12> ... are one kernel here)
+            name = row["Name"].split("(")[0].replace("void ", "").split("<")[0]
             if name.startswith("k_"):
-                avg, calls = float(row["AverageNs"]) / 1e3, int(row["Calls"])
-                if name == DOMINANT and calls > 1 and "MinNs" in row:
-                    # one of the launches is the census of resident workgroups (the same kernel, a few microseconds): leave it out
-                    avg, calls = (avg * calls - float(row["MinNs"]) / 1e3) / (calls - 1), calls - 1
-                out[name] = {"avg_us": avg, "calls": calls}
+                a = acc.setdefault(name, {"ns": 0.0, "calls": 0, "min": None})
+                a["ns"] += float(row["AverageNs"]) * int(row["Calls"])
+                a["calls"] += int(row["Calls"])
+                if "MinNs" in row:
+                    a["min"] = float(row["MinNs"]) if a["min"] is None else min(a["min"], float(row["MinNs"]))
+        for name, a in acc.items():
+            ns, calls = a["ns"], a["calls"]
+            if name == DOMINANT and calls > 1 and a["min"] is not None:
+                # one of the launches is the census of resident workgroups (the same kernel, a few microseconds): leave it out
+                ns, calls = ns - a["min"], calls - 1
+            out[name] = {"avg_us": ns / calls / 1e3, "calls": calls}
         return out, "live: rocprofv3 --kernel-trace --stats over 4 launches of %d grad-iters (child run)" % CHILD_ITERS
     except Exception as e:  # noqa: BLE001 -- measurement is best effort, the bench line must still appear
         return None, "kernel trace: %s" % e

@@ -129,6 +129,8 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
                 S[p].rpl = rpl;
                 S[p].n_li = V.cut[w.n_lines]; S[p].n_li_all = V.cut[w.n_lines_all];
                 if (changed)
+                    for (int l = 0; l < w.n_lines_all; l++) pk_list_line(V, l, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.li_cap);
+                if (changed)
                     for (int j = 0; j < PK_CACHED; j++)
                         pk_cache_init(S[p].cache[j], V, j, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.n_lines_all, it == 0);
                 if (g_recuts) g_recuts[0] += changed;
@@ -157,7 +159,7 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
             }
             for (int j = S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED; j < n_li; j++) {
                 pk_acc a;
-                const int l = pk_walk_lane(V, table, pitch, W, w.n_lines_all, j, a);
+                const int l = pk_walk_lane(V, table, pitch, W, w.n_lines_all, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.li_cap, j, a);
                 unsigned long long* s = V.sums + (size_t)l * 6;
                 s[0] += a.xs; s[1] += a.nodd; s[2] += a.r; s[3] += a.g; s[4] += a.b; s[5] += a.q;
             }

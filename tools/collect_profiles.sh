@@ -13,9 +13,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt20 -o kt -- python 
 find $O -name "*kernel_trace.csv" -delete
 # 3. in-kernel timeline of the persistent kernel (debug flavour of the library): fresh mesh, and after 4000 grad-iters
 python tools/persist_timeline.py --rebuild > $O/persist_timeline.json 2> $O/persist_timeline.err
-TPOSE_DBG_FIRST=4000 python tools/persist_timeline.py > $O/persist_timeline_4000.json 2>> $O/persist_timeline.err
+TPOSE_TIMELINE_AFTER=4000 python tools/persist_timeline.py > $O/persist_timeline_4000.json 2>> $O/persist_timeline.err
 # 4. persistent path against the two-kernel path and the oracle: parity and timing, other configurations
 python tools/persist_check.py > $O/persist_check.txt 2>&1
+python tools/long_parity.py > $O/long_parity.txt 2>&1
+python tools/time_variants.py product > $O/long_run_timing.txt 2>&1
 # 5. the schedules
 python tools/run_config2.py 600 > $O/config2.txt 2>&1
 python tools/run_config3.py > $O/config3.txt 2>&1

@@ -30,8 +30,12 @@ ctx = capi.Context(0, W, H)
 ctx.set_image(capi.IMAGE_A, img)
 ctx.upload(pts, tris, None)
 p = capi.default_params(capi.TRIANGULATE)
-first = int(os.environ.get("TPOSE_DBG_FIRST", "0"))
-ctx.iterate(p, first + 130)
+# TPOSE_TIMELINE_AFTER=n: n grad-iters first (their launches stamp too; the last launch's stamps are the ones read)
+after = int(os.environ.get("TPOSE_TIMELINE_AFTER", "0"))
+first = after + int(os.environ.get("TPOSE_DBG_FIRST", "0"))   # (TPOSE_DBG_FIRST: first stamped grad-iter of a launch, read by the library)
+if after:
+    ctx.iterate(p, after)
+ctx.iterate(p, int(os.environ.get("TPOSE_DBG_FIRST", "0")) + 130)
 ctx.synchronize()
 lib = ctx.lib
 lib.tp_debug_dump_persist.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -46,7 +50,7 @@ out = {"workload": "%dx%d / %d triangles, contrast %g, grad-iters %d.." % (W, H,
 sel = st[:, 8:IT]
 for k, lab in enumerate(labels):
     d = (sel[:, :, k + 1] - sel[:, :, k]) / 100.0
-    out[lab] = {str(q): round(float(np.percentile(d, q)), 2) for q in (1, 50, 90, 100)}
+    out[lab] = {str(q): round(float(np.percentile(d, q)), 2) for q in (1, 50, 90, 99, 100)}
 # inside P3, thread 0: columns scanned and stale records requested for both lane-items; records summed and folded into LDS
 sub = [("P3a scan + fetch", 2, 8), ("P3b sums + atomics", 8, 9), ("P3e barrier", 9, 3)]
 for lab, a, b in sub:

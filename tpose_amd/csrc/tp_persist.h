@@ -38,6 +38,8 @@ struct pk_view {
     int32_t* edges;
     int32_t* lines;
     int32_t* cut;              // [n_lines_all + 1] first lane-item of every line; the last entry: how many there are
+    int32_t* li;               // [li_cap][3] the lane-items from `base` = min(lane-items walked every grad-iter, PK_CACHED) on:
+                               // {line | chunk << 16, chunks, magic}
     pk_i4* corners;
     pk_i4* base;
     int32_t* flags;
@@ -54,6 +56,7 @@ TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     V.edges = (int32_t*)p; p += pk_align16(w.n_edges * 4);
     V.lines = (int32_t*)p; p += pk_align16(w.n_lines_all * 4);
     V.cut = (int32_t*)p; p += pk_align16((w.n_lines_all + 1) * 4);
+    V.li = (int32_t*)p; p += pk_align16(w.li_cap * 12);
     V.corners = (pk_i4*)p; p += pk_align16(w.n_corners * 16);
     V.base = (pk_i4*)p; p += pk_align16(w.n_base * 16);
     V.flags = (int32_t*)p;
@@ -138,6 +141,17 @@ TP_HD void pk_recut_write(const pk_view& V, int n, int lane, int lanes, int offs
     }
     if (lane == lanes - 1) V.cut[n] = offset;   // (the last lane's lines are the last ones, or it has none and its offset is the total)
 }
+// after a re-cut, lane l < n_lines_all: the line's lane-items from `base` on into the table
+TP_HD void pk_list_line(const pk_view& V, int l, int base, int li_cap) {
+    const int j0 = V.cut[l], j1 = V.cut[l + 1];
+    if (j1 <= base) return;
+    const int TL = j1 - j0;
+    const int32_t magic = (int32_t)pk_magic(TL);
+    for (int j = j0 < base ? base : j0; j < j1 && j - base < li_cap; j++) {
+        int32_t* e = V.li + 3 * (size_t)(j - base);
+        e[0] = l | ((j - j0) << 16); e[1] = TL; e[2] = magic;
+    }
+}
 // lane-item j -> (line l, chunk c of TL): the line whose run of lane-items holds j
 TP_HD void pk_find_item(const pk_view& V, int n_lines_all, int j, int& l, int& c, int& TL) {
     int lo = 0, hi = n_lines_all;   // cut[lo] <= j < cut[hi]
@@ -216,10 +230,16 @@ TP_HD void pk_walk_rows(pk_rows& r, const char* table, int W, pk_acc& a) {
 
 // P3, lane-item j >= PK_CACHED (a patch with more lane-items than its threads keep records for): (line l, chunk c of TL), nothing kept between
 // grad-iters.  Returns the line-sum slot, the partial sums in `a`.
-TP_HD int pk_walk_lane(const pk_view& V, const char* table, int pitch, int W, int n_lines_all, int j, pk_acc& a) {
+TP_HD int pk_walk_lane(const pk_view& V, const char* table, int pitch, int W, int n_lines_all, int base, int li_cap, int j, pk_acc& a) {
     int l, c, TL;
-    pk_find_item(V, n_lines_all, j, l, c, TL);
-    const uint32_t magic = pk_magic(TL);
+    uint32_t magic;
+    if (j - base < li_cap) {
+        const int32_t* e = V.li + 3 * (size_t)(j - base);
+        l = e[0] & 0xffff; c = e[0] >> 16; TL = e[1]; magic = (uint32_t)e[2];
+    } else {   // (the patch's lines have outgrown the table)
+        pk_find_item(V, n_lines_all, j, l, c, TL);
+        magic = pk_magic(TL);
+    }
     a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
     pk_rows r = pk_lane_rows(V.wk[l], c, TL, magic, pitch);
     pk_walk_rows<4>(r, table, W, a);

@@ -176,9 +176,11 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
             __syncthreads();
             n_li_now = V.cut[w.n_lines]; n_li_all_now = V.cut[w.n_lines_all];
             if (V.flags[1]) {
+                for (int l = tid; l < w.n_lines_all; l += PK_THREADS) pk_list_line(V, l, n_li_now < PK_CACHED ? n_li_now : PK_CACHED, w.li_cap);
 #pragma unroll
                 for (int i = 0; i < PK_NI; i++)
                     pk_cache_init(cache[i], V, tid + i * PK_THREADS, n_li_now < PK_CACHED ? n_li_now : PK_CACHED, w.n_lines_all, it == 0);
+                __syncthreads();   // (the table of the other lane-items is read by other threads than wrote it)
             }
         }
         const int n_li = emit ? n_li_all_now : n_li_now;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         // (lane-items beyond the cached ones: a patch with more than PK_CACHED, and the base lines of the last grad-iter)
         for (int j = (n_li_now < PK_CACHED ? n_li_now : PK_CACHED) + tid; j < n_li; j += PK_THREADS) {
             pk_acc a;
-            const int l = pk_walk_lane(V, table, A.px_pitch, A.vw.W, w.n_lines_all, j, a);
+            const int l = pk_walk_lane(V, table, A.px_pitch, A.vw.W, w.n_lines_all, n_li_now < PK_CACHED ? n_li_now : PK_CACHED, w.li_cap, j, a);
             fold(l, a);
         }
         __syncthreads();

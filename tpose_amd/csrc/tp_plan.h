@@ -51,6 +51,7 @@ struct pk_wg {
                                // lines into chunks itself, from the positions it has: tp_persist.h, pk_recut_line)
     int32_t n_corners;         // (own vertex, incident triangle): four lanes each, one per move
     int32_t n_base;            // triangles whose first vertex the patch owns: it writes their base variant's outputs
+    int32_t li_cap;            // entries of the table of lane-items no thread keeps records for (beyond PK_CACHED, and the last grad-iter's)
     int32_t rows;              // rows a lane of the walk takes: chunks per line = the line's rows / this (<= PK_ROWS_PER_LANE)
     int32_t off_vid;           // [n_slots] global vertex id
     int32_t off_edges;         // [n_edges] slot_u | slot_v << 16
@@ -96,6 +97,7 @@ inline int pk_lds_bytes(const pk_wg& w) {
     b += pk_align16(w.n_edges * 4);                 // edges
     b += pk_align16(w.n_lines_all * 4);             // lines
     b += pk_align16((w.n_lines_all + 1) * 4);       // first lane-item of every line (and the total)
+    b += pk_align16(w.li_cap * 12);                 // lane-items without a thread of their own
     b += pk_align16(w.n_corners * 16);              // corners
     b += pk_align16(w.n_base * 16);                 // base variants
     return b + 64;                                  // flags
@@ -307,6 +309,10 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
         }
         w.n_lines_all = (int)lines.size();
         w.n_li_all = n_li;
+        {   // (room for the lines to grow: what does not fit the table is looked up the slow way)
+            const int beyond = n_li - std::min(w.n_li, PK_CACHED);
+            w.li_cap = beyond + beyond / 8 + 64;
+        }
         if (w.n_lines_all > 65535) { P.why = "a patch walks more than 65535 lines"; return; }
         for (int k = 0; k < w.n_own_v; k++) {
             const int v = own_v[p][k];
