@@ -73,6 +73,27 @@ struct triangulation {
     }
     float hlength(int h) { return length(points[dst(h)] - points[org(h)]); }
 
+    // Per-frame sweeps (software/triangulate/main.cpp:316-346 runs `angle(h) > 0.8 PI` for every half-edge and
+    // `collapse(shortest half-edge)` for every triangle, every frame).  Both tests are almost always far from their
+    // bounds; these two filters say "cannot fire" from products alone -- no square root, division or arc cosine -- and
+    // leave every close call to the test itself, so the schedule's decisions are the same.
+    // false: angle(h) <= 0.8 PI for certain.  cos(0.8 PI) = -0.809; a cosine above -0.7885 (its square below 0.95 x
+    // 0.6545 = 0.6218 of |u|^2 |w|^2) is an angle below 2.4793 < 2.5133, float rounding (1e-6) notwithstanding;
+    // zero-length sides and NaN fall through to the test.
+    bool maybe_wider_than_08pi(int h) const {
+        const vec2 a = points[apex(h)];
+        const vec2 u = points[org(h)] - a, w = points[dst(h)] - a;
+        const float d = dot(u, w);
+        if (d >= 0) return false;
+        return !(d * d < 0.6218f * (dot(u, u) * dot(w, w)));
+    }
+    // false: every side of t is longer than 0.0101, so collapse() of any of its half-edges returns false (bound 0.01)
+    bool maybe_collapsible(int t) const {
+        const vec2 a = points[triangles[t].x], b = points[triangles[t].y], c = points[triangles[t].z];
+        const float lim = 0.0101f * 0.0101f;
+        return !(dot(b - a, b - a) > lim && dot(c - b, c - b) > lim && dot(a - c, a - c) > lim);
+    }
+
     static bool boundary(vec2 p) { return p.x <= -RATIO || p.y <= -1 || p.x >= RATIO || p.y >= 1; }
     int boundary(int t) {  // how many vertices of t lie on (or beyond) the domain boundary
         return (int)boundary(points[triangles[t].x]) + (int)boundary(points[triangles[t].y]) +
@@ -324,15 +345,20 @@ inline void doframe() {
 //     do { doframe(); retrieve(tr); } while (geterr(tr) >= threshold)
 // -- the buffers of the last frame in terr / perr / cn, its points in tr, toterr / newerr / relerr as geterr left them.
 
-// the four Buffer::retrieve calls of every frame
-inline void retrieve(triangulation* tr) {
+// the four Buffer::retrieve calls of every frame.  base_only: just the entries the host looks at before the next retrieve --
+// those of the NT base variants (id < NT: geterr, maxerrid, the flip ranking, the export) and the two behind them, which a
+// split of the same frame brings below the new NT (gettoterr then sums them, as the reference does: software/triangulate/
+// main.cpp:348); the other displaced variants only feed gradient.cs on the device
+inline size_t base_entries(const triangulation* tr) { return std::min((size_t)13 * tr->NT, (size_t)tr->NT + 2); }
+inline void retrieve(triangulation* tr, bool base_only = false) {
     const int what[4] = {TP_BUF_TENERGY, TP_BUF_PENERGY, TP_BUF_COLNUM, TP_BUF_POINTS};
     void* const dst[4] = {terr, perr, cn, &tr->points[0].x};
-    const size_t count[4] = {(size_t)13 * tr->NT, (size_t)13 * tr->NT, (size_t)13 * tr->NT, (size_t)2 * tr->NP};
+    const size_t V = base_only ? base_entries(tr) : (size_t)13 * tr->NT;
+    const size_t count[4] = {V, V, V, (size_t)2 * tr->NP};
     check(tp_retrieve_many(ctx, 4, what, dst, count), "retrieve");  // one wait for the four buffers
 }
-inline void retrieve_energy(triangulation* tr) {
-    check(tp_retrieve(ctx, TP_BUF_TENERGY, terr, (size_t)13 * tr->NT), "retrieve(tenergy)");
+inline void retrieve_energy(triangulation* tr, bool base_only = false) {
+    check(tp_retrieve(ctx, TP_BUF_TENERGY, terr, base_only ? base_entries(tr) : (size_t)13 * tr->NT), "retrieve(tenergy)");
 }
 // tcolaccbuf->retrieve(tr.NT, &tr.colors[0])
 inline void retrieve_colors(triangulation* tr) {

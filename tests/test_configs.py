@@ -93,6 +93,20 @@ def test_config2_full_topology_schedule_to_3000_triangles(tmp_path):
 
 
 @pytest.mark.gpu
+def test_config2_shortcuts_decide_like_the_literal_frame(tmp_path):
+    """config 2 to 1000 triangles twice on the HIP path: with the harness's shortcuts (entries the host looks at only,
+    filtered sweeps, radix ranking) and with `-literal` (the frame as the reference writes it): identical .tri bytes"""
+    ppm = str(tmp_path / "m.ppm")
+    write_ppm(ppm, photo_like(1200, 1381, 1234, 160))
+    gpu = build_gpu("triangulate")
+    args = ["-i", ppm, "-levels", "50,100,200,400,700,1000", "-window", "1.5", "-quiet"]
+    o1 = run(gpu, *args, "-o", str(tmp_path / "s.tri"))
+    o2 = run(gpu, *args, "-literal", "-o", str(tmp_path / "l.tri"))
+    assert o1.replace("s.tri", "X") == o2.replace("l.tri", "X") and "levels written 6" in o1
+    assert open(str(tmp_path / "s.tri"), "rb").read() == open(str(tmp_path / "l.tri"), "rb").read()
+
+
+@pytest.mark.gpu
 def test_config2_schedule_bytes_match_oracle_backend(tmp_path):
     """the same schedule with a frame cap, HIP against the oracle-backed C ABI: identical .tri bytes (the topology
     decisions depend on every energy bit)"""

@@ -80,6 +80,19 @@ def test_triangulate_schedule_on_cpu_backend(scene):
     assert len(recs) >= 1 and recs[0][1] >= 50 and abs(recs[0][0] - 160 / 120) < 1e-6
 
 
+def test_triangulate_shortcuts_decide_like_the_literal_frame(scene):
+    """the harness reads back only the entries the host looks at, filters the per-frame angle / collapse sweeps with products
+    and ranks the flip set with a radix sort; `-literal` runs the frame as the reference writes it (13 NT entries, every
+    arc cosine, comparison sort): same stdout (frames, triangles, energies per change), same .tri bytes"""
+    exe = build_cpu("triangulate")
+    args = ["-i", str(scene / "a.ppm"), "-maxframes", "2500", "-maxtris", "90", "-levels", "10,20,30,50,70,90"]
+    o1 = run(exe, *args, "-o", str(scene / "short.tri"))
+    o2 = run(exe, *args, "-literal", "-o", str(scene / "lit.tri"))
+    assert o1.replace("short.tri", "X") == o2.replace("lit.tri", "X") and "levels written" in o1
+    assert open(str(scene / "short.tri"), "rb").read() == open(str(scene / "lit.tri"), "rb").read()
+    assert len(records(str(scene / "short.tri"))) >= 3
+
+
 @pytest.mark.gpu
 def test_triangulate_gpu_matches_cpu_backend_bytes(scene):
     cpu, gpu = build_cpu("triangulate"), build_gpu("triangulate")

@@ -36,6 +36,6 @@ r = subprocess.run([os.path.join(HOST, "triangulate"), "-i", ppm, "-o", os.path.
                     "-window", "1.5", "-quiet"] + extra, capture_output=True, text=True, timeout=int(sys.argv[1]) if len(sys.argv) > 1 else 900)
 dt = time.perf_counter() - t0
 print(r.stdout.strip().splitlines()[-1])
-for line in r.stderr.strip().splitlines()[-2:]:
+for line in r.stderr.strip().splitlines()[-3:]:
     print(line)
 print("wall incl. start-up %.1f s" % dt)

@@ -751,6 +751,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
             {c->vtx_adj, adj.data(), sizeof(int) * 3 * (size_t)NT},
             {c->colors, colors, colors ? sizeof(int32_t) * 4 * (size_t)NT : 0},
         };
+        static_assert(sizeof(parts) / sizeof(parts[0]) <= TP_COPY_MAX, "one copy list");
         size_t total = 0;
         for (auto& pt : parts) total += (pt.bytes + 255) & ~(size_t)255;
         if (total > c->up_pinned_bytes) {
@@ -760,12 +761,16 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
             c->up_pinned_bytes = total * 2;
         }
         size_t o = 0;
+        tp_copy_list G{};   // (small uploads -- the schedules' -- are fetched from the staging buffer by one kernel)
+        const bool one_launch = total <= ((size_t)4 << 20);
         for (auto& pt : parts) {
             if (!pt.bytes) continue;
             memcpy(c->up_pinned + o, pt.src, pt.bytes);
-            HIP_TRY(c, hipMemcpyAsync(pt.dst, c->up_pinned + o, pt.bytes, hipMemcpyHostToDevice, c->stream));
+            if (one_launch) { G.src[G.n] = (const uint32_t*)(c->up_pinned + o); G.dst[G.n] = (uint32_t*)pt.dst; G.words[G.n] = (uint32_t)(pt.bytes / 4); G.n++; }
+            else HIP_TRY(c, hipMemcpyAsync(pt.dst, c->up_pinned + o, pt.bytes, hipMemcpyHostToDevice, c->stream));
             o += (pt.bytes + 255) & ~(size_t)255;
         }
+        if (one_launch) { tp_launch_copy_list(G, c->stream); HIP_TRY(c, hipGetLastError()); }
     }
     c->NT = NT; c->NP = NP;
     c->h_points.assign(points, points + 2 * (size_t)NP);
@@ -1163,9 +1168,18 @@ int tp_retrieve_many(tp_context* c, int n, const int* what, void* const* dst, co
         HIP_TRY(c, hipHostMalloc((void**)&c->pinned, total + total / 2, hipHostMallocDefault));
         c->pinned_bytes = total + total / 2;
     }
-    // all copies ride the context's stream behind the enqueued work: ONE wait for the whole batch
-    for (int k = 0; k < n; k++)
-        if (bytes[k]) HIP_TRY(c, hipMemcpyAsync(c->pinned + off[k], src[k], bytes[k], hipMemcpyDeviceToHost, c->stream));
+    // everything rides the context's stream behind the enqueued work: ONE wait for the whole batch.  Small batches (the
+    // per-frame read-backs of the schedules) are written into the pinned buffer by one kernel instead of one copy command each
+    if (n <= TP_COPY_MAX && total <= ((size_t)4 << 20)) {
+        tp_copy_list G{};
+        for (int k = 0; k < n; k++)
+            if (bytes[k]) { G.src[G.n] = (const uint32_t*)src[k]; G.dst[G.n] = (uint32_t*)(c->pinned + off[k]); G.words[G.n] = (uint32_t)(bytes[k] / 4); G.n++; }
+        tp_launch_copy_list(G, c->stream);
+        HIP_TRY(c, hipGetLastError());
+    } else {
+        for (int k = 0; k < n; k++)
+            if (bytes[k]) HIP_TRY(c, hipMemcpyAsync(c->pinned + off[k], src[k], bytes[k], hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, wait_stream(c->stream));
     if (int rc = check_persist_status(c)) return rc;
     for (int k = 0; k < n; k++) {

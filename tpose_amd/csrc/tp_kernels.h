@@ -52,6 +52,11 @@ void tp_launch_prefix_table(const uint8_t* img, int pitch, int W, int H, int pre
 void tp_launch_px_table(const uint8_t* img, int pitch, int W, int H, int px_pitch, uint4* P, hipStream_t s);  // rasters up to TP_PX_MAXW columns
 void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s);
 void tp_launch_selftest_line(const int4* ends, const int* H, int n, int rows, int32_t* out, hipStream_t s);
+// several arrays copied by ONE launch, either side of which may be pinned host memory (read or written by the device across
+// the link): the read-backs of a frame and the tables of an upload -- one dispatch instead of one copy command per array
+#define TP_COPY_MAX 8
+struct tp_copy_list { const uint32_t* src[TP_COPY_MAX]; uint32_t* dst[TP_COPY_MAX]; uint32_t words[TP_COPY_MAX]; int n; };
+void tp_launch_copy_list(const tp_copy_list& G, hipStream_t s);
 void tp_launch_render(const tp_launch& L, const float2* pts, int source, void* out, int out_pitch_px, hipStream_t s);
 
 // ---- persistent grad-iter kernel (tp_persist.hip): K grad-iters per launch, one workgroup per patch of the mesh

@@ -483,6 +483,20 @@ __global__ void k_publish_positions(tp_launch L) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < L.NP) publish_position(L, v, L.points[v], 0, 1);
 }
+__global__ __launch_bounds__(256) void k_copy_list(tp_copy_list G) {
+    for (int k = 0; k < G.n; k++) {
+        const uint32_t* src = G.src[k];
+        uint32_t* dst = G.dst[k];
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < G.words[k]; i += gridDim.x * 256u) dst[i] = src[i];
+    }
+}
+void tp_launch_copy_list(const tp_copy_list& G, hipStream_t s) {
+    uint32_t most = 0;
+    for (int k = 0; k < G.n; k++) most = G.words[k] > most ? G.words[k] : most;
+    if (!most) return;
+    const unsigned blocks = (most + 1023u) / 1024u;   // four words per thread of the longest array
+    hipLaunchKernelGGL(k_copy_list, dim3(blocks > 1024u ? 1024u : blocks), dim3(256), 0, s, G);
+}
 void tp_launch_vertex_refs(const tp_launch& L, int* vref, int* vvar, hipStream_t s) {
     hipLaunchKernelGGL(k_vertex_refs, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L, vref, vvar);
     hipLaunchKernelGGL(k_publish_positions, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L);

@@ -3,13 +3,16 @@
 // driven through the tpose:: host mirror (include/tpose/) on top of the HIP C ABI.
 //
 //   triangulate -i image.ppm [-o out.tri] [-window 1.5] [-maxframes N] [-maxtris N] [-levels 50,100,...]
-//               [-device D] [-quiet]
+//               [-device D] [-quiet] [-literal]
 //
 // One frame = doenergy, doshift, read back tenergy/penergy/colnum/points, then -- once the relative
 // energy change drops below 1e-4 -- export (on the 50,100,...,1000 ladder), energy-sorted flip set with
 // flip-back, split of the worst triangle; every frame: prune, wide-angle flips, short-edge collapses;
 // then computecolors at the new positions.  No window, no GL: `-window f` only selects the raster
 // (image size / f, like the reference's Tiny::window(w/1.5, h/1.5)); default f = 1 (raster == image).
+// `-literal`: the frame as the reference writes it -- all 13 NT entries of the buffers read back every frame, every angle and
+// every shortest edge evaluated, a comparison sort for the flip ranking -- instead of the shortcuts that decide the same
+// (tests compare the two byte for byte).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,7 +37,7 @@ int main(int argc, char** argv) {
     long maxframes = 1L << 40;
     int maxtris = 1 << 30, device = 0;
     std::string levels;  // export list override (the reference hard-codes 50..1000; its showcase uses 3000)
-    bool quiet = false;
+    bool quiet = false, literal = false;
     for (int a = 1; a < argc; a++) {
         const std::string k = argv[a];
         auto val = [&]() -> const char* { if (a + 1 >= argc) { std::cerr << "missing value for " << k << "\n"; std::exit(2); } return argv[++a]; };
@@ -46,6 +49,7 @@ int main(int argc, char** argv) {
         else if (k == "-levels") levels = val();
         else if (k == "-device") device = std::atoi(val());
         else if (k == "-quiet") quiet = true;
+        else if (k == "-literal") literal = true;
         else { std::cerr << "unknown option " << k << "\n"; return 2; }
     }
     if (input.empty()) { std::cout << "Please specify an input image with -i." << std::endl; return 0; }
@@ -87,7 +91,7 @@ int main(int argc, char** argv) {
 
     long frame = 0;
     bool done = false;
-    double t_device = 0, t_converged = 0, t_loops = 0;  // where the wall time goes (stderr, with "seconds")
+    double t_device = 0, t_converged = 0, t_loops = 0, t_rank = 0, t_upload = 0, t_energy = 0, t_reup = 0;  // where the wall time goes (stderr, with "seconds")
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     while (!done && frame < maxframes) {
@@ -96,7 +100,7 @@ int main(int argc, char** argv) {
         if (fresh) { tpose::doenergy(); tpose::doshift(); }
         else tpose::doframe();
         fresh = false;
-        tpose::retrieve(&tr);
+        tpose::retrieve(&tr, !literal);   // (the reference reads all 13 NT entries of three buffers every frame and looks at the first NT)
         const auto t1 = now();
         t_device += secs(t0, t1);
 
@@ -116,36 +120,65 @@ int main(int argc, char** argv) {
             // only the first one inserted survives -- the reference keeps them in a std::set keyed on the energy
             // alone.  Same order and same survivors from a stable sort + unique (a set of 3 NT nodes per
             // convergence step is the costliest host work of the schedule).
-            std::vector<std::pair<int, float>> ranked;
+            const auto r0 = now();
+            // (the order is that of a stable sort by descending energy: a stable radix sort on the float's bits, which order
+            // like the values for the non-negative sums at hand; ties stay in insertion order, 3t + k ascending)
+            std::vector<std::pair<int, float>> ranked, spare;
             ranked.reserve(tr.triangles.size() * 3);
+            bool radix_ok = !literal;
             for (int t = 0; t < (int)tr.triangles.size(); t++)
                 for (int k = 0; k < 3; k++) {
                     const int w = tr.halfedges[3 * t + k];
-                    if (w >= 0) ranked.emplace_back(3 * t + k, tpose::terr[t] + tpose::terr[w / 3]);
+                    if (w < 0) continue;
+                    const float e = tpose::terr[t] + tpose::terr[w / 3];
+                    radix_ok = radix_ok && e >= 0.0f;   // (false for negative sums, -0 and NaN alike: the comparison sort then)
+                    ranked.emplace_back(3 * t + k, e == 0.0f ? 0.0f : e);
                 }
-            std::stable_sort(ranked.begin(), ranked.end(), [](const std::pair<int, float>& l, const std::pair<int, float>& r) { return l.second > r.second; });
+            if (radix_ok) {
+                spare.resize(ranked.size());
+                for (int pass = 0; pass < 3; pass++) {   // digits of 11, 11 and 10 bits, least significant first, descending
+                    const int shift = 11 * pass, bits = pass == 2 ? 10 : 11;
+                    std::vector<uint32_t> count((size_t)1 << bits, 0);
+                    auto digit = [&](float e) { uint32_t b; memcpy(&b, &e, 4); return ((~b) >> shift) & ((1u << bits) - 1u); };
+                    for (auto& r : ranked) count[digit(r.second)]++;
+                    uint32_t run = 0;
+                    for (auto& c : count) { const uint32_t n = c; c = run; run += n; }
+                    for (auto& r : ranked) spare[count[digit(r.second)]++] = r;
+                    ranked.swap(spare);
+                }
+            } else {
+                std::stable_sort(ranked.begin(), ranked.end(), [](const std::pair<int, float>& l, const std::pair<int, float>& r) { return l.second > r.second; });
+            }
             ranked.erase(std::unique(ranked.begin(), ranked.end(), [](const std::pair<int, float>& l, const std::pair<int, float>& r) { return l.second == r.second; }), ranked.end());
             std::vector<char> locked(tr.halfedges.size(), 0);  // half-edges whose triangle already takes part in a flip
-            std::map<int, float> chosen;                        // half-edge -> pair energy before the flip
+            std::vector<std::pair<int, float>> chosen;          // half-edge -> pair energy before the flip, by half-edge (the reference's std::map order)
             for (auto& h : ranked) {
                 if (locked[h.first]) continue;
                 const int w = tr.halfedges[h.first];
                 if (w < 0) continue;
                 if (locked[w]) continue;
-                chosen[h.first] = h.second;
+                chosen.push_back(h);
                 for (int k = 0; k < 3; k++) { locked[3 * (h.first / 3) + k] = 1; locked[3 * (w / 3) + k] = 1; }
             }
+            std::sort(chosen.begin(), chosen.end(), [](const std::pair<int, float>& l, const std::pair<int, float>& r) { return l.first < r.first; });
             for (auto& h : chosen) tr.flip(h.first, 0.0f);
+            const auto r1 = now();
             tpose::upload(&tr, false);
+            const auto r2 = now();
             tpose::computecolors();
             tpose::doenergy();
-            tpose::retrieve_energy(&tr);
+            tpose::retrieve_energy(&tr, !literal);
+            const auto r3 = now();
             for (auto& h : chosen)       // undo the flips that raised their pair's energy
                 if (tpose::terr[h.first / 3] + tpose::terr[tr.halfedges[h.first] / 3] > h.second) tr.flip(h.first, 0.0f);
+            const auto r4 = now();
             tpose::upload(&tr, false);
+            const auto r5 = now();
             tpose::computecolors();
             tpose::doenergy();
-            tpose::retrieve_energy(&tr);
+            tpose::retrieve_energy(&tr, !literal);
+            const auto r6 = now();
+            t_rank += secs(r0, r1) + secs(r3, r4); t_upload += secs(r1, r2) + secs(r4, r5); t_energy += secs(r2, r3) + secs(r5, r6);
 
             const int worst = tpose::maxerrid(&tr);
             if (worst >= 0 && tr.split(worst)) updated = true;
@@ -158,14 +191,16 @@ int main(int argc, char** argv) {
                 if (tr.prune((int)t)) updated = true;
         for (size_t t = 0; t < (size_t)tr.NT; t++)
             for (int k = 0; k < 3; k++)
-                if (tr.angle(3 * (int)t + k) > 0.8 * tpose::PI) tr.flip(3 * (int)t + k, 0.0);
+                if ((literal || tr.maybe_wider_than_08pi(3 * (int)t + k)) && tr.angle(3 * (int)t + k) > 0.8 * tpose::PI) tr.flip(3 * (int)t + k, 0.0);
         for (size_t t = 0; t < tr.triangles.size(); t++) {
+            if (!literal && !tr.maybe_collapsible((int)t)) continue;   // (collapse() would refuse whichever half-edge is the shortest)
             int h = 3 * (int)t;
             float shortest = tr.hlength(h);
             if (tr.hlength(h + 1) < shortest) shortest = tr.hlength(++h);
             if (tr.hlength(h + 1) < shortest) shortest = tr.hlength(++h);
             if (tr.collapse(h)) updated = true;
         }
+        const auto t3 = now();
         if (updated) {
             const float e = tpose::gettoterr(&tr);
             if (!quiet) std::cout << tr.NT << " " << std::setprecision(16) << e << std::endl;
@@ -173,12 +208,15 @@ int main(int argc, char** argv) {
             tpose::computecolors();  // a new topology: the sweep cannot ride the next frame's fused sequence
             fresh = true;            // (upload drops the device lists; keep the reference's order of calls)
         }
-        t_loops += secs(t2, now());
+        t_loops += secs(t2, t3);
+        t_reup += secs(t3, now());
     }
     std::cout << "frames " << frame << " triangles " << tr.NT << " points " << tr.NP << " levels written "
               << (nlevels - (int)exportlist.size()) << std::endl;
     std::cerr << "frame device calls + readbacks " << t_device << " s, convergence steps (flip set, split) " << t_converged
-              << " s, per-frame host loops (prune, angle, collapse) + re-upload " << t_loops << " s" << std::endl;
+              << " s, per-frame host loops (prune, angle, collapse) " << t_loops << " s, re-upload + computecolors after a change " << t_reup << " s" << std::endl;
+    std::cerr << "inside the convergence steps: ranking + flips " << t_rank << " s, uploads " << t_upload << " s, computecolors + doenergy + read-back "
+              << t_energy << " s" << std::endl;
     std::cerr << "seconds " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
     tpose::quit();
     return 0;
