@@ -340,6 +340,13 @@ inline void doframe() {
     p.image_slot = swept_slot();
     check(tp_iterate(ctx, &p, 1), "doframe");
 }
+// n frames without the convergence test (a fixed budget per level): one enqueue
+inline void doframes(long n) {
+    tp_params p;
+    tp_default_params(flavour, &p);
+    p.image_slot = swept_slot();
+    check(tp_iterate(ctx, &p, (int)n), "doframes");
+}
 // frames until geterr < threshold (or maxframes of them), the test applied on the library's side of the boundary
 // (tp_iterate_until: no read-back per frame); afterwards everything stands as after the reference's loop
 //     do { doframe(); retrieve(tr); } while (geterr(tr) >= threshold)

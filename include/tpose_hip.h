@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TP_ABI_VERSION 2
+#define TP_ABI_VERSION 3
 #define TP_MAXT (2 << 18) /* tpose::triangulation::MAXT, source/triangulation.hpp:95; 13*NT <= MAXT */
 
 typedef struct tp_context tp_context;
@@ -96,6 +96,22 @@ int tp_set_dp(tp_context* ctx, float dp);
 enum tp_option { TP_OPT_PERSISTENT = 1 };
 enum { TP_PERSIST_OFF = 0, TP_PERSIST_AUTO = 1 };
 int tp_set_option(tp_context* ctx, int option, int64_t value);
+
+/* Band split of ONE descent over several GPUs (no counterpart in the reference, which runs a
+ * direction of a pair on one GPU: software/warp/main.cpp:214-283).  `n_bands` contexts -- one per process and GPU, all given
+ * the same images, uploads and calls, in the same order -- run one descent together: a persistent launch of context `band`
+ * runs the patches [band, band + 1) x patches_per_band of a plan of n_bands x patches_per_band patches, and the only thing that
+ * crosses between them is what crosses between workgroups: vertex positions, 16 bytes per vertex and grad-iter, posted by a
+ * vertex's owner into EVERY band's mailbox (peer memory, system-scope stores) and polled by the readers from their own.
+ * mailboxes[b]: band b's mailbox as THIS process addresses it -- its own allocation at [band], the others' mapped in
+ * (hipIpcOpenMemHandle between processes, peer access between devices); `bytes_each` >= tp_band_mailbox_bytes(points) each,
+ * zeroed by their owners before any band iterates.  patches_per_band: 0 = one per compute unit of this device.
+ * After tp_iterate every band holds ALL positions (tp_retrieve(TP_BUF_POINTS) is complete); `tenergy`, `colnum`, `colacc` and
+ * `gradient` hold the entries of the band's own patches only.  Calls too short for persistent launches, tp_iterate_until and
+ * the piecewise API run whole on every band (the same results, nothing shared).  A band that waits a second for positions
+ * gives up; every band then runs the call again on its own (tp_get_info 9 counts it).  n_bands = 1 detaches. */
+size_t tp_band_mailbox_bytes(int points);
+int tp_band_attach(tp_context* ctx, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int patches_per_band);
 
 /* `Texture tex(IMG)` (software/triangulate/main.cpp:74, warp/main.cpp:118-119): RGBA8, row 0 = top,
  * width x height texels, `stride_bytes` between rows.  Host pointer.  Like the reference's texture the image

@@ -32,10 +32,16 @@ extern "C" int emul_magic_check() {
     return bad;
 }
 
-// returns 0, or a negative code: -1 plan refused, -2 a position granule had the wrong tag
-extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, float* points, int NP, const int32_t* tris,
-                            int NT, const int32_t* ca, int flavour, float dp, float ratio, float rate, int iters,
-                            int max_parts, int lds_limit, int64_t* stats, int32_t* ten, int32_t* cn, int32_t* ca_out, int32_t* gr) {
+// Band split (tp_band_attach): band `band` of `n_bands` replays the patches [band, band + 1) * parts / n_bands only; after every
+// grad-iter `exchange` is handed the mailbox slot array its patches just posted into ({tag : 32, float : 32} granules, two per
+// vertex) and the tag of the new positions, and brings in the other bands' posts (tests: torch.distributed all_gather).
+typedef void (*emul_exchange_fn)(void* user, unsigned long long* slot_array, int NP, uint32_t tag);
+
+// returns 0, or a negative code: -1 plan refused, -2 a position granule had the wrong tag, -3 the patches do not split evenly
+static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, float* points, int NP, const int32_t* tris,
+                             int NT, const int32_t* ca, int flavour, float dp, float ratio, float rate, int iters,
+                             int max_parts, int lds_limit, int64_t* stats, int32_t* ten, int32_t* cn, int32_t* ca_out, int32_t* gr,
+                             int band, int n_bands, emul_exchange_fn exchange, void* user) {
     tp_view vw;
     vw.dp = dp; vw.ratio = ratio; vw.halfW = 0.5f * (float)W; vw.halfH = 0.5f * (float)H; vw.W = W; vw.H = H;
     // the per-image table in pixel records, as k_prefix_px builds it
@@ -70,6 +76,8 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
     pk_build_plan(NP, NT, tris, points, NE, edge_uv.data(), he_edge.data(), W, H, ratio, dp * 0.5f * (float)H, max_parts, lds_limit, P);
     if (stats) { stats[0] = P.ok; stats[1] = P.parts; stats[2] = P.lds_bytes; stats[3] = P.lines_total; stats[4] = P.foreign_total; stats[5] = NE; }
     if (!P.ok) return -1;
+    if (P.parts % n_bands) return -3;
+    const int p_lo = band * (P.parts / n_bands), p_hi = (band + 1) * (P.parts / n_bands);
 
     std::vector<part_state> S((size_t)P.parts);
     for (int p = 0; p < P.parts; p++) {
@@ -90,7 +98,7 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
     for (int it = 0; it < iters; it++) {
         const uint32_t e = 1 + it, tag = pk_tag(e), par = e & 1;
         const bool emit = it + 1 == iters && ten != nullptr;   // the last grad-iter writes the reference's buffers
-        for (int p = 0; p < P.parts; p++) {
+        for (int p = p_lo; p < p_hi; p++) {
             const pk_wg& w = P.wg[p];
             pk_view& V = S[p].V;
             const bool recut = (it & (PK_RECUT - 1)) == 0;
@@ -204,12 +212,34 @@ extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, flo
                 g[0] = ((unsigned long long)tn << 32) | bx; g[1] = ((unsigned long long)tn << 32) | by;
             }
         }
+        if (exchange) exchange(user, &posbox[((size_t)((e + 1) & 1) * NP) * 2], NP, pk_tag(e + 1));
     }
-    for (int p = 0; p < P.parts; p++) {
+    for (int p = p_lo; p < p_hi; p++) {
         const pk_wg& w = P.wg[p];
         for (int k = 0; k < w.n_own_v; k++) { points[2 * S[p].V.vid[k]] = S[p].V.pos[k].x; points[2 * S[p].V.vid[k] + 1] = S[p].V.pos[k].y; }
     }
+    if (n_bands > 1 && iters > 0) {   // the other bands' vertices: what they posted last (tp_launch_band_collect)
+        const uint32_t tn = pk_tag(1 + (uint32_t)iters);
+        const unsigned long long* slot = &posbox[((size_t)((1 + iters) & 1) * NP) * 2];
+        for (int v = 0; v < NP; v++)
+            if ((uint32_t)(slot[2 * v] >> 32) == tn && (uint32_t)(slot[2 * v + 1] >> 32) == tn) {
+                const uint32_t bx = (uint32_t)slot[2 * v], by = (uint32_t)slot[2 * v + 1];
+                memcpy(&points[2 * v], &bx, 4); memcpy(&points[2 * v + 1], &by, 4);
+            }
+    }
     return 0;
+}
+extern "C" int emul_persist(const uint8_t* img, size_t stride, int W, int H, float* points, int NP, const int32_t* tris,
+                            int NT, const int32_t* ca, int flavour, float dp, float ratio, float rate, int iters,
+                            int max_parts, int lds_limit, int64_t* stats, int32_t* ten, int32_t* cn, int32_t* ca_out, int32_t* gr) {
+    return emul_persist_impl(img, stride, W, H, points, NP, tris, NT, ca, flavour, dp, ratio, rate, iters, max_parts, lds_limit, stats, ten, cn,
+                             ca_out, gr, 0, 1, nullptr, nullptr);
+}
+extern "C" int emul_persist_band(const uint8_t* img, size_t stride, int W, int H, float* points, int NP, const int32_t* tris,
+                                 int NT, const int32_t* ca, int flavour, float dp, float ratio, float rate, int iters,
+                                 int max_parts, int lds_limit, int64_t* stats, int band, int n_bands, emul_exchange_fn exchange, void* user) {
+    return emul_persist_impl(img, stride, W, H, points, NP, tris, NT, ca, flavour, dp, ratio, rate, iters, max_parts, lds_limit, stats, nullptr,
+                             nullptr, nullptr, nullptr, band, n_bands, exchange, user);
 }
 
 // statistics of a plan, for tests of the cut itself: owner of every vertex and edge

@@ -1,0 +1,83 @@
+"""Band split of one descent (include/tpose_hip.h: tp_band_attach): several contexts run the patches
+of ONE plan between them and exchange vertex positions through each other's mailboxes.  On the one-GPU test box the bands are
+two contexts (two streams) of one process on device 0, 100 patches each -- the arithmetic of the seam and the hand-over
+protocol are the same as between two GPUs; what the box cannot show is the latency of the link."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O  # noqa: E402
+from tpose_amd import capi, synth  # noqa: E402
+from util import RATE, case  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def banded_contexts(W, H, img, imgB, pts, tris, colors, n_bands, patches):
+    import torch
+    lib = capi.load()
+    lib.tp_band_mailbox_bytes.restype = C.c_size_t
+    nbytes = int(lib.tp_band_mailbox_bytes(pts.shape[0] + 64))
+    boxes = [torch.zeros(nbytes // 8 + 1, dtype=torch.int64, device="cuda:0") for _ in range(n_bands)]
+    torch.cuda.synchronize()
+    ctxs = []
+    for b in range(n_bands):
+        ctx = capi.Context(0, W, H)
+        ctx.set_image(capi.IMAGE_A, img)
+        ctx.set_image(capi.IMAGE_B, imgB)
+        ctx.upload(pts, tris, colors)
+        ctx.band_attach(b, n_bands, [bx.data_ptr() for bx in boxes], nbytes, patches)
+        # (the census of resident workgroups wants the device to itself: on a shared device, before any band spins in a launch)
+        ctx.prepare(capi.default_params(1 if colors is not None else 0))
+        ctxs.append(ctx)
+    return ctxs, boxes
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+@pytest.mark.parametrize("n_bands,patches", [(2, 8), (3, 5)])
+def test_bands_descend_like_one_context(flavour, n_bands, patches):
+    """2 and 3 bands, calls of several lengths (single and chunked launches, odd numbers): every band ends with the
+    oracle's positions, bit for bit; the emitted buffers of a band are the oracle's on the entries of its own patches"""
+    W, H = 300, 200
+    img, imgB, pts, tris, ratio, colors = case(W, H, (15, 5))
+    ctxs, boxes = banded_contexts(W, H, img, imgB, pts, tris, colors if flavour else None, n_bands, patches)
+    p = capi.default_params(flavour)
+    total = 0
+    for n in (6, 131, 700, 5):
+        for ctx in ctxs:
+            ctx.iterate(p, n)       # (enqueued: the bands' launches run side by side)
+        for ctx in ctxs:
+            ctx.synchronize()
+        total += n
+        ref = O.iterate(imgB if flavour else img, pts, tris, flavour, ratio, RATE[flavour], total, colors=colors if flavour else None, literal=False)
+        covered = np.zeros(ref["ten"].shape[0], bool)
+        for ctx in ctxs:
+            assert ctx.info(9) == 0, "a band gave up"
+            assert ctx.info(capi.INFO_PERSIST_ITERS) == total and ctx.info(capi.INFO_PATCHES) == n_bands * patches
+            assert np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
+            ten = ctx.retrieve(capi.BUF_TENERGY)
+            covered |= ten == ref["ten"]
+        assert covered.all()        # every variant's energy was written by the band that owns it
+    for ctx in ctxs:
+        ctx.close()
+
+
+def test_band_that_never_shows_up_is_survived():
+    """band 1 never iterates: band 0 waits a second in its launch, gives up without having changed anything, and runs the
+    call on its own -- the oracle's bits again"""
+    W, H = 300, 200
+    img, imgB, pts, tris, ratio, colors = case(W, H, (15, 5))
+    ctxs, boxes = banded_contexts(W, H, img, imgB, pts, tris, None, 2, 8)
+    p = capi.default_params(0)
+    ctxs[0].iterate(p, 40)
+    ctxs[0].synchronize()
+    ref = O.iterate(img, pts, tris, 0, ratio, RATE[0], 40, literal=False)
+    assert ctxs[0].info(9) == 1
+    assert np.array_equal(ctxs[0].retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
+    assert np.array_equal(ctxs[0].retrieve(capi.BUF_TENERGY), ref["ten"])
+    for ctx in ctxs:
+        ctx.close()

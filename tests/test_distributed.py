@@ -74,6 +74,20 @@ def test_two_way_warp_world_size_2_gloo(tmp_path):
     assert t.NT == 48 and not np.array_equal(t.points, t.originpoints)
 
 
+def test_band_split_world_size_2_gloo(tmp_path):
+    """SURVEY section 8 row e3 on the CPU: two ranks, each replaying HALF of the patches of one descent (the persistent kernel's
+    lane functions, tests/emul), positions crossing the seam through a gloo all_gather of the mailbox after every grad-iter.
+    A rank that did not receive a position it needs fails with a tag mismatch; both end with the oracle's bits."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "band_worker.py"), str(tmp_path), "70"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    for r in range(2):
+        out = json.load(open(str(tmp_path / ("band%d.json" % r))))
+        assert out["rc"] == 0 and out["patches"] == 8 and out["exchanges"] == 70 and out["same_as_oracle"], out
+
+
 import pytest  # noqa: E402
 
 ROOT = os.path.dirname(HERE)

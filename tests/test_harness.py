@@ -174,7 +174,7 @@ def _hierarchies(scene, build):
         assert len(records(str(scene / ("h_%s.tri" % n)))) >= 2
 
 
-def _mutual_vs_two_ranks(scene, warp_exe, warp2_exe, tag, extra=()):
+def _mutual_vs_two_ranks(scene, warp_exe, warp2_exe, tag, extra=(), transport="fifo", per_rank=lambda r: []):
     """`warp -schedule mutual` (one process, four descents per level) against two `warp2` processes exchanging their
     meshes: the .tri.warp files must be the same bytes"""
     import shutil
@@ -186,7 +186,7 @@ def _mutual_vs_two_ranks(scene, warp_exe, warp2_exe, tag, extra=()):
     run(warp_exe, *common, "-ta", ta, "-tb", tb, "-schedule", "mutual")
     ta2, tb2 = (str(scene / ("%s_two_%s.tri" % (tag, n))) for n in ("a", "b"))
     idfile = str(scene / ("%s_link" % tag))
-    procs = [subprocess.Popen([warp2_exe, "-rank", str(r), "-idfile", idfile, "-transport", "fifo", *common, "-ta", ta2, "-tb", tb2, *extra],
+    procs = [subprocess.Popen([warp2_exe, "-rank", str(r), "-idfile", idfile, "-transport", transport, *common, "-ta", ta2, "-tb", tb2, *extra, *per_rank(r)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (0, 1)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
@@ -197,11 +197,69 @@ def _mutual_vs_two_ranks(scene, warp_exe, warp2_exe, tag, extra=()):
     assert len(records(ta + ".warp")) == len(records(str(scene / "h_a.tri"))) or len(records(ta + ".warp")) == len(records(str(scene / "h_b.tri")))
 
 
+def _mutual_vs_banded(scene, warp_exe, warp2_exe, tag, frames, extra=()):
+    """`warp -schedule mutual -fixedframes` (one process) against FOUR `warp2 -bands 2` processes -- two bands for each of the two
+    directions: both bands of a direction must write the unsplit run's bytes"""
+    import shutil
+    for who in ("one", "four"):
+        for n in ("a", "b"):
+            shutil.copy(str(scene / ("h_%s.tri" % n)), str(scene / ("%s_%s_%s.tri" % (tag, who, n))))
+    common = ["-ia", str(scene / "a.ppm"), "-ib", str(scene / "b.ppm"), "-levelframes", str(frames), "-fixedframes", "-quiet"]
+    ta, tb = (str(scene / ("%s_one_%s.tri" % (tag, n))) for n in ("a", "b"))
+    run(warp_exe, *common, "-ta", ta, "-tb", tb, "-schedule", "mutual")
+    ta4, tb4 = (str(scene / ("%s_four_%s.tri" % (tag, n))) for n in ("a", "b"))
+    idfile = str(scene / ("%s_blink" % tag))
+    procs = [subprocess.Popen([warp2_exe, "-rank", str(r), "-bands", "2", "-band", str(b), "-idfile", idfile, "-transport", "fifo", *common,
+                               "-ta", ta4, "-tb", tb4, *extra], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in (0, 1) for b in (0, 1)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for one, four in ((ta, ta4), (tb, tb4)):
+        a = open(one + ".warp", "rb").read()
+        assert len(a) > 0 and a == open(four + ".warp", "rb").read() and a == open(four + ".warp.band1", "rb").read()
+    return outs
+
+
+def test_warp2_bands_plumbing_on_cpu_backend(scene):
+    """world size 4 without a GPU: two bands per direction over named pipes (mate links, per-band cross links, stop-together);
+    the oracle-backed C ABI runs every band's descents whole, so this pins the harness, not the seam"""
+    _hierarchies(scene, build_cpu("triangulate"))
+    _mutual_vs_banded(scene, build_cpu("warp"), build_cpu("warp2", flags=["-DWARP2_NO_RCCL"]), "cpub", 40)
+
+
+@pytest.mark.gpu
+def test_warp2_bands_split_every_descent_over_two_processes(scene):
+    """SURVEY section 8 row e3 on the HIP path: every direction's descents run as two bands in two processes that map each
+    other's mailbox (hipIpcGetMemHandle) and hand vertex positions over on the device, grad-iter by grad-iter; all four share
+    GPU 0 here (a proxy for four GPUs: the same protocol without the links), 4 patches per band.  Bytes equal the unsplit
+    run's, and the launches were persistent and none gave up."""
+    import re
+    _hierarchies(scene, build_cpu("triangulate"))
+    outs = _mutual_vs_banded(scene, build_gpu("warp"), build_gpu("warp2"), "gpub", 150, extra=["-device", "0", "-bandpatches", "4"])
+    for o in outs:
+        m = re.search(r"persistent launches (\d+), patches of the plan (\d+), launches given up (\d+)", o)
+        assert m, o
+        assert int(m.group(1)) > 0 and int(m.group(2)) == 8 and int(m.group(3)) == 0, o
+
+
 def test_warp2_two_ranks_match_single_process_on_cpu_backend(scene):
     """world size 2 without a GPU: the C++ two-rank driver over named pipes, against the oracle-backed C ABI"""
     cpu_t = build_cpu("triangulate")
     _hierarchies(scene, cpu_t)
     _mutual_vs_two_ranks(scene, build_cpu("warp"), build_cpu("warp2", flags=["-DWARP2_NO_RCCL"]), "cpu")
+
+
+@pytest.mark.gpu
+def test_warp2_over_rccl_on_two_gpus(scene):
+    """the hand-over and stop-together protocol over ncclSend / ncclRecv between two GPUs (skipped on a one-GPU box: RCCL
+    refuses two ranks on one device); a stale id file of an earlier run lies in the way and is told apart by the nonce"""
+    from tpose_amd import capi
+    if capi.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _hierarchies(scene, build_cpu("triangulate"))
+    open(str(scene / "rccl_link"), "wb").write(b"\0" * 136)   # (nonce 0 + a dead unique id)
+    _mutual_vs_two_ranks(scene, build_gpu("warp"), build_gpu("warp2"), "rccl", transport="rccl", extra=["-nonce", str(os.getpid())],
+                         per_rank=lambda r: ["-device", str(r)])
 
 
 @pytest.mark.gpu

@@ -23,7 +23,8 @@ SYMBOLS = [
     "tp_get_ratio", "tp_set_dp", "tp_set_option", "tp_set_image", "tp_set_image_device", "tp_upload", "tp_accumulate",
     "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_retrieve_many", "tp_synchronize",
     "tp_get_stream", "tp_profile_iterate", "tp_profile_accumulate", "tp_get_info", "tp_selftest_walker", "tp_render",
-    "tp_prepare", "tp_selftest_line", "tp_timer_start", "tp_timer_stop", "tp_iterate_until",
+    "tp_prepare", "tp_selftest_line", "tp_timer_start", "tp_timer_stop", "tp_iterate_until", "tp_band_mailbox_bytes",
+    "tp_band_attach",
 ]
 
 
@@ -145,6 +146,12 @@ class Context:
 
     def set_persistent(self, on):
         self.set_option(OPT_PERSISTENT, PERSIST_AUTO if on else PERSIST_OFF)
+
+    def band_attach(self, band, n_bands, mailboxes, bytes_each, patches_per_band=0):
+        """mailboxes: device addresses (ints), one per band, as this process addresses them (tp_band_attach)"""
+        arr = (C.c_void_p * max(1, len(mailboxes)))(*[C.c_void_p(int(m)) for m in mailboxes])
+        self.lib.tp_band_attach.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int]
+        self._ck(self.lib.tp_band_attach(self.h, band, n_bands, arr, C.c_size_t(bytes_each), patches_per_band))
 
     def set_image(self, slot, img):
         img = np.ascontiguousarray(img, np.uint8)

@@ -134,6 +134,11 @@ struct tp_context {
     int32_t* ering_host = nullptr; size_t cap_ering_host = 0;   // pinned
     unsigned long long* posbox = nullptr;
     size_t cap_posbox = 0;   // (in vertices)
+    // band split (tp_band_attach): this context runs band `band` of `n_bands` -- the patches [band, band + 1) * band_patches of a
+    // plan of n_bands * band_patches -- and the mailbox is the caller's (one per band, mapped into every band's process)
+    int band = 0, n_bands = 1, band_patches = 0;
+    unsigned long long* band_box[PK_MAX_PEERS + 1] = {nullptr, nullptr, nullptr, nullptr};
+    size_t band_cap = 0;     // (in vertices)
     float2* points_out = nullptr; size_t cap_points_out = 0;
     unsigned* d_status = nullptr;   // [0] a lane of a persistent launch gave up waiting, [1] census counter
     uint32_t epoch = 1;             // number of the next grad-iter of a persistent launch (mailbox tags)
@@ -257,7 +262,7 @@ unsigned long long* persist_dbg_buffer(int parts, hipStream_t s) {
 #endif
 #define PK_LDS_LIMIT (160 * 1024 - 512)  /* (the kernel has a few static bytes of its own) */
 #define PK_MIN_ITERS 4        /* shorter tp_iterate calls are not worth a plan (frame-by-frame schedules) */
-#define PK_MAX_EPOCH 32000u   /* mailbox tags carry 15 bits of the grad-iter's number */
+#define PK_MAX_EPOCH 0x7f000000u   /* mailbox tags carry 31 bits of the grad-iter's number */
 
 int enqueue_two_kernel(tp_context* c, const tp_params* p, float dp, int n);
 
@@ -314,7 +319,7 @@ int take_census(tp_context* c) {
     HIP_TRY(c, hipMemcpyAsync(c->d_wg, hw.data(), sizeof(pk_wg) * hw.size(), hipMemcpyHostToDevice, c->stream));
     pk_args A{};
     A.wg = c->d_wg; A.parts = c->num_cus; A.n_iters = -1; A.status = c->d_status;
-    tp_launch_persist(A, PK_ROWS_PER_LANE, PK_LDS_LIMIT, c->stream);
+    tp_launch_persist(A, c->num_cus, PK_ROWS_PER_LANE, PK_LDS_LIMIT, c->stream);
     if (hipGetLastError() != hipSuccess) { c->census = -3; return TP_OK; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     unsigned st[2] = {1u, 0u};
@@ -338,7 +343,10 @@ int take_census(tp_context* c) {
 int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok) {
     pk_plan np;
     pk_build_plan(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
-                  c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, c->num_cus, PK_LDS_LIMIT, np, c->plan_base_every);
+                  c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, c->n_bands > 1 ? c->n_bands * c->band_patches : c->num_cus, PK_LDS_LIMIT, np,
+                  c->plan_base_every);
+    // (a band split runs equal shares of the patches: a plan with fewer patches than asked for -- a tiny mesh -- is not split)
+    if (np.ok && c->n_bands > 1 && np.parts != c->n_bands * c->band_patches) { np.ok = false; np.why = "fewer patches than the bands need"; }
     *ok = np.ok;
     if (!np.ok) { if (!c->plan.ok) c->plan = np; return TP_OK; }
     tp_context::plan_buf& B = c->plan_dev[slot];
@@ -386,10 +394,14 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false) {
         if (int rc = build_plan(c, c->h_points.data(), dp, 0, &ok)) return rc;
         if (ok) {
             const size_t np = (size_t)c->NP;
-            if (np > c->cap_posbox || !c->posbox) {
+            if (c->n_bands > 1 && np > c->band_cap) { c->plan.ok = false; c->plan.why = "more vertices than the bands' mailboxes hold"; *use = false; return TP_OK; }
+            if (c->n_bands == 1 && (np > c->cap_posbox || !c->posbox)) {
                 hipFree(c->posbox); c->posbox = nullptr; c->cap_posbox = 0;
                 const size_t n = np + np / 2 + 64;
-                HIP_TRY(c, dev_alloc(&c->posbox, n * 4)); c->cap_posbox = n;
+                HIP_TRY(c, dev_alloc(&c->posbox, n * 8)); c->cap_posbox = n;
+                // a cleared mailbox matches no tag; afterwards tags never repeat (the epoch counts on across uploads), so
+                // the granules of an earlier triangulation are never taken for this one's
+                HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 8 * sizeof(unsigned long long), c->stream));
             }
             if (int rc = grow(c, &c->points_out, &c->cap_points_out, np)) return rc;
             if (np > c->snap_cap) {
@@ -400,9 +412,6 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false) {
                 c->snap_cap = n;
             }
             for (int k = 0; k < 2; k++) if (!c->snap_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->snap_ev[k], hipEventDisableTiming));
-            // vertex numbering changed with the triangulation: stale granules of the previous one must not match a tag
-            HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 4 * sizeof(unsigned long long), c->stream));
-            c->epoch = 1;
         }
     }
     *use = c->plan.ok;
@@ -414,6 +423,7 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false) {
 int maybe_replan(tp_context* c, float dp) {
     const int k = c->snap_next;   // the older of the two snapshot slots: the one the next chunk's snapshot will overwrite
     if (!c->snap_pending[k]) return TP_OK;
+    if (c->n_bands > 1) { c->snap_pending[k] = false; return TP_OK; }   // (bands keep the plan they all cut from the upload)
     HIP_TRY(c, hipEventSynchronize(c->snap_ev[k]));
     c->snap_pending[k] = false;
     const float* q = c->snap_host[k];
@@ -439,7 +449,8 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         // long calls go chunk by chunk (a chunk and a half rather than a short tail)
         const int k = n <= PK_CHUNK + PK_CHUNK / 2 ? n : PK_CHUNK;   // (rings: the caller's chunks are shorter than this)
         if (c->epoch + (uint32_t)k > PK_MAX_EPOCH) {
-            HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 4 * sizeof(unsigned long long), c->stream));
+            if (c->n_bands > 1) return fail(c, TP_ERR_STATE, "band split: the mailbox tags are used up (2^31 grad-iters)");
+            HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 8 * sizeof(unsigned long long), c->stream));
             c->epoch = 1;
         }
         pk_args A{};
@@ -449,7 +460,16 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         A.points = c->points; A.points_out = c->points_out; A.ca = c->ca;
         A.NT = c->NT; A.NP = c->NP; A.NE = c->NE;
         A.flavour = p.flavour; A.rate = p.rate;
-        A.posbox = c->posbox;
+        const bool banded = c->n_bands > 1;
+        const int grid = banded ? c->band_patches : c->plan.parts;
+        A.posbox = banded ? c->band_box[c->band] : c->posbox;
+        A.box_stride = (unsigned)(banded ? c->band_cap : c->cap_posbox);
+        if (banded) {
+            A.part0 = c->band * c->band_patches;
+            for (int b = 0; b < c->n_bands; b++) if (b != c->band) A.peer_box[A.n_peers++] = c->band_box[b];
+            A.final_tag = 0x80000000u | ((c->epoch + (uint32_t)k) & 0x7fffffffu);
+            A.final_slot = (unsigned)(c->persist_launches & 1);
+        }
         A.epoch = c->epoch; A.n_iters = k; A.status = c->d_status;
         A.emit = n == k && !rings; A.ten = c->ten; A.cn = c->cn; A.ca_out = c->ca; A.gr = c->gr;
         if (rings) { A.ering = c->ering; A.pring = c->pring; }
@@ -457,7 +477,8 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         A.dbg = persist_dbg_buffer(c->plan.parts, c->stream);
         { const char* f = getenv("TPOSE_DBG_FIRST"); A.dbg_first = f ? atoi(f) : 0; }
 #endif
-        tp_launch_persist(A, c->plan.rows_max, c->plan.lds_bytes, c->stream);
+        tp_launch_persist(A, grid, c->plan.rows_max, c->plan.lds_bytes, c->stream);
+        if (banded) tp_launch_band_collect(make_launch(c, p.image_slot, dp), A, c->points_out, c->stream);
         tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->stream);
         c->journal.push_back({p, rings ? 0 : k});   // (a chunk of tp_iterate_until is checked by its caller: nothing to replay)
         HIP_TRY(c, hipGetLastError());
@@ -592,6 +613,32 @@ int tp_set_option(tp_context* c, int option, int64_t value) {
             return TP_OK;
         default: return fail(c, TP_ERR_INVALID, "unknown option %d", option);
     }
+}
+
+size_t tp_band_mailbox_bytes(int points) { return (size_t)(points > 0 ? points : 0) * 64 + 64; }
+
+int tp_band_attach(tp_context* c, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int patches_per_band) {
+    api_guard api_lock;
+    if (!c) return TP_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = tp_synchronize(c)) return rc;   // nothing in flight reads the mailbox or the plan
+    if (n_bands <= 1) {
+        c->band = 0; c->n_bands = 1; c->band_patches = 0; c->band_cap = 0;
+        for (auto& b : c->band_box) b = nullptr;
+        c->plan_generation = 0;
+        return TP_OK;
+    }
+    if (n_bands > PK_MAX_PEERS + 1 || band < 0 || band >= n_bands || !mailboxes) return fail(c, TP_ERR_INVALID, "band attach: band %d of %d (at most %d bands)", band, n_bands, PK_MAX_PEERS + 1);
+    for (int b = 0; b < n_bands; b++) if (!mailboxes[b]) return fail(c, TP_ERR_INVALID, "band attach: mailbox %d is NULL", b);
+    if (bytes_each < 128) return fail(c, TP_ERR_INVALID, "band attach: mailboxes of %zu bytes", bytes_each);
+    if (c->num_cus < 1) return fail(c, TP_ERR_STATE, "band attach: no compute units reported");
+    const int ppb = patches_per_band > 0 ? patches_per_band : c->num_cus;
+    if (ppb > c->num_cus) return fail(c, TP_ERR_CAPACITY, "band attach: %d patches per band on %d compute units", ppb, c->num_cus);
+    c->band = band; c->n_bands = n_bands; c->band_patches = ppb;
+    c->band_cap = (bytes_each - 64) / 64;
+    for (int b = 0; b < n_bands; b++) c->band_box[b] = (unsigned long long*)mailboxes[b];
+    c->plan_generation = 0;   // the plan is cut again, into n_bands * ppb patches
+    return TP_OK;
 }
 
 int tp_get_ratio(const tp_context* c, float* ratio) {
@@ -981,7 +1028,7 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
         return TP_OK;
     };
     bool use = false;
-    if (max_frames >= PK_MIN_ITERS) { if (int rc = ensure_plan(c, dp, &use, true)) return rc; }
+    if (max_frames >= PK_MIN_ITERS && c->n_bands == 1) { if (int rc = ensure_plan(c, dp, &use, true)) return rc; }
     int done = 0, chunk = 32;
     bool converged = false;
     while (done < max_frames && !converged) {

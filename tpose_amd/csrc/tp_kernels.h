@@ -61,6 +61,7 @@ void tp_launch_render(const tp_launch& L, const float2* pts, int source, void* o
 
 // ---- persistent grad-iter kernel (tp_persist.hip): K grad-iters per launch, one workgroup per patch of the mesh
 #define PK_DBG_ITERS 64
+#define PK_MAX_PEERS 3
 struct pk_args {
     const pk_wg* wg;            // [parts] per-patch headers (tp_plan.h)
     const int32_t* pool;        // the patches' tables
@@ -76,10 +77,19 @@ struct pk_args {
     int NT, NP, NE;
     int flavour;
     float rate;
-    unsigned long long* posbox;   // [2][NP][2] position mailbox
+    unsigned long long* posbox;   // position mailbox: [4][box_stride] slots of two 8-byte granules {tag : 32, float : 32} -- slots 0, 1: the
+                                  // positions entering a grad-iter, by its parity; 2, 3: those a launch ends with, by the launch's number
+    unsigned box_stride;          // vertices per slot array
+    // band split (tp_band_attach): this launch runs the patches [part0, part0 + gridDim.x) of the plan; every position is also
+    // posted to the other bands' mailboxes (peer memory: system-scope stores), polled from the own one
+    int part0, n_peers;
+    unsigned long long* peer_box[PK_MAX_PEERS];
+    unsigned final_tag, final_slot;   // band split: tag of the positions this launch ends with, and which of the slots 2, 3 takes them (the
+                                      // launch's number mod 2: a band cannot end launch n + 2 before every band has collected launch n, because its
+                                      // launch n + 1 needs the others' launch n + 1, which they start after collecting n)
     int32_t* ering;               // tp_iterate_until: [n_iters][NT] energy of every triangle's base variant, frame by frame (or null)
     float2* pring;                // tp_iterate_until: [n_iters][NP] positions at the START of every frame (vertices of triangles)
-    unsigned epoch;               // number of the launch's first grad-iter (tags; 1 .. 32767 between mailbox resets)
+    unsigned epoch;               // number of the launch's first grad-iter (tags carry 31 bits of it)
     int n_iters;                  // < 0: census of resident workgroups instead
     unsigned* status;             // [0] raised by a lane that gave up waiting, [1] census counter, [2] completed launches (k_persist_finish)
 #ifdef TPOSE_DEBUG
@@ -88,5 +98,8 @@ struct pk_args {
 #endif
 };
 int tp_persist_set_lds(int bytes);  // hipFuncSetAttribute(max dynamic LDS); returns the hipError_t
-void tp_launch_persist(const pk_args& A, int rows, int lds_bytes, hipStream_t s);
+void tp_launch_persist(const pk_args& A, int grid, int rows, int lds_bytes, hipStream_t s);   // grid: workgroups = patches of this launch
+// band split: the positions the launch ended with, from the own mailbox (every band posted there) into points_out; raises
+// status[0] when they do not arrive
+void tp_launch_band_collect(const tp_launch& L, const pk_args& A, float2* points_out, hipStream_t s);
 void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, hipStream_t s);  // status: of the launch before, or null

@@ -176,7 +176,7 @@ struct lds_line { int64_t x, s; int32_t ra, rb; };
 
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TP_LINES_WAVES_PER_EU))) void k_lines(tp_launch L, int eb, int lp_shift) {
     __shared__ lds_line s_ln[64];
-    __shared__ int s_rmin[LINES_EB], s_rmax[LINES_EB];
+    __shared__ int s_rmin[LINES_EB];
     __shared__ unsigned long long S[64][TP_W_WORDS];
     const int tid = threadIdx.x;
     const int TL = (int)blockDim.x >> lp_shift;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TP_LINES_W
         const int j = tid / TP_NLINES;  // edge of the workgroup
         const int e = (line0 + tid) / TP_NLINES, q = line0 + tid - e * TP_NLINES;
         const bool on = tid < nl && e < L.NE;
-        if (tid < LINES_EB) { s_rmin[tid] = 0x3fffffff; s_rmax[tid] = -1; }
+        if (tid < LINES_EB) s_rmin[tid] = 0x3fffffff;
         tp_line ln; ln.x = 0; ln.s = 0; ln.ra = 1; ln.rb = 0;
         if (on) {
             const int2 uv = L.edge_uv[e];
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TP_LINES_W
             // one edge per vertex publishes its snapped positions (k_finalize reads them)
             if (mv == 0 && ((uv.x >> 30) & 1)) L.vpos[(size_t)(uv.x & 0x3fffffff) * 5 + mu] = make_int2(Xa, Ya);
             if (mu == 0 && ((uv.y >> 30) & 1)) L.vpos[(size_t)(uv.y & 0x3fffffff) * 5 + mv] = make_int2(Xb, Yb);
-            if (ln.ra <= ln.rb) { atomicMin(&s_rmin[j], ln.ra); atomicMax(&s_rmax[j], ln.rb); }  // (after the initialisation: same wave, LDS keeps program order)
+            if (ln.ra <= ln.rb) atomicMin(&s_rmin[j], ln.ra);  // (after the initialisation: same wave, LDS keeps program order)
         }
         s_ln[tid].x = ln.x; s_ln[tid].s = ln.s; s_ln[tid].ra = ln.ra; s_ln[tid].rb = ln.rb;
 #pragma unroll
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TP_LINES_W
         int n = ln.rb >= first ? ((ln.rb - first) >> tl_log) + 1 : 0;
         // the walker of the line stepped by TL rows, and the table row pointer likewise
         int64_t x = ln.x + (int64_t)(first - ln.ra) * ln.s;
-        const int64_t xs = ln.s * TL;
-        // (byte offsets into the table fit 32 bits: 16384^2 pixels x 8 bytes = 2^31)
+        const int64_t xs = (int64_t)((uint64_t)ln.s * (uint64_t)TL);   // (unsigned: a steep two-row line may wrap; its step is never used)
+        // (byte offsets into the table: uint32 arithmetic, 16384 rows x 4100 records x 32 bytes < 2^32)
         const char* table = reinterpret_cast<const char*>(L.prefix);
         uint32_t row = (uint32_t)(n > 0 ? first : 0) * (uint32_t)L.prefix_pitch * 32u;
         const uint32_t rs = (uint32_t)TL * (uint32_t)L.prefix_pitch * 32u;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TP_LINES_W
                     col[u] = xc < 0 ? 0 : (xc > W ? W : xc);
                     const uint4* rec = reinterpret_cast<const uint4*>(table + (row + (((uint32_t)col[u] & ~3u) << 3)));
                     d0[u] = rec[0]; d1[u] = rec[1];
-                    x += xs; row += rs;
+                    x = (int64_t)((uint64_t)x + (uint64_t)xs); row += rs;
                 }
             }
             acc_records(a, col, d0, d1);

@@ -342,8 +342,9 @@ TP_HD void pk_walk_cached(pk_lane_cache<R>& C, const pk_view& V, const char* tab
     pk_walk_sum<RR>(C, S, table, W, a);
 }
 
-// tag of grad-iter `epoch` (1 .. 32767 between two resets of the mailbox): never 0, differs between e and e - 2
-TP_HD uint32_t pk_tag(uint32_t epoch) { return 0x8000u | (epoch & 0x7fffu); }
+// tag of grad-iter `epoch`: never 0 (a cleared mailbox matches nothing), and no two grad-iters of a context's life share one
+// (epochs count on across uploads and launches; 2^31 of them)
+TP_HD uint32_t pk_tag(uint32_t epoch) { return 0x80000000u | (epoch & 0x7fffffffu); }
 
 // signed sum of three line sums: the exact pixel moments of a variant (tp_raster.h, "Edge-centric form")
 TP_HD tp_moments pk_moments3(int c0, const unsigned long long* S0, int c1, const unsigned long long* S1, int c2, const unsigned long long* S2) {

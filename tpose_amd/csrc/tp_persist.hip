@@ -24,7 +24,9 @@
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 #define PK_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define PK_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 #define PK_TIMEOUT_TICKS 3000000ull  // 30 ms of the 100 MHz wall clock (a hand-over takes microseconds)
+#define PK_TIMEOUT_BANDS 100000000ull  // 1 s when other processes take part (their launches start when their hosts get to it)
 
 #ifdef TPOSE_DEBUG
 #define PK_STAMP(k) do { if (threadIdx.x == 0 && A.dbg && it >= A.dbg_first && it < A.dbg_first + PK_DBG_ITERS) A.dbg[((size_t)blockIdx.x * PK_DBG_ITERS + (it - A.dbg_first)) * 16 + (k)] = wall_clock64(); } while (0)
@@ -37,12 +39,12 @@ namespace {
 struct spin_state { unsigned spins; unsigned long long t0; };
 
 // one more turn of a polling loop; true: give up (somebody raised the status word, or this lane waited too long)
-__device__ __forceinline__ bool spin_fail(spin_state& st, gu32* status) {
+__device__ __forceinline__ bool spin_fail(spin_state& st, gu32* status, unsigned long long limit = PK_TIMEOUT_TICKS) {
     if ((++st.spins & 63u) == 0u) {
         if (__hip_atomic_load(status, PK_RLX_AGENT) != 0u) return true;
         const unsigned long long now = wall_clock64();
         if (st.t0 == 0ull) st.t0 = now;
-        else if (now - st.t0 > PK_TIMEOUT_TICKS) { __hip_atomic_store(status, 1u, PK_RLX_AGENT); return true; }
+        else if (now - st.t0 > limit) { __hip_atomic_store(status, 1u, PK_RLX_AGENT); return true; }
     }
     __builtin_amdgcn_s_sleep(1);
     return false;
@@ -61,7 +63,7 @@ template <int RR>
 __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    const int part = patch_of_block((int)blockIdx.x, A.parts);
+    const int part = A.part0 + patch_of_block((int)blockIdx.x, (int)gridDim.x);
     const pk_wg w = A.wg[part];
     pk_view V;
     pk_carve(smem, w, V);
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
             gu32* cnt = status + 1;
             __hip_atomic_fetch_add(cnt, 1u, PK_RLX_AGENT);
             spin_state st = {0u, 0ull};
-            while (__hip_atomic_load(cnt, PK_RLX_AGENT) < (unsigned)A.parts)
+            while (__hip_atomic_load(cnt, PK_RLX_AGENT) < gridDim.x)
                 if (spin_fail(st, status)) break;
         }
         return;
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
     // this thread's lane-item of the walk and the table records of its rows: in registers for the whole launch
     pk_lane_cache<RR> cache[PK_NI];
     gu64* posbox = (gu64*)A.posbox;
+    const bool banded = A.n_peers > 0;
     int failed = 0;
     int n_li_now = 0, n_li_all_now = 0;   // lane-items of the lines walked every grad-iter / with the last one's base lines
     __syncthreads();
@@ -126,13 +129,14 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
         // ---- P0: positions of the neighbouring vertices this patch uses (the first grad-iter of a launch read `points`)
         if (it > 0) {
             for (int s = w.n_own_v + tid; s < w.n_slots; s += PK_THREADS) {
-                gu64* g = posbox + ((size_t)par * A.NP + V.vid[s]) * 2;
+                gu64* g = posbox + ((size_t)par * A.box_stride + V.vid[s]) * 2;
                 spin_state st = {0u, 0ull};
                 unsigned long long a, b;
                 for (;;) {
-                    a = __hip_atomic_load(g, PK_RLX_AGENT); b = __hip_atomic_load(g + 1, PK_RLX_AGENT);
+                    if (banded) { a = __hip_atomic_load(g, PK_RLX_SYSTEM); b = __hip_atomic_load(g + 1, PK_RLX_SYSTEM); }   // (written by another device)
+                    else { a = __hip_atomic_load(g, PK_RLX_AGENT); b = __hip_atomic_load(g + 1, PK_RLX_AGENT); }
                     if ((uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag) break;
-                    if (spin_fail(st, status)) { failed = 1; break; }
+                    if (spin_fail(st, status, banded ? PK_TIMEOUT_BANDS : PK_TIMEOUT_TICKS)) { failed = 1; break; }
                 }
                 V.pos[s].x = __uint_as_float((uint32_t)a); V.pos[s].y = __uint_as_float((uint32_t)b);
             }
@@ -275,11 +279,20 @@ __global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
 #endif
             V.pos[k] = p;
             if (last) A.points_out[v] = make_float2(p.x, p.y);
-            else {
-                const unsigned long long T = (unsigned long long)pk_tag(epoch + 1u) << 32;
-                gu64* g = posbox + ((size_t)((epoch + 1u) & 1u) * A.NP + v) * 2;
-                __hip_atomic_store(g, T | __float_as_uint(p.x), PK_RLX_AGENT);
-                __hip_atomic_store(g + 1, T | __float_as_uint(p.y), PK_RLX_AGENT);
+            if (!last || banded) {
+                // (band split: the positions a launch ends with go to the slots 2, 3 of every band's mailbox, for tp_launch_band_collect)
+                const unsigned long long T = (unsigned long long)(last ? A.final_tag : pk_tag(epoch + 1u)) << 32;
+                const size_t at = ((size_t)(last ? 2u + A.final_slot : (epoch + 1u) & 1u) * A.box_stride + v) * 2;
+                const unsigned long long gx = T | __float_as_uint(p.x), gy = T | __float_as_uint(p.y);
+                if (banded) {
+                    __hip_atomic_store(posbox + at, gx, PK_RLX_SYSTEM); __hip_atomic_store(posbox + at + 1, gy, PK_RLX_SYSTEM);
+                    for (int b = 0; b < A.n_peers; b++) {
+                        gu64* g = (gu64*)A.peer_box[b] + at;
+                        __hip_atomic_store(g, gx, PK_RLX_SYSTEM); __hip_atomic_store(g + 1, gy, PK_RLX_SYSTEM);
+                    }
+                } else {
+                    __hip_atomic_store(posbox + at, gx, PK_RLX_AGENT); __hip_atomic_store(posbox + at + 1, gy, PK_RLX_AGENT);
+                }
             }
         }
         if (!last) {
@@ -298,8 +311,8 @@ int tp_persist_set_lds(int bytes) {
     return rc;
 }
 // rows: the most rows per lane of any patch of the plan (pk_plan::rows_max); the census passes PK_ROWS_PER_LANE
-void tp_launch_persist(const pk_args& A, int rows, int lds_bytes, hipStream_t s) {
-    const dim3 g((unsigned)A.parts), b(PK_THREADS);
+void tp_launch_persist(const pk_args& A, int grid, int rows, int lds_bytes, hipStream_t s) {
+    const dim3 g((unsigned)grid), b(PK_THREADS);
     // (one row more than the plan's rows per lane where there is an instantiation for it: a line that has grown by a chunk's
     // worth of rows since the plan was cut still fits the records its lanes keep)
     if (rows <= 7) hipLaunchKernelGGL(k_persist<8>, g, b, (size_t)lds_bytes, s, A);
@@ -308,3 +321,26 @@ void tp_launch_persist(const pk_args& A, int rows, int lds_bytes, hipStream_t s)
     else hipLaunchKernelGGL(k_persist<PK_ROWS_PER_LANE>, g, b, (size_t)lds_bytes, s, A);
 }
 
+
+// band split, after a launch: every band posted the positions its vertices ended with into slot 2 + (launch number mod 2) of
+// every mailbox; each band takes them all from its own.  A position that does not arrive (a band gave up) raises the status
+// word: this launch, too, is run again on the two-kernel path.
+__global__ void k_band_collect(tp_launch L, pk_args A, float2* points_out) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    gu32* status = (gu32*)A.status;
+    if (v >= L.NP || L.vtx_off[v + 1] <= L.vtx_off[v]) return;
+    if (__hip_atomic_load(status, PK_RLX_AGENT) != 0u) return;
+    gu64* g = (gu64*)A.posbox + ((size_t)(2u + A.final_slot) * A.box_stride + v) * 2;
+    spin_state st = {0u, 0ull};
+    for (;;) {
+        const unsigned long long a = __hip_atomic_load(g, PK_RLX_SYSTEM), b = __hip_atomic_load(g + 1, PK_RLX_SYSTEM);
+        if ((uint32_t)(a >> 32) == A.final_tag && (uint32_t)(b >> 32) == A.final_tag) {
+            points_out[v] = make_float2(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)b));
+            return;
+        }
+        if (spin_fail(st, status, PK_TIMEOUT_BANDS)) return;
+    }
+}
+void tp_launch_band_collect(const tp_launch& L, const pk_args& A, float2* points_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_band_collect, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L, A, points_out);
+}

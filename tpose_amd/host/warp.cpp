@@ -2,7 +2,7 @@
 // a pair of stacked triangulations (software/warp/main.cpp:214-283) through the tpose:: host mirror.
 //
 //   warp -ia A.ppm -ib B.ppm -ta A.tri -tb B.tri [-schedule as_written|two_way]
-//        [-maxframes N] [-levelframes N] [-device D] [-quiet]
+//        [-maxframes N] [-levelframes N] [-fixedframes] [-device D] [-quiet]
 //
 // Per frame: doreset (count), doenergy against the OTHER image with the stored triangle colours,
 // doshift; when the relative energy change falls below 1e-6 the optimised triangulation's reverse
@@ -13,6 +13,7 @@
 //   two_way:    both directions per level (the README's description; `||` instead of `&&`).
 //   mutual:     the two-way form with independent directions inside a phase (warp_core.hpp) -- what warp2 runs on two
 //               GPUs at once; here its four descents per level run one after the other.  Same bytes.
+//               -fixedframes: every descent runs exactly -levelframes frames, without the convergence test.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -28,7 +29,8 @@
 using namespace tpose;
 
 // -schedule mutual on one GPU
-static int run_mutual(const std::string& ta, const std::string& tb, long levelframes) {
+static int run_mutual(const std::string& ta, const std::string& tb, long levelframes, bool fixed) {
+    auto descend = [&](warpcore::direction& d) { return fixed ? warpcore::descend_fixed(d, levelframes) : warpcore::descend(d, levelframes); };
     warpcore::direction A, B;
     A.warpA = true; B.warpA = false;
     io::read(&A.tr, ta);
@@ -36,15 +38,15 @@ static int run_mutual(const std::string& ta, const std::string& tb, long levelfr
     long frames = 0;
     int level = 0;
     while (true) {
-        frames += warpcore::descend(A, levelframes);   // phase 1
-        frames += warpcore::descend(B, levelframes);
+        frames += descend(A);   // phase 1
+        frames += descend(B);
         triangulation peerA, peerB;                      // the meshes handed over
         warpcore::unpack(warpcore::pack(A.tr), peerA);
         warpcore::unpack(warpcore::pack(B.tr), peerB);
         warpcore::reseed(A, peerB);
         warpcore::reseed(B, peerA);
-        frames += warpcore::descend(A, levelframes);   // phase 2
-        frames += warpcore::descend(B, levelframes);
+        frames += descend(A);   // phase 2
+        frames += descend(B);
         io::write(&A.tr, ta + ".warp");
         io::write(&B.tr, tb + ".warp");
         level++;
@@ -59,11 +61,12 @@ int main(int argc, char** argv) {
     std::string ia, ib, ta, tb, schedule = "as_written";
     long maxframes = 1L << 40, levelframes = 1L << 40;
     int device = 0;
-    bool quiet = false;
+    bool quiet = false, fixed = false;
     for (int a = 1; a < argc; a++) {
         const std::string k = argv[a];
         auto val = [&]() -> const char* { if (a + 1 >= argc) { std::cerr << "missing value for " << k << "\n"; std::exit(2); } return argv[++a]; };
         if (k == "-ia") ia = val();
+        else if (k == "-fixedframes") fixed = true;
         else if (k == "-ib") ib = val();
         else if (k == "-ta") ta = val();
         else if (k == "-tb") tb = val();
@@ -89,7 +92,7 @@ int main(int argc, char** argv) {
     tpose::image(TP_IMAGE_B, B.rgba.data(), (size_t)B.w * 4);
 
     if (schedule == "mutual") {
-        const int rc = run_mutual(ta, tb, levelframes);
+        const int rc = run_mutual(ta, tb, levelframes, fixed);
         tpose::quit();
         return rc;
     }

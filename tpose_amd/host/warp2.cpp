@@ -12,10 +12,22 @@
 // (source/triangulation.hpp:492-520), descends again and appends its level to <tri>.warp.  The output is byte-identical
 // to `warp -schedule mutual` on one GPU.
 //
-//   -transport rccl   (default) ncclSend / ncclRecv between the two GPUs; the unique id travels through -idfile
+//   -transport rccl   (default) ncclSend / ncclRecv between the two GPUs; the unique id travels through -idfile, tagged with
+//                     -nonce N (the same number for both ranks, e.g. the launcher's pid) so that a file left by an earlier
+//                     run is never taken for this run's id
 //   -transport fifo   two named pipes <idfile>.0to1 / <idfile>.1to0 -- for the CPU test of the schedule (built with
 //                     -DWARP2_NO_RCCL against the oracle-backed C ABI) and for one-GPU boxes, where RCCL refuses
 //                     two ranks on the same device
+//   -bands 2 -band b   every direction is split over TWO processes / GPUs: band b of a direction runs half of
+//                     the patches of each descent (tp_band_attach) and hands vertex positions over to its band-mate on the
+//                     device, through mailboxes mapped into each other's process (hipIpcGetMemHandle; the handles travel
+//                     through the pipes <idfile>.mate<rank>.*).  Four processes: -rank {0,1} x -band {0,1}; band b of one
+//                     direction exchanges meshes with band b of the other (its own -idfile: <idfile>.b<band>), so both
+//                     bands hold the same meshes at every step.  Band 0 writes <tri>.warp, band 1 <tri>.warp.band1 (the
+//                     same bytes).  Needs -fixedframes: banded launches carry no per-frame energies for the convergence
+//                     test.  -bandpatches N: patches per band (default: one per compute unit; two bands sharing ONE
+//                     device -- the one-GPU test box -- must not ask for more than the device has between them)
+//   -fixedframes      every descent runs exactly -levelframes frames (no convergence test)
 //   -selftest         one rank sends a mesh-sized buffer to itself through RCCL and checks it (exercises the library,
 //                     the stream and the device buffers on a one-GPU box)
 #include <chrono>
@@ -24,6 +36,7 @@
 #include <fcntl.h>
 #include <iostream>
 #include <string>
+#include <sys/file.h>
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
@@ -41,6 +54,7 @@
 using namespace tpose;
 
 namespace {
+long long g_nonce = 0;   // -nonce: names this run in the id file
 
 [[noreturn]] void die(const std::string& what) {
     std::cerr << "warp2: " << what << std::endl;
@@ -95,21 +109,30 @@ struct rccl_transport : transport {
     rccl_transport(int rank_, int nranks_, int device, const std::string& idfile) : rank(rank_), nranks(nranks_), peer(nranks_ == 1 ? 0 : 1 - rank_) {
         HIPCHECK(hipSetDevice(device));
         ncclUniqueId id;
+        // the id file carries a nonce both ranks were started with (-nonce, default 0): a file left by an earlier run is not
+        // this run's id (ncclCommInitRank with a stale id never returns)
         if (rank == 0) {
+            std::remove(idfile.c_str());
             NCCLCHECK(ncclGetUniqueId(&id));
             const std::string tmp = idfile + ".tmp";
             FILE* f = std::fopen(tmp.c_str(), "wb");
-            if (!f || std::fwrite(&id, sizeof id, 1, f) != 1) die("cannot write " + tmp);
+            if (!f || std::fwrite(&g_nonce, sizeof g_nonce, 1, f) != 1 || std::fwrite(&id, sizeof id, 1, f) != 1) die("cannot write " + tmp);
             std::fclose(f);
             if (std::rename(tmp.c_str(), idfile.c_str()) != 0) die("cannot publish " + idfile);
         } else {
-            FILE* f = nullptr;
-            for (int tries = 0; tries < 3000 && !(f = std::fopen(idfile.c_str(), "rb")); tries++)
-                std::this_thread::sleep_for(std::chrono::milliseconds(10));
-            if (!f || std::fread(&id, sizeof id, 1, f) != 1) die("no RCCL id in " + idfile);
-            std::fclose(f);
+            bool got = false;
+            for (int tries = 0; tries < 3000 && !got; tries++) {
+                if (FILE* f = std::fopen(idfile.c_str(), "rb")) {
+                    long long n = 0;
+                    got = std::fread(&n, sizeof n, 1, f) == 1 && n == g_nonce && std::fread(&id, sizeof id, 1, f) == 1;
+                    std::fclose(f);
+                }
+                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+            if (!got) die("no RCCL id of this run (nonce) in " + idfile);
         }
         NCCLCHECK(ncclCommInitRank(&comm, nranks, id, rank));
+        if (rank == 0) std::remove(idfile.c_str());   // (every rank has read it: the communicator exists)
         HIPCHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     }
     ~rccl_transport() override {
@@ -155,8 +178,8 @@ struct rccl_transport : transport {
 int main(int argc, char** argv) {
     std::string ia, ib, ta, tb, idfile, how = "rccl";
     long levelframes = 1L << 40;
-    int device = -1, rank = -1;
-    bool quiet = false, selftest = false;
+    int device = -1, rank = -1, bands = 1, band = 0, bandpatches = 0;
+    bool quiet = false, selftest = false, fixed = false;
     for (int a = 1; a < argc; a++) {
         const std::string k = argv[a];
         auto val = [&]() -> const char* { if (a + 1 >= argc) die("missing value for " + k); return argv[++a]; };
@@ -166,10 +189,15 @@ int main(int argc, char** argv) {
         else if (k == "-tb") tb = val();
         else if (k == "-rank") rank = std::atoi(val());
         else if (k == "-idfile") idfile = val();
+        else if (k == "-nonce") g_nonce = std::atoll(val());
         else if (k == "-transport") how = val();
         else if (k == "-levelframes") levelframes = std::atol(val());
         else if (k == "-device") device = std::atoi(val());
         else if (k == "-quiet") quiet = true;
+        else if (k == "-bands") bands = std::atoi(val());
+        else if (k == "-band") band = std::atoi(val());
+        else if (k == "-bandpatches") bandpatches = std::atoi(val());
+        else if (k == "-fixedframes") fixed = true;
         else if (k == "-selftest") selftest = true;
         else die("unknown option " + k);
     }
@@ -202,7 +230,11 @@ int main(int argc, char** argv) {
     }
     if (rank != 0 && rank != 1) die("-rank 0 or -rank 1");
     if (ia.empty() || ib.empty() || ta.empty() || tb.empty() || idfile.empty()) die("need -ia -ib -ta -tb -idfile");
-    if (device < 0) device = rank;  // one process per GPU
+    if (bands != 1 && bands != 2) die("-bands 1 or 2");
+    if (band < 0 || band >= bands) die("-band out of range");
+    if (bands == 2 && !fixed) die("-bands 2 needs -fixedframes");
+    if (bands == 2) idfile += ".b" + std::to_string(band);   // band b of one direction talks to band b of the other
+    if (device < 0) device = rank * bands + band;  // one process per GPU
     Raster A, B;
     if (!load_raster(ia, A) || !load_raster(ib, B)) die("failed to load the images");
     if (A.w != B.w || A.h != B.h) die("images do not have the same dimension");
@@ -226,21 +258,72 @@ int main(int argc, char** argv) {
     mine.warpA = rank == 0;
     const std::string my_tri = rank == 0 ? ta : tb;
     io::read(&mine.tr, my_tri);
+    void* boxes[2] = {nullptr, nullptr};
+    if (bands == 2) {
+        // the two bands of this direction: one mailbox each, mapped into the other's process
+        const std::string mate_base = idfile.substr(0, idfile.size() - 3) + ".mate" + std::to_string(rank);
+        fifo_transport mate(band, mate_base);
+        const size_t bytes = tp_band_mailbox_bytes(1 << 16);
+#ifndef WARP2_NO_RCCL
+        HIPCHECK(hipSetDevice(device));
+        HIPCHECK(hipMalloc(&boxes[band], bytes));
+        HIPCHECK(hipMemset(boxes[band], 0, bytes));
+        HIPCHECK(hipDeviceSynchronize());
+        hipIpcMemHandle_t h;
+        HIPCHECK(hipIpcGetMemHandle(&h, boxes[band]));
+        std::vector<int32_t> out(sizeof h / 4);
+        std::memcpy(out.data(), &h, sizeof h);
+        const std::vector<int32_t> in = mate.exchange(out);
+        if (in.size() != out.size()) die("band-mate sent no mailbox handle");
+        std::memcpy(&h, in.data(), sizeof h);
+        HIPCHECK(hipIpcOpenMemHandle(&boxes[1 - band], h, hipIpcMemLazyEnablePeerAccess));
+#else
+        static char dummy[2][128];   // (the CPU stand-in of the C ABI runs every band's descents whole)
+        boxes[0] = dummy[0]; boxes[1] = dummy[1];
+        (void)mate.exchange(std::vector<int32_t>(1, band));
+#endif
+        if (tp_band_attach(tpose::ctx, band, 2, boxes, bytes, bandpatches) != TP_OK) die(std::string("tp_band_attach: ") + tp_last_error(tpose::ctx));
+        // the census of resident workgroups and the first plan, while no band spins in a launch yet (two bands may share a device)
+        tpose::warpA = mine.warpA;
+        tpose::upload(&mine.tr);
+        tp_params p0;
+        tp_default_params(TP_WARP, &p0);
+        p0.image_slot = mine.warpA ? TP_IMAGE_B : TP_IMAGE_A;
+        {   // (one process at a time: a census shares its device with nobody -- the four may have been given the same one)
+            const std::string lock_name = idfile.substr(0, idfile.size() - 3) + ".census";
+            const int lock = open(lock_name.c_str(), O_CREAT | O_RDWR, 0600);
+            if (lock >= 0) flock(lock, LOCK_EX);
+            const int rc = tp_prepare(tpose::ctx, &p0);
+            if (rc == TP_OK) tp_synchronize(tpose::ctx);
+            if (lock >= 0) { flock(lock, LOCK_UN); close(lock); }
+            if (rc != TP_OK) die(std::string("tp_prepare: ") + tp_last_error(tpose::ctx));
+        }
+        (void)mate.exchange(std::vector<int32_t>(1, band));   // both are ready
+    }
+    auto descend = [&](warpcore::direction& d) { return fixed ? warpcore::descend_fixed(d, levelframes) : warpcore::descend(d, levelframes); };
+    const std::string out_name = my_tri + ".warp" + (band ? ".band1" : "");
     long frames = 0;
     int level = 0;
     while (true) {
-        frames += warpcore::descend(mine, levelframes);                      // phase 1
+        frames += descend(mine);                                             // phase 1
         triangulation peer;
         warpcore::unpack(link->exchange(warpcore::pack(mine.tr)), peer);    // hand-over
         warpcore::reseed(mine, peer);
-        frames += warpcore::descend(mine, levelframes);                      // phase 2
-        io::write(&mine.tr, my_tri + ".warp");
+        frames += descend(mine);                                             // phase 2
+        io::write(&mine.tr, out_name);
         level++;
         const int32_t more = io::read(&mine.tr, my_tri, true) ? 1 : 0;
         const std::vector<int32_t> theirs = link->exchange(std::vector<int32_t>(1, more));
         if (!more || theirs.empty() || !theirs[0]) break;  // stacks may differ in depth: stop together
     }
     std::cout << "rank " << rank << " frames " << frames << " levels " << level << std::endl;
+    if (bands == 2) {
+        int64_t launches = 0, failures = 0, patches = 0;
+        int64_t census = 0;
+        tp_get_info(tpose::ctx, 5, &launches); tp_get_info(tpose::ctx, 9, &failures); tp_get_info(tpose::ctx, 2, &patches); tp_get_info(tpose::ctx, 7, &census);
+        std::cout << "band " << band << " of rank " << rank << ": persistent launches " << launches << ", patches of the plan " << patches
+                  << ", launches given up " << failures << " (census " << census << ")" << std::endl;
+    }
     delete link;
     tpose::quit();
     return 0;

@@ -42,6 +42,16 @@ inline long descend(direction& d, long levelframes) {
     return frames;
 }
 
+// exactly `frames` frames, no convergence test (-fixedframes: a fixed budget per descent, e.g. for descents split over
+// bands of GPUs, whose launches carry no per-frame energies): upload, one enqueue, one read-back
+inline long descend_fixed(direction& d, long frames) {
+    tpose::warpA = d.warpA;
+    tpose::upload(&d.tr);
+    tpose::doframes(frames);
+    tpose::retrieve(&d.tr);
+    return frames;
+}
+
 // the mesh a side hands over: {NT, NP, triangles ivec4[NT], points vec2[NP], originpoints vec2[NP]}
 inline std::vector<int32_t> pack(const tpose::triangulation& t) {
     std::vector<int32_t> b(2 + 4 * (size_t)t.NT + 4 * (size_t)t.NP);

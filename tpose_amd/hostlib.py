@@ -17,12 +17,17 @@ def load():
         # make decides staleness (host_capi.cpp AND the include/tpose/*.hpp headers are its prerequisites); ranks started
         # together (torchrun) must not build into the same file at once: one builds under an exclusive lock, the rest wait
         import fcntl
-        with open(os.path.join(_HERE, "host", ".build.lock"), "w") as lock:
-            fcntl.flock(lock, fcntl.LOCK_EX)
-            try:
-                subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "host"), "libtpose_host.so"])
-            finally:
-                fcntl.flock(lock, fcntl.LOCK_UN)
+        try:
+            with open(os.path.join(_HERE, "host", ".build.lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "host"), "libtpose_host.so"])
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
+        except (OSError, subprocess.CalledProcessError):
+            # a read-only install, or a box without make: the library that is there is the one to load
+            if not os.path.exists(_SO):
+                raise
         lib = C.CDLL(_SO)
         lib.tph_new.restype = C.c_void_p
         lib.tph_get_ratio.restype = C.c_float
