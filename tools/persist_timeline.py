@@ -58,6 +58,11 @@ for lab, a, b in sub:
     ok = (sel[:, :, a] > 0) & (sel[:, :, b] > 0)
     if ok.any():
         out[lab] = {str(q): round(float(np.percentile(d[ok], q)), 2) for q in (1, 50, 90, 100)}
+# the first grad-iters of the launch (prologue behind them: tables into LDS, the first cut of the lines, every record fetched)
+for it0 in (0, 1, 2):
+    out["grad-iter %d of the launch, median per phase" % it0] = {lab.split()[0]: round(float(np.median((st[:, it0, k + 1] - st[:, it0, k]) / 100.0)), 2)
+                                                                  for k, lab in enumerate(labels)}
+out["first stamp to start of grad-iter 8, median"] = round(float(np.median((st[:, 8, 0] - st[:, 0, 0]) / 100.0)), 2)
 period = (st[:, IT - 1, 0] - st[:, 8, 0]) / 100.0 / (IT - 1 - 8)
 out["grad-iter period"] = {"mean": round(float(period.mean()), 3), "min": round(float(period.min()), 3), "max": round(float(period.max()), 3)}
 start = (st[:, 0, 0] - st[:, 0, 0].min()) / 100.0

@@ -141,6 +141,7 @@ struct tp_context {
     size_t band_cap = 0;     // (in vertices)
     float2* points_out = nullptr; size_t cap_points_out = 0;
     unsigned* d_status = nullptr;   // [0] a lane of a persistent launch gave up waiting, [1] census counter
+    unsigned* h_status = nullptr;   // pinned mirror of [0] and [2], written by k_persist_finish: read after a wait, no copy
     uint32_t epoch = 1;             // number of the next grad-iter of a persistent launch (mailbox tags)
     bool persist_unchecked = false; // persistent launches were enqueued since the status word was last read
     struct journal_entry { tp_params p; int iters; };
@@ -260,7 +261,7 @@ unsigned long long* persist_dbg_buffer(int parts, hipStream_t s) {
     return parts <= 512 ? g_persist_dbg : nullptr;
 }
 #endif
-#define PK_LDS_LIMIT (160 * 1024 - 512)  /* (the kernel has a few static bytes of its own) */
+#define PK_LDS_LIMIT (160 * 1024 / PK_WG_PER_CU - 512)  /* per workgroup (the kernel has a few static bytes of its own) */
 #define PK_MIN_ITERS 4        /* shorter tp_iterate calls are not worth a plan (frame-by-frame schedules) */
 #define PK_MAX_EPOCH 0x7f000000u   /* mailbox tags carry 31 bits of the grad-iter's number */
 
@@ -275,12 +276,13 @@ int enqueue_two_kernel(tp_context* c, const tp_params* p, float dp, int n);
 int check_persist_status(tp_context* c) {
     if (!c->persist_unchecked || !c->d_status) return TP_OK;
     c->persist_unchecked = false;
-    unsigned st[3] = {0u, 0u, 0u};
-    HIP_TRY(c, hipMemcpy(st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
+    // (every caller has waited for the stream: the mirror is what the last k_persist_finish left)
+    const unsigned st[3] = {c->h_status[0], 0u, c->h_status[2]};
     const size_t completed = (size_t)(st[2] - c->done_base);
     c->done_base = st[2];
     if (st[0] == 0u) { c->journal.clear(); return TP_OK; }
     HIP_TRY(c, hipMemset(c->d_status, 0, sizeof(unsigned)));
+    c->h_status[0] = 0u;
     c->census = -6;  // two kernels per grad-iter from now on in this context
     c->persist_failures++;
     std::vector<tp_context::journal_entry> todo(c->journal.begin() + (completed < c->journal.size() ? completed : c->journal.size()), c->journal.end());
@@ -311,22 +313,24 @@ int take_census(tp_context* c) {
     c->census = -1;
     if (c->num_cus < 1) return TP_OK;
     if (!c->d_status) { HIP_TRY(c, dev_alloc(&c->d_status, 4)); }
+    if (!c->h_status) { HIP_TRY(c, hipHostMalloc((void**)&c->h_status, 4 * sizeof(unsigned), hipHostMallocDefault)); memset(c->h_status, 0, 4 * sizeof(unsigned)); }
     HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 4 * sizeof(unsigned), c->stream));
     if (tp_persist_set_lds(PK_LDS_LIMIT) != 0) { (void)hipGetLastError(); c->census = -2; return TP_OK; }
     c->lds_attr = PK_LDS_LIMIT;
-    std::vector<pk_wg> hw((size_t)c->num_cus, pk_wg());
+    const int full = c->num_cus * PK_WG_PER_CU;   // the grid that must be resident at once
+    std::vector<pk_wg> hw((size_t)full, pk_wg());
     if (int rc = grow(c, &c->d_wg, &c->cap_wg, hw.size())) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->d_wg, hw.data(), sizeof(pk_wg) * hw.size(), hipMemcpyHostToDevice, c->stream));
     pk_args A{};
-    A.wg = c->d_wg; A.parts = c->num_cus; A.n_iters = -1; A.status = c->d_status;
-    tp_launch_persist(A, c->num_cus, PK_ROWS_PER_LANE, PK_LDS_LIMIT, c->stream);
+    A.wg = c->d_wg; A.parts = full; A.n_iters = -1; A.status = c->d_status;
+    tp_launch_persist(A, full, PK_ROWS_PER_LANE, PK_LDS_LIMIT, c->stream);
     if (hipGetLastError() != hipSuccess) { c->census = -3; return TP_OK; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     unsigned st[2] = {1u, 0u};
     HIP_TRY(c, hipMemcpy(st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemset(c->d_status, 0, 4 * sizeof(unsigned)));
     c->done_base = 0;
-    if (st[0] == 0u && st[1] == (unsigned)c->num_cus) c->census = 1;
+    if (st[0] == 0u && st[1] == (unsigned)full) c->census = 1;
     else c->census = -4 - (int)(st[0] != 0u);
     return TP_OK;
 }
@@ -343,7 +347,7 @@ int take_census(tp_context* c) {
 int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok) {
     pk_plan np;
     pk_build_plan(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
-                  c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, c->n_bands > 1 ? c->n_bands * c->band_patches : c->num_cus, PK_LDS_LIMIT, np,
+                  c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, c->n_bands > 1 ? c->n_bands * c->band_patches : c->num_cus * PK_WG_PER_CU, PK_LDS_LIMIT, np,
                   c->plan_base_every);
     // (a band split runs equal shares of the patches: a plan with fewer patches than asked for -- a tiny mesh -- is not split)
     if (np.ok && c->n_bands > 1 && np.parts != c->n_bands * c->band_patches) { np.ok = false; np.why = "fewer patches than the bands need"; }
@@ -479,7 +483,7 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
 #endif
         tp_launch_persist(A, grid, c->plan.rows_max, c->plan.lds_bytes, c->stream);
         if (banded) tp_launch_band_collect(make_launch(c, p.image_slot, dp), A, c->points_out, c->stream);
-        tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->stream);
+        tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->h_status, c->stream);
         c->journal.push_back({p, rings ? 0 : k});   // (a chunk of tp_iterate_until is checked by its caller: nothing to replay)
         HIP_TRY(c, hipGetLastError());
         c->epoch += (uint32_t)k;
@@ -570,6 +574,7 @@ int tp_destroy(tp_context* c) {
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->prefix[0]); hipFree(c->prefix[1]); hipFree(c->px[0]); hipFree(c->px[1]);
     hipFree(c->render_pic); hipFree(c->render_pts);
     hipFree(c->d_wg); hipFree(c->d_pool); hipFree(c->posbox); hipFree(c->points_out); hipFree(c->d_status);
+    if (c->h_status) hipHostFree(c->h_status);
     hipFree(c->ering); hipFree(c->pring);
     if (c->ering_host) hipHostFree(c->ering_host);
     for (int k = 0; k < 2; k++) {
@@ -632,8 +637,8 @@ int tp_band_attach(tp_context* c, int band, int n_bands, void* const* mailboxes,
     for (int b = 0; b < n_bands; b++) if (!mailboxes[b]) return fail(c, TP_ERR_INVALID, "band attach: mailbox %d is NULL", b);
     if (bytes_each < 128) return fail(c, TP_ERR_INVALID, "band attach: mailboxes of %zu bytes", bytes_each);
     if (c->num_cus < 1) return fail(c, TP_ERR_STATE, "band attach: no compute units reported");
-    const int ppb = patches_per_band > 0 ? patches_per_band : c->num_cus;
-    if (ppb > c->num_cus) return fail(c, TP_ERR_CAPACITY, "band attach: %d patches per band on %d compute units", ppb, c->num_cus);
+    const int ppb = patches_per_band > 0 ? patches_per_band : c->num_cus * PK_WG_PER_CU;
+    if (ppb > c->num_cus * PK_WG_PER_CU) return fail(c, TP_ERR_CAPACITY, "band attach: %d patches per band on %d compute units", ppb, c->num_cus);
     c->band = band; c->n_bands = n_bands; c->band_patches = ppb;
     c->band_cap = (bytes_each - 64) / 64;
     for (int b = 0; b < n_bands; b++) c->band_box[b] = (unsigned long long*)mailboxes[b];
@@ -1066,7 +1071,7 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
             // back to the start of the last frame that counts, and that frame once more on the two-kernel path: it writes the
             // buffers the reference reads back (`tenergy`, `colnum`, `colacc`, `gradient`) and takes the step
             const int last = converged ? j : C - 1;
-            tp_launch_persist_finish(make_launch(c, p->image_slot, dp), c->pring + (size_t)last * c->NP, nullptr, c->stream);
+            tp_launch_persist_finish(make_launch(c, p->image_slot, dp), c->pring + (size_t)last * c->NP, nullptr, nullptr, c->stream);
             enqueue_iter(c, *p, dp);
             HIP_TRY(c, hipGetLastError());
             break;

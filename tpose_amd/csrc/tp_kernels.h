@@ -102,4 +102,5 @@ void tp_launch_persist(const pk_args& A, int grid, int rows, int lds_bytes, hipS
 // band split: the positions the launch ended with, from the own mailbox (every band posted there) into points_out; raises
 // status[0] when they do not arrive
 void tp_launch_band_collect(const tp_launch& L, const pk_args& A, float2* points_out, hipStream_t s);
-void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, hipStream_t s);  // status: of the launch before, or null
+void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, unsigned* host_status, hipStream_t s);  // status: of the
+// launch before, or null; host_status: pinned mirror of {gave up, -, launches completed}

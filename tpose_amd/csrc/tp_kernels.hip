@@ -680,11 +680,16 @@ void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s
 // uses are not owned by any patch and keep theirs), and every vertex files its position with its edges (k_lines reads
 // endpoints by edge)
 // A launch that gave up (status[0] raised: its workgroups were not all resident, tp_context.hip) leaves everything as it was.
-__global__ void k_persist_finish(tp_launch L, const float2* points_out, unsigned* status) {
+__global__ void k_persist_finish(tp_launch L, const float2* points_out, unsigned* status, unsigned* host_status) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (status) {
-        if (status[0] != 0u) return;
-        if (v == 0) status[2] += 1u;   // (launches complete one after the other: no atomic)
+        const unsigned gave_up = status[0];
+        if (v == 0) {
+            const unsigned done = status[2] + (gave_up ? 0u : 1u);   // (launches complete one after the other: no atomic)
+            status[2] = done;
+            if (host_status) { host_status[0] = gave_up; host_status[2] = done; }   // what the host looks at after its next wait: no copy
+        }
+        if (gave_up != 0u) return;
     }
     if (v >= L.NP) return;
     float2 p = L.points[v];
@@ -697,8 +702,8 @@ __global__ void k_persist_finish(tp_launch L, const float2* points_out, unsigned
     L.points[v] = p;
     publish_position(L, v, p, 0, 1);
 }
-void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, hipStream_t s) {
-    hipLaunchKernelGGL(k_persist_finish, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L, points_out, status);
+void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, unsigned* host_status, hipStream_t s) {
+    hipLaunchKernelGGL(k_persist_finish, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L, points_out, status, host_status);
 }
 
 // tpose::upload colour replication (source/triangulation.hpp:633-641): col[i*NT + k] = colors[k]

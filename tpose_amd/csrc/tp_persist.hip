@@ -60,7 +60,7 @@ __device__ __forceinline__ int patch_of_block(int b, int parts) {
 // RR: table records a lane keeps per lane-item = the most rows per lane of any patch of the plan (the launcher picks the
 // smallest instantiation that covers the plan: fewer rows, fewer registers and less straight-line code)
 template <int RR>
-__global__ __launch_bounds__(PK_THREADS) void k_persist(pk_args A) {
+__global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_persist(pk_args A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int part = A.part0 + patch_of_block((int)blockIdx.x, (int)gridDim.x);

@@ -26,7 +26,12 @@
 #include <vector>
 
 #define PK_NLINES 9
+#ifndef PK_THREADS
 #define PK_THREADS 512
+#endif
+#ifndef PK_WG_PER_CU
+#define PK_WG_PER_CU 1        /* workgroups (patches) per compute unit: PK_THREADS x this = 512 threads, two waves per SIMD */
+#endif
 #define PK_NI 2                /* lane-items of the walk a thread keeps table records for, in registers */
 #define PK_CACHED (PK_THREADS * PK_NI)
 #ifndef PK_ROWS_PER_LANE
