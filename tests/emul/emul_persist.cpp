@@ -37,6 +37,27 @@ extern "C" int emul_magic_check() {
 // vertex) and the tag of the new positions, and brings in the other bands' posts (tests: torch.distributed all_gather).
 typedef void (*emul_exchange_fn)(void* user, unsigned long long* slot_array, int NP, uint32_t tag);
 
+// the packed line sums at their limit: a line of 4096 rows crossing column 4096 of an all-white raster, folded from 256
+// lanes' partial sums of 16 rows each, read back through pk_moments3 -- mismatches against plain 64-bit sums
+extern "C" int emul_fold_check() {
+    unsigned long long words[3][PK_SUM_WORDS] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    int64_t want[6] = {0, 0, 0, 0, 0, 0};
+    for (int lane = 0; lane < 256; lane++) {
+        pk_acc a;
+        a.xs = 16u * 4096u; a.nodd = 16u * 4096u; a.r = a.g = a.b = 16ull * 4096ull * 255ull; a.q = 16ull * 4096ull * 195075ull;
+        unsigned long long wd[PK_SUM_WORDS];
+        pk_fold_words(a, wd);
+        for (int q = 0; q < PK_SUM_WORDS; q++) words[0][q] += wd[q];
+        want[0] += a.xs; want[1] += a.nodd; want[2] += (int64_t)a.r; want[3] += (int64_t)a.g; want[4] += (int64_t)a.b; want[5] += (int64_t)a.q;
+    }
+    const tp_moments m = pk_moments3(1, words[0], 0, words[1], -1, words[2]);
+    const tp_moments n = pk_moments3(-1, words[0], 1, words[1], 0, words[2]);
+    int bad = 0;
+    bad += m.n != want[0]; bad += m.nodd != want[1]; bad += m.sr != want[2]; bad += m.sg != want[3]; bad += m.sb != want[4]; bad += m.q != want[5];
+    bad += n.n != -want[0]; bad += n.nodd != -want[1]; bad += n.sr != -want[2]; bad += n.sg != -want[3]; bad += n.sb != -want[4]; bad += n.q != -want[5];
+    return bad;
+}
+
 // returns 0, or a negative code: -1 plan refused, -2 a position granule had the wrong tag, -3 the patches do not split evenly
 static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, float* points, int NP, const int32_t* tris,
                              int NT, const int32_t* ca, int flavour, float dp, float ratio, float rate, int iters,
@@ -117,7 +138,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                 pk_setup_lane(V, vw, l, wkr);
                 V.wk[l] = wkr;
             }
-            memset(V.sums, 0, sizeof(unsigned long long) * 6 * (size_t)w.n_lines_all);
+            memset(V.sums, 0, sizeof(unsigned long long) * PK_SUM_WORDS * (size_t)w.n_lines_all);
             if (recut) {   // the wave's lanes one after the other
                 const int RRk = P.rows_max <= 7 ? 8 : P.rows_max <= 9 ? 10 : P.rows_max <= 10 ? 11 : 12;   // tp_launch_persist's choice
                 int changed = 0, sum[64];
@@ -162,14 +183,18 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             for (int j = 0; j < PK_CACHED; j++) {   // the cached slots (a slot without a lane-item walks nothing)
                 pk_acc a;
                 pk_walk_cached<PK_ROWS_PER_LANE>(S[p].cache[j], V, table, pitch, W, a);
-                unsigned long long* s = V.sums + (size_t)S[p].cache[j].l * 6;
-                s[0] += a.xs; s[1] += a.nodd; s[2] += a.r; s[3] += a.g; s[4] += a.b; s[5] += a.q;
+                unsigned long long* s = V.sums + (size_t)S[p].cache[j].l * PK_SUM_WORDS;
+                unsigned long long wd[PK_SUM_WORDS];
+                pk_fold_words(a, wd);
+                for (int q = 0; q < PK_SUM_WORDS; q++) s[q] += wd[q];
             }
             for (int j = S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED; j < n_li; j++) {
                 pk_acc a;
                 const int l = pk_walk_lane(V, table, pitch, W, w.n_lines_all, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.li_cap, j, a);
-                unsigned long long* s = V.sums + (size_t)l * 6;
-                s[0] += a.xs; s[1] += a.nodd; s[2] += a.r; s[3] += a.g; s[4] += a.b; s[5] += a.q;
+                unsigned long long* s = V.sums + (size_t)l * PK_SUM_WORDS;
+                unsigned long long wd[PK_SUM_WORDS];
+                pk_fold_words(a, wd);
+                for (int q = 0; q < PK_SUM_WORDS; q++) s[q] += wd[q];
             }
             // P6
             for (int k = 0; k < w.n_corners; k++) {

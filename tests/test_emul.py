@@ -297,6 +297,7 @@ def test_persistent_lines_are_cut_again_on_the_device(emp):
     assert np.array_equal(p.view(np.uint32), ref["points"].view(np.uint32))
     assert np.array_equal(stats_out["ten"], ref["ten"]) and np.array_equal(stats_out["gr"], ref["gr"])
     assert emp.emul_magic_check() == 0
+    assert emp.emul_fold_check() == 0   # the packed line sums at a 4096 x 4096 all-white raster
 
 
 def test_persistent_plan_on_soups_and_bad_vertices(emp):

@@ -380,7 +380,7 @@ int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok)
 // persistent path
 int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false) {
     *use = false;
-    if (c->persist_mode == TP_PERSIST_OFF || !c->px_pitch) return TP_OK;  // (rasters wider than 4096 columns have no pixel-record table)
+    if (c->persist_mode == TP_PERSIST_OFF || !c->px_pitch) return TP_OK;  // (rasters beyond 4096 columns or rows have no pixel-record table)
     if (int rc = take_census(c)) return rc;
     if (c->census != 1) return TP_OK;
     if (c->plan_generation == c->generation && base_every && !c->plan_base_every) {
@@ -546,7 +546,9 @@ int tp_create(int device, int width, int height, tp_context** out) {
     tp_context* c = new tp_context();
     c->device = device; c->W = width; c->H = height;
     c->prefix_pitch = tp_prefix_pitch(width);
-    c->px_pitch = width <= TP_PX_MAXW ? tp_px_pitch(width) : 0;
+    // (pixel records, the persistent kernel's table: rasters of at most 4096 columns AND rows -- a line's sums of r and g share
+    // a 64-bit word in LDS, tp_persist.h: pk_fold_words)
+    c->px_pitch = width <= TP_PX_MAXW && height <= TP_PX_MAXW ? tp_px_pitch(width) : 0;
     c->ratio = (float)width / (float)height;
     {
         hipDeviceProp_t prop;

@@ -29,7 +29,7 @@ struct pk_walker { int64_t x, s; int32_t ra, rb; };  // tp_line
 
 // the workgroup's LDS, carved in the order of pk_lds_bytes (tp_plan.h)
 struct pk_view {
-    unsigned long long* sums;  // [n_lines_all][6] line sums {sum x, n_odd, sum r, sum g, sum b, q}
+    unsigned long long* sums;  // [n_lines_all][PK_SUM_WORDS] line sums {sum x | n_odd << 32, sum r | sum g << 32, sum b, q} (pk_fold_words)
     pk_walker* wk;             // [n_lines_all]
     pk_f2* pos;                // [n_slots]
     pk_i2* snap;               // own slot k: [5 k + move]; neighbour slot s: [5 n_own_v + s - n_own_v] (unmoved)
@@ -47,7 +47,7 @@ struct pk_view {
 
 TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     char* p = base;
-    V.sums = (unsigned long long*)p; p += pk_align16(w.n_lines_all * 48);
+    V.sums = (unsigned long long*)p; p += pk_align16(w.n_lines_all * 8 * PK_SUM_WORDS);
     V.wk = (pk_walker*)p; p += pk_align16(w.n_lines_all * 24);
     V.pos = (pk_f2*)p; p += pk_align16(w.n_slots * 8);
     V.snap = (pk_i2*)p; p += pk_align16((4 * w.n_own_v + w.n_slots) * 8);
@@ -126,7 +126,7 @@ TP_HD int pk_recut_count(const pk_view& V, int n, int n_every, int lane, int lan
     for (int l = lane * B; l < n && l < (lane + 1) * B; l++) {
         const int t = pk_recut_line(V, l, rpl, first);
         changed |= first || t != V.cut[l + 1] - V.cut[l];
-        V.sums[6 * (size_t)l] = (unsigned long long)t;
+        V.sums[PK_SUM_WORDS * (size_t)l] = (unsigned long long)t;
         sum += t;
         sum_every += l < n_every ? t : 0;
     }
@@ -136,8 +136,8 @@ TP_HD void pk_recut_write(const pk_view& V, int n, int lane, int lanes, int offs
     const int B = (n + lanes - 1) / lanes;
     for (int l = lane * B; l < n && l < (lane + 1) * B; l++) {
         V.cut[l] = offset;
-        offset += (int)V.sums[6 * (size_t)l];
-        V.sums[6 * (size_t)l] = 0ull;
+        offset += (int)V.sums[PK_SUM_WORDS * (size_t)l];
+        V.sums[PK_SUM_WORDS * (size_t)l] = 0ull;
     }
     if (lane == lanes - 1) V.cut[n] = offset;   // (the last lane's lines are the last ones, or it has none and its offset is the total)
 }
@@ -291,14 +291,17 @@ TP_HD pk_scan pk_walk_scan(const pk_lane_cache<R>& C, const pk_view& V, int pitc
     if (C.TL == 0) { S.r.n = 0; S.r.x = 0; S.r.xs = 0; S.r.row = 0; S.r.rs = 0; }
     else S.r = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
     S.live = S.r.n >= 32 ? 0xffffffffu : ((1u << S.r.n) - 1u);   // bit u: row u exists
-    S.sx = 0; S.stale = S.r.row ^ C.row0;                          // (another first row: every record is another row's)
+    S.sx = 0; S.stale = 0;
     pk_rows t = S.r;
 #pragma unroll
     for (int u = 0; u < RR; u++) {
         const int32_t col = pk_next_col(t, W) & (int32_t)(0u - ((S.live >> u) & 1u));
         S.sx += (uint32_t)col;
-        S.stale |= (uint32_t)(col ^ C.col[u]);
+        // (a sum, not an OR: xor-and-add is one instruction; the terms are differences of columns <= 4096 and cannot cancel --
+        // with nothing cached, col[u] = -1, row0 differs anyway)
+        S.stale += (uint32_t)(col ^ C.col[u]);
     }
+    S.stale |= S.r.row ^ C.row0;                                   // (another first row: every record is another row's)
     return S;
 }
 // step 2, only when S.stale: walk again and fetch what changed (loads are issued, not waited for)
@@ -347,10 +350,29 @@ TP_HD void pk_walk_cached(pk_lane_cache<R>& C, const pk_view& V, const char* tab
 TP_HD uint32_t pk_tag(uint32_t epoch) { return 0x80000000u | (epoch & 0x7fffffffu); }
 
 // signed sum of three line sums: the exact pixel moments of a variant (tp_raster.h, "Edge-centric form")
+// A line's sums in LDS: four 64-bit words {sum x | n_odd << 32, sum r | sum g << 32, sum b, q}.  The halves cannot carry into each
+// other: over a whole line sum x and n_odd are at most rows x W <= 2^24, and sum r, sum g at most 255 x 2^24 < 2^32 (rasters of the
+// persistent path have at most 4096 rows and columns) -- four LDS atomics per lane-item instead of six, twelve words instead of
+// eighteen per variant.
+TP_HD void pk_fold_words(const pk_acc& a, unsigned long long w[PK_SUM_WORDS]) {
+    w[0] = (unsigned long long)a.xs | ((unsigned long long)a.nodd << 32);
+    w[1] = a.r | (a.g << 32);
+    w[2] = a.b;
+    w[3] = a.q;
+}
 TP_HD tp_moments pk_moments3(int c0, const unsigned long long* S0, int c1, const unsigned long long* S1, int c2, const unsigned long long* S2) {
     int64_t mo[6];
+    const unsigned long long* S[3] = {S0, S1, S2};
+    const int c[3] = {c0, c1, c2};
 #pragma unroll
-    for (int q = 0; q < 6; q++) mo[q] = (int64_t)c0 * (int64_t)S0[q] + (int64_t)c1 * (int64_t)S1[q] + (int64_t)c2 * (int64_t)S2[q];
+    for (int q = 0; q < 6; q++) mo[q] = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const unsigned long long w0 = S[k][0], w1 = S[k][1], w2 = S[k][2], w3 = S[k][3];
+        mo[0] += (int64_t)c[k] * (int64_t)(uint32_t)w0; mo[1] += (int64_t)c[k] * (int64_t)(w0 >> 32);
+        mo[2] += (int64_t)c[k] * (int64_t)(uint32_t)w1; mo[3] += (int64_t)c[k] * (int64_t)(w1 >> 32);
+        mo[4] += (int64_t)c[k] * (int64_t)w2; mo[5] += (int64_t)c[k] * (int64_t)w3;
+    }
     const tp_moments mm = {mo[0], mo[1], mo[2], mo[3], mo[4], mo[5]};
     return mm;
 }
@@ -368,8 +390,8 @@ TP_HD tp_moments pk_corner_moments(const pk_wg& w, const pk_view& V, int k, int 
     const int cs = s == 0 ? c[0] : s == 1 ? c[1] : c[2];
     const int cn = sn == 0 ? c[0] : sn == 1 ? c[1] : c[2];
     const int cp = sp == 0 ? c[0] : sp == 1 ? c[1] : c[2];
-    return pk_moments3(cs, V.sums + (size_t)((cr.z & 0xffff) + m - 1) * 6, cp, V.sums + (size_t)(((cr.z >> 16) & 0xffff) + m - 1) * 6,
-                       cn, V.sums + (size_t)(cr.w & 0xffff) * 6);
+    return pk_moments3(cs, V.sums + (size_t)((cr.z & 0xffff) + m - 1) * PK_SUM_WORDS, cp, V.sums + (size_t)(((cr.z >> 16) & 0xffff) + m - 1) * PK_SUM_WORDS,
+                       cn, V.sums + (size_t)(cr.w & 0xffff) * PK_SUM_WORDS);
 }
 // energy of a variant as k_update's emit_variant forms it (triangle.fs:37-43; warp: against the stored colour, :46-53)
 TP_HD int32_t pk_energy(const tp_moments& mm, int flavour, pk_i4 col) {
@@ -384,8 +406,8 @@ TP_HD tp_moments pk_base_moments(const pk_wg& w, const pk_view& V, int k, int& t
     const pk_i2 p0 = V.snap[pk_snap_index(w, own, 0)], p1 = V.snap[pk_snap_index(w, s1, 0)], p2 = V.snap[pk_snap_index(w, s2, 0)];
     X[0] = p0.x; Y[0] = p0.y; X[1] = p1.x; Y[1] = p1.y; X[2] = p2.x; Y[2] = p2.y;
     tp_variant_coeffs(X, Y, c);
-    return pk_moments3(c[0], V.sums + (size_t)(b.z & 0xffff) * 6, c[1], V.sums + (size_t)((b.z >> 16) & 0xffff) * 6,
-                       c[2], V.sums + (size_t)(b.w & 0xffff) * 6);
+    return pk_moments3(c[0], V.sums + (size_t)(b.z & 0xffff) * PK_SUM_WORDS, c[1], V.sums + (size_t)((b.z >> 16) & 0xffff) * PK_SUM_WORDS,
+                       c[2], V.sums + (size_t)(b.w & 0xffff) * PK_SUM_WORDS);
 }
 
 // P7, own vertex k with gradient (gx, gy): the shift.cs step (shift.cs:16-47).  Vertices 0..3 never move.

@@ -26,6 +26,7 @@
 #include <vector>
 
 #define PK_NLINES 9
+#define PK_SUM_WORDS 4          /* 64-bit words of a line's sums in LDS (tp_persist.h: pk_fold_words) */
 #ifndef PK_THREADS
 #define PK_THREADS 512
 #endif
@@ -93,7 +94,7 @@ PK_HD int pk_chunks(int rows, int rpl) {
 }
 inline int pk_lds_bytes(const pk_wg& w) {
     int b = 0;
-    b += pk_align16(w.n_lines_all * 48);            // line sums: six 64-bit words
+    b += pk_align16(w.n_lines_all * 8 * PK_SUM_WORDS);   // line sums
     b += pk_align16(w.n_lines_all * 24);            // walkers
     b += pk_align16(w.n_slots * 8);                 // positions
     b += pk_align16((4 * w.n_own_v + w.n_slots) * 8);  // snapped positions: neighbours unmoved only, own slots + 4 moves
