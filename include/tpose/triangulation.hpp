@@ -87,6 +87,23 @@ struct triangulation {
         if (d >= 0) return false;
         return !(d * d < 0.6218f * (dot(u, u) * dot(w, w)));
     }
+    // both filters for the three half-edges of triangle t at once (no h / 3, h % 3 per call): bit k = maybe_wider_than_08pi(3 t + k),
+    // bit 3 = maybe_collapsible(t)
+    int sweep_candidates(int t) const {
+        const ivec4 v = triangles[t];
+        const vec2 a = points[v.x], b = points[v.y], c = points[v.z];
+        const vec2 ab = b - a, bc = c - b, ca = a - c;
+        const float lab = dot(ab, ab), lbc = dot(bc, bc), lca = dot(ca, ca);
+        // half-edge k runs vertex k -> k + 1; angle(3 t + k) is the angle at the third vertex: k = 0 at c, 1 at a, 2 at b
+        const float dc = -dot(ca, bc), da = -dot(ab, ca), db = -dot(bc, ab);   // (u . w with u, w pointing away from the apex)
+        int m = 0;
+        if (!(dc >= 0) && !(dc * dc < 0.6218f * (lca * lbc))) m |= 1;
+        if (!(da >= 0) && !(da * da < 0.6218f * (lab * lca))) m |= 2;
+        if (!(db >= 0) && !(db * db < 0.6218f * (lbc * lab))) m |= 4;
+        const float lim = 0.0101f * 0.0101f;
+        if (!(lab > lim && lbc > lim && lca > lim)) m |= 8;
+        return m;
+    }
     // false: every side of t is longer than 0.0101, so collapse() of any of its half-edges returns false (bound 0.01)
     bool maybe_collapsible(int t) const {
         const vec2 a = points[triangles[t].x], b = points[triangles[t].y], c = points[triangles[t].z];

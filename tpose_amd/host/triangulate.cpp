@@ -189,11 +189,16 @@ int main(int argc, char** argv) {
         for (size_t t = 0; t < (size_t)tr.NT; t++)
             if (tr.boundary((int)t) == 3)
                 if (tr.prune((int)t)) updated = true;
-        for (size_t t = 0; t < (size_t)tr.NT; t++)
+        for (size_t t = 0; t < (size_t)tr.NT; t++) {
+            int maybe = literal ? 7 : tr.sweep_candidates((int)t);   // (bit k: angle(3 t + k) may exceed 0.8 PI)
             for (int k = 0; k < 3; k++)
-                if ((literal || tr.maybe_wider_than_08pi(3 * (int)t + k)) && tr.angle(3 * (int)t + k) > 0.8 * tpose::PI) tr.flip(3 * (int)t + k, 0.0);
+                if (((maybe >> k) & 1) && tr.angle(3 * (int)t + k) > 0.8 * tpose::PI) {
+                    tr.flip(3 * (int)t + k, 0.0);
+                    if (!literal) maybe = tr.sweep_candidates((int)t);   // (the flip may have changed triangle t)
+                }
+        }
         for (size_t t = 0; t < tr.triangles.size(); t++) {
-            if (!literal && !tr.maybe_collapsible((int)t)) continue;   // (collapse() would refuse whichever half-edge is the shortest)
+            if (!literal && !(tr.sweep_candidates((int)t) & 8)) continue;   // (collapse() would refuse whichever half-edge is the shortest)
             int h = 3 * (int)t;
             float shortest = tr.hlength(h);
             if (tr.hlength(h + 1) < shortest) shortest = tr.hlength(++h);
