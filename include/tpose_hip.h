@@ -104,14 +104,18 @@ int tp_set_option(tp_context* ctx, int option, int64_t value);
  * crosses between them is what crosses between workgroups: vertex positions, 16 bytes per vertex and grad-iter, posted by a
  * vertex's owner into EVERY band's mailbox (peer memory, system-scope stores) and polled by the readers from their own.
  * mailboxes[b]: band b's mailbox as THIS process addresses it -- its own allocation at [band], the others' mapped in
- * (hipIpcOpenMemHandle between processes, peer access between devices); `bytes_each` >= tp_band_mailbox_bytes(points) each,
- * zeroed by their owners before any band iterates.  patches_per_band: 0 = one per compute unit of this device.
+ * (hipIpcOpenMemHandle between processes, peer access between devices); `bytes_each` >= tp_band_mailbox_bytes(points,
+ * triangles) each (the most vertices and triangles any upload will have; besides the position slots it holds the per-frame
+ * rings of tp_iterate_until), zeroed by their owners before any band iterates.  patches_per_band: 0 = one per compute unit.
  * After tp_iterate every band holds ALL positions (tp_retrieve(TP_BUF_POINTS) is complete); `tenergy`, `colnum`, `colacc` and
- * `gradient` hold the entries of the band's own patches only.  Calls too short for persistent launches, tp_iterate_until and
- * the piecewise API run whole on every band (the same results, nothing shared).  A band that waits a second for positions
+ * `gradient` hold the entries of the band's own patches only.  tp_iterate_until splits its frames the same way -- every band
+ * writes the energies of its triangles into every band's ring, and every band's host applies the convergence test to all of
+ * them -- and ends, like the unsplit call, with the last frame run whole (all buffers complete on every band).  Calls too
+ * short for persistent launches and the piecewise API run whole on every band.  A band that waits a second for positions
  * gives up; every band then runs the call again on its own (tp_get_info 9 counts it).  n_bands = 1 detaches. */
-size_t tp_band_mailbox_bytes(int points);
-int tp_band_attach(tp_context* ctx, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int patches_per_band);
+size_t tp_band_mailbox_bytes(int points, int triangles);
+int tp_band_attach(tp_context* ctx, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int points, int triangles,
+                   int patches_per_band);
 
 /* `Texture tex(IMG)` (software/triangulate/main.cpp:74, warp/main.cpp:118-119): RGBA8, row 0 = top,
  * width x height texels, `stride_bytes` between rows.  Host pointer.  Like the reference's texture the image

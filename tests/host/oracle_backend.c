@@ -174,9 +174,9 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
 }
 
 /* band split (tp_band_attach): the stand-in runs every band's descents whole -- the same results, nothing shared */
-size_t tp_band_mailbox_bytes(int points) { return (size_t)(points > 0 ? points : 0) * 64 + 64; }
-int tp_band_attach(tp_context* c, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int patches_per_band) {
-    (void)c; (void)band; (void)n_bands; (void)mailboxes; (void)bytes_each; (void)patches_per_band;
+size_t tp_band_mailbox_bytes(int points, int triangles) { (void)triangles; return (size_t)(points > 0 ? points : 0) * 64 + 64; }
+int tp_band_attach(tp_context* c, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int points, int triangles, int patches_per_band) {
+    (void)c; (void)band; (void)n_bands; (void)mailboxes; (void)bytes_each; (void)points; (void)triangles; (void)patches_per_band;
     return TP_OK;
 }
 int tp_prepare(tp_context* c, const tp_params* p) { (void)c; (void)p; return TP_OK; }

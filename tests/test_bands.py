@@ -19,9 +19,8 @@ pytestmark = pytest.mark.gpu
 
 def banded_contexts(W, H, img, imgB, pts, tris, colors, n_bands, patches):
     import torch
-    lib = capi.load()
-    lib.tp_band_mailbox_bytes.restype = C.c_size_t
-    nbytes = int(lib.tp_band_mailbox_bytes(pts.shape[0] + 64))
+    cap_p, cap_t = pts.shape[0] + 64, tris.shape[0] + 64
+    nbytes = capi.band_mailbox_bytes(cap_p, cap_t)
     boxes = [torch.zeros(nbytes // 8 + 1, dtype=torch.int64, device="cuda:0") for _ in range(n_bands)]
     torch.cuda.synchronize()
     ctxs = []
@@ -30,7 +29,7 @@ def banded_contexts(W, H, img, imgB, pts, tris, colors, n_bands, patches):
         ctx.set_image(capi.IMAGE_A, img)
         ctx.set_image(capi.IMAGE_B, imgB)
         ctx.upload(pts, tris, colors)
-        ctx.band_attach(b, n_bands, [bx.data_ptr() for bx in boxes], nbytes, patches)
+        ctx.band_attach(b, n_bands, [bx.data_ptr() for bx in boxes], nbytes, cap_p, cap_t, patches)
         # (the census of resident workgroups wants the device to itself: on a shared device, before any band spins in a launch)
         ctx.prepare(capi.default_params(1 if colors is not None else 0))
         ctxs.append(ctx)
@@ -64,6 +63,46 @@ def test_bands_descend_like_one_context(flavour, n_bands, patches):
         assert covered.all()        # every variant's energy was written by the band that owns it
     for ctx in ctxs:
         ctx.close()
+
+
+@pytest.mark.parametrize("flavour,threshold,cap", [(0, 1e-4, 300), (1, 1e-6, 90)])
+def test_bands_run_the_reference_loop_to_its_convergence_test(flavour, threshold, cap):
+    """tp_iterate_until on two bands (one host thread each: the call blocks on the other band's frames): the same number of
+    frames, the same running total and -- the last frame is run whole on every band -- the same buffers as the unsplit call"""
+    import threading
+    W, H, grid = 300, 200, (15, 5)
+    img = synth.photo_contrast(synth.voronoi_raster(W, H, seed=7, sites=12), 0.3)
+    imgB = synth.displaced_raster(img, amp=6.0)
+    ratio = float(np.float32(W) / np.float32(H))
+    pts, tris, _ = synth.grid_triangulation(grid[0], grid[1], ratio=ratio)
+    colors = synth.mean_colors(img, pts, tris, ratio) if flavour else None
+    p = capi.default_params(flavour)
+    one = capi.Context(0, W, H)
+    one.set_image(capi.IMAGE_A, img)
+    one.set_image(capi.IMAGE_B, imgB)
+    one.upload(pts, tris, colors)
+    want = [one.iterate_until(p, cap, threshold, 1.0)]
+    want.append(one.iterate_until(p, cap, threshold, want[0][1]))   # (a second leg: the running total carries over)
+    ctxs, boxes = banded_contexts(W, H, img, imgB, pts, tris, colors, 2, 8)
+    got = [[None, None], [None, None]]
+
+    def leg(b):
+        got[b][0] = ctxs[b].iterate_until(p, cap, threshold, 1.0)
+        got[b][1] = ctxs[b].iterate_until(p, cap, threshold, got[b][0][1])
+
+    th = [threading.Thread(target=leg, args=(b,)) for b in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    bits = lambda r: (r[0], np.float32(r[1]).view(np.uint32), np.float32(r[2]).view(np.uint32))  # noqa: E731
+    for b in range(2):
+        assert [bits(r) for r in got[b]] == [bits(r) for r in want], (got[b], want)
+        assert ctxs[b].info(9) == 0 and ctxs[b].info(capi.INFO_PERSIST_ITERS) > 0
+        for buf in (capi.BUF_POINTS, capi.BUF_TENERGY, capi.BUF_COLNUM, capi.BUF_GRADIENT):
+            assert np.array_equal(ctxs[b].retrieve(buf).view(np.uint32), one.retrieve(buf).view(np.uint32)), buf
+    for c in ctxs + [one]:
+        c.close()
 
 
 def test_band_that_never_shows_up_is_survived():

@@ -197,14 +197,14 @@ def _mutual_vs_two_ranks(scene, warp_exe, warp2_exe, tag, extra=(), transport="f
     assert len(records(ta + ".warp")) == len(records(str(scene / "h_a.tri"))) or len(records(ta + ".warp")) == len(records(str(scene / "h_b.tri")))
 
 
-def _mutual_vs_banded(scene, warp_exe, warp2_exe, tag, frames, extra=()):
+def _mutual_vs_banded(scene, warp_exe, warp2_exe, tag, frames, extra=(), fixed=True):
     """`warp -schedule mutual -fixedframes` (one process) against FOUR `warp2 -bands 2` processes -- two bands for each of the two
     directions: both bands of a direction must write the unsplit run's bytes"""
     import shutil
     for who in ("one", "four"):
         for n in ("a", "b"):
             shutil.copy(str(scene / ("h_%s.tri" % n)), str(scene / ("%s_%s_%s.tri" % (tag, who, n))))
-    common = ["-ia", str(scene / "a.ppm"), "-ib", str(scene / "b.ppm"), "-levelframes", str(frames), "-fixedframes", "-quiet"]
+    common = ["-ia", str(scene / "a.ppm"), "-ib", str(scene / "b.ppm"), "-levelframes", str(frames), "-quiet"] + (["-fixedframes"] if fixed else [])
     ta, tb = (str(scene / ("%s_one_%s.tri" % (tag, n))) for n in ("a", "b"))
     run(warp_exe, *common, "-ta", ta, "-tb", tb, "-schedule", "mutual")
     ta4, tb4 = (str(scene / ("%s_four_%s.tri" % (tag, n))) for n in ("a", "b"))
@@ -236,6 +236,8 @@ def test_warp2_bands_split_every_descent_over_two_processes(scene):
     import re
     _hierarchies(scene, build_cpu("triangulate"))
     outs = _mutual_vs_banded(scene, build_gpu("warp"), build_gpu("warp2"), "gpub", 150, extra=["-device", "0", "-bandpatches", "4"])
+    # ... and with the schedule's own convergence test (tp_iterate_until on bands: every band's host tests all bands' energies)
+    outs += _mutual_vs_banded(scene, build_gpu("warp"), build_gpu("warp2"), "gpuc", 150, extra=["-device", "0", "-bandpatches", "4"], fixed=False)
     for o in outs:
         m = re.search(r"persistent launches (\d+), patches of the plan (\d+), launches given up (\d+)", o)
         assert m, o

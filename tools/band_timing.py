@@ -22,13 +22,12 @@ W = H = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 NT = int(sys.argv[2]) if len(sys.argv) > 2 else 12000
 STEPS = 512
 img, pts, tris, he, ratio = synth.workload(W, H, NT, contrast=0.1)
-lib = capi.load()
-lib.tp_band_mailbox_bytes.restype = C.c_size_t
 p = capi.default_params(0)
 
 
 def make(n_bands, patches):
-    nbytes = int(lib.tp_band_mailbox_bytes(pts.shape[0] + 64))
+    cap_p, cap_t = pts.shape[0] + 64, tris.shape[0] + 64
+    nbytes = capi.band_mailbox_bytes(cap_p, cap_t)
     boxes = [torch.zeros(nbytes // 8 + 1, dtype=torch.int64, device="cuda:0") for _ in range(n_bands)]
     torch.cuda.synchronize()
     ctxs = []
@@ -37,7 +36,7 @@ def make(n_bands, patches):
         ctx.set_image(capi.IMAGE_A, img)
         ctx.upload(pts, tris, None)
         if n_bands > 1:
-            ctx.band_attach(b, n_bands, [bx.data_ptr() for bx in boxes], nbytes, patches)
+            ctx.band_attach(b, n_bands, [bx.data_ptr() for bx in boxes], nbytes, cap_p, cap_t, patches)
         ctx.prepare(p)
         ctx.synchronize()
         ctxs.append(ctx)

@@ -28,6 +28,13 @@ SYMBOLS = [
 ]
 
 
+def band_mailbox_bytes(points, triangles):
+    lib = load()
+    lib.tp_band_mailbox_bytes.restype = C.c_size_t
+    lib.tp_band_mailbox_bytes.argtypes = [C.c_int, C.c_int]
+    return int(lib.tp_band_mailbox_bytes(points, triangles))
+
+
 RENDER_AVERAGE, RENDER_STORED = 0, 1
 OPT_PERSISTENT = 1
 PERSIST_OFF, PERSIST_AUTO = 0, 1
@@ -147,11 +154,12 @@ class Context:
     def set_persistent(self, on):
         self.set_option(OPT_PERSISTENT, PERSIST_AUTO if on else PERSIST_OFF)
 
-    def band_attach(self, band, n_bands, mailboxes, bytes_each, patches_per_band=0):
-        """mailboxes: device addresses (ints), one per band, as this process addresses them (tp_band_attach)"""
+    def band_attach(self, band, n_bands, mailboxes, bytes_each, points, triangles, patches_per_band=0):
+        """mailboxes: device addresses (ints), one per band, as this process addresses them, each of band_mailbox_bytes(points,
+        triangles) bytes or more (tp_band_attach)"""
         arr = (C.c_void_p * max(1, len(mailboxes)))(*[C.c_void_p(int(m)) for m in mailboxes])
-        self.lib.tp_band_attach.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int]
-        self._ck(self.lib.tp_band_attach(self.h, band, n_bands, arr, C.c_size_t(bytes_each), patches_per_band))
+        self.lib.tp_band_attach.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int]
+        self._ck(self.lib.tp_band_attach(self.h, band, n_bands, arr, C.c_size_t(bytes_each), points, triangles, patches_per_band))
 
     def set_image(self, slot, img):
         img = np.ascontiguousarray(img, np.uint8)

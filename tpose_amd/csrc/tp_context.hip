@@ -138,7 +138,7 @@ struct tp_context {
     // plan of n_bands * band_patches -- and the mailbox is the caller's (one per band, mapped into every band's process)
     int band = 0, n_bands = 1, band_patches = 0;
     unsigned long long* band_box[PK_MAX_PEERS + 1] = {nullptr, nullptr, nullptr, nullptr};
-    size_t band_cap = 0;     // (in vertices)
+    size_t band_cap = 0, band_cap_tris = 0;   // (vertices, triangles the mailboxes were sized for)
     float2* points_out = nullptr; size_t cap_points_out = 0;
     unsigned* d_status = nullptr;   // [0] a lane of a persistent launch gave up waiting, [1] census counter
     unsigned* h_status = nullptr;   // pinned mirror of [0] and [2], written by k_persist_finish: read after a wait, no copy
@@ -380,6 +380,9 @@ int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok)
 // persistent path
 int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false) {
     *use = false;
+    // (bands keep ONE plan for tp_iterate and tp_iterate_until -- the one that walks every triangle's base lines in every grad-iter:
+    // cutting a plan again allocates, and an allocation may wait for a device on which another band is already waiting for this one)
+    if (c->n_bands > 1) base_every = true;
     if (c->persist_mode == TP_PERSIST_OFF || !c->px_pitch) return TP_OK;  // (rasters beyond 4096 columns or rows have no pixel-record table)
     if (int rc = take_census(c)) return rc;
     if (c->census != 1) return TP_OK;
@@ -446,6 +449,16 @@ int maybe_replan(tp_context* c, float dp) {
     return TP_OK;
 }
 
+// a band's mailbox: [4][cap] position slots of 16 bytes, then the rings of tp_iterate_until -- PK_RING_FRAMES frames of
+// cap_tris base energies (int32) and of cap positions (float2)
+#define PK_RING_FRAMES 256
+static size_t band_slots_bytes(size_t cap) { return (cap * 64 + 255) & ~(size_t)255; }
+static size_t band_ering_bytes(size_t cap_tris) { return ((size_t)PK_RING_FRAMES * cap_tris * 4 + 255) & ~(size_t)255; }
+// band split: the rings of tp_iterate_until live in the bands' mailboxes (behind the position slots)
+bool banded_rings(const tp_context* c) { return c->n_bands > 1 && c->band_cap_tris > 0; }
+int32_t* band_ering(const tp_context* c, int b) { return (int32_t*)((char*)c->band_box[b] + band_slots_bytes(c->band_cap)); }
+float2* band_pring(const tp_context* c, int b) { return (float2*)((char*)c->band_box[b] + band_slots_bytes(c->band_cap) + band_ering_bytes(c->band_cap_tris)); }
+
 // n grad-iters of the persistent kernel -- the last one writes `tenergy`, `colnum`, `colacc`, `gradient` --, then
 // `points_out` -> `points` / `epos`
 int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings = false) {
@@ -476,7 +489,12 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         }
         A.epoch = c->epoch; A.n_iters = k; A.status = c->d_status;
         A.emit = n == k && !rings; A.ten = c->ten; A.cn = c->cn; A.ca_out = c->ca; A.gr = c->gr;
-        if (rings) { A.ering = c->ering; A.pring = c->pring; }
+        if (rings && !banded_rings(c)) { A.ering = c->ering; A.pring = c->pring; }
+        if (rings && banded_rings(c)) {
+            A.ering = band_ering(c, c->band); A.pring = band_pring(c, c->band);
+            int n = 0;
+            for (int b = 0; b < c->n_bands; b++) if (b != c->band) { A.peer_ering[n] = band_ering(c, b); A.peer_pring[n] = band_pring(c, b); n++; }
+        }
 #ifdef TPOSE_DEBUG
         A.dbg = persist_dbg_buffer(c->plan.parts, c->stream);
         { const char* f = getenv("TPOSE_DBG_FIRST"); A.dbg_first = f ? atoi(f) : 0; }
@@ -622,27 +640,32 @@ int tp_set_option(tp_context* c, int option, int64_t value) {
     }
 }
 
-size_t tp_band_mailbox_bytes(int points) { return (size_t)(points > 0 ? points : 0) * 64 + 64; }
+size_t tp_band_mailbox_bytes(int points, int triangles) {
+    const size_t cap = (size_t)(points > 0 ? points : 0), ct = (size_t)(triangles > 0 ? triangles : 0);
+    return band_slots_bytes(cap) + band_ering_bytes(ct) + (size_t)PK_RING_FRAMES * cap * 8 + 256;
+}
 
-int tp_band_attach(tp_context* c, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int patches_per_band) {
+int tp_band_attach(tp_context* c, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int points, int triangles, int patches_per_band) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = tp_synchronize(c)) return rc;   // nothing in flight reads the mailbox or the plan
     if (n_bands <= 1) {
-        c->band = 0; c->n_bands = 1; c->band_patches = 0; c->band_cap = 0;
+        c->band = 0; c->n_bands = 1; c->band_patches = 0; c->band_cap = 0; c->band_cap_tris = 0;
         for (auto& b : c->band_box) b = nullptr;
         c->plan_generation = 0;
         return TP_OK;
     }
     if (n_bands > PK_MAX_PEERS + 1 || band < 0 || band >= n_bands || !mailboxes) return fail(c, TP_ERR_INVALID, "band attach: band %d of %d (at most %d bands)", band, n_bands, PK_MAX_PEERS + 1);
     for (int b = 0; b < n_bands; b++) if (!mailboxes[b]) return fail(c, TP_ERR_INVALID, "band attach: mailbox %d is NULL", b);
-    if (bytes_each < 128) return fail(c, TP_ERR_INVALID, "band attach: mailboxes of %zu bytes", bytes_each);
     if (c->num_cus < 1) return fail(c, TP_ERR_STATE, "band attach: no compute units reported");
     const int ppb = patches_per_band > 0 ? patches_per_band : c->num_cus * PK_WG_PER_CU;
     if (ppb > c->num_cus * PK_WG_PER_CU) return fail(c, TP_ERR_CAPACITY, "band attach: %d patches per band on %d compute units", ppb, c->num_cus);
+    if (points < 1 || triangles < 0 || tp_band_mailbox_bytes(points, triangles) > bytes_each)
+        return fail(c, TP_ERR_INVALID, "band attach: %zu bytes for %d points, %d triangles", bytes_each, points, triangles);
+    const size_t cap = (size_t)points, cap_tris = (size_t)triangles;
     c->band = band; c->n_bands = n_bands; c->band_patches = ppb;
-    c->band_cap = (bytes_each - 64) / 64;
+    c->band_cap = cap; c->band_cap_tris = cap_tris;
     for (int b = 0; b < n_bands; b++) c->band_box[b] = (unsigned long long*)mailboxes[b];
     c->plan_generation = 0;   // the plan is cut again, into n_bands * ppb patches
     return TP_OK;
@@ -1035,7 +1058,8 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
         return TP_OK;
     };
     bool use = false;
-    if (max_frames >= PK_MIN_ITERS && c->n_bands == 1) { if (int rc = ensure_plan(c, dp, &use, true)) return rc; }
+    if (max_frames >= PK_MIN_ITERS && (c->n_bands == 1 || banded_rings(c))) { if (int rc = ensure_plan(c, dp, &use, true)) return rc; }
+    if (banded_rings(c) && (size_t)NT > c->band_cap_tris) use = false;   // (more triangles than the bands' rings were sized for: every band on its own)
     int done = 0, chunk = 32;
     bool converged = false;
     while (done < max_frames && !converged) {
@@ -1053,11 +1077,16 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
         }
         // a chunk of frames inside one persistent launch: every frame leaves its base energies and its starting positions
         const int C = left < chunk ? left : chunk;
-        if (int rc = grow(c, &c->ering, &c->cap_ering, (size_t)C * NT)) return rc;
-        if (int rc = grow(c, &c->pring, &c->cap_pring, (size_t)C * c->NP)) return rc;
-        if (int rc = host_ring((size_t)C * NT)) return rc;
+        const bool shared = banded_rings(c);   // (band split: the rings are in the bands' mailboxes, every band writes into all of them)
+        if (!shared) {
+            if (int rc = grow(c, &c->ering, &c->cap_ering, (size_t)C * NT)) return rc;
+            if (int rc = grow(c, &c->pring, &c->cap_pring, (size_t)C * c->NP)) return rc;
+        }
+        const int32_t* ering = shared ? band_ering(c, c->band) : c->ering;
+        const float2* pring = shared ? band_pring(c, c->band) : c->pring;
+        if (int rc = host_ring((size_t)256 * NT)) return rc;   // (for the longest chunk at once: freeing pinned memory waits for the device)
         if (int rc = enqueue_persistent(c, *p, dp, C, true)) return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->ering_host, c->ering, sizeof(int32_t) * (size_t)C * NT, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->ering_host, ering, sizeof(int32_t) * (size_t)C * NT, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, wait_stream(c->stream));
         {
             const int64_t fails = c->persist_failures;
@@ -1073,7 +1102,7 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
             // back to the start of the last frame that counts, and that frame once more on the two-kernel path: it writes the
             // buffers the reference reads back (`tenergy`, `colnum`, `colacc`, `gradient`) and takes the step
             const int last = converged ? j : C - 1;
-            tp_launch_persist_finish(make_launch(c, p->image_slot, dp), c->pring + (size_t)last * c->NP, nullptr, nullptr, c->stream);
+            tp_launch_persist_finish(make_launch(c, p->image_slot, dp), pring + (size_t)last * c->NP, nullptr, nullptr, c->stream);
             enqueue_iter(c, *p, dp);
             HIP_TRY(c, hipGetLastError());
             break;

@@ -89,6 +89,8 @@ struct pk_args {
                                       // launch n + 1 needs the others' launch n + 1, which they start after collecting n)
     int32_t* ering;               // tp_iterate_until: [n_iters][NT] energy of every triangle's base variant, frame by frame (or null)
     float2* pring;                // tp_iterate_until: [n_iters][NP] positions at the START of every frame (vertices of triangles)
+    int32_t* peer_ering[PK_MAX_PEERS];   // band split: the other bands' rings -- every band's host applies the convergence test to
+    float2* peer_pring[PK_MAX_PEERS];    // ALL triangles' energies, so what a band writes into its own rings it writes into theirs
     unsigned epoch;               // number of the launch's first grad-iter (tags carry 31 bits of it)
     int n_iters;                  // < 0: census of resident workgroups instead
     unsigned* status;             // [0] raised by a lane that gave up waiting, [1] census counter, [2] completed launches (k_persist_finish)

@@ -154,7 +154,14 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             for (int j = PK_THREADS - 1 - tid; j < nsnap; j += PK_THREADS) pk_snap_lane(w, V, A.vw, j);
             for (int k = tid; k < w.n_own_v; k += PK_THREADS) {
                 V.grad[k].x = 0; V.grad[k].y = 0;
-                if (A.pring) A.pring[(size_t)it * A.NP + V.vid[k]] = make_float2(V.pos[k].x, V.pos[k].y);   // (a frame can be returned to)
+                if (A.pring) {   // (a frame can be returned to)
+                    const size_t at = (size_t)it * A.NP + V.vid[k];
+                    if (banded) {   // (system scope, write-through: the other bands' posts land in the same lines)
+                        const unsigned long long w8 = (unsigned long long)__float_as_uint(V.pos[k].x) | ((unsigned long long)__float_as_uint(V.pos[k].y) << 32);
+                        __hip_atomic_store((gu64*)A.pring + at, w8, PK_RLX_SYSTEM);
+                        for (int b = 0; b < A.n_peers; b++) __hip_atomic_store((gu64*)A.peer_pring[b] + at, w8, PK_RLX_SYSTEM);
+                    } else A.pring[at] = make_float2(V.pos[k].x, V.pos[k].y);
+                }
             }
         }
         __syncthreads();
@@ -253,7 +260,12 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 const tp_moments mm = pk_base_moments(w, V, k, t);
                 pk_i4 col = {0, 0, 0, 0};
                 if (A.flavour == 1) { const int4 c = A.ca[t]; col.x = c.x; col.y = c.y; col.z = c.z; }
-                A.ering[(size_t)it * A.NT + t] = pk_energy(mm, A.flavour, col);
+                const int32_t en = pk_energy(mm, A.flavour, col);
+                const size_t at = (size_t)it * A.NT + t;
+                if (banded) {
+                    __hip_atomic_store((gu32*)A.ering + at, (unsigned)en, PK_RLX_SYSTEM);
+                    for (int b = 0; b < A.n_peers; b++) __hip_atomic_store((gu32*)A.peer_ering[b] + at, (unsigned)en, PK_RLX_SYSTEM);
+                } else A.ering[at] = en;
             }
         }
         if (emit) {   // base variants (i = 0) of the triangles whose first vertex this patch owns
@@ -286,6 +298,9 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 const size_t at = ((size_t)(last ? 2u + A.final_slot : (epoch + 1u) & 1u) * A.box_stride + v) * 2;
                 const unsigned long long gx = T | __float_as_uint(p.x), gy = T | __float_as_uint(p.y);
                 if (banded) {
+                    // (what a launch ends with is a RELEASE: whoever collects it also sees the rings this workgroup wrote -- the
+                    // barriers between the phases order the other threads' ring stores before this one)
+                    if (last) __atomic_thread_fence(__ATOMIC_RELEASE);
                     __hip_atomic_store(posbox + at, gx, PK_RLX_SYSTEM); __hip_atomic_store(posbox + at + 1, gy, PK_RLX_SYSTEM);
                     for (int b = 0; b < A.n_peers; b++) {
                         gu64* g = (gu64*)A.peer_box[b] + at;
@@ -336,6 +351,7 @@ __global__ void k_band_collect(tp_launch L, pk_args A, float2* points_out) {
     for (;;) {
         const unsigned long long a = __hip_atomic_load(g, PK_RLX_SYSTEM), b = __hip_atomic_load(g + 1, PK_RLX_SYSTEM);
         if ((uint32_t)(a >> 32) == A.final_tag && (uint32_t)(b >> 32) == A.final_tag) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);   // (pairs with the posters' release: their rings are visible behind this kernel)
             points_out[v] = make_float2(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)b));
             return;
         }

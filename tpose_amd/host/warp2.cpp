@@ -24,8 +24,8 @@
 //                     through the pipes <idfile>.mate<rank>.*).  Four processes: -rank {0,1} x -band {0,1}; band b of one
 //                     direction exchanges meshes with band b of the other (its own -idfile: <idfile>.b<band>), so both
 //                     bands hold the same meshes at every step.  Band 0 writes <tri>.warp, band 1 <tri>.warp.band1 (the
-//                     same bytes).  Needs -fixedframes: banded launches carry no per-frame energies for the convergence
-//                     test.  -bandpatches N: patches per band (default: one per compute unit; two bands sharing ONE
+//                     same bytes).  The convergence test of a descent runs on every band's host over all bands' per-frame
+//                     energies (they travel like the positions).  -bandpatches N: patches per band (default: one per compute unit; two bands sharing ONE
 //                     device -- the one-GPU test box -- must not ask for more than the device has between them)
 //   -fixedframes      every descent runs exactly -levelframes frames (no convergence test)
 //   -selftest         one rank sends a mesh-sized buffer to itself through RCCL and checks it (exercises the library,
@@ -232,7 +232,6 @@ int main(int argc, char** argv) {
     if (ia.empty() || ib.empty() || ta.empty() || tb.empty() || idfile.empty()) die("need -ia -ib -ta -tb -idfile");
     if (bands != 1 && bands != 2) die("-bands 1 or 2");
     if (band < 0 || band >= bands) die("-band out of range");
-    if (bands == 2 && !fixed) die("-bands 2 needs -fixedframes");
     if (bands == 2) idfile += ".b" + std::to_string(band);   // band b of one direction talks to band b of the other
     if (device < 0) device = rank * bands + band;  // one process per GPU
     Raster A, B;
@@ -263,7 +262,8 @@ int main(int argc, char** argv) {
         // the two bands of this direction: one mailbox each, mapped into the other's process
         const std::string mate_base = idfile.substr(0, idfile.size() - 3) + ".mate" + std::to_string(rank);
         fifo_transport mate(band, mate_base);
-        const size_t bytes = tp_band_mailbox_bytes(1 << 16);
+        const int cap_points = 1 << 15, cap_tris = 1 << 16;   // (what the mailboxes and their rings are sized for)
+        const size_t bytes = tp_band_mailbox_bytes(cap_points, cap_tris);
 #ifndef WARP2_NO_RCCL
         HIPCHECK(hipSetDevice(device));
         HIPCHECK(hipMalloc(&boxes[band], bytes));
@@ -282,7 +282,7 @@ int main(int argc, char** argv) {
         boxes[0] = dummy[0]; boxes[1] = dummy[1];
         (void)mate.exchange(std::vector<int32_t>(1, band));
 #endif
-        if (tp_band_attach(tpose::ctx, band, 2, boxes, bytes, bandpatches) != TP_OK) die(std::string("tp_band_attach: ") + tp_last_error(tpose::ctx));
+        if (tp_band_attach(tpose::ctx, band, 2, boxes, bytes, cap_points, cap_tris, bandpatches) != TP_OK) die(std::string("tp_band_attach: ") + tp_last_error(tpose::ctx));
         // the census of resident workgroups and the first plan, while no band spins in a launch yet (two bands may share a device)
         tpose::warpA = mine.warpA;
         tpose::upload(&mine.tr);
