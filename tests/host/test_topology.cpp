@@ -248,6 +248,39 @@ int main(int argc, char** argv) {
         }
         CHECK(ops[0] > 500 && ops[1] > 200 && ops[2] > 200 && ops[3] > 20);  // the sequences really exercised the operations
     }
+    {   // the per-frame sweeps' filters never say "cannot fire" when the test itself fires: random triangles, and triangles
+        // pushed to the bounds (angles around 0.8 PI, sides around 0.01)
+        uint32_t seed = 99u;
+        auto frand = [&]() { seed = seed * 1664525u + 1013904223u; return (float)(seed >> 8) / 16777216.0f; };
+        triangulation tr;
+        int wide = 0, filtered = 0, shortish = 0;
+        for (int trial = 0; trial < 200000; trial++) {
+            vec2 a(frand() * 3 - 1.5f, frand() * 2 - 1), b(frand() * 3 - 1.5f, frand() * 2 - 1), c;
+            const int kind = trial % 4;
+            if (kind == 0) c = vec2(frand() * 3 - 1.5f, frand() * 2 - 1);
+            else if (kind == 1) {   // apex c sees a and b under an angle near 0.8 PI
+                const float ang = 0.8f * PI + (frand() - 0.5f) * 0.2f, r1 = 0.05f + frand(), r2 = 0.05f + frand(), t0 = frand() * 6.2831853f;
+                c = vec2(0.1f * (frand() - 0.5f), 0.1f * (frand() - 0.5f));
+                a = c + r1 * vec2(std::cos(t0), std::sin(t0));
+                b = c + r2 * vec2(std::cos(t0 + ang), std::sin(t0 + ang));
+            } else if (kind == 2) { b = a + (0.01f + (frand() - 0.5f) * 0.002f) * vec2(std::cos(frand() * 6.28f), std::sin(frand() * 6.28f)); c = vec2(frand() * 3 - 1.5f, frand() * 2 - 1); }
+            else { b = a; c = frand() < 0.5f ? a : vec2(frand(), frand()); }   // zero-length sides
+            tr.points[0] = a; tr.points[1] = b; tr.points[2] = c;
+            tr.triangles[0] = ivec4(0, 1, 2, 0);
+            const int m = tr.sweep_candidates(0);
+            for (int k = 0; k < 3; k++) {
+                const bool fires = tr.angle(k) > 0.8 * PI;
+                wide += fires;
+                CHECK(((m >> k) & 1) == (tr.maybe_wider_than_08pi(k) ? 1 : 0));
+                if (fires) CHECK((m >> k) & 1);
+                else filtered += !((m >> k) & 1);
+            }
+            CHECK(((m >> 3) & 1) == (tr.maybe_collapsible(0) ? 1 : 0));
+            for (int k = 0; k < 3; k++)
+                if (!(tr.hlength(k) > 0.01)) { shortish++; CHECK((m >> 3) & 1); }
+        }
+        CHECK(wide > 10000 && shortish > 10000 && filtered > 200000);   // the bounds were really exercised, and the filters filter
+    }
     std::printf(fails ? "%d FAILED\n" : "host mirror OK\n", fails);
     return fails ? 1 : 0;
 }
