@@ -626,3 +626,50 @@ def test_two_contexts_iterate_concurrently_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "two_contexts.py")], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_frame_mirror_returns_what_the_device_holds(flavour):
+    """single frames (tp_iterate(1), or energy + shift) leave the first NT + 64 entries of `tenergy` / `colnum` and the points
+    in pinned memory as well, and small read-backs right behind them are served from there: every such read-back equals the
+    copy from device memory (a batch with a buffer the mirror does not hold takes the copy path), also across the calls that
+    must invalidate it"""
+    W, H = 300, 200
+    img, imgB, pts, tris, ratio, colors = case(W, H, (15, 5))
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.set_image(capi.IMAGE_B, imgB)
+    ctx.upload(pts, tris, colors if flavour else None)
+    p = capi.default_params(flavour)
+    NT = tris.shape[0]
+
+    def check(tag):
+        small = [ctx.retrieve(capi.BUF_TENERGY, NT + 2)[: NT + 2], ctx.retrieve(capi.BUF_COLNUM, NT + 2)[: NT + 2], ctx.retrieve(capi.BUF_POINTS)]
+        full = ctx.retrieve_many([capi.BUF_TENERGY, capi.BUF_COLNUM, capi.BUF_POINTS, capi.BUF_COLACC])   # (colacc: the copy path)
+        assert np.array_equal(small[0], full[0][: NT + 2]), tag
+        assert np.array_equal(small[1], full[1][: NT + 2]), tag
+        assert np.array_equal(small[2].view(np.uint32), full[2].view(np.uint32)), tag
+
+    slot = capi.IMAGE_B if flavour else capi.IMAGE_A
+    for rep in range(3):
+        ctx.iterate(p, 1); check("frame")
+        ctx.iterate(p, 1); ctx.iterate(p, 1); check("two frames")
+        ctx.accumulate(flavour, slot); ctx.energy(flavour); check("energy")
+        ctx.shift(RATE[flavour]); check("energy + shift")
+        ctx.iterate(p, 1); ctx.accumulate(flavour, slot); check("frame, then a sweep")
+        ctx.iterate(p, 1); ctx.iterate(p, 7); check("frame, then a persistent call")
+        ctx.iterate(p, 1)
+        moved = ctx.retrieve(capi.BUF_POINTS)
+        ctx.upload(moved, tris, colors if flavour else None); check("frame, then an upload")
+        ctx.iterate(p, 1); ctx.set_dp(0.02); ctx.accumulate(flavour, slot); ctx.energy(flavour); check("another dp")
+        ctx.set_dp(0.0)
+    # and the frames are the oracle's
+    ctx.upload(pts, tris, colors if flavour else None)
+    for k in range(5):
+        ctx.iterate(p, 1)
+        got = ctx.retrieve(capi.BUF_POINTS)
+    ref = O.iterate(imgB if flavour else img, pts, tris, flavour, ratio, RATE[flavour], 5, colors=colors if flavour else None, literal=False)
+    assert np.array_equal(got.view(np.uint32), ref["points"].view(np.uint32))
+    assert np.array_equal(ctx.retrieve(capi.BUF_TENERGY, NT)[:NT], ref["ten"][:NT])
+    ctx.close()

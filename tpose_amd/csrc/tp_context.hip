@@ -142,6 +142,12 @@ struct tp_context {
     float2* points_out = nullptr; size_t cap_points_out = 0;
     unsigned* d_status = nullptr;   // [0] a lane of a persistent launch gave up waiting, [1] census counter
     unsigned* h_status = nullptr;   // pinned mirror of [0] and [2], written by k_persist_finish: read after a wait, no copy
+    // frame mirror: a single frame (tp_iterate(ctx, p, 1) on the two-kernel path) leaves the first frame_n entries of `tenergy` and
+    // `colnum` and all points in pinned memory as well; tp_retrieve_many takes them from there while nothing has touched the
+    // context since (`mutations` counts every call that may change what a retrieve returns)
+    uint8_t* frame_mirror = nullptr; size_t frame_mirror_bytes = 0;
+    int frame_n = 0; size_t frame_np = 0;
+    uint64_t mutations = 0, ten_stamp = ~0ull, pts_stamp = ~0ull;   // (the mirror's energies / points are current while stamp == mutations)
     uint32_t epoch = 1;             // number of the next grad-iter of a persistent launch (mailbox tags)
     bool persist_unchecked = false; // persistent launches were enqueued since the status word was last read
     struct journal_entry { tp_params p; int iters; };
@@ -285,6 +291,7 @@ int check_persist_status(tp_context* c) {
     c->h_status[0] = 0u;
     c->census = -6;  // two kernels per grad-iter from now on in this context
     c->persist_failures++;
+    c->mutations++;  // (what a retrieve returns is about to change)
     std::vector<tp_context::journal_entry> todo(c->journal.begin() + (completed < c->journal.size() ? completed : c->journal.size()), c->journal.end());
     c->journal.clear();
     for (auto& e : todo) {
@@ -293,6 +300,14 @@ int check_persist_status(tp_context* c) {
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return TP_OK;
+}
+
+// before work that is NOT a persistent launch goes onto the stream: were the persistent launches ahead of it completed?  (A launch
+// that gave up is run again at the next check -- and that must be before anything that continues from its result.)
+int settle_persistent(tp_context* c) {
+    if (!c->persist_unchecked) return TP_OK;
+    HIP_TRY(c, wait_stream(c->stream));
+    return check_persist_status(c);
 }
 
 template <class T>
@@ -524,10 +539,30 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
 }
 
 // enqueue one grad-iter on the context stream (no sync)
-void enqueue_iter(tp_context* c, const tp_params& p, float dp) {
+// the frame mirror of this triangulation (pinned; grown when the triangulation outgrows it) into a launch
+int frame_mirror_into(tp_context* c, tp_launch& L) {
+    const int fn = (int)std::min<size_t>((size_t)13 * c->NT, (size_t)c->NT + 64);
+    const size_t need = (size_t)8 * fn + (size_t)8 * c->NP;
+    if (need > c->frame_mirror_bytes) {
+        if (c->frame_mirror) hipHostFree(c->frame_mirror);
+        c->frame_mirror = nullptr; c->frame_mirror_bytes = 0;
+        HIP_TRY(c, hipHostMalloc((void**)&c->frame_mirror, need * 2, hipHostMallocDefault));
+        c->frame_mirror_bytes = need * 2;
+    }
+    if (fn != c->frame_n || (size_t)c->NP != c->frame_np) { c->ten_stamp = c->pts_stamp = ~0ull; }   // (another layout: nothing in it is current)
+    c->frame_n = fn; c->frame_np = (size_t)c->NP;
+    L.mirror_n = fn;
+    L.mirror_ten = (int32_t*)c->frame_mirror;
+    L.mirror_cn = L.mirror_ten + fn;
+    L.mirror_pts = (float2*)(L.mirror_cn + fn);
+    return TP_OK;
+}
+int enqueue_iter(tp_context* c, const tp_params& p, float dp, bool mirror = false) {
     tp_launch L = make_launch(c, p.image_slot, dp);
+    if (mirror) { if (int rc = frame_mirror_into(c, L)) return rc; }
     tp_launch_lines(L, c->stream);                       // vertex stage + the nine line sums of every edge
     tp_launch_update(L, p.flavour, p.rate, c->stream);  // variants + gradient + shift
+    return TP_OK;
 }
 
 int enqueue_iters(tp_context* c, const tp_params* p, int n_iters);
@@ -595,6 +630,7 @@ int tp_destroy(tp_context* c) {
     hipFree(c->render_pic); hipFree(c->render_pts);
     hipFree(c->d_wg); hipFree(c->d_pool); hipFree(c->posbox); hipFree(c->points_out); hipFree(c->d_status);
     if (c->h_status) hipHostFree(c->h_status);
+    if (c->frame_mirror) hipHostFree(c->frame_mirror);
     hipFree(c->ering); hipFree(c->pring);
     if (c->ering_host) hipHostFree(c->ering_host);
     for (int k = 0; k < 2; k++) {
@@ -615,6 +651,7 @@ int tp_destroy(tp_context* c) {
 int tp_set_ratio(tp_context* c, float ratio) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
+    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
     if (!(ratio > 0.0f)) return fail(c, TP_ERR_INVALID, "RATIO must be positive");
     if (ratio != c->ratio) { c->ratio = ratio; c->generation++; c->accumulated = c->energized = false; }
     return TP_OK;
@@ -623,6 +660,7 @@ int tp_set_ratio(tp_context* c, float ratio) {
 int tp_set_dp(tp_context* c, float dp) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
+    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
     c->dp_override = dp;  // piecewise calls only; tp_iterate takes dp from its params (part of the graph key)
     c->accumulated = c->energized = false;
     return TP_OK;
@@ -631,6 +669,7 @@ int tp_set_dp(tp_context* c, float dp) {
 int tp_set_option(tp_context* c, int option, int64_t value) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
+    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
     switch (option) {
         case TP_OPT_PERSISTENT:
             if (value != TP_PERSIST_OFF && value != TP_PERSIST_AUTO) return fail(c, TP_ERR_INVALID, "TP_OPT_PERSISTENT: bad value %lld", (long long)value);
@@ -648,6 +687,7 @@ size_t tp_band_mailbox_bytes(int points, int triangles) {
 int tp_band_attach(tp_context* c, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int points, int triangles, int patches_per_band) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
+    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = tp_synchronize(c)) return rc;   // nothing in flight reads the mailbox or the plan
     if (n_bands <= 1) {
@@ -679,6 +719,7 @@ int tp_get_ratio(const tp_context* c, float* ratio) {
 
 static int set_image_common(tp_context* c, int slot, const void* src, size_t stride, hipMemcpyKind kind) {
     if (!c) return TP_ERR_INVALID;
+    c->mutations++;
     if (slot != TP_IMAGE_A && slot != TP_IMAGE_B) return fail(c, TP_ERR_INVALID, "bad image slot %d", slot);
     if (!src) return fail(c, TP_ERR_INVALID, "image pointer is NULL");
     if (stride < (size_t)c->W * 4) return fail(c, TP_ERR_INVALID, "stride %zu < 4*width", stride);
@@ -712,6 +753,7 @@ int tp_set_image_device(tp_context* c, int slot, const void* dev, size_t stride)
 int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, int NT, const int32_t* colors) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
+    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
     if (!points || !tris || NP < 1 || NT < 1) return fail(c, TP_ERR_INVALID, "upload: bad arguments (NP=%d NT=%d)", NP, NT);
     if ((size_t)13 * NT > (size_t)TP_MAXT) return fail(c, TP_ERR_CAPACITY, "13*NT = %d exceeds MAXT = %d", 13 * NT, TP_MAXT);
     if ((size_t)NP > (size_t)TP_MAXT) return fail(c, TP_ERR_CAPACITY, "NP = %d exceeds MAXT = %d", NP, TP_MAXT);
@@ -872,10 +914,12 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
 int tp_accumulate(tp_context* c, int flavour, int slot) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
+    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
     if (flavour != TP_TRIANGULATE && flavour != TP_WARP) return fail(c, TP_ERR_INVALID, "bad flavour %d", flavour);
     if (!c->uploaded) return fail(c, TP_ERR_STATE, "accumulate before upload");
     if (int rc = check_slot(c, slot)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = settle_persistent(c)) return rc;
     tp_launch L = make_launch(c, slot, resolve_dp(c, flavour, c->dp_override));
     tp_launch_lines(L, c->stream);
     HIP_TRY(c, hipGetLastError());
@@ -887,13 +931,17 @@ int tp_accumulate(tp_context* c, int flavour, int slot) {
 int tp_energy(tp_context* c, int flavour) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
+    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
     if (flavour != TP_TRIANGULATE && flavour != TP_WARP) return fail(c, TP_ERR_INVALID, "bad flavour %d", flavour);
     if (!c->accumulated) return fail(c, TP_ERR_STATE, "energy before accumulate");
     if (flavour != c->acc_flavour) return fail(c, TP_ERR_STATE, "energy flavour %d differs from the accumulate pass (%d)", flavour, c->acc_flavour);
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = settle_persistent(c)) return rc;
     tp_launch L = make_launch(c, c->acc_slot, 0.0f);
+    if (int rc = frame_mirror_into(c, L)) return rc;
     tp_launch_finalize(L, flavour, true, c->stream);
     HIP_TRY(c, hipGetLastError());
+    c->ten_stamp = c->mutations;   // (the first entries of `tenergy` / `colnum` are in the frame mirror as well)
     c->energized = true; c->last_flavour = flavour;
     return TP_OK;
 }
@@ -901,11 +949,17 @@ int tp_energy(tp_context* c, int flavour) {
 int tp_shift(tp_context* c, float rate) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
+    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
     if (!c->energized) return fail(c, TP_ERR_STATE, "shift before energy");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = settle_persistent(c)) return rc;
     tp_launch L = make_launch(c, c->acc_slot, 0.0f);
+    const bool energies_current = c->ten_stamp == c->mutations - 1;   // (tp_energy was the call before: the step leaves its energies alone)
+    if (int rc = frame_mirror_into(c, L)) return rc;
     tp_launch_shift(L, rate, c->stream);
     HIP_TRY(c, hipGetLastError());
+    c->pts_stamp = c->mutations;
+    if (energies_current && c->ten_stamp != ~0ull) c->ten_stamp = c->mutations;
     c->accumulated = c->energized = false;  // geometry moved
     return TP_OK;
 }
@@ -983,7 +1037,13 @@ int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
             left = 0;
         }
     }
-    if (int rc = enqueue_two_kernel(c, p, dp, left)) return rc;
+    if (left > 0) { if (int rc = settle_persistent(c)) return rc; }
+    if (n_iters == 1 && left == 1) {
+        // a single frame (the schedules run them one by one and read back after each): its outputs also go to the frame mirror
+        if (int rc = enqueue_iter(c, *p, dp, true)) return rc;
+        HIP_TRY(c, hipGetLastError());
+        c->ten_stamp = c->pts_stamp = c->mutations;
+    } else if (int rc = enqueue_two_kernel(c, p, dp, left)) return rc;
     c->acc_slot = p->image_slot; c->last_flavour = p->flavour;
     c->accumulated = c->energized = false;
     return TP_OK;
@@ -1014,6 +1074,7 @@ int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
     if (int rc = validate_params(c, p, n_iters)) return rc;
     if (n_iters == 0) return TP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    c->mutations++;
     return enqueue_iters(c, p, n_iters);
 }
 
@@ -1038,6 +1099,8 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
     if (relerr) *relerr = 0.0f;
     if (max_frames == 0) return TP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    c->mutations++;
+    if (int rc = settle_persistent(c)) return rc;
     const float dp = resolve_dp(c, p->flavour, p->dp);
     const int NT = c->NT;
     float tot = *toterr, rel = 0.0f;
@@ -1120,8 +1183,10 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
 int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* accumulate_us) {
     api_guard api_lock;
     if (!c || !accumulate_us) return TP_ERR_INVALID;
+    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
     if (int rc = validate_params(c, p, n_iters)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = settle_persistent(c)) return rc;
     const float dp = resolve_dp(c, p->flavour, p->dp);
     // Eager launches enqueued back to back (no host sync in between); every k_lines dispatch
     // carries its own begin/end timestamps in an event pair.  (Timed launches record nothing when
@@ -1150,6 +1215,7 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
 int tp_profile_accumulate(tp_context* c, const tp_params* p, int launches, double* accumulate_us) {
     api_guard api_lock;
     if (!c || !accumulate_us) return TP_ERR_INVALID;
+    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
     if (int rc = validate_params(c, p, launches)) return rc;
     if (launches < 1) return fail(c, TP_ERR_INVALID, "launches < 1");
     if (int rc = tp_synchronize(c)) return rc;
@@ -1236,6 +1302,34 @@ int tp_retrieve_many(tp_context* c, int n, const int* what, void* const* dst, co
     if (n < 0 || (n && (!what || !dst || !count))) return fail(c, TP_ERR_INVALID, "retrieve: bad arguments");
     if (!c->uploaded) return fail(c, TP_ERR_STATE, "retrieve before upload");
     HIP_TRY(c, hipSetDevice(c->device));
+    // the frame mirror: right behind a single frame the schedules' read-back (first entries of `tenergy` / `colnum`, the points)
+    // is already in pinned memory -- wait for the stream and take it from there
+    auto mirrored = [&]() {
+        if (!c->frame_mirror) return false;
+        for (int k = 0; k < n; k++) {
+            const bool small = (what[k] == TP_BUF_TENERGY || what[k] == TP_BUF_COLNUM) && count[k] <= (size_t)c->frame_n && c->ten_stamp == c->mutations;
+            const bool pts = what[k] == TP_BUF_POINTS && count[k] <= 2 * c->frame_np && c->frame_np == (size_t)c->NP && c->pts_stamp == c->mutations;
+            if (!small && !pts && what[k] != TP_BUF_PENERGY) return false;
+            if (!dst[k] && count[k]) return false;
+        }
+        return true;
+    };
+    if (mirrored()) {
+        HIP_TRY(c, wait_stream(c->stream));
+        if (int rc = check_persist_status(c)) return rc;
+        if (mirrored()) {   // (still: nothing had to be run again)
+            const int32_t* ten = (const int32_t*)c->frame_mirror;
+            const int32_t* cn = ten + c->frame_n;
+            const float* pts = (const float*)(cn + c->frame_n);
+            for (int k = 0; k < n; k++) {
+                if (what[k] == TP_BUF_TENERGY) memcpy(dst[k], ten, count[k] * 4);
+                else if (what[k] == TP_BUF_COLNUM) memcpy(dst[k], cn, count[k] * 4);
+                else if (what[k] == TP_BUF_POINTS) memcpy(dst[k], pts, count[k] * 4);
+                else memset(dst[k], 0, count[k] * 4);
+            }
+            return TP_OK;
+        }
+    }
     std::vector<const void*> src(n);
     std::vector<size_t> bytes(n), off(n);
     size_t total = 0;

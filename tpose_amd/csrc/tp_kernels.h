@@ -36,6 +36,9 @@ struct tp_launch {
     int4* ca;
     int2* gr;
     int64_t* moments;          // optional int64[13NT][6]
+    // frame mirror (single frames of the schedules: tp_iterate(1) then tp_retrieve_many): the kernels that write `tenergy`, `colnum`
+    // and `points` also write the first mirror_n entries / every point into pinned host memory -- the read-back needs no copy
+    int32_t* mirror_ten; int32_t* mirror_cn; float2* mirror_pts; int mirror_n;
 #ifdef TPOSE_DEBUG
     unsigned long long* dbg;   // per-block phase timestamps (debug flavour of the library only)
 #endif

@@ -329,6 +329,7 @@ __device__ __forceinline__ int32_t emit_variant(const tp_launch& L, int flavour,
     if (store) {
         L.ten[id] = e32;
         L.cn[id] = tp_wrap32(m.n);
+        if (L.mirror_ten && id < L.mirror_n) { L.mirror_ten[id] = e32; L.mirror_cn[id] = tp_wrap32(m.n); }
     }
     if (write_moments) {
         int64_t* o = L.moments + (size_t)id * 6;
@@ -392,7 +393,10 @@ __global__ __launch_bounds__(256) void k_shift(tp_launch L, float rate) {
         gy += (uint32_t)e[(4 * s + 3) * NT] - (uint32_t)e[(4 * s + 4) * NT];
     }
     L.gr[gid] = make_int2((int)gx, (int)gy);
-    if (gid < 4) return;  // shift.cs:20 -- the four corners never move
+    if (gid < 4) {  // shift.cs:20 -- the four corners never move
+        if (L.mirror_pts) L.mirror_pts[gid] = L.points[gid];
+        return;
+    }
 
     float tgx = (float)(int)gx, tgy = (float)(int)gy;
     float2 p = L.points[gid];
@@ -403,6 +407,7 @@ __global__ __launch_bounds__(256) void k_shift(tp_launch L, float rate) {
     p.x = tp_fsub(p.x, tp_shift_scale(tp_fmul(rate, tgx)));
     p.y = tp_fsub(p.y, tp_shift_scale(tp_fmul(rate, tgy)));
     L.points[gid] = p;
+    if (L.mirror_pts) L.mirror_pts[gid] = p;
     publish_position(L, gid, p, 0, 1);
 }
 void tp_launch_shift(const tp_launch& L, float rate, hipStream_t s) {
@@ -657,6 +662,7 @@ __global__ __launch_bounds__(UPD_THREADS) void k_update(tp_launch L, int flavour
                 L.points[v] = make_float2(x, y);
                 newp = make_float2(x, y); moved = 1;
             }
+            if (L.mirror_pts) L.mirror_pts[v] = moved ? newp : p;
         }
         // the new position goes to every edge the vertex ends (k_lines reads endpoints by edge)
         if (__shfl(moved, 0)) {
