@@ -107,14 +107,15 @@ def test_bands_run_the_reference_loop_to_its_convergence_test(flavour, threshold
 
 def test_band_that_never_shows_up_is_survived():
     """band 1 never iterates: band 0 waits a second in its launch, gives up without having changed anything, and runs the
-    call on its own -- the oracle's bits again"""
+    call on its own -- the oracle's bits again, also when a short call was enqueued right behind the launch that gave up"""
     W, H = 300, 200
     img, imgB, pts, tris, ratio, colors = case(W, H, (15, 5))
     ctxs, boxes = banded_contexts(W, H, img, imgB, pts, tris, None, 2, 8)
     p = capi.default_params(0)
     ctxs[0].iterate(p, 40)
+    ctxs[0].iterate(p, 2)      # (too short for a persistent launch: it must not overtake the 40 that are about to be run again)
     ctxs[0].synchronize()
-    ref = O.iterate(img, pts, tris, 0, ratio, RATE[0], 40, literal=False)
+    ref = O.iterate(img, pts, tris, 0, ratio, RATE[0], 42, literal=False)
     assert ctxs[0].info(9) == 1
     assert np.array_equal(ctxs[0].retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
     assert np.array_equal(ctxs[0].retrieve(capi.BUF_TENERGY), ref["ten"])
