@@ -83,7 +83,8 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
 
     // a launch behind one that gave up does nothing (tp_context.hip: the grad-iters are run again on the two-kernel path)
-    if (__hip_atomic_load(status, PK_RLX_AGENT) != 0u) return;
+    // (one answer for the whole workgroup: the word may be raised while its threads look)
+    if (__syncthreads_or(__hip_atomic_load(status, PK_RLX_AGENT) != 0u)) return;
 
     // ---- prologue: the patch's tables and positions into LDS
     {
