@@ -10,9 +10,11 @@
 // never leave a workgroup (a first version handed the sums of border edges over instead of recomputing them: each hop cost
 // 2.4 us or more against 0.7 us for positions -- profiles/r03_*); the price is that the base line of a border edge is
 // walked by up to three workgroups (+10 % lines at 3000 triangles) and its band of the table is read by each of them.
-// Ownership is decided ONCE per upload from the topology and the upload-time positions (recursive coordinate
-// bisection balanced by table look-ups), never by where a vertex has drifted to: there is nothing to re-bin while
-// the descent runs, and results cannot depend on the cut (integer sums commute; every float operation is per vertex).
+// Ownership is decided from the topology and the positions the plan is cut from (recursive coordinate bisection balanced
+// by table look-ups) and stays fixed for a launch: there is nothing to re-bin while grad-iters run.  A long descent cuts a
+// new plan between launches when the mesh has drifted (tp_context.hip: maybe_replan); how each patch cuts its LINES into
+// lane chunks is decided by the workgroup itself, again and again (tp_persist.h: pk_recut_line).  Results cannot depend on
+// either cut (integer sums commute; every float operation is per vertex).
 //
 // Plain C++ (no HIP): tests/emul compiles this header with g++ and replays the kernel's lane functions
 // (tp_persist.h) phase by phase on the CPU.
