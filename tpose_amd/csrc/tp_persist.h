@@ -42,6 +42,7 @@ struct pk_view {
                                // {line | chunk << 16, chunks, magic}
     pk_i4* corners;
     pk_i4* base;
+    int32_t* coef;             // [4 n_corners] (corner, move): signs of its three line sums, pk_coef_lane
     int32_t* flags;
 };
 
@@ -59,6 +60,7 @@ TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     V.li = (int32_t*)p; p += pk_align16(w.li_cap * 12);
     V.corners = (pk_i4*)p; p += pk_align16(w.n_corners * 16);
     V.base = (pk_i4*)p; p += pk_align16(w.n_base * 16);
+    V.coef = (int32_t*)p; p += pk_align16(w.n_corners * 16);
     V.flags = (int32_t*)p;
 }
 
@@ -77,9 +79,7 @@ TP_HD void pk_snap_lane(const pk_wg& w, const pk_view& V, const tp_view& vw, int
 }
 
 // P1b, lane l < n_lines: line l = (local edge, version) -- the walker of the whole line
-TP_HD void pk_setup_lane(const pk_view& V, const tp_view& vw, int l, pk_walker& out) {
-    const int le = V.lines[l] & 0xffff, q = V.lines[l] >> 16;
-    const int su = V.edges[le] & 0xffff, sv = (V.edges[le] >> 16) & 0xffff;
+TP_HD void pk_setup_ends(const pk_view& V, const tp_view& vw, int su, int sv, int q, pk_walker& out) {
     const pk_f2 pu = V.pos[su], pv = V.pos[sv];
     // line q: endpoint u displaced by move mu, endpoint v by move mv (tp_kernels.hip: k_lines)
     const int mu = (q >= 1 && q <= 4) ? q : 0, mv = q >= 5 ? q - 4 : 0;
@@ -89,6 +89,10 @@ TP_HD void pk_setup_lane(const pk_view& V, const tp_view& vw, int l, pk_walker& 
     tp_line ln;
     tp_setup_line(Xa, Ya, Xb, Yb, vw.H, ln);
     out.x = ln.x; out.s = ln.s; out.ra = ln.ra; out.rb = ln.rb;
+}
+TP_HD void pk_setup_lane(const pk_view& V, const tp_view& vw, int l, pk_walker& out) {
+    const int le = V.lines[l] & 0xffff, q = V.lines[l] >> 16;
+    pk_setup_ends(V, vw, V.edges[le] & 0xffff, (V.edges[le] >> 16) & 0xffff, q, out);
 }
 
 // x / d for the item's chunk count d (magic = floor(2^32 / d) + 1, exact for x d < 2^32; d == 1: magic 0)
@@ -325,15 +329,51 @@ TP_HD void pk_walk_fetch(pk_lane_cache<R>& C, const pk_scan& S, const char* tabl
     }
 }
 // step 3: the line's partial sums of this lane
+#if defined(PK_EXP_LEAN)
+struct pk_scan_out { uint32_t sx; int n; };
+// steps 1 and 2 in one pass: every row's crossing column once; a row whose column has left its cached record is fetched
+// right there (loads are issued, not waited for)
+template <int RR, int R>
+TP_HD pk_scan_out pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int pitch, const char* table, int W) {
+    pk_rows t;
+    if (C.TL == 0) { t.n = 0; t.x = 0; t.xs = 0; t.row = 0; t.rs = 0; }
+    else t = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
+    const uint32_t live = t.n >= 32 ? 0xffffffffu : ((1u << t.n) - 1u);
+    const bool all = t.row != C.row0;
+    C.row0 = t.row;
+    pk_scan_out S; S.sx = 0; S.n = t.n;
+    uint32_t row = t.row;
+#pragma unroll
+    for (int u = 0; u < RR; u++) {
+        const uint32_t on = 0u - ((live >> u) & 1u);
+        const int32_t col = pk_next_col(t, W) & (int32_t)on;
+        S.sx += (uint32_t)col;
+        if (all || col != C.col[u]) {
+            C.rec[u] = *reinterpret_cast<const pk_rec*>(table + ((row & on) + ((uint32_t)col << 4)));
+            C.col[u] = col;
+        }
+        row += t.rs;
+    }
+    return S;
+}
+template <int RR, int R>
+TP_HD void pk_walk_sum(const pk_lane_cache<R>& C, const pk_scan_out& S, const pk_view& V, int pitch, const char* table, int W, pk_acc& a) {
+#else
 template <int RR, int R>
 TP_HD void pk_walk_sum(const pk_lane_cache<R>& C, const pk_scan& S, const char* table, int W, pk_acc& a) {
+#endif
     a.xs = S.sx; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
     uint64_t lo = 0, hi = 0;
 #pragma unroll
     for (int u = 0; u < RR; u++) { lo += C.rec[u].lo; hi += C.rec[u].hi; }
     pk_add_unpacked(lo, hi, a);
+#if defined(PK_EXP_LEAN)   // (the rows are worked out again in the rare case: nothing of the scan but two words stays live until here)
+    if (S.n > RR) {
+        pk_rows r = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
+#else
     if (S.r.n > RR) {   // the line has grown beyond the rows this workgroup's lanes keep
         pk_rows r = S.r;
+#endif
         r.n -= RR; r.x = (int64_t)((uint64_t)r.x + (uint64_t)RR * (uint64_t)r.xs); r.row += (uint32_t)RR * r.rs;
         pk_walk_rows<4>(r, table, W, a);
     }
@@ -342,7 +382,12 @@ template <int RR, int R>
 TP_HD void pk_walk_cached(pk_lane_cache<R>& C, const pk_view& V, const char* table, int pitch, int W, pk_acc& a) {
     const pk_scan S = pk_walk_scan<RR>(C, V, pitch, W);
     if (S.stale != 0u) pk_walk_fetch<RR>(C, S, table, W);
+#if defined(PK_EXP_LEAN)
+    const pk_scan_out So = {S.sx, S.r.n};
+    pk_walk_sum<RR>(C, So, V, pitch, table, W, a);
+#else
     pk_walk_sum<RR>(C, S, table, W, a);
+#endif
 }
 
 // tag of grad-iter `epoch`: never 0 (a cleared mailbox matches nothing), and no two grad-iters of a context's life share one
@@ -392,6 +437,29 @@ TP_HD tp_moments pk_corner_moments(const pk_wg& w, const pk_view& V, int k, int 
     const int cp = sp == 0 ? c[0] : sp == 1 ? c[1] : c[2];
     return pk_moments3(cs, V.sums + (size_t)((cr.z & 0xffff) + m - 1) * PK_SUM_WORDS, cp, V.sums + (size_t)(((cr.z >> 16) & 0xffff) + m - 1) * PK_SUM_WORDS,
                        cn, V.sums + (size_t)(cr.w & 0xffff) * PK_SUM_WORDS);
+}
+// P1, lane (corner k, move m): with which signs the three line sums enter the variant's moments -- from the positions alone, so
+// it is done while other lanes set the lines up, and P6 starts from the sums.  Two bits each: edge leaving the vertex | edge
+// arriving << 2 | opposite edge << 4.
+TP_HD int32_t pk_coef_lane(const pk_view& V, const tp_view& vw, int k, int m) {
+    const pk_i4 cr = V.corners[k];
+    const int s = cr.y & 3, own = (cr.y >> 2) & 0x3ff, sa = (cr.y >> 12) & 0x3ff, sb = (cr.y >> 22) & 0x3ff;
+    const int sn = s == 2 ? 0 : s + 1, sp = s == 0 ? 2 : s - 1;
+    int32_t X[3], Y[3], c[3];
+    const pk_f2 pv = V.pos[own], pa = V.pos[sa], pb = V.pos[sb];
+    tp_vertex_stage(pv.x, pv.y, m, 0, vw, X[s], Y[s]);
+    tp_vertex_stage(pa.x, pa.y, 0, 0, vw, X[sn], Y[sn]);
+    tp_vertex_stage(pb.x, pb.y, 0, 0, vw, X[sp], Y[sp]);
+    tp_variant_coeffs(X, Y, c);
+    const int cs = s == 0 ? c[0] : s == 1 ? c[1] : c[2];
+    const int cn = sn == 0 ? c[0] : sn == 1 ? c[1] : c[2];
+    const int cp = sp == 0 ? c[0] : sp == 1 ? c[1] : c[2];
+    return (cs & 3) | ((cp & 3) << 2) | ((cn & 3) << 4);
+}
+// P6, the same lane: the variant's moments from the three line sums (slots of the edge leaving the vertex, arriving at it, opposite)
+TP_HD tp_moments pk_coef_moments(const pk_view& V, int32_t cf, int so, int si, int sopp) {
+    const int cs = (int32_t)((uint32_t)cf << 30) >> 30, cp = (int32_t)((uint32_t)cf << 28) >> 30, cn = (int32_t)((uint32_t)cf << 26) >> 30;
+    return pk_moments3(cs, V.sums + (size_t)so * PK_SUM_WORDS, cp, V.sums + (size_t)si * PK_SUM_WORDS, cn, V.sums + (size_t)sopp * PK_SUM_WORDS);
 }
 // energy of a variant as k_update's emit_variant forms it (triangle.fs:37-43; warp: against the stored colour, :46-53)
 TP_HD int32_t pk_energy(const tp_moments& mm, int flavour, pk_i4 col) {

@@ -108,6 +108,7 @@ inline int pk_lds_bytes(const pk_wg& w) {
     b += pk_align16(w.li_cap * 12);                 // lane-items without a thread of their own
     b += pk_align16(w.n_corners * 16);              // corners
     b += pk_align16(w.n_base * 16);                 // base variants
+    b += pk_align16(w.n_corners * 16);              // signs of the three line sums of every corner variant (this grad-iter's)
     return b + 64;                                  // flags
 }
 
