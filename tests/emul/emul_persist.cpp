@@ -138,6 +138,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                 pk_setup_lane(V, vw, l, wkr);
                 V.wk[l] = wkr;
             }
+            for (int j = 0; j < 4 * w.n_corners; j++) V.coef[j] = pk_coef_lane(V, vw, j >> 2, (j & 3) + 1);
             memset(V.sums, 0, sizeof(unsigned long long) * PK_SUM_WORDS * (size_t)w.n_lines_all);
             if (recut) {   // the wave's lanes one after the other
                 const int RRk = P.rows_max <= 7 ? 8 : P.rows_max <= 9 ? 10 : P.rows_max <= 10 ? 11 : 12;   // tp_launch_persist's choice
@@ -171,10 +172,18 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                 int64_t* ws = g_walk_stats + 6 * (size_t)it;
                 const int RRk = P.rows_max <= 7 ? 8 : P.rows_max <= 9 ? 10 : P.rows_max <= 10 ? 11 : 12;   // tp_launch_persist's choice
                 int64_t over_rows = 0, stale = 0;
-                for (int j = 0; j < PK_CACHED; j++) {
-                    const pk_scan sc = pk_walk_scan<PK_ROWS_PER_LANE>(S[p].cache[j], V, pitch, W);
-                    if (sc.stale) { ws[0]++; stale++; }
-                    if (sc.r.n > RRk) { ws[2]++; ws[3] += sc.r.n - RRk; over_rows += sc.r.n - RRk; }
+                for (int j = 0; j < PK_CACHED; j++) {   // (what pk_walk_pass is about to find, without changing anything)
+                    const auto& C = S[p].cache[j];
+                    if (C.TL == 0) continue;
+                    pk_rows r = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
+                    const int n = r.n;
+                    bool st = r.row != C.row0;
+                    for (int u = 0; u < PK_ROWS_PER_LANE; u++) {
+                        const int32_t col = u < n ? pk_next_col(r, W) : 0;
+                        st = st || col != C.col[u];
+                    }
+                    if (st) { ws[0]++; stale++; }
+                    if (n > RRk) { ws[2]++; ws[3] += n - RRk; over_rows += n - RRk; }
                 }
                 if (over_rows > ws[4]) ws[4] = over_rows;
                 if (stale > ws[5]) ws[5] = stale;
@@ -204,7 +213,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                 for (int m = 1; m <= 4; m++) {
                     pk_i4 col = {0, 0, 0, 0};
                     if (flavour == 1 && ca) { const int32_t* c4 = ca + 4 * ((size_t)(4 * s + m) * NT + t); col.x = c4[0]; col.y = c4[1]; col.z = c4[2]; }
-                    const tp_moments mm = pk_corner_moments(w, V, k, m);
+                    const tp_moments mm = pk_coef_moments(V, V.coef[4 * k + m - 1], (cr.z & 0xffff) + m - 1, ((cr.z >> 16) & 0xffff) + m - 1, cr.w & 0xffff);
                     en[m] = pk_energy(mm, flavour, col);
                     if (emit) {
                         const size_t id = (size_t)(4 * s + m) * NT + t;

@@ -282,112 +282,63 @@ TP_HD void pk_cache_init(pk_lane_cache<R>& C, const pk_view& V, int slot, int n_
 #pragma unroll
     for (int u = 0; u < R; u++) { C.col[u] = live ? -1 : 0; C.rec[u].lo = 0; C.rec[u].hi = 0; }
 }
-// The walk of a cached lane-item in three steps, so that a thread can run each step for all its lane-items before the next
-// (the fetches of both are in flight together).  RR <= R: how many of the R cached rows the lanes of this workgroup use
-// (the plan's rows per lane, rounded up to one of the instantiated values: the loops are straight-line code, rows a lane
-// does not have cost what the others cost).
-struct pk_scan { pk_rows r; uint32_t live, sx, stale; };
-// step 1, straight-line: this grad-iter's rows and crossing columns; has any column left its cached record?
+// The walk of a cached lane-item in two steps, so that a thread can run each step for all its lane-items before the next
+// (the fetches of all of them are in flight while the sums begin).  RR <= R: how many of the R cached rows the lanes of this
+// workgroup use (the plan's rows per lane, rounded up to one of the instantiated values: the loops are straight-line code,
+// rows a lane does not have cost what the others cost).
+// step 1: every row's crossing column, once; a row whose column has left its cached record is fetched right there (loads
+// are issued, not waited for).  Returns the rows of the lane.  (Round 3 began with a scan that only compared, and a second
+// walk that fetched when anything in the WAVE was stale -- which is nearly always: one pass is 0.3 us per grad-iter less.)
 template <int RR, int R>
-TP_HD pk_scan pk_walk_scan(const pk_lane_cache<R>& C, const pk_view& V, int pitch, int W) {
+TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int pitch, const char* table, int W) {
     static_assert(RR <= R && RR <= TP_PX_MAXSUM, "records added before unpacking");
-    pk_scan S;
-    if (C.TL == 0) { S.r.n = 0; S.r.x = 0; S.r.xs = 0; S.r.row = 0; S.r.rs = 0; }
-    else S.r = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
-    S.live = S.r.n >= 32 ? 0xffffffffu : ((1u << S.r.n) - 1u);   // bit u: row u exists
-    S.sx = 0; S.stale = 0;
-    pk_rows t = S.r;
-#pragma unroll
-    for (int u = 0; u < RR; u++) {
-        const int32_t col = pk_next_col(t, W) & (int32_t)(0u - ((S.live >> u) & 1u));
-        S.sx += (uint32_t)col;
-        // (a sum, not an OR: xor-and-add is one instruction; the terms are differences of columns <= 4096 and cannot cancel --
-        // with nothing cached, col[u] = -1, row0 differs anyway)
-        S.stale += (uint32_t)(col ^ C.col[u]);
-    }
-    S.stale |= S.r.row ^ C.row0;                                   // (another first row: every record is another row's)
-    return S;
-}
-// step 2, only when S.stale: walk again and fetch what changed (loads are issued, not waited for)
-template <int RR, int R>
-TP_HD void pk_walk_fetch(pk_lane_cache<R>& C, const pk_scan& S, const char* table, int W) {
-    const bool all = S.r.row != C.row0;
-    C.row0 = S.r.row;
-    pk_rows t = S.r;
-#pragma unroll
-    for (int u = 0; u < RR; u++) {
-        const uint32_t on = 0u - ((S.live >> u) & 1u);
-        const int32_t col = pk_next_col(t, W) & (int32_t)on;
-        if (all || col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
-#if !defined(PK_EXP_NOLOAD)   // timing experiments only (tools/build_variants.py); never defined in the product
-            C.rec[u] = *reinterpret_cast<const pk_rec*>(table + (((S.r.row + (uint32_t)u * S.r.rs) & on) + ((uint32_t)col << 4)));
-#endif
-#if !defined(PK_EXP_NOCACHE)
-            C.col[u] = col;
-#endif
-        }
-    }
-}
-// step 3: the line's partial sums of this lane
-#if defined(PK_EXP_LEAN)
-struct pk_scan_out { uint32_t sx; int n; };
-// steps 1 and 2 in one pass: every row's crossing column once; a row whose column has left its cached record is fetched
-// right there (loads are issued, not waited for)
-template <int RR, int R>
-TP_HD pk_scan_out pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int pitch, const char* table, int W) {
     pk_rows t;
     if (C.TL == 0) { t.n = 0; t.x = 0; t.xs = 0; t.row = 0; t.rs = 0; }
     else t = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
-    const uint32_t live = t.n >= 32 ? 0xffffffffu : ((1u << t.n) - 1u);
-    const bool all = t.row != C.row0;
-    C.row0 = t.row;
-    pk_scan_out S; S.sx = 0; S.n = t.n;
+    const uint32_t live = t.n >= 32 ? 0xffffffffu : ((1u << t.n) - 1u);   // bit u: row u exists
+    if (t.row != C.row0) {   // another first row: every record is another row's (an endpoint crossed a pixel row)
+        C.row0 = t.row;
+#pragma unroll
+        for (int u = 0; u < RR; u++) C.col[u] = -1;
+    }
+    const int n = t.n;
     uint32_t row = t.row;
 #pragma unroll
     for (int u = 0; u < RR; u++) {
         const uint32_t on = 0u - ((live >> u) & 1u);
         const int32_t col = pk_next_col(t, W) & (int32_t)on;
-        S.sx += (uint32_t)col;
-        if (all || col != C.col[u]) {
+        if (col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
+#if !defined(PK_EXP_NOLOAD)   // timing experiments only (tools/build_variants.py); never defined in the product
             C.rec[u] = *reinterpret_cast<const pk_rec*>(table + ((row & on) + ((uint32_t)col << 4)));
+#endif
             C.col[u] = col;
         }
         row += t.rs;
     }
-    return S;
+    return n;
 }
+// step 2: the line's partial sums of this lane (the crossing columns are the cached ones by now: they are added up here,
+// behind the fetches).  n: the lane's rows, from step 1
 template <int RR, int R>
-TP_HD void pk_walk_sum(const pk_lane_cache<R>& C, const pk_scan_out& S, const pk_view& V, int pitch, const char* table, int W, pk_acc& a) {
-#else
-template <int RR, int R>
-TP_HD void pk_walk_sum(const pk_lane_cache<R>& C, const pk_scan& S, const char* table, int W, pk_acc& a) {
-#endif
-    a.xs = S.sx; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
+TP_HD void pk_walk_sum(const pk_lane_cache<R>& C, int n, const pk_view& V, int pitch, const char* table, int W, pk_acc& a) {
+    a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
+#pragma unroll
+    for (int u = 0; u < RR; u++) a.xs += (uint32_t)C.col[u];
     uint64_t lo = 0, hi = 0;
 #pragma unroll
     for (int u = 0; u < RR; u++) { lo += C.rec[u].lo; hi += C.rec[u].hi; }
     pk_add_unpacked(lo, hi, a);
-#if defined(PK_EXP_LEAN)   // (the rows are worked out again in the rare case: nothing of the scan but two words stays live until here)
-    if (S.n > RR) {
+    if (n > RR) {   // the line has grown beyond the rows this workgroup's lanes keep (its rows are worked out again here, in
+                    // the rare case, so that nothing of step 1 but `n` stays in registers across the fetches)
         pk_rows r = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
-#else
-    if (S.r.n > RR) {   // the line has grown beyond the rows this workgroup's lanes keep
-        pk_rows r = S.r;
-#endif
         r.n -= RR; r.x = (int64_t)((uint64_t)r.x + (uint64_t)RR * (uint64_t)r.xs); r.row += (uint32_t)RR * r.rs;
         pk_walk_rows<4>(r, table, W, a);
     }
 }
 template <int RR, int R>
 TP_HD void pk_walk_cached(pk_lane_cache<R>& C, const pk_view& V, const char* table, int pitch, int W, pk_acc& a) {
-    const pk_scan S = pk_walk_scan<RR>(C, V, pitch, W);
-    if (S.stale != 0u) pk_walk_fetch<RR>(C, S, table, W);
-#if defined(PK_EXP_LEAN)
-    const pk_scan_out So = {S.sx, S.r.n};
-    pk_walk_sum<RR>(C, So, V, pitch, table, W, a);
-#else
-    pk_walk_sum<RR>(C, S, table, W, a);
-#endif
+    const int n = pk_walk_pass<RR>(C, V, pitch, table, W);
+    pk_walk_sum<RR>(C, n, V, pitch, table, W, a);
 }
 
 // tag of grad-iter `epoch`: never 0 (a cleared mailbox matches nothing), and no two grad-iters of a context's life share one
@@ -420,23 +371,6 @@ TP_HD tp_moments pk_moments3(int c0, const unsigned long long* S0, int c1, const
     }
     const tp_moments mm = {mo[0], mo[1], mo[2], mo[3], mo[4], mo[5]};
     return mm;
-}
-// P6, lane (corner k, move m = 1..4): the moments of variant (t, 4 s + m) of the corner's triangle -- the corner's vertex
-// displaced by move m
-TP_HD tp_moments pk_corner_moments(const pk_wg& w, const pk_view& V, int k, int m) {
-    const pk_i4 cr = V.corners[k];
-    const int s = cr.y & 3, own = (cr.y >> 2) & 0x3ff, sa = (cr.y >> 12) & 0x3ff, sb = (cr.y >> 22) & 0x3ff;
-    const int sn = s == 2 ? 0 : s + 1, sp = s == 0 ? 2 : s - 1;
-    int32_t X[3], Y[3], c[3];
-    const pk_i2 pv = V.snap[pk_snap_index(w, own, m)], pa = V.snap[pk_snap_index(w, sa, 0)], pb = V.snap[pk_snap_index(w, sb, 0)];
-    X[s] = pv.x; Y[s] = pv.y; X[sn] = pa.x; Y[sn] = pa.y; X[sp] = pb.x; Y[sp] = pb.y;
-    tp_variant_coeffs(X, Y, c);
-    // edge s leaves the vertex, edge sp arrives at it, edge sn is opposite
-    const int cs = s == 0 ? c[0] : s == 1 ? c[1] : c[2];
-    const int cn = sn == 0 ? c[0] : sn == 1 ? c[1] : c[2];
-    const int cp = sp == 0 ? c[0] : sp == 1 ? c[1] : c[2];
-    return pk_moments3(cs, V.sums + (size_t)((cr.z & 0xffff) + m - 1) * PK_SUM_WORDS, cp, V.sums + (size_t)(((cr.z >> 16) & 0xffff) + m - 1) * PK_SUM_WORDS,
-                       cn, V.sums + (size_t)(cr.w & 0xffff) * PK_SUM_WORDS);
 }
 // P1, lane (corner k, move m): with which signs the three line sums enter the variant's moments -- from the positions alone, so
 // it is done while other lanes set the lines up, and P6 starts from the sums.  Two bits each: edge leaving the vertex | edge

@@ -110,14 +110,13 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const int4 c = A.ca[(size_t)(4 * s + m) * A.NT + t];
         col0.x = c.x; col0.y = c.y; col0.z = c.z; col0.w = c.w;
     }
-#if defined(PK_EXP_P1REGS)   // the ends of this thread's first line never change during a launch
+    // the ends of this thread's first line never change during a launch: slot u | slot v << 10 | version << 20
     int my_ends = 0;
     if (tid < w.n_lines_all) {
         const int ln_ = A.pool[w.off_lines + tid], ed_ = A.pool[w.off_edges + (ln_ & 0xffff)];
         my_ends = (ed_ & 0x3ff) | (((ed_ >> 16) & 0x3ff) << 10) | ((ln_ >> 16) << 20);
     }
-#endif
-#if defined(PK_EXP_COEF)     // ... and neither do the line-sum slots of its first corner variant
+    // ... and neither do the line-sum slots of its first corner variant: edge leaving the vertex | arriving << 16; opposite | own slot << 16
     int my_c0 = 0, my_c1 = 0;
     if (tid < 4 * w.n_corners) {
         const int32_t* cr_ = A.pool + w.off_corners + 4 * (tid >> 2);
@@ -125,7 +124,6 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         my_c0 = ((cr_[2] & 0xffff) + m_) | ((((cr_[2] >> 16) & 0xffff) + m_) << 16);
         my_c1 = (cr_[3] & 0xffff) | (((cr_[1] >> 2) & 0x3ff) << 16);
     }
-#endif
     const char* table = reinterpret_cast<const char*>(A.px);
     // this thread's lane-item of the walk and the table records of its rows: in registers for the whole launch
     pk_lane_cache<RR> cache[PK_NI];
@@ -145,11 +143,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         PK_STAMP(0);
         // ---- P0: positions of the neighbouring vertices this patch uses (the first grad-iter of a launch read `points`)
         if (it > 0) {
-#if defined(PK_EXP_POLLWAVE)   // (the second wave polls while the first takes the steps)
-            for (int s = w.n_own_v + ((tid + PK_THREADS - 64) & (PK_THREADS - 1)); s < w.n_slots; s += PK_THREADS) {
-#else
             for (int s = w.n_own_v + tid; s < w.n_slots; s += PK_THREADS) {
-#endif
                 gu64* g = posbox + ((size_t)par * A.box_stride + V.vid[s]) * 2;
                 spin_state st = {0u, 0ull};
                 unsigned long long a, b;
@@ -167,19 +161,15 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // ---- P1: line set-up (low threads), snapped positions (high threads), gradient reset
         for (int l = tid; l < n_setup; l += PK_THREADS) {
             pk_walker wk;
-#if defined(PK_EXP_P1REGS)
             if (l == tid) pk_setup_ends(V, A.vw, my_ends & 0x3ff, (my_ends >> 10) & 0x3ff, my_ends >> 20, wk);
-            else
-#endif
-            pk_setup_lane(V, A.vw, l, wk);
+            else pk_setup_lane(V, A.vw, l, wk);
             V.wk[l] = wk;
         }
         {
             const int nsnap = 5 * w.n_own_v + (w.n_slots - w.n_own_v);
             for (int j = PK_THREADS - 1 - tid; j < nsnap; j += PK_THREADS) pk_snap_lane(w, V, A.vw, j);
-#if defined(PK_EXP_COEF)
+            // (the signs of the corner variants' line sums, by the waves that set up no lines: P6 starts from the sums)
             for (int j = (tid + PK_THREADS / 2) & (PK_THREADS - 1); j < 4 * w.n_corners; j += PK_THREADS) V.coef[j] = pk_coef_lane(V, A.vw, j >> 2, (j & 3) + 1);
-#endif
             for (int k = tid; k < w.n_own_v; k += PK_THREADS) {
                 V.grad[k].x = 0; V.grad[k].y = 0;
                 if (A.pring) {   // (a frame can be returned to)
@@ -236,50 +226,17 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         };
         // (each step for both lane-items of the thread before the next step: their fetches are in flight together)
         {
-#if defined(PK_EXP_LEAN)
-            pk_scan_out So[PK_NI];
+            int rows[PK_NI];
 #pragma unroll
-            for (int i = 0; i < PK_NI; i++) {
-#if defined(PK_EXP_ONEPASS)
-                So[i] = pk_walk_pass<RR>(cache[i], V, A.px_pitch, table, A.vw.W);
-#else
-                const pk_scan S = pk_walk_scan<RR>(cache[i], V, A.px_pitch, A.vw.W);
-                if (S.stale != 0u) pk_walk_fetch<RR>(cache[i], S, table, A.vw.W);
-                So[i].sx = S.sx; So[i].n = S.r.n;
-#endif
-            }
+            for (int i = 0; i < PK_NI; i++) rows[i] = pk_walk_pass<RR>(cache[i], V, A.px_pitch, table, A.vw.W);
             PK_STAMP(8);
 #pragma unroll
             for (int i = 0; i < PK_NI; i++) {
                 pk_acc a;
-                pk_walk_sum<RR>(cache[i], So[i], V, A.px_pitch, table, A.vw.W, a);
+                pk_walk_sum<RR>(cache[i], rows[i], V, A.px_pitch, table, A.vw.W, a);
                 fold(cache[i].l, a);
             }
             PK_STAMP(9);
-#else
-            pk_scan S[PK_NI];
-#if defined(PK_EXP_ORDER)   // (the second lane-item's scan runs while the first one's fetches are in flight)
-#pragma unroll
-            for (int i = 0; i < PK_NI; i++) {
-                S[i] = pk_walk_scan<RR>(cache[i], V, A.px_pitch, A.vw.W);
-                if (S[i].stale != 0u) pk_walk_fetch<RR>(cache[i], S[i], table, A.vw.W);
-            }
-#else
-#pragma unroll
-            for (int i = 0; i < PK_NI; i++) S[i] = pk_walk_scan<RR>(cache[i], V, A.px_pitch, A.vw.W);
-#pragma unroll
-            for (int i = 0; i < PK_NI; i++)
-                if (S[i].stale != 0u) pk_walk_fetch<RR>(cache[i], S[i], table, A.vw.W);
-#endif
-            PK_STAMP(8);
-#pragma unroll
-            for (int i = 0; i < PK_NI; i++) {
-                pk_acc a;
-                pk_walk_sum<RR>(cache[i], S[i], table, A.vw.W, a);
-                fold(cache[i].l, a);
-            }
-            PK_STAMP(9);
-#endif
         }
         // (lane-items beyond the cached ones: a patch with more than PK_CACHED, and the base lines of the last grad-iter)
         for (int j = (n_li_now < PK_CACHED ? n_li_now : PK_CACHED) + tid; j < n_li; j += PK_THREADS) {
@@ -299,7 +256,6 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 const int4 c = A.ca[(size_t)(4 * (cq.y & 3) + m) * A.NT + cq.x];
                 col.x = c.x; col.y = c.y; col.z = c.z;
             }
-#if defined(PK_EXP_COEF)
             int so, si, sopp, own;
             if (j == tid) { so = my_c0 & 0xffff; si = (int)((unsigned)my_c0 >> 16); sopp = my_c1 & 0xffff; own = my_c1 >> 16; }
             else {
@@ -307,19 +263,12 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 so = (cq.z & 0xffff) + m - 1; si = ((cq.z >> 16) & 0xffff) + m - 1; sopp = cq.w & 0xffff; own = (cq.y >> 2) & 0x3ff;
             }
             const tp_moments mm = pk_coef_moments(V, V.coef[j], so, si, sopp);
-#else
-            const pk_i4 cr = V.corners[k];
-            const tp_moments mm = pk_corner_moments(w, V, k, m);
-            const int own = (cr.y >> 2) & 0x3ff;
-#endif
             const int32_t e = pk_energy(mm, A.flavour, col);
             const uint32_t d = (uint32_t)e - (uint32_t)__shfl_xor(e, 1);   // lanes 4k+0/1: E(+dx), E(-dx); 4k+2/3: E(+dy), E(-dy)
             if ((j & 3) == 0) atomicAdd(&V.grad[own].x, (int)d);
             if ((j & 3) == 2) atomicAdd(&V.grad[own].y, (int)d);
             if (emit) {
-#if defined(PK_EXP_COEF)
-                const pk_i4 cr = V.corners[k];
-#endif   // the variant's outputs in the reference's layout, id = i NT + t (triangle.vs:47-48)
+                const pk_i4 cr = V.corners[k];   // the variant's outputs in the reference's layout, id = i NT + t (triangle.vs:47-48)
                 const size_t id = (size_t)(4 * (cr.y & 3) + m) * A.NT + cr.x;
                 if (A.flavour == 0) A.ca_out[id] = make_int4(tp_wrap32(mm.sr), tp_wrap32(mm.sg), tp_wrap32(mm.sb), 0);
                 A.ten[id] = e; A.cn[id] = tp_wrap32(mm.n);
