@@ -141,7 +141,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             for (int j = 0; j < 4 * w.n_corners; j++) V.coef[j] = pk_coef_lane(V, vw, j >> 2, (j & 3) + 1);
             memset(V.sums, 0, sizeof(unsigned long long) * PK_SUM_WORDS * (size_t)w.n_lines_all);
             if (recut) {   // the wave's lanes one after the other
-                const int RRk = P.rows_max <= 7 ? 8 : P.rows_max <= 9 ? 10 : P.rows_max <= 10 ? 11 : 12;   // tp_launch_persist's choice
+                const int RRk = pk_rr_for(P.rows_max);   // tp_launch_persist's choice
                 int changed = 0, sum[64];
                 int rpl = it == 0 ? w.rows : S[p].rpl;
                 bool first = it == 0;
@@ -170,7 +170,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             // P3
             if (g_walk_stats && it < g_walk_stats_iters) {
                 int64_t* ws = g_walk_stats + 6 * (size_t)it;
-                const int RRk = P.rows_max <= 7 ? 8 : P.rows_max <= 9 ? 10 : P.rows_max <= 10 ? 11 : 12;   // tp_launch_persist's choice
+                const int RRk = pk_rr_for(P.rows_max);   // tp_launch_persist's choice
                 int64_t over_rows = 0, stale = 0;
                 for (int j = 0; j < PK_CACHED; j++) {   // (what pk_walk_pass is about to find, without changing anything)
                     const auto& C = S[p].cache[j];

@@ -291,7 +291,7 @@ TP_HD void pk_cache_init(pk_lane_cache<R>& C, const pk_view& V, int slot, int n_
 // walk that fetched when anything in the WAVE was stale -- which is nearly always: one pass is 0.3 us per grad-iter less.)
 template <int RR, int R>
 TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int pitch, const char* table, int W) {
-    static_assert(RR <= R && RR <= TP_PX_MAXSUM, "records added before unpacking");
+    static_assert(RR <= R && RR <= 32, "one bit per row");
     pk_rows t;
     if (C.TL == 0) { t.n = 0; t.x = 0; t.xs = 0; t.row = 0; t.rs = 0; }
     else t = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
@@ -324,10 +324,13 @@ TP_HD void pk_walk_sum(const pk_lane_cache<R>& C, int n, const pk_view& V, int p
     a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
 #pragma unroll
     for (int u = 0; u < RR; u++) a.xs += (uint32_t)C.col[u];
-    uint64_t lo = 0, hi = 0;
 #pragma unroll
-    for (int u = 0; u < RR; u++) { lo += C.rec[u].lo; hi += C.rec[u].hi; }
-    pk_add_unpacked(lo, hi, a);
+    for (int u0 = 0; u0 < RR; u0 += TP_PX_MAXSUM) {   // (so many records add up before a field carries into the next)
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int u = u0; u < RR && u < u0 + TP_PX_MAXSUM; u++) { lo += C.rec[u].lo; hi += C.rec[u].hi; }
+        pk_add_unpacked(lo, hi, a);
+    }
     if (n > RR) {   // the line has grown beyond the rows this workgroup's lanes keep (its rows are worked out again here, in
                     // the rare case, so that nothing of step 1 but `n` stays in registers across the fetches)
         pk_rows r = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);

@@ -340,21 +340,21 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 
 int tp_persist_set_lds(int bytes) {
-    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<8>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<10>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<11>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<PK_RR0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<PK_RR1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<PK_RR2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<PK_ROWS_PER_LANE>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     return rc;
 }
 // rows: the most rows per lane of any patch of the plan (pk_plan::rows_max); the census passes PK_ROWS_PER_LANE
 void tp_launch_persist(const pk_args& A, int grid, int rows, int lds_bytes, hipStream_t s) {
     const dim3 g((unsigned)grid), b(PK_THREADS);
-    // (one row more than the plan's rows per lane where there is an instantiation for it: a line that has grown by a chunk's
-    // worth of rows since the plan was cut still fits the records its lanes keep)
-    if (rows <= 7) hipLaunchKernelGGL(k_persist<8>, g, b, (size_t)lds_bytes, s, A);
-    else if (rows <= 9) hipLaunchKernelGGL(k_persist<10>, g, b, (size_t)lds_bytes, s, A);
-    else if (rows <= 10) hipLaunchKernelGGL(k_persist<11>, g, b, (size_t)lds_bytes, s, A);
-    else hipLaunchKernelGGL(k_persist<PK_ROWS_PER_LANE>, g, b, (size_t)lds_bytes, s, A);
+    switch (pk_rr_for(rows)) {
+        case PK_RR0: hipLaunchKernelGGL(k_persist<PK_RR0>, g, b, (size_t)lds_bytes, s, A); break;
+        case PK_RR1: hipLaunchKernelGGL(k_persist<PK_RR1>, g, b, (size_t)lds_bytes, s, A); break;
+        case PK_RR2: hipLaunchKernelGGL(k_persist<PK_RR2>, g, b, (size_t)lds_bytes, s, A); break;
+        default: hipLaunchKernelGGL(k_persist<PK_ROWS_PER_LANE>, g, b, (size_t)lds_bytes, s, A); break;
+    }
 }
 
 

@@ -35,11 +35,17 @@
 #ifndef PK_WG_PER_CU
 #define PK_WG_PER_CU 1        /* workgroups (patches) per compute unit: PK_THREADS x this = 512 threads, two waves per SIMD */
 #endif
+#ifndef PK_NI
 #define PK_NI 2                /* lane-items of the walk a thread keeps table records for, in registers */
+#endif
 #define PK_CACHED (PK_THREADS * PK_NI)
 #ifndef PK_ROWS_PER_LANE
 #define PK_ROWS_PER_LANE 12  /* table records a lane of the walk keeps in registers: the most rows per lane */
 #endif
+/* the instantiations of the kernel: rows a lane keeps records for (fewer rows, fewer registers and less straight-line code) */
+#define PK_RR0 (PK_ROWS_PER_LANE * 2 / 3)
+#define PK_RR1 (PK_ROWS_PER_LANE * 5 / 6)
+#define PK_RR2 (PK_ROWS_PER_LANE * 11 / 12)
 #define PK_MAX_SLOTS 1023    /* position slots of a workgroup (10-bit fields of the corner records) */
 #define PK_MAX_TL 4095       /* chunks per line */
 #ifndef PK_SLACK_ROWS
@@ -89,6 +95,9 @@ struct pk_plan {
 #define PK_HD inline
 #endif
 PK_HD int pk_align16(int v) { return (v + 15) & ~15; }
+// the instantiation that runs a plan whose patches take at most `rows` rows per lane: one row more than the plan's where
+// there is one (a line that has grown by a chunk's worth of rows since the plan was cut still fits the records its lanes keep)
+PK_HD int pk_rr_for(int rows) { return rows < PK_RR0 ? PK_RR0 : rows < PK_RR1 ? PK_RR1 : rows < PK_RR2 ? PK_RR2 : PK_ROWS_PER_LANE; }
 // chunks of a line of `rows` pixel rows when a lane takes `rpl` of them
 PK_HD int pk_chunks(int rows, int rpl) {
     const int t = (rows + PK_SLACK_ROWS + rpl - 1) / rpl;
