@@ -167,7 +167,9 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         {
             const int nsnap = 5 * w.n_own_v + (w.n_slots - w.n_own_v);
-            for (int j = PK_THREADS - 1 - tid; j < nsnap; j += PK_THREADS) pk_snap_lane(w, V, A.vw, j);
+            // (snapped positions: only the base variants' moments read them -- the last grad-iter of a call, and every frame of tp_iterate_until)
+            if (emit || A.ering)
+                for (int j = PK_THREADS - 1 - tid; j < nsnap; j += PK_THREADS) pk_snap_lane(w, V, A.vw, j);
             // (the signs of the corner variants' line sums, by the waves that set up no lines: P6 starts from the sums)
             for (int j = (tid + PK_THREADS / 2) & (PK_THREADS - 1); j < 4 * w.n_corners; j += PK_THREADS) V.coef[j] = pk_coef_lane(V, A.vw, j >> 2, (j & 3) + 1);
             for (int k = tid; k < w.n_own_v; k += PK_THREADS) {
