@@ -183,7 +183,7 @@ def cold_cache_figure(capi, synth, device, params, pts, tris, flavour, planes=5,
                 colors = synth.mean_colors(img_k, pts, tris, float(W) / float(H))
             c.upload(pts, tris, colors)
             c.prepare(params)
-            c.iterate(params, steps_per_call)
+            c.iterate(params, 2048)   # (past the first, fast phase of the descent, like the context of the timed region)
             c.synchronize()
             ctxs.append(c)
 

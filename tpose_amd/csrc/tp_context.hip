@@ -18,6 +18,8 @@
 #include <unordered_map>
 #include <vector>
 #include <chrono>
+#include <future>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 
@@ -128,6 +130,19 @@ struct tp_context {
     int snap_next = 0;
     int iters_since_snap = 0;
     int64_t replans = 0;
+    // a new plan being cut on another host thread (2.6 ms at 3000 triangles: a call of a few grad-iters must not wait for it).
+    // The job owns copies of everything it reads; its result is installed by the next chunk that finds it finished, and
+    // dropped when the triangulation or the kind of plan has changed meanwhile.
+    struct replan_job {
+        std::future<void> done;
+        pk_plan plan;
+        std::vector<float> points;
+        std::vector<int32_t> tris, edge_uv, he_edge;
+        uint64_t generation = 0;
+        bool base_every = false;
+        float dp = 0.0f;
+    };
+    std::unique_ptr<replan_job> job;
     bool plan_base_every = false;   // the current plan walks every triangle's base lines in every grad-iter (tp_iterate_until)
     int32_t* ering = nullptr; float2* pring = nullptr;   // tp_iterate_until: per-frame base energies / positions of a chunk
     size_t cap_ering = 0, cap_pring = 0;
@@ -357,17 +372,9 @@ int take_census(tp_context* c) {
 #define PK_REPLAN_PX 2.0f     /* a vertex this far from where the plan saw it: cut a new plan */
 #endif
 
-// cut a plan from `points` and send it to plan buffer `slot` (through that buffer's pinned staging area: the copy rides
-// the stream and the host does not wait for it).  c->plan is replaced only when the new plan is usable.
-int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok) {
-    pk_plan np;
-    pk_build_plan(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
-                  c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, c->n_bands > 1 ? c->n_bands * c->band_patches : c->num_cus * PK_WG_PER_CU, PK_LDS_LIMIT, np,
-                  c->plan_base_every);
-    // (a band split runs equal shares of the patches: a plan with fewer patches than asked for -- a tiny mesh -- is not split)
-    if (np.ok && c->n_bands > 1 && np.parts != c->n_bands * c->band_patches) { np.ok = false; np.why = "fewer patches than the bands need"; }
-    *ok = np.ok;
-    if (!np.ok) { if (!c->plan.ok) c->plan = np; return TP_OK; }
+// send a plan that was cut from `points` to plan buffer `slot` (through that buffer's pinned staging area: the copy rides
+// the stream and the host does not wait for it) and make it the context's plan
+int install_plan(tp_context* c, pk_plan& np, const float* points, int slot) {
     tp_context::plan_buf& B = c->plan_dev[slot];
     if (int rc = grow(c, &B.wg, &B.cap_wg, np.wg.size())) return rc;
     if (int rc = grow(c, &B.pool, &B.cap_pool, np.pool.size())) return rc;
@@ -388,6 +395,49 @@ int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok)
     c->plan = std::move(np);
     c->plan_slot = slot;
     c->plan_points.assign(points, points + 2 * (size_t)c->NP);
+    return TP_OK;
+}
+int plan_patches(const tp_context* c) { return c->n_bands > 1 ? c->n_bands * c->band_patches : c->num_cus * PK_WG_PER_CU; }
+
+// cut a plan from `points` and install it in plan buffer `slot`.  c->plan is replaced only when the new plan is usable.
+int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok) {
+    pk_plan np;
+    pk_build_plan(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
+                  c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, plan_patches(c), PK_LDS_LIMIT, np,
+                  c->plan_base_every);
+    // (a band split runs equal shares of the patches: a plan with fewer patches than asked for -- a tiny mesh -- is not split)
+    if (np.ok && c->n_bands > 1 && np.parts != c->n_bands * c->band_patches) { np.ok = false; np.why = "fewer patches than the bands need"; }
+    *ok = np.ok;
+    if (!np.ok) { if (!c->plan.ok) c->plan = np; return TP_OK; }
+    return install_plan(c, np, points, slot);
+}
+
+// the same cut on another host thread, from a snapshot of the positions (maybe_replan); nothing of the context is touched
+// until take_replan() finds the job finished
+void start_replan(tp_context* c, const float* points, float dp) {
+    auto j = std::make_unique<tp_context::replan_job>();
+    j->points.assign(points, points + 2 * (size_t)c->NP);
+    j->tris = c->h_tris; j->edge_uv = c->h_edge_uv; j->he_edge = c->h_he_edge;
+    j->generation = c->generation; j->base_every = c->plan_base_every; j->dp = dp;
+    tp_context::replan_job* J = j.get();
+    const int NP = c->NP, NT = c->NT, NE = c->NE, W = c->W, H = c->H, parts = plan_patches(c);
+    const float ratio = c->ratio;
+    j->done = std::async(std::launch::async, [J, NP, NT, NE, W, H, ratio, parts]() {
+        pk_build_plan(NP, NT, J->tris.data(), J->points.data(), NE, J->edge_uv.data(), J->he_edge.data(), W, H, ratio,
+                      J->dp * 0.5f * (float)H, parts, PK_LDS_LIMIT, J->plan, J->base_every);
+    });
+    c->job = std::move(j);
+}
+// a finished job's plan becomes the context's (for the launches enqueued from now on); a job of another triangulation, or of
+// the other kind of plan, is dropped
+int take_replan(tp_context* c, bool wait = false) {
+    if (!c->job) return TP_OK;
+    if (!wait && c->job->done.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return TP_OK;
+    c->job->done.get();
+    std::unique_ptr<tp_context::replan_job> j = std::move(c->job);
+    if (j->generation != c->generation || c->plan_generation != c->generation || j->base_every != c->plan_base_every || !j->plan.ok || c->n_bands > 1) return TP_OK;
+    if (int rc = install_plan(c, j->plan, j->points.data(), c->plan_slot ^ 1)) return rc;
+    c->replans++;
     return TP_OK;
 }
 
@@ -457,10 +507,8 @@ int maybe_replan(tp_context* c, float dp) {
         const float d = (dx < 0 ? -dx : dx) > (dy < 0 ? -dy : dy) ? (dx < 0 ? -dx : dx) : (dy < 0 ? -dy : dy);
         if (d > worst) worst = d;   // (NaN never compares greater: a vertex gone to NaN does not trigger)
     }
-    if (worst <= PK_REPLAN_PX) return TP_OK;
-    bool ok = false;
-    if (int rc = build_plan(c, q, dp, c->plan_slot ^ 1, &ok)) return rc;
-    if (ok) c->replans++;
+    if (worst <= PK_REPLAN_PX || c->job) return TP_OK;   // (one cut at a time: the one under way is from positions nearly as new)
+    start_replan(c, q, dp);
     return TP_OK;
 }
 
@@ -477,7 +525,10 @@ float2* band_pring(const tp_context* c, int b) { return (float2*)((char*)c->band
 // n grad-iters of the persistent kernel -- the last one writes `tenergy`, `colnum`, `colacc`, `gradient` --, then
 // `points_out` -> `points` / `epos`
 int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings = false) {
-    while (n > 0) {
+    for (bool first = true; n > 0; first = false) {
+        // a plan cut on the side: at the start of a call, only if it is ready (a call of a few grad-iters never waits for
+        // the cut); between the chunks of a long call the host waits for it -- the GPU has the chunk before to run meanwhile
+        if (int rc = take_replan(c, !first)) return rc;
         // long calls go chunk by chunk (a chunk and a half rather than a short tail)
         const int k = n <= PK_CHUNK + PK_CHUNK / 2 ? n : PK_CHUNK;   // (rings: the caller's chunks are shorter than this)
         if (c->epoch + (uint32_t)k > PK_MAX_EPOCH) {
