@@ -104,6 +104,14 @@ TP_HD uint32_t pk_div(uint32_t x, uint32_t magic) {
 #endif
 }
 
+// a * b for a, b < 2^24 (full rate on this part; 32-bit integer multiplications run at a quarter of it)
+TP_HD uint32_t pk_mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
 TP_HD uint32_t pk_magic(int d) { return d == 1 ? 0u : (uint32_t)(4294967296.0 / (double)d) + 1u; }
 
 // ---- The chunks of a patch's lines.  A line of r rows is walked by ceil((r + slack) / rows-per-lane) lanes (its chunks,
@@ -188,16 +196,16 @@ struct pk_rows { int n; int64_t x, xs; uint32_t row, rs; };
 TP_HD pk_rows pk_lane_rows(const pk_walker& ln, int c, int TL, uint32_t magic, int pitch) {
     pk_rows r; r.n = 0; r.x = 0; r.xs = 0; r.row = 0; r.rs = 0;
     if (ln.ra > ln.rb) return r;
-    int d = c - (ln.ra - (int)pk_div((uint32_t)ln.ra, magic) * TL);   // c - ra mod TL
+    int d = c - (ln.ra - (int)pk_mul24(pk_div((uint32_t)ln.ra, magic), (uint32_t)TL));   // c - ra mod TL (rows and chunks < 2^13)
     d += d < 0 ? TL : 0;
     const int first = ln.ra + d;
     if (ln.rb < first) return r;
     r.n = (int)pk_div((uint32_t)(ln.rb - first), magic) + 1;
     r.x = ln.x + (int64_t)d * ln.s;
     r.xs = (int64_t)((uint64_t)ln.s * (uint64_t)TL);                              // (unsigned: a steep two-row line may wrap, unused then)
-    // (byte offsets into the table fit 32 bits: 4096 rows x 4104 records x 16 bytes < 2^29)
-    r.row = (uint32_t)first * (uint32_t)pitch * 16u;
-    r.rs = (uint32_t)TL * (uint32_t)pitch * 16u;
+    // (byte offsets into the table fit 32 bits: 4096 rows x 4104 records x 16 bytes < 2^29; rows, chunks < 2^13 and a row's bytes < 2^17)
+    r.row = pk_mul24((uint32_t)first, (uint32_t)pitch * 16u);
+    r.rs = pk_mul24((uint32_t)TL, (uint32_t)pitch * 16u);
     return r;
 }
 // crossing column of the current row, clamped to [0, W]; then one row on
@@ -296,24 +304,30 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int pitch, const c
     if (C.TL == 0) { t.n = 0; t.x = 0; t.xs = 0; t.row = 0; t.rs = 0; }
     else t = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
     const uint32_t live = t.n >= 32 ? 0xffffffffu : ((1u << t.n) - 1u);   // bit u: row u exists
-    if (t.row != C.row0) {   // another first row: every record is another row's (an endpoint crossed a pixel row)
-        C.row0 = t.row;
+    const bool moved = t.row != C.row0;   // another first row: every record is another row's (an endpoint crossed a pixel row)
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__any(moved)) {   // (one answer per wave, and kept a branch: as selects the rare case would cost every row an instruction)
+        asm volatile("" ::: "memory");
+#else
+    {
+#endif
+        if (moved) {
+            C.row0 = t.row;
 #pragma unroll
-        for (int u = 0; u < RR; u++) C.col[u] = -1;
+            for (int u = 0; u < RR; u++) C.col[u] = -1;
+        }
     }
     const int n = t.n;
-    uint32_t row = t.row;
 #pragma unroll
     for (int u = 0; u < RR; u++) {
         const uint32_t on = 0u - ((live >> u) & 1u);
         const int32_t col = pk_next_col(t, W) & (int32_t)on;
         if (col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
 #if !defined(PK_EXP_NOLOAD)   // timing experiments only (tools/build_variants.py); never defined in the product
-            C.rec[u] = *reinterpret_cast<const pk_rec*>(table + ((row & on) + ((uint32_t)col << 4)));
+            C.rec[u] = *reinterpret_cast<const pk_rec*>(table + (((t.row + (uint32_t)u * t.rs) & on) + ((uint32_t)col << 4)));
 #endif
             C.col[u] = col;
         }
-        row += t.rs;
     }
     return n;
 }

@@ -60,7 +60,7 @@ __device__ __forceinline__ int patch_of_block(int b, int parts) {
 // RR: table records a lane keeps per lane-item = the most rows per lane of any patch of the plan (the launcher picks the
 // smallest instantiation that covers the plan: fewer rows, fewer registers and less straight-line code)
 template <int RR>
-__global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_persist(pk_args A) {
+__global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_THREADS / 256, PK_THREADS / 256))) void k_persist(pk_args A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int part = A.part0 + patch_of_block((int)blockIdx.x, (int)gridDim.x);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (emit || A.ering)
                 for (int j = PK_THREADS - 1 - tid; j < nsnap; j += PK_THREADS) pk_snap_lane(w, V, A.vw, j);
             // (the signs of the corner variants' line sums, by the waves that set up no lines: P6 starts from the sums)
-            for (int j = (tid + PK_THREADS / 2) & (PK_THREADS - 1); j < 4 * w.n_corners; j += PK_THREADS) V.coef[j] = pk_coef_lane(V, A.vw, j >> 2, (j & 3) + 1);
+            for (int j = tid >= PK_THREADS / 2 ? tid - PK_THREADS / 2 : tid + PK_THREADS / 2; j < 4 * w.n_corners; j += PK_THREADS) V.coef[j] = pk_coef_lane(V, A.vw, j >> 2, (j & 3) + 1);
             for (int k = tid; k < w.n_own_v; k += PK_THREADS) {
                 V.grad[k].x = 0; V.grad[k].y = 0;
                 if (A.pring) {   // (a frame can be returned to)
