@@ -59,7 +59,10 @@ __device__ __forceinline__ int patch_of_block(int b, int parts) {
 
 // RR: table records a lane keeps per lane-item = the most rows per lane of any patch of the plan (the launcher picks the
 // smallest instantiation that covers the plan: fewer rows, fewer registers and less straight-line code)
-template <int RR>
+// MODE: 0 a plain tp_iterate, 1 with the rings of tp_iterate_until, 2 a band of a split descent (rings decided at run time).
+// (One kernel for all three kept a dozen pointers of the rare cases in scalar registers -- 130 of them spilled to vector
+// lanes -- and cost every grad-iter of the common case 0.3 us.)
+template <int RR, int MODE>
 __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_THREADS / 256, PK_THREADS / 256))) void k_persist(pk_args A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -128,7 +131,9 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
     // this thread's lane-item of the walk and the table records of its rows: in registers for the whole launch
     pk_lane_cache<RR> cache[PK_NI];
     gu64* posbox = (gu64*)A.posbox;
-    const bool banded = A.n_peers > 0;
+    const bool banded = MODE == 2;
+    int32_t* const ering = MODE == 0 ? nullptr : A.ering;
+    float2* const pring = MODE == 0 ? nullptr : A.pring;
     int failed = 0;
     int n_li_now = 0, n_li_all_now = 0;   // lane-items of the lines walked every grad-iter / with the last one's base lines
     __syncthreads();
@@ -168,19 +173,19 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         {
             const int nsnap = 5 * w.n_own_v + (w.n_slots - w.n_own_v);
             // (snapped positions: only the base variants' moments read them -- the last grad-iter of a call, and every frame of tp_iterate_until)
-            if (emit || A.ering)
+            if (emit || ering)
                 for (int j = PK_THREADS - 1 - tid; j < nsnap; j += PK_THREADS) pk_snap_lane(w, V, A.vw, j);
             // (the signs of the corner variants' line sums, by the waves that set up no lines: P6 starts from the sums)
             for (int j = tid >= PK_THREADS / 2 ? tid - PK_THREADS / 2 : tid + PK_THREADS / 2; j < 4 * w.n_corners; j += PK_THREADS) V.coef[j] = pk_coef_lane(V, A.vw, j >> 2, (j & 3) + 1);
             for (int k = tid; k < w.n_own_v; k += PK_THREADS) {
                 V.grad[k].x = 0; V.grad[k].y = 0;
-                if (A.pring) {   // (a frame can be returned to)
+                if (pring) {   // (a frame can be returned to)
                     const size_t at = (size_t)it * A.NP + V.vid[k];
                     if (banded) {   // (system scope, write-through: the other bands' posts land in the same lines)
                         const unsigned long long w8 = (unsigned long long)__float_as_uint(V.pos[k].x) | ((unsigned long long)__float_as_uint(V.pos[k].y) << 32);
-                        __hip_atomic_store((gu64*)A.pring + at, w8, PK_RLX_SYSTEM);
+                        __hip_atomic_store((gu64*)pring + at, w8, PK_RLX_SYSTEM);
                         for (int b = 0; b < A.n_peers; b++) __hip_atomic_store((gu64*)A.peer_pring[b] + at, w8, PK_RLX_SYSTEM);
-                    } else A.pring[at] = make_float2(V.pos[k].x, V.pos[k].y);
+                    } else pring[at] = make_float2(V.pos[k].x, V.pos[k].y);
                 }
             }
         }
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 A.ten[id] = e; A.cn[id] = tp_wrap32(mm.n);
             }
         }
-        if (A.ering && !emit) {   // tp_iterate_until: the energy of the base variants, frame by frame (the plan walks their lines every grad-iter)
+        if (ering && !emit) {   // tp_iterate_until: the energy of the base variants, frame by frame (the plan walks their lines every grad-iter)
             for (int k = tid; k < w.n_base; k += PK_THREADS) {
                 int t;
                 const tp_moments mm = pk_base_moments(w, V, k, t);
@@ -285,9 +290,9 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 const int32_t en = pk_energy(mm, A.flavour, col);
                 const size_t at = (size_t)it * A.NT + t;
                 if (banded) {
-                    __hip_atomic_store((gu32*)A.ering + at, (unsigned)en, PK_RLX_SYSTEM);
+                    __hip_atomic_store((gu32*)ering + at, (unsigned)en, PK_RLX_SYSTEM);
                     for (int b = 0; b < A.n_peers; b++) __hip_atomic_store((gu32*)A.peer_ering[b] + at, (unsigned)en, PK_RLX_SYSTEM);
-                } else A.ering[at] = en;
+                } else ering[at] = en;
             }
         }
         if (emit) {   // base variants (i = 0) of the triangles whose first vertex this patch owns
@@ -341,21 +346,37 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
     }
 }
 
+namespace {
+template <int RR>
+int set_lds_rr(int bytes) {
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<RR, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<RR, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<RR, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return rc;
+}
+template <int RR>
+void launch_rr(const pk_args& A, dim3 g, dim3 b, size_t lds, hipStream_t s) {
+    if (A.n_peers > 0) hipLaunchKernelGGL((k_persist<RR, 2>), g, b, lds, s, A);
+    else if (A.ering || A.pring) hipLaunchKernelGGL((k_persist<RR, 1>), g, b, lds, s, A);
+    else hipLaunchKernelGGL((k_persist<RR, 0>), g, b, lds, s, A);
+}
+}  // namespace
+
 int tp_persist_set_lds(int bytes) {
-    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<PK_RR0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<PK_RR1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<PK_RR2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<PK_ROWS_PER_LANE>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    int rc = set_lds_rr<PK_RR0>(bytes);
+    if (!rc) rc = set_lds_rr<PK_RR1>(bytes);
+    if (!rc) rc = set_lds_rr<PK_RR2>(bytes);
+    if (!rc) rc = set_lds_rr<PK_ROWS_PER_LANE>(bytes);
     return rc;
 }
 // rows: the most rows per lane of any patch of the plan (pk_plan::rows_max); the census passes PK_ROWS_PER_LANE
 void tp_launch_persist(const pk_args& A, int grid, int rows, int lds_bytes, hipStream_t s) {
     const dim3 g((unsigned)grid), b(PK_THREADS);
     switch (pk_rr_for(rows)) {
-        case PK_RR0: hipLaunchKernelGGL(k_persist<PK_RR0>, g, b, (size_t)lds_bytes, s, A); break;
-        case PK_RR1: hipLaunchKernelGGL(k_persist<PK_RR1>, g, b, (size_t)lds_bytes, s, A); break;
-        case PK_RR2: hipLaunchKernelGGL(k_persist<PK_RR2>, g, b, (size_t)lds_bytes, s, A); break;
-        default: hipLaunchKernelGGL(k_persist<PK_ROWS_PER_LANE>, g, b, (size_t)lds_bytes, s, A); break;
+        case PK_RR0: launch_rr<PK_RR0>(A, g, b, (size_t)lds_bytes, s); break;
+        case PK_RR1: launch_rr<PK_RR1>(A, g, b, (size_t)lds_bytes, s); break;
+        case PK_RR2: launch_rr<PK_RR2>(A, g, b, (size_t)lds_bytes, s); break;
+        default: launch_rr<PK_ROWS_PER_LANE>(A, g, b, (size_t)lds_bytes, s); break;
     }
 }
 
