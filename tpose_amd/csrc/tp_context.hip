@@ -141,6 +141,7 @@ struct tp_context {
         uint64_t generation = 0;
         bool base_every = false;
         float dp = 0.0f;
+        bool superseded = false;   // a newer plan was cut on the calling thread meanwhile
     };
     std::unique_ptr<replan_job> job;
     bool plan_base_every = false;   // the current plan walks every triangle's base lines in every grad-iter (tp_iterate_until)
@@ -430,12 +431,12 @@ void start_replan(tp_context* c, const float* points, float dp) {
 }
 // a finished job's plan becomes the context's (for the launches enqueued from now on); a job of another triangulation, or of
 // the other kind of plan, is dropped
-int take_replan(tp_context* c, bool wait = false) {
+int take_replan(tp_context* c) {
     if (!c->job) return TP_OK;
-    if (!wait && c->job->done.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return TP_OK;
+    if (c->job->done.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return TP_OK;
     c->job->done.get();
     std::unique_ptr<tp_context::replan_job> j = std::move(c->job);
-    if (j->generation != c->generation || c->plan_generation != c->generation || j->base_every != c->plan_base_every || !j->plan.ok || c->n_bands > 1) return TP_OK;
+    if (j->superseded || j->generation != c->generation || c->plan_generation != c->generation || j->base_every != c->plan_base_every || !j->plan.ok || c->n_bands > 1) return TP_OK;
     if (int rc = install_plan(c, j->plan, j->points.data(), c->plan_slot ^ 1)) return rc;
     c->replans++;
     return TP_OK;
@@ -492,7 +493,10 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false) {
 
 // after a chunk has been enqueued: the snapshot taken after the chunk before it, if there is one -- a new plan for the
 // chunks to come when the mesh has drifted
-int maybe_replan(tp_context* c, float dp) {
+// more_chunks: the call has more chunks to enqueue behind the one just enqueued -- the cut is made right here, on the calling
+// thread (the GPU runs that chunk meanwhile, and the next one starts on the new plan); otherwise on another thread, and a
+// later call picks the plan up (a call of a few grad-iters never waits 2.6 ms for a cut)
+int maybe_replan(tp_context* c, float dp, bool more_chunks) {
     const int k = c->snap_next;   // the older of the two snapshot slots: the one the next chunk's snapshot will overwrite
     if (!c->snap_pending[k]) return TP_OK;
     if (c->n_bands > 1) { c->snap_pending[k] = false; return TP_OK; }   // (bands keep the plan they all cut from the upload)
@@ -507,8 +511,13 @@ int maybe_replan(tp_context* c, float dp) {
         const float d = (dx < 0 ? -dx : dx) > (dy < 0 ? -dy : dy) ? (dx < 0 ? -dx : dx) : (dy < 0 ? -dy : dy);
         if (d > worst) worst = d;   // (NaN never compares greater: a vertex gone to NaN does not trigger)
     }
-    if (worst <= PK_REPLAN_PX || c->job) return TP_OK;   // (one cut at a time: the one under way is from positions nearly as new)
-    start_replan(c, q, dp);
+    if (worst <= PK_REPLAN_PX) return TP_OK;
+    if (more_chunks) {
+        if (c->job) c->job->superseded = true;
+        bool ok = false;
+        if (int rc = build_plan(c, q, dp, c->plan_slot ^ 1, &ok)) return rc;
+        if (ok) c->replans++;
+    } else if (!c->job) start_replan(c, q, dp);   // (one cut at a time: the one under way is from positions nearly as new)
     return TP_OK;
 }
 
@@ -525,10 +534,8 @@ float2* band_pring(const tp_context* c, int b) { return (float2*)((char*)c->band
 // n grad-iters of the persistent kernel -- the last one writes `tenergy`, `colnum`, `colacc`, `gradient` --, then
 // `points_out` -> `points` / `epos`
 int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings = false) {
-    for (bool first = true; n > 0; first = false) {
-        // a plan cut on the side: at the start of a call, only if it is ready (a call of a few grad-iters never waits for
-        // the cut); between the chunks of a long call the host waits for it -- the GPU has the chunk before to run meanwhile
-        if (int rc = take_replan(c, !first)) return rc;
+    while (n > 0) {
+        if (int rc = take_replan(c)) return rc;   // (a plan cut on the side since an earlier call, if it is ready)
         // long calls go chunk by chunk (a chunk and a half rather than a short tail)
         const int k = n <= PK_CHUNK + PK_CHUNK / 2 ? n : PK_CHUNK;   // (rings: the caller's chunks are shorter than this)
         if (c->epoch + (uint32_t)k > PK_MAX_EPOCH) {
@@ -584,7 +591,7 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
             c->iters_since_snap = 0;
         }
         // with this chunk on the stream (the GPU has work while the host cuts): does the mesh want a new plan?
-        if (int rc = maybe_replan(c, dp)) return rc;
+        if (int rc = maybe_replan(c, dp, n > 0)) return rc;
     }
     return TP_OK;
 }
