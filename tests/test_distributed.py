@@ -125,6 +125,10 @@ def test_bench_line_contract_one_gpu():
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["single_thread_value"] > 0 and cb["cpu_model"]
     assert line["ms_per_step_readback_every_iter"] > line["ms_per_step"]
+    cc = line["cold_cache"]   # SURVEY 8d caveat (iii): more tables than the Infinity Cache holds, cycled
+    assert "error" not in cc, cc
+    assert cc["contexts"] >= 5 and cc["raster_and_table_bytes_cycled"] > 256 * 2 ** 20
+    assert cc["ms_per_step"] > 0 and cc["ms_per_step_same_loop_one_context"] > 0
 
 
 @pytest.mark.gpu

@@ -215,6 +215,37 @@ def test_fast_moving_vertices_match_oracle(persistent):
     ctx.close()
 
 
+def test_short_calls_replan_on_the_side_and_keep_the_bits():
+    """A loop of calls of a few hundred grad-iters on a drifting mesh: the plan of the persistent launches is cut again
+    on another host thread after a call (never inside one: such a call has no second chunk), a later call installs it,
+    and nothing of that shows in the results -- positions and energies bit-equal to the two-kernel path after every call."""
+    W, H, NT = 640, 480, 3000
+    img, pts, tris, he, ratio = synth.workload(W, H, NT, contrast=0.3)
+    params = capi.default_params(0)
+    ctxs = []
+    for persistent in (1, 0):
+        c = capi.Context(0, W, H)
+        c.set_persistent(persistent)
+        c.set_image(capi.IMAGE_A, img)
+        c.upload(pts, tris)
+        ctxs.append(c)
+    a, b = ctxs
+    import time
+    for call in range(14):
+        a.iterate(params, 300)
+        b.iterate(params, 300)
+        pa, pb = a.retrieve(capi.BUF_POINTS), b.retrieve(capi.BUF_POINTS)
+        assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32)), call
+        assert np.array_equal(a.retrieve(capi.BUF_TENERGY), b.retrieve(capi.BUF_TENERGY)), call
+        time.sleep(0.01)   # (the cut takes a few milliseconds: let a later call find it finished)
+    assert a.info(capi.INFO_PERSIST_ITERS) == 14 * 300
+    moved = np.abs(a.retrieve(capi.BUF_POINTS) - pts).max() * H / 2
+    assert moved > 2.0, moved
+    assert a.info(capi.INFO_REPLANS) >= 1, "the mesh drifted %.1f px and no plan was cut on the side" % moved
+    for c in ctxs:
+        c.close()
+
+
 @pytest.mark.parametrize("W,H", [(1011, 674), (2048, 2048)])
 def test_two_triangle_start_state_large_raster(W, H):
     """The reference's 2-triangle start state on big rasters: lines of hundreds to thousands of rows
