@@ -280,20 +280,25 @@ def main():
     ctx.iterate(params, args.warmup)
     sync_all()
     # the timed region: exactly K steps, barrier + synchronize on both sides, max over ranks; repeated REPEATS times
-    # (each repeat continues the descent from where the last one stopped), the MEDIAN is reported.  HIP events on the
-    # library's own stream bracket the same region (what the device spent, without the host's launch and wait).
+    # (each repeat continues the descent from where the last one stopped), the MEDIAN is reported.
     times, dev_us = [], []
     for rep in range(args.repeats):
         sync_all()
         t0 = time.perf_counter()
-        ctx.timer_start()
         ctx.iterate(params, args.steps)
-        dev_us.append(ctx.timer_stop())   # (waits for the end of the region on the library's stream)
+        ctx.synchronize()
         torch.cuda.synchronize()
         dt_rep = time.perf_counter() - t0
         if dist is not None:
             dt_rep = dist_util.max_over_ranks(dist, dt_rep, device)  # the job is as slow as its slowest rank
         times.append(dt_rep)
+    # the same regions again with HIP events on the library's stream around them (what the device spent, without the host's
+    # launch and wait) -- in regions of their own: recording the events costs the host a few microseconds per region
+    for rep in range(args.repeats):
+        sync_all()
+        ctx.timer_start()
+        ctx.iterate(params, args.steps)
+        dev_us.append(ctx.timer_stop())   # (waits for the end of the region on the library's stream)
     dt = sorted(times)[len(times) // 2]
     if dist is not None:
         dist.barrier()
@@ -362,8 +367,8 @@ def main():
             "timing": "median of %d timed regions of %d steps; ms_per_step of each: %s" % (
                 len(times), args.steps, ", ".join("%.5f" % (t / args.steps * 1e3) for t in times)),
             "ms_per_step_device": sorted(dev_us)[len(dev_us) // 2] / args.steps / 1e3,
-            "ms_per_step_device_note": "HIP events on the library's stream around the same timed regions (median): what the "
-                                       "device spent, without the host's launch and wait",
+            "ms_per_step_device_note": "HIP events on the library's stream around %d more regions of the same length (median): what "
+                                       "the device spent, without the host's launch and wait" % args.repeats,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "ms_per_step_two_kernel_path": two_kernel_ms,
             "ms_per_step_readback_every_iter": readback_ms,
