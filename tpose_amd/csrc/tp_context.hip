@@ -18,8 +18,9 @@
 #include <unordered_map>
 #include <vector>
 #include <chrono>
-#include <future>
+#include <condition_variable>
 #include <memory>
+#include <thread>
 #include <mutex>
 #include <shared_mutex>
 
@@ -130,20 +131,24 @@ struct tp_context {
     int snap_next = 0;
     int iters_since_snap = 0;
     int64_t replans = 0;
-    // a new plan being cut on another host thread (2.6 ms at 3000 triangles: a call of a few grad-iters must not wait for it).
-    // The job owns copies of everything it reads; its result is installed by the next chunk that finds it finished, and
-    // dropped when the triangulation or the kind of plan has changed meanwhile.
-    struct replan_job {
-        std::future<void> done;
+    int64_t iters_since_cut = 0;   // grad-iters enqueued since the current plan was cut
+    // After the LAST chunk of a call a new plan is cut on a worker thread of the context (2.6 ms at 3000 triangles: a call of a
+    // few grad-iters must not wait for it); a later call installs it when it finds it finished.  ONE thread for the life of the
+    // context, started at the first such cut, working on its own copies of everything it reads.
+    struct replan_worker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        bool stop = false, go = false, busy = false, done = false, superseded = false;
         pk_plan plan;
         std::vector<float> points;
         std::vector<int32_t> tris, edge_uv, he_edge;
+        int NP = 0, NT = 0, NE = 0, W = 0, H = 0, parts = 0;
+        float ratio = 0.0f, dp = 0.0f;
         uint64_t generation = 0;
         bool base_every = false;
-        float dp = 0.0f;
-        bool superseded = false;   // a newer plan was cut on the calling thread meanwhile
     };
-    std::unique_ptr<replan_job> job;
+    std::unique_ptr<replan_worker> worker;
     bool plan_base_every = false;   // the current plan walks every triangle's base lines in every grad-iter (tp_iterate_until)
     int32_t* ering = nullptr; float2* pring = nullptr;   // tp_iterate_until: per-frame base energies / positions of a chunk
     size_t cap_ering = 0, cap_pring = 0;
@@ -373,6 +378,7 @@ int take_census(tp_context* c) {
 #define PK_REPLAN_PX 2.0f     /* a vertex this far from where the plan saw it: cut a new plan */
 #endif
 
+
 // send a plan that was cut from `points` to plan buffer `slot` (through that buffer's pinned staging area: the copy rides
 // the stream and the host does not wait for it) and make it the context's plan
 int install_plan(tp_context* c, pk_plan& np, const float* points, int slot) {
@@ -380,6 +386,7 @@ int install_plan(tp_context* c, pk_plan& np, const float* points, int slot) {
     if (int rc = grow(c, &B.wg, &B.cap_wg, np.wg.size())) return rc;
     if (int rc = grow(c, &B.pool, &B.cap_pool, np.pool.size())) return rc;
     const size_t b_wg = sizeof(pk_wg) * np.wg.size(), b_pool = sizeof(int32_t) * np.pool.size();
+    static_assert(sizeof(pk_wg) % 4 == 0, "plans travel as 32-bit words");
     if (b_wg + b_pool > B.cap_stage) {
         // (the staging area may still feed a copy enqueued for an earlier plan in this buffer: wait before dropping it)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -391,11 +398,18 @@ int install_plan(tp_context* c, pk_plan& np, const float* points, int slot) {
     }
     memcpy(B.stage, np.wg.data(), b_wg);
     memcpy(B.stage + b_wg, np.pool.data(), b_pool);
-    HIP_TRY(c, hipMemcpyAsync(B.wg, B.stage, b_wg, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(B.pool, B.stage + b_wg, b_pool, hipMemcpyHostToDevice, c->stream));
+    // (ONE kernel reads the staging area across the link.  Two hipMemcpyAsync did this before; issued on an IDLE stream --
+    // a plan cut on the side, installed at the start of a call -- they returned after 8 ms once in ~30 times.)
+    tp_copy_list G{};
+    G.src[0] = (const uint32_t*)B.stage; G.dst[0] = (uint32_t*)B.wg; G.words[0] = (uint32_t)(b_wg / 4);
+    G.src[1] = (const uint32_t*)(B.stage + b_wg); G.dst[1] = (uint32_t*)B.pool; G.words[1] = (uint32_t)(b_pool / 4);
+    G.n = 2;
+    tp_launch_copy_list(G, c->stream);
+    HIP_TRY(c, hipGetLastError());
     c->plan = std::move(np);
     c->plan_slot = slot;
     c->plan_points.assign(points, points + 2 * (size_t)c->NP);
+    c->iters_since_cut = 0;
     return TP_OK;
 }
 int plan_patches(const tp_context* c) { return c->n_bands > 1 ? c->n_bands * c->band_patches : c->num_cus * PK_WG_PER_CU; }
@@ -413,33 +427,55 @@ int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok)
     return install_plan(c, np, points, slot);
 }
 
-// the same cut on another host thread, from a snapshot of the positions (maybe_replan); nothing of the context is touched
-// until take_replan() finds the job finished
-void start_replan(tp_context* c, const float* points, float dp) {
-    auto j = std::make_unique<tp_context::replan_job>();
-    j->points.assign(points, points + 2 * (size_t)c->NP);
-    j->tris = c->h_tris; j->edge_uv = c->h_edge_uv; j->he_edge = c->h_he_edge;
-    j->generation = c->generation; j->base_every = c->plan_base_every; j->dp = dp;
-    tp_context::replan_job* J = j.get();
-    const int NP = c->NP, NT = c->NT, NE = c->NE, W = c->W, H = c->H, parts = plan_patches(c);
-    const float ratio = c->ratio;
-    j->done = std::async(std::launch::async, [J, NP, NT, NE, W, H, ratio, parts]() {
-        pk_build_plan(NP, NT, J->tris.data(), J->points.data(), NE, J->edge_uv.data(), J->he_edge.data(), W, H, ratio,
-                      J->dp * 0.5f * (float)H, parts, PK_LDS_LIMIT, J->plan, J->base_every);
-    });
-    c->job = std::move(j);
+// the same cut on the context's worker thread, from a snapshot of the positions (maybe_replan); nothing of the context is
+// touched until take_replan() finds the cut finished
+void replan_worker_main(tp_context::replan_worker* w) {
+    std::unique_lock<std::mutex> lk(w->m);
+    for (;;) {
+        w->cv.wait(lk, [w] { return w->go || w->stop; });
+        if (w->stop) return;
+        w->go = false;
+        lk.unlock();
+        pk_build_plan(w->NP, w->NT, w->tris.data(), w->points.data(), w->NE, w->edge_uv.data(), w->he_edge.data(), w->W, w->H, w->ratio,
+                      w->dp * 0.5f * (float)w->H, w->parts, PK_LDS_LIMIT, w->plan, w->base_every);
+        lk.lock();
+        w->busy = false; w->done = true;
+    }
 }
-// a finished job's plan becomes the context's (for the launches enqueued from now on); a job of another triangulation, or of
-// the other kind of plan, is dropped
+void start_replan(tp_context* c, const float* points, float dp) {
+    if (!c->worker) {
+        c->worker.reset(new tp_context::replan_worker());
+        c->worker->th = std::thread(replan_worker_main, c->worker.get());
+    }
+    tp_context::replan_worker* w = c->worker.get();
+    std::lock_guard<std::mutex> lk(w->m);
+    if (w->busy || w->done) return;   // (one cut at a time: the one under way is from positions nearly as new)
+    w->points.assign(points, points + 2 * (size_t)c->NP);
+    w->tris = c->h_tris; w->edge_uv = c->h_edge_uv; w->he_edge = c->h_he_edge;
+    w->NP = c->NP; w->NT = c->NT; w->NE = c->NE; w->W = c->W; w->H = c->H; w->parts = plan_patches(c);
+    w->ratio = c->ratio; w->dp = dp; w->generation = c->generation; w->base_every = c->plan_base_every;
+    w->superseded = false; w->busy = true; w->go = true;
+    w->cv.notify_one();
+}
+// a finished cut becomes the context's plan (for the launches enqueued from now on); one of another triangulation, of the other
+// kind of plan, or overtaken by a cut on the calling thread is dropped
 int take_replan(tp_context* c) {
-    if (!c->job) return TP_OK;
-    if (c->job->done.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return TP_OK;
-    c->job->done.get();
-    std::unique_ptr<tp_context::replan_job> j = std::move(c->job);
-    if (j->superseded || j->generation != c->generation || c->plan_generation != c->generation || j->base_every != c->plan_base_every || !j->plan.ok || c->n_bands > 1) return TP_OK;
-    if (int rc = install_plan(c, j->plan, j->points.data(), c->plan_slot ^ 1)) return rc;
+    tp_context::replan_worker* w = c->worker.get();
+    if (!w) return TP_OK;
+    std::lock_guard<std::mutex> lk(w->m);
+    if (!w->done) return TP_OK;
+    w->done = false;
+    if (w->superseded || w->generation != c->generation || c->plan_generation != c->generation || w->base_every != c->plan_base_every || !w->plan.ok || c->n_bands > 1) return TP_OK;
+    if (int rc = install_plan(c, w->plan, w->points.data(), c->plan_slot ^ 1)) return rc;
     c->replans++;
     return TP_OK;
+}
+void stop_replan_worker(tp_context* c) {
+    if (!c->worker) return;
+    { std::lock_guard<std::mutex> lk(c->worker->m); c->worker->stop = true; }
+    c->worker->cv.notify_one();
+    if (c->worker->th.joinable()) c->worker->th.join();
+    c->worker.reset();
 }
 
 // the plan of the current triangulation (built on first use after an upload); *use = whether tp_iterate may take the
@@ -494,8 +530,8 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false) {
 // after a chunk has been enqueued: the snapshot taken after the chunk before it, if there is one -- a new plan for the
 // chunks to come when the mesh has drifted
 // more_chunks: the call has more chunks to enqueue behind the one just enqueued -- the cut is made right here, on the calling
-// thread (the GPU runs that chunk meanwhile, and the next one starts on the new plan); otherwise on another thread, and a
-// later call picks the plan up (a call of a few grad-iters never waits 2.6 ms for a cut)
+// thread (the GPU runs that chunk meanwhile, and the next one starts on the new plan); otherwise on the context's worker
+// thread, and a later call picks the plan up (a call of a few grad-iters never waits 2.6 ms for a cut)
 int maybe_replan(tp_context* c, float dp, bool more_chunks) {
     const int k = c->snap_next;   // the older of the two snapshot slots: the one the next chunk's snapshot will overwrite
     if (!c->snap_pending[k]) return TP_OK;
@@ -512,12 +548,11 @@ int maybe_replan(tp_context* c, float dp, bool more_chunks) {
         if (d > worst) worst = d;   // (NaN never compares greater: a vertex gone to NaN does not trigger)
     }
     if (worst <= PK_REPLAN_PX) return TP_OK;
-    if (more_chunks) {
-        if (c->job) c->job->superseded = true;
-        bool ok = false;
-        if (int rc = build_plan(c, q, dp, c->plan_slot ^ 1, &ok)) return rc;
-        if (ok) c->replans++;
-    } else if (!c->job) start_replan(c, q, dp);   // (one cut at a time: the one under way is from positions nearly as new)
+    if (!more_chunks) { start_replan(c, q, dp); return TP_OK; }
+    if (c->worker) { std::lock_guard<std::mutex> lk(c->worker->m); c->worker->superseded = true; }
+    bool ok = false;
+    if (int rc = build_plan(c, q, dp, c->plan_slot ^ 1, &ok)) return rc;
+    if (ok) c->replans++;
     return TP_OK;
 }
 
@@ -580,7 +615,7 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         c->epoch += (uint32_t)k;
         c->persist_unchecked = true;
         c->persist_launches++; c->persist_iters += k;
-        c->iters_since_snap += k;
+        c->iters_since_snap += k; c->iters_since_cut += k;
         n -= k;
         if (c->iters_since_snap >= PK_CHUNK / 2) {   // the positions after this chunk, for a later maybe_replan
             const int sl = c->snap_next;
@@ -682,6 +717,7 @@ int tp_destroy(tp_context* c) {
     if (!c) return TP_OK;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    stop_replan_worker(c);
     drop_graphs(c);
     free_triangulation(c);
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->prefix[0]); hipFree(c->prefix[1]); hipFree(c->px[0]); hipFree(c->px[1]);
