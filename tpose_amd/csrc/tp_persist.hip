@@ -102,7 +102,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             V.pos[i].x = p.x; V.pos[i].y = p.y;
         }
         for (int i = tid; i < PK_SUM_WORDS * w.n_lines_all; i += PK_THREADS) V.sums[i] = 0ull;
-        if (tid == 0) V.flags[0] = 0;
+        if (tid == 0) { V.flags[0] = 0; V.flags[3] = 0; }
     }
     // the stored colour of this lane's variant (warp flavour: `colacc` as uploaded, triangle.fs:49-50) never changes
     // during a launch; the first pass of the corner lanes keeps it in registers
@@ -161,7 +161,11 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 V.pos[s].x = __uint_as_float((uint32_t)a); V.pos[s].y = __uint_as_float((uint32_t)b);
             }
         }
-        if (__syncthreads_or(failed)) return;
+        // (a lane that gave up says so in LDS; ONE barrier, then everybody reads the word -- __syncthreads_or is a wave
+        // reduction, three barriers and three dependent LDS operations: 0.2 us of every grad-iter)
+        if (failed) V.flags[3] = 1;
+        __syncthreads();
+        if (V.flags[3]) return;
         PK_STAMP(1);
         // ---- P1: line set-up (low threads), snapped positions (high threads), gradient reset
         for (int l = tid; l < n_setup; l += PK_THREADS) {
