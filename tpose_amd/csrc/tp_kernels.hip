@@ -687,10 +687,11 @@ void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s
 // endpoints by edge)
 // A launch that gave up (status[0] raised: its workgroups were not all resident, tp_context.hip) leaves everything as it was.
 __global__ void k_persist_finish(tp_launch L, const float2* points_out, unsigned* status, unsigned* host_status) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = gid >> 3, lane = gid & 7;   // eight lanes per vertex: one incident edge each (the table reads are dependent ones)
     if (status) {
         const unsigned gave_up = status[0];
-        if (v == 0) {
+        if (gid == 0) {
             const unsigned done = status[2] + (gave_up ? 0u : 1u);   // (launches complete one after the other: no atomic)
             status[2] = done;
             if (host_status) { host_status[0] = gave_up; host_status[2] = done; }   // what the host looks at after its next wait: no copy
@@ -705,11 +706,12 @@ __global__ void k_persist_finish(tp_launch L, const float2* points_out, unsigned
         p.x = p.x <= -R ? -R : (p.x >= R ? R : p.x);
         p.y = p.y <= -1.0f ? -1.0f : (p.y >= 1.0f ? 1.0f : p.y);
     }
-    L.points[v] = p;
-    publish_position(L, v, p, 0, 1);
+    // (every lane has read the old position before any lane of the vertex writes the new one: the eight lanes of a vertex sit in one wave)
+    if (lane == 0) L.points[v] = p;
+    publish_position(L, v, p, lane, 8);
 }
 void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, unsigned* host_status, hipStream_t s) {
-    hipLaunchKernelGGL(k_persist_finish, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L, points_out, status, host_status);
+    hipLaunchKernelGGL(k_persist_finish, dim3((unsigned)((8 * L.NP + 255) / 256)), dim3(256), 0, s, L, points_out, status, host_status);
 }
 
 // tpose::upload colour replication (source/triangulation.hpp:633-641): col[i*NT + k] = colors[k]
