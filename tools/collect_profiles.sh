@@ -18,6 +18,7 @@ TPOSE_TIMELINE_AFTER=4000 python tools/persist_timeline.py > $O/persist_timeline
 python tools/persist_check.py > $O/persist_check.txt 2>&1
 python tools/long_parity.py > $O/long_parity.txt 2>&1
 python tools/time_variants.py product > $O/long_run_timing.txt 2>&1
+python tools/call_length.py > $O/call_length.txt 2>&1
 # 5. row e3: a hand-over between two processes through an IPC-mapped granule; the band split's protocol with both bands on this device
 bash tools/run_ipc_handover.sh > $O/ipc_handover.txt 2>&1
 python tools/band_timing.py > $O/band_timing_4096_12000.json 2> $O/band_timing.err
@@ -27,3 +28,4 @@ python tools/run_config2.py 600 > $O/config2.txt 2>&1
 python tools/run_config3.py > $O/config3.txt 2>&1
 python tools/run_batch.py --pairs 8 --iters 512 > $O/config4.json 2> $O/config4.err
 ls -la $O
+# then, in the development container: tools/copy_profiles.sh (gpurun_out/r03 -> profiles/r03_*)
