@@ -139,7 +139,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                 V.wk[l] = wkr;
             }
             for (int j = 0; j < 4 * w.n_corners; j++) V.coef[j] = pk_coef_lane(V, vw, j >> 2, (j & 3) + 1);
-            memset(V.sums, 0, sizeof(unsigned long long) * PK_SUM_WORDS * (size_t)w.n_lines_all);
+            memset(V.sums, 0, sizeof(unsigned long long) * PK_SUM_STRIDE * (size_t)w.n_lines_all);
             if (recut) {   // the wave's lanes one after the other
                 const int RRk = pk_rr_for(P.rows_max);   // tp_launch_persist's choice
                 int changed = 0, sum[64];
@@ -192,7 +192,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             for (int j = 0; j < PK_CACHED; j++) {   // the cached slots (a slot without a lane-item walks nothing)
                 pk_acc a;
                 pk_walk_cached<PK_ROWS_PER_LANE>(S[p].cache[j], V, table, pitch, W, a);
-                unsigned long long* s = V.sums + (size_t)S[p].cache[j].l * PK_SUM_WORDS;
+                unsigned long long* s = V.sums + (size_t)S[p].cache[j].l * PK_SUM_STRIDE;
                 unsigned long long wd[PK_SUM_WORDS];
                 pk_fold_words(a, wd);
                 for (int q = 0; q < PK_SUM_WORDS; q++) s[q] += wd[q];
@@ -200,7 +200,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             for (int j = S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED; j < n_li; j++) {
                 pk_acc a;
                 const int l = pk_walk_lane(V, table, pitch, W, w.n_lines_all, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.li_cap, j, a);
-                unsigned long long* s = V.sums + (size_t)l * PK_SUM_WORDS;
+                unsigned long long* s = V.sums + (size_t)l * PK_SUM_STRIDE;
                 unsigned long long wd[PK_SUM_WORDS];
                 pk_fold_words(a, wd);
                 for (int q = 0; q < PK_SUM_WORDS; q++) s[q] += wd[q];

@@ -29,7 +29,7 @@ struct pk_walker { int64_t x, s; int32_t ra, rb; };  // tp_line
 
 // the workgroup's LDS, carved in the order of pk_lds_bytes (tp_plan.h)
 struct pk_view {
-    unsigned long long* sums;  // [n_lines_all][PK_SUM_WORDS] line sums {sum x | n_odd << 32, sum r | sum g << 32, sum b, q} (pk_fold_words)
+    unsigned long long* sums;  // [n_lines_all][PK_SUM_STRIDE] line sums (PK_SUM_WORDS of them used) {sum x | n_odd << 32, sum r | sum g << 32, sum b, q} (pk_fold_words)
     pk_walker* wk;             // [n_lines_all]
     pk_f2* pos;                // [n_slots]
     pk_i2* snap;               // own slot k: [5 k + move]; neighbour slot s: [5 n_own_v + s - n_own_v] (unmoved)
@@ -48,7 +48,7 @@ struct pk_view {
 
 TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     char* p = base;
-    V.sums = (unsigned long long*)p; p += pk_align16(w.n_lines_all * 8 * PK_SUM_WORDS);
+    V.sums = (unsigned long long*)p; p += pk_align16(w.n_lines_all * 8 * PK_SUM_STRIDE);
     V.wk = (pk_walker*)p; p += pk_align16(w.n_lines_all * 24);
     V.pos = (pk_f2*)p; p += pk_align16(w.n_slots * 8);
     V.snap = (pk_i2*)p; p += pk_align16((4 * w.n_own_v + w.n_slots) * 8);
@@ -138,7 +138,7 @@ TP_HD int pk_recut_count(const pk_view& V, int n, int n_every, int lane, int lan
     for (int l = lane * B; l < n && l < (lane + 1) * B; l++) {
         const int t = pk_recut_line(V, l, rpl, first);
         changed |= first || t != V.cut[l + 1] - V.cut[l];
-        V.sums[PK_SUM_WORDS * (size_t)l] = (unsigned long long)t;
+        V.sums[PK_SUM_STRIDE * (size_t)l] = (unsigned long long)t;
         sum += t;
         sum_every += l < n_every ? t : 0;
     }
@@ -148,8 +148,8 @@ TP_HD void pk_recut_write(const pk_view& V, int n, int lane, int lanes, int offs
     const int B = (n + lanes - 1) / lanes;
     for (int l = lane * B; l < n && l < (lane + 1) * B; l++) {
         V.cut[l] = offset;
-        offset += (int)V.sums[PK_SUM_WORDS * (size_t)l];
-        V.sums[PK_SUM_WORDS * (size_t)l] = 0ull;
+        offset += (int)V.sums[PK_SUM_STRIDE * (size_t)l];
+        V.sums[PK_SUM_STRIDE * (size_t)l] = 0ull;
     }
     if (lane == lanes - 1) V.cut[n] = offset;   // (the last lane's lines are the last ones, or it has none and its offset is the total)
 }
@@ -412,7 +412,7 @@ TP_HD int32_t pk_coef_lane(const pk_view& V, const tp_view& vw, int k, int m) {
 // P6, the same lane: the variant's moments from the three line sums (slots of the edge leaving the vertex, arriving at it, opposite)
 TP_HD tp_moments pk_coef_moments(const pk_view& V, int32_t cf, int so, int si, int sopp) {
     const int cs = (int32_t)((uint32_t)cf << 30) >> 30, cp = (int32_t)((uint32_t)cf << 28) >> 30, cn = (int32_t)((uint32_t)cf << 26) >> 30;
-    return pk_moments3(cs, V.sums + (size_t)so * PK_SUM_WORDS, cp, V.sums + (size_t)si * PK_SUM_WORDS, cn, V.sums + (size_t)sopp * PK_SUM_WORDS);
+    return pk_moments3(cs, V.sums + (size_t)so * PK_SUM_STRIDE, cp, V.sums + (size_t)si * PK_SUM_STRIDE, cn, V.sums + (size_t)sopp * PK_SUM_STRIDE);
 }
 // energy of a variant as k_update's emit_variant forms it (triangle.fs:37-43; warp: against the stored colour, :46-53)
 TP_HD int32_t pk_energy(const tp_moments& mm, int flavour, pk_i4 col) {
@@ -427,8 +427,8 @@ TP_HD tp_moments pk_base_moments(const pk_wg& w, const pk_view& V, int k, int& t
     const pk_i2 p0 = V.snap[pk_snap_index(w, own, 0)], p1 = V.snap[pk_snap_index(w, s1, 0)], p2 = V.snap[pk_snap_index(w, s2, 0)];
     X[0] = p0.x; Y[0] = p0.y; X[1] = p1.x; Y[1] = p1.y; X[2] = p2.x; Y[2] = p2.y;
     tp_variant_coeffs(X, Y, c);
-    return pk_moments3(c[0], V.sums + (size_t)(b.z & 0xffff) * PK_SUM_WORDS, c[1], V.sums + (size_t)((b.z >> 16) & 0xffff) * PK_SUM_WORDS,
-                       c[2], V.sums + (size_t)(b.w & 0xffff) * PK_SUM_WORDS);
+    return pk_moments3(c[0], V.sums + (size_t)(b.z & 0xffff) * PK_SUM_STRIDE, c[1], V.sums + (size_t)((b.z >> 16) & 0xffff) * PK_SUM_STRIDE,
+                       c[2], V.sums + (size_t)(b.w & 0xffff) * PK_SUM_STRIDE);
 }
 
 // P7, own vertex k with gradient (gx, gy): the shift.cs step (shift.cs:16-47).  Vertices 0..3 never move.

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             const float2 p = A.points[pool[w.off_vid + i]];
             V.pos[i].x = p.x; V.pos[i].y = p.y;
         }
-        for (int i = tid; i < PK_SUM_WORDS * w.n_lines_all; i += PK_THREADS) V.sums[i] = 0ull;
+        for (int i = tid; i < PK_SUM_STRIDE * w.n_lines_all; i += PK_THREADS) V.sums[i] = 0ull;
         if (tid == 0) { V.flags[0] = 0; V.flags[3] = 0; }
     }
     // the stored colour of this lane's variant (warp flavour: `colacc` as uploaded, triangle.fs:49-50) never changes
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         // ---- P3: walk -- one table record per (line, row); chunks of a line meet in LDS
         auto fold = [&](int l, const pk_acc& a) {
             if (a.xs | a.nodd | a.r | a.q) {
-                unsigned long long* s = V.sums + (size_t)l * PK_SUM_WORDS;
+                unsigned long long* s = V.sums + (size_t)l * PK_SUM_STRIDE;
                 unsigned long long wd[PK_SUM_WORDS];
                 pk_fold_words(a, wd);
 #pragma unroll
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             }
         }
         if (!last) {
-            for (int i = PK_THREADS - 1 - tid; i < PK_SUM_WORDS * w.n_lines; i += PK_THREADS) V.sums[i] = 0ull;
+            for (int i = PK_THREADS - 1 - tid; i < PK_SUM_STRIDE * w.n_lines; i += PK_THREADS) V.sums[i] = 0ull;
         }
         PK_STAMP(5);
         // (no barrier here: P0 of the next grad-iter touches foreign position slots only, and its barrier orders the rest)

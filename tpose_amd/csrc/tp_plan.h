@@ -29,6 +29,10 @@
 
 #define PK_NLINES 9
 #define PK_SUM_WORDS 4          /* 64-bit words of a line's sums in LDS (tp_persist.h: pk_fold_words) */
+#ifndef PK_SUM_STRIDE
+#define PK_SUM_STRIDE 5         /* ... and the words from one line's sums to the next: at 4 (32 bytes) the lines a wave folds into fall on
+                                   8 of the 32 LDS banks; at 5 they spread over all of them */
+#endif
 #ifndef PK_THREADS
 #define PK_THREADS 512
 #endif
@@ -105,7 +109,7 @@ PK_HD int pk_chunks(int rows, int rpl) {
 }
 inline int pk_lds_bytes(const pk_wg& w) {
     int b = 0;
-    b += pk_align16(w.n_lines_all * 8 * PK_SUM_WORDS);   // line sums
+    b += pk_align16(w.n_lines_all * 8 * PK_SUM_STRIDE);  // line sums
     b += pk_align16(w.n_lines_all * 24);            // walkers
     b += pk_align16(w.n_slots * 8);                 // positions
     b += pk_align16((4 * w.n_own_v + w.n_slots) * 8);  // snapped positions: neighbours unmoved only, own slots + 4 moves
