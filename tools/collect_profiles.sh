@@ -19,6 +19,7 @@ python tools/persist_check.py > $O/persist_check.txt 2>&1
 python tools/long_parity.py > $O/long_parity.txt 2>&1
 python tools/time_variants.py product > $O/long_run_timing.txt 2>&1
 python tools/call_length.py > $O/call_length.txt 2>&1
+TPOSE_PMC_TARGET=persist python tools/pmc_kernels.py $O/pmc_persist.json > /dev/null 2> $O/pmc_persist.err   # counters of k_persist (separate --pmc passes)
 # 5. row e3: a hand-over between two processes through an IPC-mapped granule; the band split's protocol with both bands on this device
 bash tools/run_ipc_handover.sh > $O/ipc_handover.txt 2>&1
 python tools/band_timing.py > $O/band_timing_4096_12000.json 2> $O/band_timing.err

@@ -19,4 +19,5 @@ cp $S/config2.txt $D/r03_config2_schedule.txt
 cp $S/config3.txt $D/r03_config3_warp.txt
 cp $S/config4.json $D/r03_config4_batch.json
 [ -f $S/call_length.txt ] && cp $S/call_length.txt $D/r03_call_length.txt
+[ -f $S/pmc_persist.json ] && cp $S/pmc_persist.json $D/r03_pmc_persist.json
 ls -la $D/r03_*
