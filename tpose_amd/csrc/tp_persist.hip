@@ -275,7 +275,9 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             }
             const tp_moments mm = pk_coef_moments(V, V.coef[j], so, si, sopp);
             const int32_t e = pk_energy(mm, A.flavour, col);
-            const uint32_t d = (uint32_t)e - (uint32_t)__shfl_xor(e, 1);   // lanes 4k+0/1: E(+dx), E(-dx); 4k+2/3: E(+dy), E(-dy)
+            // lanes 4k+0/1: E(+dx), E(-dx); 4k+2/3: E(+dy), E(-dy) -- the neighbour's energy by a DPP quad permute [1,0,3,2] (__shfl_xor
+            // goes through the LDS crossbar: a hundred cycles on this chain)
+            const uint32_t d = (uint32_t)e - (uint32_t)__builtin_amdgcn_mov_dpp(e, 0xB1, 0xF, 0xF, true);
             if ((j & 3) == 0) atomicAdd(&V.grad[own].x, (int)d);
             if ((j & 3) == 2) atomicAdd(&V.grad[own].y, (int)d);
             if (emit) {
