@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TP_ABI_VERSION 3
+#define TP_ABI_VERSION 4
 #define TP_MAXT (2 << 18) /* tpose::triangulation::MAXT, source/triangulation.hpp:95; 13*NT <= MAXT */
 
 typedef struct tp_context tp_context;
@@ -112,8 +112,18 @@ int tp_set_option(tp_context* ctx, int option, int64_t value);
  * writes the energies of its triangles into every band's ring, and every band's host applies the convergence test to all of
  * them -- and ends, like the unsplit call, with the last frame run whole (all buffers complete on every band).  Calls too
  * short for persistent launches and the piecewise API run whole on every band.  A band that waits a second for positions
- * gives up; every band then runs the call again on its own (tp_get_info 9 counts it).  n_bands = 1 detaches. */
+ * gives up; every band then runs the call again on its own (tp_get_info 9 counts it).  n_bands = 1 detaches.
+ * Attaching starts the bands' common history: mailbox tags, final-slot and ring parities count from the attachment on
+ * every band, whatever a context ran before it (so the bands need the same calls AFTER attaching, not before).
+ * MEMORY TYPE: a mailbox is polled by a running kernel while other devices write it, so it must be FINE-GRAINED device memory
+ * (tp_band_mailbox_alloc: hipExtMallocWithFlags(hipDeviceMallocFinegrained), zeroed).  Ordinary hipMalloc memory is coherent
+ * with a peer's writes at kernel boundaries only: bands on different devices would wait out their time limit in every launch
+ * (bands that share ONE device, as on a one-GPU test box, work with either kind).  tp_band_attach enables peer access from this
+ * context's device to the devices the other mailboxes live on (same-process bands); between processes map them with
+ * hipIpcOpenMemHandle first. */
 size_t tp_band_mailbox_bytes(int points, int triangles);
+int tp_band_mailbox_alloc(tp_context* ctx, size_t bytes, void** mailbox);
+int tp_band_mailbox_free(tp_context* ctx, void* mailbox);
 int tp_band_attach(tp_context* ctx, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int points, int triangles,
                    int patches_per_band);
 
@@ -205,7 +215,9 @@ int tp_render(tp_context* ctx, int source, const float* points, uint8_t* dst_rgb
  * current triangulation (rows of a line are shared by that many lanes); persistent path: 2 = patches (workgroups) of
  * the current plan, 0 if none, 3 = its LDS bytes per workgroup, 4 = lines all patches walk per grad-iter (9 per edge if none were walked twice),
  * 5 = persistent launches so far, 6 = grad-iters run inside them, 7 = census (1 a full grid is resident, -1 not,
- * 0 not taken yet), 8 = plans cut again during long descents (vertices had drifted from where the plan saw them) */
+ * 0 not taken yet; below -1: why not), 8 = plans cut again during long descents (vertices had drifted from where the plan saw
+ * them), 9 = persistent launches that gave up waiting and were run again on the two-kernel path, 10 = this band's mailbox came
+ * from tp_band_mailbox_alloc (fine-grained memory) */
 int tp_get_info(tp_context* ctx, int what, int64_t* value);
 
 /* device self-test of the exact span walker (tp_raster.h): for each (N0, step, d), the 32 values

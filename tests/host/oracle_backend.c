@@ -179,6 +179,8 @@ int tp_band_attach(tp_context* c, int band, int n_bands, void* const* mailboxes,
     (void)c; (void)band; (void)n_bands; (void)mailboxes; (void)bytes_each; (void)points; (void)triangles; (void)patches_per_band;
     return TP_OK;
 }
+int tp_band_mailbox_alloc(tp_context* c, size_t bytes, void** out) { (void)c; if (!out) return TP_ERR_INVALID; *out = calloc(bytes ? bytes : 1, 1); return *out ? TP_OK : TP_ERR_CAPACITY; }
+int tp_band_mailbox_free(tp_context* c, void* box) { (void)c; free(box); return TP_OK; }
 int tp_prepare(tp_context* c, const tp_params* p) { (void)c; (void)p; return TP_OK; }
 int tp_get_info(tp_context* c, int what, int64_t* value) { (void)c; (void)what; if (value) *value = 0; return TP_OK; }
 int tp_synchronize(tp_context* c) { (void)c; return TP_OK; }

@@ -1,0 +1,157 @@
+"""GPU parity of the PERSISTENT kernel (k_persist: what bench.py times) against the oracle AT THE BENCHMARKED SIZES.
+
+Every case runs tp_iterate of four or more grad-iters with persistent launches on, asserts that the grad-iters really ran
+inside persistent launches (INFO_PERSIST_ITERS), and compares `tenergy`, `colnum`, `colacc`, `gradient` and the float32
+vertex positions with oracle.iterate(..., literal=False) bit for bit (tolerance 0 ulp):
+  * 2048^2 / 3000 triangles on bench.py's raster (contrast 0.1) and on SURVEY section 8(d)'s full-contrast raster, both flavours;
+  * the same through tp_iterate_until (the instantiation that forms all 13 variants in every grad-iter);
+  * 4096^2 / 12 000 (BASELINE config 4's element): more lane-items per workgroup than threads keep records for;
+  * 674 x 449 / 150 triangles x 200 grad-iters (BASELINE config 1 as written: software/triangulate/main.cpp:53,190-204);
+  * hostile vertex sets at the metric size with enough grad-iters for the persistent path.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tpose_amd import capi, synth
+from util import RATE
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(W, H, NT, flavour, contrast):
+    img, pts, tris, he, ratio = synth.workload(W, H, NT, contrast=contrast)
+    imgB, colors = None, None
+    if flavour == 1:
+        imgB = synth.displaced_raster(img)
+        colors = synth.mean_colors(img, pts, tris, ratio)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    if flavour == 1:
+        ctx.set_image(capi.IMAGE_B, imgB)
+    ctx.upload(pts, tris, colors)
+    return ctx, (imgB if flavour == 1 else img), pts, tris, ratio, colors
+
+
+def _compare(ctx, ref, flavour, tag=""):
+    assert np.array_equal(ctx.retrieve(capi.BUF_TENERGY), ref["ten"]), "tenergy " + tag
+    assert np.array_equal(ctx.retrieve(capi.BUF_COLNUM), ref["cn"]), "colnum " + tag
+    if flavour == 0:
+        assert np.array_equal(ctx.retrieve(capi.BUF_COLACC)[:, :3], ref["ca"][:, :3]), "colacc " + tag
+    assert np.array_equal(ctx.retrieve(capi.BUF_GRADIENT), ref["gr"]), "gradient " + tag
+    assert np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32)), "points " + tag
+
+
+@pytest.mark.parametrize("contrast", [0.1, 1.0])
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_persistent_is_the_oracle_at_the_metric_size(flavour, contrast):
+    """2048^2 / 3000: 12 grad-iters in ONE persistent launch (k_persist<RR, 0>, 256 patches -- the kernel and size BENCH times)"""
+    iters = 12
+    ctx, sweep, pts, tris, ratio, colors = _setup(2048, 2048, 3000, flavour, contrast)
+    p = capi.default_params(flavour)
+    ctx.prepare(p)
+    ctx.iterate(p, iters)
+    ctx.synchronize()
+    assert ctx.info(capi.INFO_PERSIST_ITERS) == iters and ctx.info(capi.INFO_PATCHES) >= 128
+    assert ctx.info(9) == 0   # no launch gave up (nothing was replayed on the two-kernel path)
+    ref = O.iterate(sweep, pts, tris, flavour, ratio, RATE[flavour], iters, colors=colors, literal=False)
+    _compare(ctx, ref, flavour)
+    # ... and a second call continues from there (another launch, the plan and the mailbox epochs carried over)
+    ctx.iterate(p, 5)
+    ref2 = O.iterate(sweep, ref["points"], tris, flavour, ratio, RATE[flavour], 5, colors=colors, literal=False)
+    _compare(ctx, ref2, flavour, "second call")
+    assert ctx.info(capi.INFO_PERSIST_ITERS) == iters + 5
+    ctx.close()
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_iterate_until_at_the_metric_size(flavour):
+    """2048^2 / 3000 through tp_iterate_until (k_persist<RR, 1>: base lines, hence all 13 variants, in EVERY grad-iter): a
+    threshold nothing meets, so exactly `frames` frames run; the state is the oracle's after as many grad-iters"""
+    frames = 9
+    ctx, sweep, pts, tris, ratio, colors = _setup(2048, 2048, 3000, flavour, 0.1)
+    p = capi.default_params(flavour)
+    n, tot, rel = ctx.iterate_until(p, frames, 0.0, 1.0)
+    assert n == frames
+    assert ctx.info(capi.INFO_PERSIST_ITERS) >= frames - 1   # (the last frame runs once more on the two-kernel path)
+    ref = O.iterate(sweep, pts, tris, flavour, ratio, RATE[flavour], frames, colors=colors, literal=False)
+    _compare(ctx, ref, flavour)
+    # the running total is geterr's float32 sum of the LAST frame's base energies (source/triangulation.hpp:653-674)
+    newerr = np.float32(0)
+    for v in ref["ten"][: tris.shape[0]].astype(np.float32):
+        newerr = np.float32(newerr + v)
+    assert np.float32(tot).view(np.uint32) == newerr.view(np.uint32)
+    ctx.close()
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_persistent_is_the_oracle_at_the_batch_size(flavour):
+    """4096^2 / 12 000 (BASELINE config 4's element): ~3400 lane-items per workgroup, more than its threads keep records
+    for -- the overflow path of the walk"""
+    iters = 4
+    ctx, sweep, pts, tris, ratio, colors = _setup(4096, 4096, 12000, flavour, 0.1)
+    p = capi.default_params(flavour)
+    ctx.iterate(p, iters)
+    ctx.synchronize()
+    assert ctx.info(capi.INFO_PERSIST_ITERS) == iters and ctx.info(9) == 0
+    ref = O.iterate(sweep, pts, tris, flavour, ratio, RATE[flavour], iters, colors=colors, literal=False)
+    _compare(ctx, ref, flavour)
+    ctx.close()
+
+
+@pytest.mark.parametrize("contrast", [0.1, 1.0])
+def test_config1_as_written(contrast):
+    """BASELINE config 1: the 674 x 449 window of fruit.png (1011 x 674 / 1.5), 150 triangles, 200 grad-iters, triangulate
+    flavour (software/triangulate/main.cpp:53, 190-204) -- one call, and the same in calls of 37 grad-iters"""
+    W, H, NT, iters = 674, 449, 150, 200
+    ctx, sweep, pts, tris, ratio, colors = _setup(W, H, NT, 0, contrast)
+    p = capi.default_params(0)
+    ctx.iterate(p, iters)
+    ctx.synchronize()
+    assert ctx.info(capi.INFO_PERSIST_ITERS) == iters and ctx.info(9) == 0
+    ref = O.iterate(sweep, pts, tris, 0, ratio, RATE[0], iters, literal=False)
+    _compare(ctx, ref, 0)
+    ctx.upload(pts, tris, None)
+    done = 0
+    while done < iters:
+        k = min(37, iters - done)
+        ctx.iterate(p, k)
+        done += k
+    _compare(ctx, ref, 0, "calls of 37")
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["huge", "allsame", "concentrated", "nan", "inf"])
+def test_hostile_vertex_sets_on_the_persistent_path(kind):
+    """the hostile vertex sets of test_hip_parity.py with enough grad-iters (6) for the persistent path: no fault, and --
+    where the positions are numbers -- the oracle's bits.  A plan may refuse such a mesh (then the call runs on the
+    two-kernel path); when it does not, the grad-iters must have run inside persistent launches."""
+    W = H = 2048
+    img, pts, tris, he, ratio = synth.workload(W, H, 3000)
+    bad = pts.copy()
+    sel = (np.arange(bad.shape[0]) % 7 == 5)
+    if kind == "nan":
+        bad[sel] = np.nan
+    elif kind == "inf":
+        bad[sel] = np.inf
+    elif kind == "huge":
+        bad *= np.float32(1e6)
+    elif kind == "allsame":
+        bad[:] = 0
+    else:
+        bad[4:] = bad[4:] * np.float32(0.1) * np.array([1.0, 0.5], np.float32) + np.float32(0.3)
+    iters = 6
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(bad, tris, None)
+    p = capi.default_params(capi.TRIANGULATE)
+    ctx.iterate(p, iters)
+    ctx.synchronize()
+    if ctx.info(capi.INFO_PATCHES) > 0:
+        assert ctx.info(capi.INFO_PERSIST_ITERS) == iters
+    if kind in ("huge", "allsame", "concentrated"):
+        ref = O.iterate(img, bad, tris, O.TRIANGULATE, ratio, RATE[0], iters, literal=False)
+        _compare(ctx, ref, 0, kind)
+    else:
+        assert ctx.retrieve(capi.BUF_POINTS).shape == bad.shape
+    ctx.close()

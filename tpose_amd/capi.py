@@ -24,7 +24,7 @@ SYMBOLS = [
     "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_retrieve_many", "tp_synchronize",
     "tp_get_stream", "tp_profile_iterate", "tp_profile_accumulate", "tp_get_info", "tp_selftest_walker", "tp_render",
     "tp_prepare", "tp_selftest_line", "tp_timer_start", "tp_timer_stop", "tp_iterate_until", "tp_band_mailbox_bytes",
-    "tp_band_attach",
+    "tp_band_attach", "tp_band_mailbox_alloc", "tp_band_mailbox_free",
 ]
 
 
@@ -39,6 +39,7 @@ RENDER_AVERAGE, RENDER_STORED = 0, 1
 OPT_PERSISTENT = 1
 PERSIST_OFF, PERSIST_AUTO = 0, 1
 INFO_PATCHES, INFO_PATCH_LDS, INFO_PATCH_LINES, INFO_PERSIST_LAUNCHES, INFO_PERSIST_ITERS, INFO_CENSUS, INFO_REPLANS = 2, 3, 4, 5, 6, 7, 8
+INFO_PERSIST_FAILURES, INFO_BOX_FINEGRAINED = 9, 10
 
 
 class Params(C.Structure):
@@ -160,6 +161,17 @@ class Context:
         arr = (C.c_void_p * max(1, len(mailboxes)))(*[C.c_void_p(int(m)) for m in mailboxes])
         self.lib.tp_band_attach.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int]
         self._ck(self.lib.tp_band_attach(self.h, band, n_bands, arr, C.c_size_t(bytes_each), points, triangles, patches_per_band))
+
+    def band_mailbox_alloc(self, nbytes):
+        """a zeroed mailbox in fine-grained memory of this context's device (tp_band_mailbox_alloc); returns its device address"""
+        out = C.c_void_p()
+        self.lib.tp_band_mailbox_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        self._ck(self.lib.tp_band_mailbox_alloc(self.h, C.c_size_t(nbytes), C.byref(out)))
+        return out.value
+
+    def band_mailbox_free(self, box):
+        self.lib.tp_band_mailbox_free.argtypes = [C.c_void_p, C.c_void_p]
+        self._ck(self.lib.tp_band_mailbox_free(self.h, C.c_void_p(box)))
 
     def set_image(self, slot, img):
         img = np.ascontiguousarray(img, np.uint8)

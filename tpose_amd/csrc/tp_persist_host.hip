@@ -1,0 +1,364 @@
+// tp_persist_host.hip -- host side of the persistent grad-iter kernel (tp_persist.hip): the status words of a launch and
+// the replay of one that gave up, the census of resident workgroups, the plan of the current triangulation, the launches of a
+// tp_iterate call, and tp_iterate_until (the reference's frame loop up to its convergence test: software/triangulate/main.cpp:
+// 201-210, software/warp/main.cpp:226-231, source/triangulation.hpp:653-674).
+#include "tp_context.h"
+
+namespace tpctx {
+
+// ---- persistent grad-iter kernel: status, census, plan ------------------------------------------------------------
+#ifdef TPOSE_DEBUG  // debug flavour of the library (tools/persist_timeline.py): per-workgroup phase timestamps
+static unsigned long long* g_persist_dbg = nullptr;
+static const size_t PERSIST_DBG_WORDS = (size_t)512 * PK_DBG_ITERS * 16;
+unsigned long long* persist_dbg_buffer(int parts, hipStream_t s) {
+    if (!g_persist_dbg) { hipMalloc((void**)&g_persist_dbg, PERSIST_DBG_WORDS * 8); }
+    hipMemsetAsync(g_persist_dbg, 0, PERSIST_DBG_WORDS * 8, s);
+    return parts <= 512 ? g_persist_dbg : nullptr;
+}
+#endif
+
+// After the stream was synchronised: did a lane of a persistent launch give up waiting?  That happens when the launch's
+// workgroups were not all resident together -- another process or another context had a persistent launch of its own on
+// the same GPU at that moment (the census only shows that a full grid fits an otherwise idle device).  A launch that
+// gives up changes nothing: `points` is only written by the small kernel behind it, which does nothing once the status
+// word is raised, and so do all later persistent launches.  So the grad-iters of the launches that did not complete are
+// run again here, on the two-kernel path, and the context stops using persistent launches.
+int check_persist_status(tp_context* c) {
+    if (!c->persist_unchecked || !c->d_status) return TP_OK;
+    c->persist_unchecked = false;
+    // (every caller has waited for the stream: the mirror is what the last k_persist_finish left)
+    const unsigned st[3] = {c->h_status[0], 0u, c->h_status[2]};
+    const size_t completed = (size_t)(st[2] - c->done_base);
+    c->done_base = st[2];
+    if (st[0] == 0u) { c->journal.clear(); return TP_OK; }
+    HIP_TRY(c, hipMemset(c->d_status, 0, sizeof(unsigned)));
+    c->h_status[0] = 0u;
+    c->census = -6;  // two kernels per grad-iter from now on in this context
+    c->persist_failures++;
+    c->mutations++;  // (what a retrieve returns is about to change)
+    std::vector<tp_context::journal_entry> todo(c->journal.begin() + (completed < c->journal.size() ? completed : c->journal.size()), c->journal.end());
+    c->journal.clear();
+    for (auto& e : todo) {
+        if (e.iters <= 0) continue;
+        if (int rc = enqueue_two_kernel(c, &e.p, resolve_dp(c, e.p.flavour, e.p.dp), e.iters)) return rc;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return TP_OK;
+}
+
+// before work that is NOT a persistent launch goes onto the stream: were the persistent launches ahead of it completed?  (A launch
+// that gave up is run again at the next check -- and that must be before anything that continues from its result.)
+int settle_persistent(tp_context* c) {
+    if (!c->persist_unchecked) return TP_OK;
+    HIP_TRY(c, wait_stream(c->stream));
+    return check_persist_status(c);
+}
+
+// once per context: launch a full grid of the persistent kernel in census mode -- every workgroup arrives at a counter and
+// waits for all the others.  If that times out, workgroups of such a grid are not resident together on this device
+// (CU masking, another process) and hand-overs inside a launch would never complete: the context keeps to two kernels.
+int take_census(tp_context* c) {
+    if (c->census != 0) return TP_OK;
+    c->census = -1;
+    if (c->num_cus < 1) return TP_OK;
+    if (!c->d_status) { HIP_TRY(c, dev_alloc(&c->d_status, 4)); }
+    if (!c->h_status) { HIP_TRY(c, hipHostMalloc((void**)&c->h_status, 4 * sizeof(unsigned), hipHostMallocDefault)); memset(c->h_status, 0, 4 * sizeof(unsigned)); }
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 4 * sizeof(unsigned), c->stream));
+    if (tp_persist_set_lds(PK_LDS_LIMIT) != 0) { (void)hipGetLastError(); c->census = -2; return TP_OK; }
+    c->lds_attr = PK_LDS_LIMIT;
+    const int full = c->num_cus * PK_WG_PER_CU;   // the grid that must be resident at once
+    std::vector<pk_wg> hw((size_t)full, pk_wg());
+    if (int rc = grow(c, &c->d_wg, &c->cap_wg, hw.size())) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_wg, hw.data(), sizeof(pk_wg) * hw.size(), hipMemcpyHostToDevice, c->stream));
+    pk_args A{};
+    A.wg = c->d_wg; A.parts = full; A.n_iters = -1; A.status = c->d_status;
+    tp_launch_persist(A, full, PK_ROWS_PER_LANE, PK_LDS_LIMIT, c->stream);
+    if (hipGetLastError() != hipSuccess) { c->census = -3; return TP_OK; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned st[2] = {1u, 0u};
+    HIP_TRY(c, hipMemcpy(st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemset(c->d_status, 0, 4 * sizeof(unsigned)));
+    c->done_base = 0;
+    if (st[0] == 0u && st[1] == (unsigned)full) c->census = 1;
+    else c->census = -4 - (int)(st[0] != 0u);
+    return TP_OK;
+}
+
+// send a plan that was cut from `points` to plan buffer `slot` (through that buffer's pinned staging area: the copy rides
+// the stream and the host does not wait for it) and make it the context's plan
+int install_plan(tp_context* c, pk_plan& np, const float* points, int slot) {
+    tp_context::plan_buf& B = c->plan_dev[slot];
+    if (int rc = grow(c, &B.wg, &B.cap_wg, np.wg.size())) return rc;
+    if (int rc = grow(c, &B.pool, &B.cap_pool, np.pool.size())) return rc;
+    const size_t b_wg = sizeof(pk_wg) * np.wg.size(), b_pool = sizeof(int32_t) * np.pool.size();
+    static_assert(sizeof(pk_wg) % 4 == 0, "plans travel as 32-bit words");
+    if (b_wg + b_pool > B.cap_stage) {
+        // (the staging area may still feed a copy enqueued for an earlier plan in this buffer: wait before dropping it)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (B.stage) hipHostFree(B.stage);
+        B.stage = nullptr; B.cap_stage = 0;
+        const size_t n = (b_wg + b_pool) * 3 / 2 + 4096;
+        HIP_TRY(c, hipHostMalloc((void**)&B.stage, n, hipHostMallocDefault));
+        B.cap_stage = n;
+    }
+    memcpy(B.stage, np.wg.data(), b_wg);
+    memcpy(B.stage + b_wg, np.pool.data(), b_pool);
+    // (ONE kernel reads the staging area across the link.  Two hipMemcpyAsync did this before; issued on an IDLE stream --
+    // a plan cut on the side, installed at the start of a call -- they returned after 8 ms once in ~30 times.)
+    tp_copy_list G{};
+    G.src[0] = (const uint32_t*)B.stage; G.dst[0] = (uint32_t*)B.wg; G.words[0] = (uint32_t)(b_wg / 4);
+    G.src[1] = (const uint32_t*)(B.stage + b_wg); G.dst[1] = (uint32_t*)B.pool; G.words[1] = (uint32_t)(b_pool / 4);
+    G.n = 2;
+    tp_launch_copy_list(G, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    c->plan = std::move(np);
+    c->plan_slot = slot;
+    c->plan_points.assign(points, points + 2 * (size_t)c->NP);
+    c->iters_since_cut = 0;
+    return TP_OK;
+}
+int plan_patches(const tp_context* c) { return c->n_bands > 1 ? c->n_bands * c->band_patches : c->num_cus * PK_WG_PER_CU; }
+
+// cut a plan from `points` and install it in plan buffer `slot`.  c->plan is replaced only when the new plan is usable.
+int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok) {
+    pk_plan np;
+    pk_build_plan(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
+                  c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, plan_patches(c), PK_LDS_LIMIT, np,
+                  c->plan_base_every);
+    // (a band split runs equal shares of the patches: a plan with fewer patches than asked for -- a tiny mesh -- is not split)
+    if (np.ok && c->n_bands > 1 && np.parts != c->n_bands * c->band_patches) { np.ok = false; np.why = "fewer patches than the bands need"; }
+    *ok = np.ok;
+    if (!np.ok) { if (!c->plan.ok) c->plan = np; return TP_OK; }
+    return install_plan(c, np, points, slot);
+}
+
+// the plan of the current triangulation (built on first use after an upload); *use = whether tp_iterate may take the
+// persistent path
+int ensure_plan(tp_context* c, float dp, bool* use, bool base_every) {
+    *use = false;
+    // (bands keep ONE plan for tp_iterate and tp_iterate_until -- the one that walks every triangle's base lines in every grad-iter:
+    // cutting a plan again allocates, and an allocation may wait for a device on which another band is already waiting for this one)
+    if (c->n_bands > 1) base_every = true;
+    if (c->persist_mode == TP_PERSIST_OFF || !c->px_pitch) return TP_OK;  // (rasters beyond 4096 columns or rows have no pixel-record table)
+    if (int rc = take_census(c)) return rc;
+    if (c->census != 1) return TP_OK;
+    if (c->plan_generation == c->generation && base_every && !c->plan_base_every) {
+        // the plan of this triangulation does not walk the base lines in every grad-iter yet: cut it again (from the
+        // upload-time positions; a later re-plan follows the mesh) -- nothing in flight reads the plan buffers by then
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->plan_generation = 0;
+    }
+    if (c->plan_generation != c->generation) {
+        c->plan_generation = c->generation;
+        c->plan = pk_plan();
+        c->plan_base_every = base_every;
+        c->snap_pending[0] = c->snap_pending[1] = false;   // (uploads synchronise the stream: nothing is in flight)
+        bool ok = false;
+        if (int rc = build_plan(c, c->h_points.data(), dp, 0, &ok)) return rc;
+        if (ok) {
+            const size_t np = (size_t)c->NP;
+            if (c->n_bands > 1 && np > c->band_cap) { c->plan.ok = false; c->plan.why = "more vertices than the bands' mailboxes hold"; *use = false; return TP_OK; }
+            if (c->n_bands == 1 && (np > c->cap_posbox || !c->posbox)) {
+                hipFree(c->posbox); c->posbox = nullptr; c->cap_posbox = 0;
+                const size_t n = np + np / 2 + 64;
+                HIP_TRY(c, dev_alloc(&c->posbox, n * 8)); c->cap_posbox = n;
+                // a cleared mailbox matches no tag; afterwards tags never repeat (the epoch counts on across uploads), so
+                // the granules of an earlier triangulation are never taken for this one's
+                HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 8 * sizeof(unsigned long long), c->stream));
+            }
+            if (int rc = grow(c, &c->points_out, &c->cap_points_out, np)) return rc;
+            if (np > c->snap_cap) {
+                for (int k = 0; k < 2; k++) { if (c->snap_host[k]) hipHostFree(c->snap_host[k]); c->snap_host[k] = nullptr; }
+                c->snap_cap = 0;
+                const size_t n = np + np / 2 + 64;
+                for (int k = 0; k < 2; k++) HIP_TRY(c, hipHostMalloc((void**)&c->snap_host[k], n * 2 * sizeof(float), hipHostMallocDefault));
+                c->snap_cap = n;
+            }
+            for (int k = 0; k < 2; k++) if (!c->snap_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->snap_ev[k], hipEventDisableTiming));
+        }
+    }
+    *use = c->plan.ok;
+    return TP_OK;
+}
+
+// n grad-iters of the persistent kernel -- the last one writes `tenergy`, `colnum`, `colacc`, `gradient` --, then
+// `points_out` -> `points` / `epos`
+int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings) {
+    while (n > 0) {
+        if (int rc = take_replan(c)) return rc;   // (a plan cut on the side since an earlier call, if it is ready)
+        // long calls go chunk by chunk (a chunk and a half rather than a short tail)
+        const int k = n <= PK_CHUNK + PK_CHUNK / 2 ? n : PK_CHUNK;   // (rings: the caller's chunks are shorter than this)
+        if (c->epoch + (uint32_t)k > PK_MAX_EPOCH) {
+            if (c->n_bands > 1) return fail(c, TP_ERR_STATE, "band split: the mailbox tags are used up (2^31 grad-iters)");
+            HIP_TRY(c, hipMemsetAsync(c->posbox, 0, c->cap_posbox * 8 * sizeof(unsigned long long), c->stream));
+            c->epoch = 1;
+        }
+        pk_args A{};
+        A.wg = c->plan_dev[c->plan_slot].wg; A.pool = c->plan_dev[c->plan_slot].pool; A.parts = c->plan.parts;
+        A.vw.dp = dp; A.vw.ratio = c->ratio; A.vw.halfW = 0.5f * (float)c->W; A.vw.halfH = 0.5f * (float)c->H; A.vw.W = c->W; A.vw.H = c->H;
+        A.px = c->px[p.image_slot]; A.px_pitch = c->px_pitch;
+        A.points = c->points; A.points_out = c->points_out; A.ca = c->ca;
+        A.NT = c->NT; A.NP = c->NP; A.NE = c->NE;
+        A.flavour = p.flavour; A.rate = p.rate;
+        const bool banded = c->n_bands > 1;
+        const int grid = banded ? c->band_patches : c->plan.parts;
+        A.posbox = banded ? c->band_box[c->band] : c->posbox;
+        A.box_stride = (unsigned)(banded ? c->band_cap : c->cap_posbox);
+        if (banded) {
+            A.part0 = c->band * c->band_patches;
+            for (int b = 0; b < c->n_bands; b++) if (b != c->band) A.peer_box[A.n_peers++] = c->band_box[b];
+            A.final_tag = 0x80000000u | ((c->epoch + (uint32_t)k) & 0x7fffffffu);
+            A.final_slot = (unsigned)(c->band_seq++ & 1);
+        }
+        A.epoch = c->epoch; A.n_iters = k; A.status = c->d_status;
+        A.emit = n == k && !rings; A.ten = c->ten; A.cn = c->cn; A.ca_out = c->ca; A.gr = c->gr;
+        if (rings && !banded_rings(c)) { A.ering = c->ering; A.pring = c->pring; }
+        if (rings && banded_rings(c)) {
+            // (the half of the rings this chunk writes: the next chunk's frame 0 needs nothing from the other bands, so a band that is
+            // a chunk ahead would otherwise store into a ring whose last chunk this band's host is still reading -- tp_iterate_until)
+            const size_t eo = (size_t)c->ring_half * (PK_RING_FRAMES / 2) * (size_t)c->NT, po = (size_t)c->ring_half * (PK_RING_FRAMES / 2) * (size_t)c->NP;
+            A.ering = band_ering(c, c->band) + eo; A.pring = band_pring(c, c->band) + po;
+            int n = 0;
+            for (int b = 0; b < c->n_bands; b++) if (b != c->band) { A.peer_ering[n] = band_ering(c, b) + eo; A.peer_pring[n] = band_pring(c, b) + po; n++; }
+        }
+#ifdef TPOSE_DEBUG
+        A.dbg = persist_dbg_buffer(c->plan.parts, c->stream);
+        { const char* f = getenv("TPOSE_DBG_FIRST"); A.dbg_first = f ? atoi(f) : 0; }
+#endif
+        tp_launch_persist(A, grid, c->plan.rows_max, c->plan.lds_bytes, c->stream);
+        if (banded) tp_launch_band_collect(make_launch(c, p.image_slot, dp), A, c->points_out, c->stream);
+        tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->h_status, c->stream);
+        c->journal.push_back({p, rings ? 0 : k});   // (a chunk of tp_iterate_until is checked by its caller: nothing to replay)
+        HIP_TRY(c, hipGetLastError());
+        c->epoch += (uint32_t)k;
+        c->persist_unchecked = true;
+        c->persist_launches++; c->persist_iters += k;
+        c->iters_since_snap += k; c->iters_since_cut += k;
+        n -= k;
+        if (c->iters_since_snap >= PK_CHUNK / 2) {   // the positions after this chunk, for a later maybe_replan
+            const int sl = c->snap_next;
+            HIP_TRY(c, hipMemcpyAsync(c->snap_host[sl], c->points, sizeof(float) * 2 * (size_t)c->NP, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipEventRecord(c->snap_ev[sl], c->stream));
+            c->snap_pending[sl] = true;
+            c->snap_next = sl ^ 1;
+            c->iters_since_snap = 0;
+        }
+        // with this chunk on the stream (the GPU has work while the host cuts): does the mesh want a new plan?
+        if (int rc = maybe_replan(c, dp, n > 0)) return rc;
+    }
+    return TP_OK;
+}
+
+}  // namespace tpctx
+
+using namespace tpctx;
+
+extern "C" {
+
+int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double threshold, float* toterr, int* frames, float* relerr) {
+    api_guard api_lock;
+    if (!c) return TP_ERR_INVALID;
+    if (int rc = validate_params(c, p, max_frames)) return rc;
+    if (!toterr || !frames) return fail(c, TP_ERR_INVALID, "iterate_until: toterr / frames is NULL");
+    *frames = 0;
+    if (relerr) *relerr = 0.0f;
+    if (max_frames == 0) return TP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->mutations++;
+    if (int rc = settle_persistent(c)) return rc;
+    const float dp = resolve_dp(c, p->flavour, p->dp);
+    const int NT = c->NT;
+    float tot = *toterr, rel = 0.0f;
+    // geterr (source/triangulation.hpp:653-674) on the base energies of one frame: float32, ascending t
+    auto frame_err = [&](const int32_t* terr) {
+        float newerr = 0.0f;
+        for (int i = 0; i < NT; i++) { float err = 0.0f; err += (float)terr[i]; newerr += err; }
+        rel = (tot - newerr) / tot;
+        tot = newerr;
+        return (double)std::fabs(rel);   // (the reference compares the float with a double literal)
+    };
+    auto host_ring = [&](size_t ints) -> int {
+        if (ints <= c->cap_ering_host && c->ering_host) return TP_OK;
+        if (c->ering_host) hipHostFree(c->ering_host);
+        c->ering_host = nullptr; c->cap_ering_host = 0;
+        HIP_TRY(c, hipHostMalloc((void**)&c->ering_host, ints * sizeof(int32_t), hipHostMallocDefault));
+        c->cap_ering_host = ints;
+        return TP_OK;
+    };
+    bool use = false;
+    if (max_frames >= PK_MIN_ITERS && (c->n_bands == 1 || banded_rings(c))) { if (int rc = ensure_plan(c, dp, &use, true)) return rc; }
+    if (banded_rings(c) && (size_t)NT > c->band_cap_tris) use = false;   // (more triangles than the bands' rings were sized for: every band on its own)
+    int done = 0, chunk = 32;
+    bool converged = false;
+    while (done < max_frames && !converged) {
+        const int left = max_frames - done;
+        if (!use || left < PK_MIN_ITERS) {
+            // frame by frame on the two-kernel path: one frame, then the base energies come back
+            if (int rc = host_ring((size_t)NT)) return rc;
+            enqueue_iter(c, *p, dp);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(c->ering_host, c->ten, sizeof(int32_t) * (size_t)NT, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, wait_stream(c->stream));
+            done++;
+            converged = frame_err(c->ering_host) < threshold;
+            continue;
+        }
+        // a chunk of frames inside one persistent launch: every frame leaves its base energies and its starting positions
+        const bool shared = banded_rings(c);   // (band split: the rings are in the bands' mailboxes, every band writes into all of them)
+        // (... in halves of PK_RING_FRAMES / 2 frames used in turn, chunk after chunk, over the life of the attachment: a band cannot be
+        // two chunks ahead of another -- frames beyond the first need the others' positions of the same launch -- so a half is never
+        // written while a host still reads the chunk before last from it)
+        const int cap_frames = shared ? PK_RING_FRAMES / 2 : 256;
+        const int C = left < chunk ? (left < cap_frames ? left : cap_frames) : (chunk < cap_frames ? chunk : cap_frames);
+        if (shared) c->ring_half = (int)(c->ring_seq++ & 1);
+        if (!shared) {
+            if (int rc = grow(c, &c->ering, &c->cap_ering, (size_t)C * NT)) return rc;
+            if (int rc = grow(c, &c->pring, &c->cap_pring, (size_t)C * c->NP)) return rc;
+        }
+        const int32_t* ering = shared ? band_ering(c, c->band) + (size_t)c->ring_half * (PK_RING_FRAMES / 2) * (size_t)NT : c->ering;
+        const float2* pring = shared ? band_pring(c, c->band) + (size_t)c->ring_half * (PK_RING_FRAMES / 2) * (size_t)c->NP : c->pring;
+        if (int rc = host_ring((size_t)256 * NT)) return rc;   // (for the longest chunk at once: freeing pinned memory waits for the device)
+        if (int rc = enqueue_persistent(c, *p, dp, C, true)) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->ering_host, ering, sizeof(int32_t) * (size_t)C * NT, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, wait_stream(c->stream));
+        {
+            const int64_t fails = c->persist_failures;
+            if (int rc = check_persist_status(c)) return rc;
+            if (c->persist_failures != fails) { use = false; continue; }   // the chunk gave up (nothing changed): frame by frame from here
+        }
+        int j = 0;
+        for (; j < C; j++) {
+            done++;
+            if (frame_err(c->ering_host + (size_t)j * NT) < threshold) { converged = true; break; }
+        }
+        if (converged || done >= max_frames) {
+            // back to the start of the last frame that counts, and that frame once more on the two-kernel path: it writes the
+            // buffers the reference reads back (`tenergy`, `colnum`, `colacc`, `gradient`) and takes the step
+            const int last = converged ? j : C - 1;
+            tp_launch_persist_finish(make_launch(c, p->image_slot, dp), pring + (size_t)last * c->NP, nullptr, nullptr, c->stream);
+            enqueue_iter(c, *p, dp);
+            HIP_TRY(c, hipGetLastError());
+            break;
+        }
+        if (chunk < 256) chunk *= 2;
+    }
+    if (!use || max_frames < PK_MIN_ITERS) { /* (the two-kernel frames left the buffers of the last frame in place) */ }
+    c->acc_slot = p->image_slot; c->last_flavour = p->flavour;
+    c->accumulated = c->energized = false;
+    *toterr = tot; *frames = done;
+    if (relerr) *relerr = rel;
+    return TP_OK;
+}
+
+#ifdef TPOSE_DEBUG
+// debug flavour only (tools/persist_timeline.py): [workgroup][grad-iter < 64][8] phase timestamps of the last persistent launch
+int tp_debug_dump_persist(tp_context* c, unsigned long long* out, int n) {
+    api_guard api_lock;
+    if (!g_persist_dbg) return TP_ERR_STATE;
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(out, g_persist_dbg, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost);
+    return TP_OK;
+}
+#endif
+
+}  // extern "C"

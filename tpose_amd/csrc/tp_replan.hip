@@ -1,0 +1,87 @@
+// tp_replan.hip -- re-planning while a long descent runs: vertices drift, lines grow, and the patches
+// of the plan a descent started with go out of balance.  The cut itself is tp_plan.h: pk_build_plan.
+#include "tp_context.h"
+
+namespace tpctx {
+
+// the same cut on the context's worker thread, from a snapshot of the positions (maybe_replan); nothing of the context is
+// touched until take_replan() finds the cut finished
+void replan_worker_main(tp_context::replan_worker* w) {
+    std::unique_lock<std::mutex> lk(w->m);
+    for (;;) {
+        w->cv.wait(lk, [w] { return w->go || w->stop; });
+        if (w->stop) return;
+        w->go = false;
+        lk.unlock();
+        pk_build_plan(w->NP, w->NT, w->tris.data(), w->points.data(), w->NE, w->edge_uv.data(), w->he_edge.data(), w->W, w->H, w->ratio,
+                      w->dp * 0.5f * (float)w->H, w->parts, PK_LDS_LIMIT, w->plan, w->base_every);
+        lk.lock();
+        w->busy = false; w->done = true;
+    }
+}
+void start_replan(tp_context* c, const float* points, float dp) {
+    if (!c->worker) {
+        c->worker.reset(new tp_context::replan_worker());
+        c->worker->th = std::thread(replan_worker_main, c->worker.get());
+    }
+    tp_context::replan_worker* w = c->worker.get();
+    std::lock_guard<std::mutex> lk(w->m);
+    if (w->busy || w->done) return;   // (one cut at a time: the one under way is from positions nearly as new)
+    w->points.assign(points, points + 2 * (size_t)c->NP);
+    w->tris = c->h_tris; w->edge_uv = c->h_edge_uv; w->he_edge = c->h_he_edge;
+    w->NP = c->NP; w->NT = c->NT; w->NE = c->NE; w->W = c->W; w->H = c->H; w->parts = plan_patches(c);
+    w->ratio = c->ratio; w->dp = dp; w->generation = c->generation; w->base_every = c->plan_base_every;
+    w->superseded = false; w->busy = true; w->go = true;
+    w->cv.notify_one();
+}
+// a finished cut becomes the context's plan (for the launches enqueued from now on); one of another triangulation, of the other
+// kind of plan, or overtaken by a cut on the calling thread is dropped
+int take_replan(tp_context* c) {
+    tp_context::replan_worker* w = c->worker.get();
+    if (!w) return TP_OK;
+    std::lock_guard<std::mutex> lk(w->m);
+    if (!w->done) return TP_OK;
+    w->done = false;
+    if (w->superseded || w->generation != c->generation || c->plan_generation != c->generation || w->base_every != c->plan_base_every || !w->plan.ok || c->n_bands > 1) return TP_OK;
+    if (int rc = install_plan(c, w->plan, w->points.data(), c->plan_slot ^ 1)) return rc;
+    c->replans++;
+    return TP_OK;
+}
+void stop_replan_worker(tp_context* c) {
+    if (!c->worker) return;
+    { std::lock_guard<std::mutex> lk(c->worker->m); c->worker->stop = true; }
+    c->worker->cv.notify_one();
+    if (c->worker->th.joinable()) c->worker->th.join();
+    c->worker.reset();
+}
+
+// after a chunk has been enqueued: the snapshot taken after the chunk before it, if there is one -- a new plan for the
+// chunks to come when the mesh has drifted
+// more_chunks: the call has more chunks to enqueue behind the one just enqueued -- the cut is made right here, on the calling
+// thread (the GPU runs that chunk meanwhile, and the next one starts on the new plan); otherwise on the context's worker
+// thread, and a later call picks the plan up (a call of a few grad-iters never waits 2.6 ms for a cut)
+int maybe_replan(tp_context* c, float dp, bool more_chunks) {
+    const int k = c->snap_next;   // the older of the two snapshot slots: the one the next chunk's snapshot will overwrite
+    if (!c->snap_pending[k]) return TP_OK;
+    if (c->n_bands > 1) { c->snap_pending[k] = false; return TP_OK; }   // (bands keep the plan they all cut from the upload)
+    HIP_TRY(c, hipEventSynchronize(c->snap_ev[k]));
+    c->snap_pending[k] = false;
+    const float* q = c->snap_host[k];
+    const float* o = c->plan_points.data();
+    const float sx = 0.5f * (float)c->W / c->ratio, sy = 0.5f * (float)c->H;
+    float worst = 0.0f;
+    for (size_t i = 0, n = 2 * (size_t)c->NP; i < n; i += 2) {
+        const float dx = (q[i] - o[i]) * sx, dy = (q[i + 1] - o[i + 1]) * sy;
+        const float d = (dx < 0 ? -dx : dx) > (dy < 0 ? -dy : dy) ? (dx < 0 ? -dx : dx) : (dy < 0 ? -dy : dy);
+        if (d > worst) worst = d;   // (NaN never compares greater: a vertex gone to NaN does not trigger)
+    }
+    if (worst <= PK_REPLAN_PX) return TP_OK;
+    if (!more_chunks) { start_replan(c, q, dp); return TP_OK; }
+    if (c->worker) { std::lock_guard<std::mutex> lk(c->worker->m); c->worker->superseded = true; }
+    bool ok = false;
+    if (int rc = build_plan(c, q, dp, c->plan_slot ^ 1, &ok)) return rc;
+    if (ok) c->replans++;
+    return TP_OK;
+}
+
+}  // namespace tpctx

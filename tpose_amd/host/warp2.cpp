@@ -179,7 +179,7 @@ int main(int argc, char** argv) {
     std::string ia, ib, ta, tb, idfile, how = "rccl";
     long levelframes = 1L << 40;
     int device = -1, rank = -1, bands = 1, band = 0, bandpatches = 0;
-    bool quiet = false, selftest = false, fixed = false;
+    bool quiet = false, selftest = false, fixed = false, coarse = false;
     for (int a = 1; a < argc; a++) {
         const std::string k = argv[a];
         auto val = [&]() -> const char* { if (a + 1 >= argc) die("missing value for " + k); return argv[++a]; };
@@ -198,6 +198,7 @@ int main(int argc, char** argv) {
         else if (k == "-band") band = std::atoi(val());
         else if (k == "-bandpatches") bandpatches = std::atoi(val());
         else if (k == "-fixedframes") fixed = true;
+        else if (k == "-coarse") coarse = true;
         else if (k == "-selftest") selftest = true;
         else die("unknown option " + k);
     }
@@ -266,11 +267,24 @@ int main(int argc, char** argv) {
         const size_t bytes = tp_band_mailbox_bytes(cap_points, cap_tris);
 #ifndef WARP2_NO_RCCL
         HIPCHECK(hipSetDevice(device));
-        HIPCHECK(hipMalloc(&boxes[band], bytes));
-        HIPCHECK(hipMemset(boxes[band], 0, bytes));
-        HIPCHECK(hipDeviceSynchronize());
+        // fine-grained device memory: the mate's GPU writes positions into it while this band's kernel polls it (tpose_hip.h:
+        // tp_band_attach, MEMORY TYPE).  -coarse keeps the round-3 allocation (plain hipMalloc) for A/B timing on one device.
         hipIpcMemHandle_t h;
-        HIPCHECK(hipIpcGetMemHandle(&h, boxes[band]));
+        bool fine = !coarse;
+        if (fine && tp_band_mailbox_alloc(tpose::ctx, bytes, &boxes[band]) != TP_OK) die(std::string("tp_band_mailbox_alloc: ") + tp_last_error(tpose::ctx));
+        if (fine && hipIpcGetMemHandle(&h, boxes[band]) != hipSuccess) {
+            (void)hipGetLastError();
+            std::cerr << "warp2: fine-grained memory cannot be shared between processes on this system; falling back to hipMalloc "
+                         "(bands on DIFFERENT devices will time out in every launch)" << std::endl;
+            tp_band_mailbox_free(tpose::ctx, boxes[band]); boxes[band] = nullptr; fine = false;
+        }
+        if (!fine) {
+            HIPCHECK(hipMalloc(&boxes[band], bytes));
+            HIPCHECK(hipMemset(boxes[band], 0, bytes));
+            HIPCHECK(hipDeviceSynchronize());
+            HIPCHECK(hipIpcGetMemHandle(&h, boxes[band]));
+        }
+        if (!quiet) std::cout << "band " << band << " of rank " << rank << ": mailbox in " << (fine ? "fine-grained" : "coarse-grained") << " device memory" << std::endl;
         std::vector<int32_t> out(sizeof h / 4);
         std::memcpy(out.data(), &h, sizeof h);
         const std::vector<int32_t> in = mate.exchange(out);
