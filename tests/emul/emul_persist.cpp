@@ -113,6 +113,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
         memcpy(V.base, &P.pool[w.off_base], sizeof(int32_t) * 4 * w.n_base);
         for (int s = 0; s < w.n_slots; s++) { V.pos[s].x = points[2 * V.vid[s]]; V.pos[s].y = points[2 * V.vid[s] + 1]; }
         S[p].cache.resize(PK_CACHED);
+        memset((void*)S[p].cache.data(), 0xCD, sizeof(S[p].cache[0]) * S[p].cache.size());   // (registers hold anything when a kernel starts)
     }
     std::vector<unsigned long long> posbox((size_t)2 * NP * 2, 0);
     const char* table = reinterpret_cast<const char*>(T.data());
@@ -142,7 +143,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             memset(V.sums, 0, sizeof(unsigned long long) * PK_SUM_STRIDE * (size_t)w.n_lines_all);
             if (recut) {   // the wave's lanes one after the other
                 const int RRk = pk_rr_for(P.rows_max);   // tp_launch_persist's choice
-                int changed = 0, sum[64];
+                int changed = it == 0 ? 1 : 0, sum[64];
                 int rpl = it == 0 ? w.rows : S[p].rpl;
                 bool first = it == 0;
                 for (;;) {
@@ -166,7 +167,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                 if (g_recuts) g_recuts[0] += changed;
             }
             const int n_li = emit ? S[p].n_li_all : S[p].n_li;
-            for (int k = 0; k < w.n_own_v; k++) { V.grad[k].x = 0; V.grad[k].y = 0; }
+            for (int k = 0; k < w.n_own_v; k++) { V.gacc[2 * k] = 0ull; V.gacc[2 * k + 1] = 0ull; }
             // P3
             if (g_walk_stats && it < g_walk_stats_iters) {
                 int64_t* ws = g_walk_stats + 6 * (size_t)it;
@@ -221,8 +222,8 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                         ten[id] = en[m]; cn[id] = tp_wrap32(mm.n);
                     }
                 }
-                V.grad[own].x = (int32_t)((uint32_t)V.grad[own].x + ((uint32_t)en[1] - (uint32_t)en[2]));
-                V.grad[own].y = (int32_t)((uint32_t)V.grad[own].y + ((uint32_t)en[3] - (uint32_t)en[4]));
+                V.gacc[2 * own] += pk_gacc_word((uint32_t)en[1] - (uint32_t)en[2]);       // (the kernel: one returning LDS atomic each)
+                V.gacc[2 * own + 1] += pk_gacc_word((uint32_t)en[3] - (uint32_t)en[4]);
             }
             if (emit)
                 for (int k = 0; k < w.n_base; k++) {
@@ -236,8 +237,14 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             // P7: posts go to the OTHER parity of the mailbox, so workgroups replayed later in this sweep still read this
             // grad-iter's positions
             for (int k = 0; k < w.n_own_v; k++) {
-                if (emit && gr) { gr[2 * V.vid[k]] = V.grad[k].x; gr[2 * V.vid[k] + 1] = V.grad[k].y; }
-                const pk_f2 np_ = pk_vertex_lane(V.pos[k], V.grad[k].x, V.grad[k].y, V.vid[k], ratio, rate);
+                // (every corner of the vertex has been counted on both axes; the sums are the high words)
+                int ncorn = 0;
+                for (int q = 0; q < w.n_corners; q++) ncorn += ((V.corners[q].y >> 2) & 0x3ff) == k;
+                if ((uint32_t)V.gacc[2 * k] != (uint32_t)ncorn || (uint32_t)V.gacc[2 * k + 1] != (uint32_t)ncorn) return -4;
+                const int32_t gx_ = (int32_t)(uint32_t)(V.gacc[2 * k] >> 32), gy_ = (int32_t)(uint32_t)(V.gacc[2 * k + 1] >> 32);
+                if (emit && gr) { gr[2 * V.vid[k]] = gx_; gr[2 * V.vid[k] + 1] = gy_; }
+                pk_f2 np_ = V.pos[k];
+                if (V.vid[k] >= 4) { np_.x = pk_step_axis(np_.x, gx_, ratio, rate); np_.y = pk_step_axis(np_.y, gy_, 1.0f, rate); }
                 V.pos[k] = np_;
                 uint32_t bx, by;
                 memcpy(&bx, &np_.x, 4); memcpy(&by, &np_.y, 4);

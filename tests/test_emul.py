@@ -363,3 +363,18 @@ def test_pixel_records_are_exact(em, W, H):
             np.full((H, W, 4), 255, np.uint8) if kind == 1 else (rng.integers(0, 2, (H, W, 4), dtype=np.uint8) * 255)
         img = np.ascontiguousarray(img)
         assert em.emul_px_check(img.ctypes.data_as(C.c_void_p), C.c_size_t(img.strides[0]), W, H) == 0
+
+
+def test_persistent_patch_without_vertices(emp):
+    """a crowded mesh (3000 triangles squeezed into ~200 x 100 pixels of a 2048^2 raster, the four corners left in place) is cut
+    into patches of which one owns nothing: its threads must decide so at the first cut of a launch instead of walking whatever
+    their registers held (the emulator fills the lane caches with garbage like a kernel's registers at launch)"""
+    W = H = 2048
+    img, pts, tris, he, ratio = synth.workload(W, H, 3000)
+    bad = pts.copy()
+    bad[4:] = bad[4:] * np.float32(0.1) * np.array([1.0, 0.5], np.float32) + np.float32(0.3)
+    rc, p, stats = emul_persist(emp, img, bad, tris, 0, ratio, 0.00005, 2, max_parts=256, lds=160 * 1024 - 512)
+    assert rc == 0
+    ref = O.iterate(img, bad, tris, 0, ratio, 0.00005, 2, literal=False)
+    assert np.array_equal(p.view(np.uint32), ref["points"].view(np.uint32))
+    assert np.array_equal(stats_out["ten"], ref["ten"])

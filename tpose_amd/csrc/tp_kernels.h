@@ -64,6 +64,8 @@ void tp_launch_render(const tp_launch& L, const float2* pts, int source, void* o
 
 // ---- persistent grad-iter kernel (tp_persist.hip): K grad-iters per launch, one workgroup per patch of the mesh
 #define PK_DBG_ITERS 64
+#define PK_DBG_WITERS 32                                /* grad-iters with per-wave stamps (debug flavour) */
+#define PK_DBG_WBASE ((size_t)512 * PK_DBG_ITERS * 16) /* ... which follow the per-workgroup stamps in the debug buffer */
 #define PK_MAX_PEERS 3
 struct pk_args {
     const pk_wg* wg;            // [parts] per-patch headers (tp_plan.h)
@@ -102,6 +104,9 @@ struct pk_args {
     int dbg_first;
 #endif
 };
+#ifdef TPOSE_DEBUG
+int tp_persist_debug_faults(unsigned long long out[16]);   // debug flavour: table offsets beyond the table seen by k_persist
+#endif
 int tp_persist_set_lds(int bytes);  // hipFuncSetAttribute(max dynamic LDS); returns the hipError_t
 void tp_launch_persist(const pk_args& A, int grid, int rows, int lds_bytes, hipStream_t s);   // grid: workgroups = patches of this launch
 // band split: the positions the launch ended with, from the own mailbox (every band posted there) into points_out; raises

@@ -33,7 +33,11 @@ struct pk_view {
     pk_walker* wk;             // [n_lines_all]
     pk_f2* pos;                // [n_slots]
     pk_i2* snap;               // own slot k: [5 k + move]; neighbour slot s: [5 n_own_v + s - n_own_v] (unmoved)
-    pk_i2* grad;               // [n_own_v]
+    unsigned long long* gacc;  // [n_own_v][2] per own vertex and axis: {corners that have added their central difference this grad-iter : 32 (low),
+                               // the int32 wrapping sum of those differences : 32 (high)} -- ONE returning 64-bit LDS atomic per corner and axis
+                               // adds (difference << 32) | 1, and the lane whose returned count completes the vertex (vdeg) holds the whole sum:
+                               // it takes that axis' step right there, no workgroup barrier between the corners and the steps
+    int32_t* vdeg;             // [n_own_v] corners of the vertex
     int32_t* vid;              // static tables, copied from the plan's pool at the start of the launch
     int32_t* edges;
     int32_t* lines;
@@ -52,7 +56,8 @@ TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     V.wk = (pk_walker*)p; p += pk_align16(w.n_lines_all * 24);
     V.pos = (pk_f2*)p; p += pk_align16(w.n_slots * 8);
     V.snap = (pk_i2*)p; p += pk_align16((4 * w.n_own_v + w.n_slots) * 8);
-    V.grad = (pk_i2*)p; p += pk_align16(w.n_own_v * 8);
+    V.gacc = (unsigned long long*)p; p += pk_align16(w.n_own_v * 16);
+    V.vdeg = (int32_t*)p; p += pk_align16(w.n_own_v * 4);
     V.vid = (int32_t*)p; p += pk_align16(w.n_slots * 4);
     V.edges = (int32_t*)p; p += pk_align16(w.n_edges * 4);
     V.lines = (int32_t*)p; p += pk_align16(w.n_lines_all * 4);
@@ -79,16 +84,20 @@ TP_HD void pk_snap_lane(const pk_wg& w, const pk_view& V, const tp_view& vw, int
 }
 
 // P1b, lane l < n_lines: line l = (local edge, version) -- the walker of the whole line
-TP_HD void pk_setup_ends(const pk_view& V, const tp_view& vw, int su, int sv, int q, pk_walker& out) {
+// ... its endpoints displaced by (dxu, dyu) and (dxv, dyv) t-pose units (a thread's first line: worked out once per launch)
+TP_HD void pk_setup_moved(const pk_view& V, const tp_view& vw, int su, int sv, float dxu, float dyu, float dxv, float dyv, pk_walker& out) {
     const pk_f2 pu = V.pos[su], pv = V.pos[sv];
-    // line q: endpoint u displaced by move mu, endpoint v by move mv (tp_kernels.hip: k_lines)
-    const int mu = (q >= 1 && q <= 4) ? q : 0, mv = q >= 5 ? q - 4 : 0;
     int32_t Xa, Ya, Xb, Yb;
-    tp_vertex_stage(pu.x, pu.y, mu, 0, vw, Xa, Ya);
-    tp_vertex_stage(pv.x, pv.y, mv, 0, vw, Xb, Yb);
+    tp_vertex_stage_d(pu.x, pu.y, dxu, dyu, vw, Xa, Ya);
+    tp_vertex_stage_d(pv.x, pv.y, dxv, dyv, vw, Xb, Yb);
     tp_line ln;
     tp_setup_line(Xa, Ya, Xb, Yb, vw.H, ln);
     out.x = ln.x; out.s = ln.s; out.ra = ln.ra; out.rb = ln.rb;
+}
+TP_HD void pk_setup_ends(const pk_view& V, const tp_view& vw, int su, int sv, int q, pk_walker& out) {
+    // line q: endpoint u displaced by move mu, endpoint v by move mv (tp_kernels.hip: k_lines)
+    const int mu = (q >= 1 && q <= 4) ? q : 0, mv = q >= 5 ? q - 4 : 0;
+    pk_setup_moved(V, vw, su, sv, tp_move_dx(mu, vw.dp), tp_move_dy(mu, vw.dp), tp_move_dx(mv, vw.dp), tp_move_dy(mv, vw.dp), out);
 }
 TP_HD void pk_setup_lane(const pk_view& V, const tp_view& vw, int l, pk_walker& out) {
     const int le = V.lines[l] & 0xffff, q = V.lines[l] >> 16;
@@ -181,6 +190,23 @@ struct pk_acc {
 
 struct pk_rec { uint64_t lo, hi; };   // one pixel record (tp_raster.h, "Pixel records")
 
+// a record of the table at byte offset `off`.  (Debug flavour of the library only: offsets beyond the table are counted, the
+// first one is kept -- g_pk_fault = {table bytes, faults, offset, block | thread << 32} -- and the load is not made.)
+#if defined(TPOSE_DEBUG) && defined(__HIPCC__)
+static __device__ unsigned long long g_pk_fault[16];   // (one per translation unit; the kernel's and its reader are both in tp_persist.hip)
+#endif
+#if defined(TPOSE_DEBUG) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ pk_rec pk_load_rec(const char* table, uint32_t off) {
+    if ((unsigned long long)off + 16ull > g_pk_fault[0]) {
+        if (atomicAdd(&g_pk_fault[1], 1ull) == 0ull) { g_pk_fault[2] = off; g_pk_fault[3] = (unsigned long long)blockIdx.x | ((unsigned long long)threadIdx.x << 32); }
+        pk_rec z; z.lo = 0; z.hi = 0; return z;
+    }
+    return *reinterpret_cast<const pk_rec*>(table + off);
+}
+#else
+TP_HD pk_rec pk_load_rec(const char* table, uint32_t off) { return *reinterpret_cast<const pk_rec*>(table + off); }
+#endif
+
 // the sum of up to TP_PX_MAXSUM records into the partial sums of a lane
 TP_HD void pk_add_unpacked(uint64_t lo, uint64_t hi, pk_acc& a) {
     uint32_t no, r, g, b; uint64_t q;
@@ -228,7 +254,11 @@ TP_HD void pk_walk_rows(pk_rows& r, const char* table, int W, pk_acc& a) {
             if (u < r.n) {
                 const uint32_t col = (uint32_t)pk_next_col(r, W);
                 sx += col;
-                d[u] = *reinterpret_cast<const pk_rec*>(table + (r.row + (col << 4)));
+#if defined(TPOSE_DEBUG) && defined(__HIP_DEVICE_COMPILE__)
+                if ((unsigned long long)(r.row + (col << 4)) + 16ull > g_pk_fault[0] && atomicAdd(&g_pk_fault[14], 1ull) == 0ull)
+                    g_pk_fault[15] = (unsigned long long)r.row | ((unsigned long long)(uint32_t)r.n << 32);
+#endif
+                d[u] = pk_load_rec(table, r.row + (col << 4));
                 r.row += r.rs;
             }
         }
@@ -324,7 +354,15 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int pitch, const c
         const int32_t col = pk_next_col(t, W) & (int32_t)on;
         if (col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
 #if !defined(PK_EXP_NOLOAD)   // timing experiments only (tools/build_variants.py); never defined in the product
-            C.rec[u] = *reinterpret_cast<const pk_rec*>(table + (((t.row + (uint32_t)u * t.rs) & on) + ((uint32_t)col << 4)));
+#if defined(TPOSE_DEBUG) && defined(__HIP_DEVICE_COMPILE__)
+            if ((unsigned long long)(((t.row + (uint32_t)u * t.rs) & on) + ((uint32_t)col << 4)) + 16ull > g_pk_fault[0] && atomicAdd(&g_pk_fault[4], 1ull) == 0ull) {
+                g_pk_fault[5] = t.row; g_pk_fault[6] = (unsigned long long)u | ((unsigned long long)t.rs << 32); g_pk_fault[7] = (unsigned long long)(uint32_t)col | ((unsigned long long)(uint32_t)n << 32);
+                g_pk_fault[8] = (unsigned long long)(uint32_t)C.l | ((unsigned long long)(uint32_t)C.c << 32); g_pk_fault[9] = (unsigned long long)(uint32_t)C.TL | ((unsigned long long)C.magic << 32);
+                g_pk_fault[10] = (unsigned long long)(uint32_t)V.wk[C.l].ra | ((unsigned long long)(uint32_t)V.wk[C.l].rb << 32); g_pk_fault[11] = (unsigned long long)V.wk[C.l].x; g_pk_fault[12] = (unsigned long long)V.wk[C.l].s;
+                g_pk_fault[13] = (unsigned long long)blockIdx.x | ((unsigned long long)threadIdx.x << 32);
+            }
+#endif
+            C.rec[u] = pk_load_rec(table, ((t.row + (uint32_t)u * t.rs) & on) + ((uint32_t)col << 4));
 #endif
             C.col[u] = col;
         }
@@ -432,14 +470,16 @@ TP_HD tp_moments pk_base_moments(const pk_wg& w, const pk_view& V, int k, int& t
 }
 
 // P7, own vertex k with gradient (gx, gy): the shift.cs step (shift.cs:16-47).  Vertices 0..3 never move.
+// one coordinate of it: clamped to [-bound, bound] (and its gradient dropped) BEFORE the step (shift.cs:25-45); bound = RATIO for x, 1 for y
+TP_HD float pk_step_axis(float p, int32_t g, float bound, float rate) {
+    float tg = (float)g;
+    if (p <= -bound) { p = -bound; tg = 0.0f; } else if (p >= bound) { p = bound; tg = 0.0f; }
+    return tp_fsub(p, tp_shift_scale(tp_fmul(rate, tg)));
+}
 TP_HD pk_f2 pk_vertex_lane(pk_f2 p, int32_t gx, int32_t gy, int vid, float ratio, float rate) {
     if (vid < 4) return p;
-    float tgx = (float)gx, tgy = (float)gy;
-    float x = p.x, y = p.y;
-    if (x <= -ratio) { x = -ratio; tgx = 0.0f; } else if (x >= ratio) { x = ratio; tgx = 0.0f; }
-    if (y <= -1.0f) { y = -1.0f; tgy = 0.0f; } else if (y >= 1.0f) { y = 1.0f; tgy = 0.0f; }
-    x = tp_fsub(x, tp_shift_scale(tp_fmul(rate, tgx)));
-    y = tp_fsub(y, tp_shift_scale(tp_fmul(rate, tgy)));
-    pk_f2 r; r.x = x; r.y = y;
+    pk_f2 r; r.x = pk_step_axis(p.x, gx, ratio, rate); r.y = pk_step_axis(p.y, gy, 1.0f, rate);
     return r;
 }
+// what a corner adds to its vertex's accumulator of one axis, and what the accumulator then says
+TP_HD unsigned long long pk_gacc_word(uint32_t d) { return ((unsigned long long)d << 32) | 1ull; }

@@ -30,8 +30,12 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 
 #ifdef TPOSE_DEBUG
 #define PK_STAMP(k) do { if (threadIdx.x == 0 && A.dbg && it >= A.dbg_first && it < A.dbg_first + PK_DBG_ITERS) A.dbg[((size_t)blockIdx.x * PK_DBG_ITERS + (it - A.dbg_first)) * 16 + (k)] = wall_clock64(); } while (0)
+// the same per WAVE (its first lane; 16 stamps x 8 waves x PK_DBG_WITERS grad-iters per workgroup, behind the per-workgroup stamps)
+#define PK_WSTAMP(k) do { if ((threadIdx.x & 63) == 0 && A.dbg && it >= A.dbg_first && it < A.dbg_first + PK_DBG_WITERS) \
+    A.dbg[PK_DBG_WBASE + (((size_t)blockIdx.x * PK_DBG_WITERS + (it - A.dbg_first)) * (PK_THREADS / 64) + (threadIdx.x >> 6)) * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define PK_STAMP(k) do { } while (0)
+#define PK_WSTAMP(k) do { } while (0)
 #endif
 
 namespace {
@@ -85,6 +89,9 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         return;
     }
 
+#ifdef TPOSE_DEBUG
+    if (tid == 0) g_pk_fault[0] = (unsigned long long)A.vw.H * (unsigned long long)A.px_pitch * 16ull;
+#endif
     // a launch behind one that gave up does nothing (tp_context.hip: the grad-iters are run again on the two-kernel path)
     // (one answer for the whole workgroup: the word may be raised while its threads look)
     if (__syncthreads_or(__hip_atomic_load(status, PK_RLX_AGENT) != 0u)) return;
@@ -102,8 +109,12 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             V.pos[i].x = p.x; V.pos[i].y = p.y;
         }
         for (int i = tid; i < PK_SUM_STRIDE * w.n_lines_all; i += PK_THREADS) V.sums[i] = 0ull;
+        for (int k = tid; k < w.n_own_v; k += PK_THREADS) { V.gacc[2 * k] = 0ull; V.gacc[2 * k + 1] = 0ull; V.vdeg[k] = 0; }
         if (tid == 0) { V.flags[0] = 0; V.flags[3] = 0; }
     }
+    __syncthreads();
+    // corners of every own vertex: the lane that brings a vertex's count to this number has seen all its central differences
+    for (int k = tid; k < w.n_corners; k += PK_THREADS) atomicAdd(&V.vdeg[(A.pool[w.off_corners + 4 * k + 1] >> 2) & 0x3ff], 1);
     // the stored colour of this lane's variant (warp flavour: `colacc` as uploaded, triangle.fs:49-50) never changes
     // during a launch; the first pass of the corner lanes keeps it in registers
     pk_i4 col0 = {0, 0, 0, 0};
@@ -115,9 +126,12 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
     }
     // the ends of this thread's first line never change during a launch: slot u | slot v << 10 | version << 20
     int my_ends = 0;
+    float my_dxu = 0.0f, my_dyu = 0.0f, my_dxv = 0.0f, my_dyv = 0.0f;   // (... and how its endpoints are displaced)
     if (tid < w.n_lines_all) {
         const int ln_ = A.pool[w.off_lines + tid], ed_ = A.pool[w.off_edges + (ln_ & 0xffff)];
         my_ends = (ed_ & 0x3ff) | (((ed_ >> 16) & 0x3ff) << 10) | ((ln_ >> 16) << 20);
+        const int q_ = ln_ >> 16, mu_ = (q_ >= 1 && q_ <= 4) ? q_ : 0, mv_ = q_ >= 5 ? q_ - 4 : 0;
+        my_dxu = tp_move_dx(mu_, A.vw.dp); my_dyu = tp_move_dy(mu_, A.vw.dp); my_dxv = tp_move_dx(mv_, A.vw.dp); my_dyv = tp_move_dy(mv_, A.vw.dp);
     }
     // ... and neither do the line-sum slots of its first corner variant: edge leaving the vertex | arriving << 16; opposite | own slot << 16
     int my_c0 = 0, my_c1 = 0;
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         // every PK_RECUT grad-iters the patch looks at the chunks of its lines again (tp_persist.h, pk_recut_line)
         const bool recut = (it & (PK_RECUT - 1)) == 0;
         const int n_lines = emit ? w.n_lines_all : w.n_lines, n_setup = recut ? w.n_lines_all : n_lines;
-        PK_STAMP(0);
+        PK_STAMP(0); PK_WSTAMP(0);
         // ---- P0: positions of the neighbouring vertices this patch uses (the first grad-iter of a launch read `points`)
         if (it > 0) {
             for (int s = w.n_own_v + tid; s < w.n_slots; s += PK_THREADS) {
@@ -164,13 +178,15 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         // (a lane that gave up says so in LDS; ONE barrier, then everybody reads the word -- __syncthreads_or is a wave
         // reduction, three barriers and three dependent LDS operations: 0.2 us of every grad-iter)
         if (failed) V.flags[3] = 1;
+        PK_WSTAMP(1);
         __syncthreads();
+        PK_WSTAMP(2);
         if (V.flags[3]) return;
         PK_STAMP(1);
         // ---- P1: line set-up (low threads), snapped positions (high threads), gradient reset
         for (int l = tid; l < n_setup; l += PK_THREADS) {
             pk_walker wk;
-            if (l == tid) pk_setup_ends(V, A.vw, my_ends & 0x3ff, (my_ends >> 10) & 0x3ff, my_ends >> 20, wk);
+            if (l == tid) pk_setup_moved(V, A.vw, my_ends & 0x3ff, (my_ends >> 10) & 0x3ff, my_dxu, my_dyu, my_dxv, my_dyv, wk);
             else pk_setup_lane(V, A.vw, l, wk);
             V.wk[l] = wk;
         }
@@ -181,8 +197,10 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 for (int j = PK_THREADS - 1 - tid; j < nsnap; j += PK_THREADS) pk_snap_lane(w, V, A.vw, j);
             // (the signs of the corner variants' line sums, by the waves that set up no lines: P6 starts from the sums)
             for (int j = tid >= PK_THREADS / 2 ? tid - PK_THREADS / 2 : tid + PK_THREADS / 2; j < 4 * w.n_corners; j += PK_THREADS) V.coef[j] = pk_coef_lane(V, A.vw, j >> 2, (j & 3) + 1);
+            // (the line sums of the grad-iter before: every corner has read them by now -- the barrier behind P0 was passed)
+            if (it > 0)
+                for (int i = PK_THREADS - 1 - tid; i < PK_SUM_STRIDE * w.n_lines; i += PK_THREADS) V.sums[i] = 0ull;
             for (int k = tid; k < w.n_own_v; k += PK_THREADS) {
-                V.grad[k].x = 0; V.grad[k].y = 0;
                 if (pring) {   // (a frame can be returned to)
                     const size_t at = (size_t)it * A.NP + V.vid[k];
                     if (banded) {   // (system scope, write-through: the other bands' posts land in the same lines)
@@ -193,10 +211,14 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 }
             }
         }
+        PK_WSTAMP(3);
         __syncthreads();
+        PK_WSTAMP(4);
         if (recut) {
             if (tid < 64) {
-                int changed = 0, rpl = it == 0 ? w.rows : V.flags[2];
+                // (the first cut of a launch always counts as a change: every thread's lane-items are decided there -- also in a patch
+                // without lines, whose threads would otherwise walk whatever their registers held)
+                int changed = it == 0 ? 1 : 0, rpl = it == 0 ? w.rows : V.flags[2];
                 bool first = it == 0;
                 for (;;) {
                     int every;
@@ -240,7 +262,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             int rows[PK_NI];
 #pragma unroll
             for (int i = 0; i < PK_NI; i++) rows[i] = pk_walk_pass<RR>(cache[i], V, A.px_pitch, table, A.vw.W);
-            PK_STAMP(8);
+            PK_STAMP(8); PK_WSTAMP(5);
 #pragma unroll
             for (int i = 0; i < PK_NI; i++) {
                 pk_acc a;
@@ -255,8 +277,25 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             const int l = pk_walk_lane(V, table, A.px_pitch, A.vw.W, w.n_lines_all, n_li_now < PK_CACHED ? n_li_now : PK_CACHED, w.li_cap, j, a);
             fold(l, a);
         }
+        PK_WSTAMP(6);
         __syncthreads();
-        PK_STAMP(3);
+        PK_STAMP(3); PK_WSTAMP(7);
+        if (ering && !emit) {   // tp_iterate_until: the energy of the base variants, frame by frame (the plan walks their lines every grad-iter)
+            for (int k = tid; k < w.n_base; k += PK_THREADS) {
+                int t;
+                const tp_moments mm = pk_base_moments(w, V, k, t);
+                pk_i4 col = {0, 0, 0, 0};
+                if (A.flavour == 1) { const int4 c = A.ca[t]; col.x = c.x; col.y = c.y; col.z = c.z; }
+                const int32_t en = pk_energy(mm, A.flavour, col);
+                const size_t at = (size_t)it * A.NT + t;
+                if (banded) {
+                    __hip_atomic_store((gu32*)ering + at, (unsigned)en, PK_RLX_SYSTEM);
+                    for (int b = 0; b < A.n_peers; b++) __hip_atomic_store((gu32*)A.peer_ering[b] + at, (unsigned)en, PK_RLX_SYSTEM);
+                } else ering[at] = en;
+            }
+        }
+        // (band split: what a launch ends with is a release for the rings -- the last posts below must not overtake this grad-iter's ring stores)
+        if (banded && last) __syncthreads();
         // ---- P6: corners -- four displaced variants each, central differences into the vertex's gradient (int32 wrapping
         // sums, like the reference's atomics: gradient.cs:24-35)
         for (int j = tid; j < 4 * w.n_corners; j += PK_THREADS) {
@@ -278,27 +317,50 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             // lanes 4k+0/1: E(+dx), E(-dx); 4k+2/3: E(+dy), E(-dy) -- the neighbour's energy by a DPP quad permute [1,0,3,2] (__shfl_xor
             // goes through the LDS crossbar: a hundred cycles on this chain)
             const uint32_t d = (uint32_t)e - (uint32_t)__builtin_amdgcn_mov_dpp(e, 0xB1, 0xF, 0xF, true);
-            if ((j & 3) == 0) atomicAdd(&V.grad[own].x, (int)d);
-            if ((j & 3) == 2) atomicAdd(&V.grad[own].y, (int)d);
             if (emit) {
                 const pk_i4 cr = V.corners[k];   // the variant's outputs in the reference's layout, id = i NT + t (triangle.vs:47-48)
                 const size_t id = (size_t)(4 * (cr.y & 3) + m) * A.NT + cr.x;
                 if (A.flavour == 0) A.ca_out[id] = make_int4(tp_wrap32(mm.sr), tp_wrap32(mm.sg), tp_wrap32(mm.sb), 0);
                 A.ten[id] = e; A.cn[id] = tp_wrap32(mm.n);
             }
-        }
-        if (ering && !emit) {   // tp_iterate_until: the energy of the base variants, frame by frame (the plan walks their lines every grad-iter)
-            for (int k = tid; k < w.n_base; k += PK_THREADS) {
-                int t;
-                const tp_moments mm = pk_base_moments(w, V, k, t);
-                pk_i4 col = {0, 0, 0, 0};
-                if (A.flavour == 1) { const int4 c = A.ca[t]; col.x = c.x; col.y = c.y; col.z = c.z; }
-                const int32_t en = pk_energy(mm, A.flavour, col);
-                const size_t at = (size_t)it * A.NT + t;
-                if (banded) {
-                    __hip_atomic_store((gu32*)ering + at, (unsigned)en, PK_RLX_SYSTEM);
-                    for (int b = 0; b < A.n_peers; b++) __hip_atomic_store((gu32*)A.peer_ering[b] + at, (unsigned)en, PK_RLX_SYSTEM);
-                } else ering[at] = en;
+            // ---- P7, by the lane that completes an axis of a vertex.  Lanes 4k + 0 / 4k + 2 add the corner's x / y difference to the vertex's
+            // accumulator of that axis with ONE returning atomic, (difference << 32) | 1: the lane whose returned count is the vertex's last
+            // holds the sum of all the others in the same word -- nothing else to read, nothing to order -- and takes that axis' shift.cs
+            // step right here, no workgroup barrier in between; the new coordinate goes to the mailbox of the next grad-iter (one granule per
+            // coordinate) or, after the last one, to `points_out`.
+            if ((j & 1) == 0) {
+                const int ax = (j >> 1) & 1;   // 0: x, 1: y
+                unsigned long long* acc = V.gacc + 2 * own + ax;
+                const unsigned long long old = atomicAdd(acc, pk_gacc_word(d));
+                if ((uint32_t)old + 1u == (uint32_t)V.vdeg[own]) {
+                    const int32_t g = (int32_t)((uint32_t)(old >> 32) + d);
+                    *acc = 0ull;   // (for the next grad-iter: every corner of the vertex has added to it)
+                    const int v = V.vid[own];
+                    float* const pc = ax ? &V.pos[own].y : &V.pos[own].x;
+                    if (emit) reinterpret_cast<int32_t*>(A.gr + v)[ax] = g;
+#if defined(PK_EXP_FREEZE)  // timing experiments only: the mesh stands still
+                    const float pn = *pc;
+#else
+                    const float pn = v < 4 ? *pc : pk_step_axis(*pc, g, ax ? 1.0f : A.vw.ratio, A.rate);   // (vertices 0..3 never move: shift.cs:20)
+#endif
+                    *pc = pn;
+                    if (last) reinterpret_cast<float*>(A.points_out + v)[ax] = pn;
+                    if (!last || banded) {
+                        // (band split: the positions a launch ends with go to the slots 2, 3 of every band's mailbox, for tp_launch_band_collect)
+                        const unsigned long long T = (unsigned long long)(last ? A.final_tag : pk_tag(epoch + 1u)) << 32;
+                        const size_t at = ((size_t)(last ? 2u + A.final_slot : (epoch + 1u) & 1u) * A.box_stride + v) * 2 + ax;
+                        const unsigned long long gw = T | __float_as_uint(pn);
+                        if (banded) {
+                            // (what a launch ends with is a RELEASE: whoever collects it also sees the rings this workgroup wrote -- the
+                            // barriers between the phases, and the one in front of the last grad-iter's corners, order them before this)
+                            if (last) __atomic_thread_fence(__ATOMIC_RELEASE);
+                            __hip_atomic_store(posbox + at, gw, PK_RLX_SYSTEM);
+                            for (int b = 0; b < A.n_peers; b++) __hip_atomic_store((gu64*)A.peer_box[b] + at, gw, PK_RLX_SYSTEM);
+                        } else {
+                            __hip_atomic_store(posbox + at, gw, PK_RLX_AGENT);
+                        }
+                    }
+                }
             }
         }
         if (emit) {   // base variants (i = 0) of the triangles whose first vertex this patch owns
@@ -311,43 +373,11 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 A.ten[t] = pk_energy(mm, A.flavour, col); A.cn[t] = tp_wrap32(mm.n);
             }
         }
+#if defined(PK_EXP_C1_ENDBAR)
         __syncthreads();
-        PK_STAMP(4);
-        // ---- P7: the step of the patch's own vertices; the new positions go to the mailbox of the next grad-iter (or, after
-        // the last one, to `points_out`); the other threads clear the line sums for the next grad-iter
-        for (int k = tid; k < w.n_own_v; k += PK_THREADS) {
-            const int v = V.vid[k];
-            if (emit) A.gr[v] = make_int2(V.grad[k].x, V.grad[k].y);
-#if defined(PK_EXP_FREEZE)  // timing experiments only: the mesh stands still
-            const pk_f2 p = pk_vertex_lane(V.pos[k], V.grad[k].x, V.grad[k].y, v, A.vw.ratio, 0.0f);
-#else
-            const pk_f2 p = pk_vertex_lane(V.pos[k], V.grad[k].x, V.grad[k].y, v, A.vw.ratio, A.rate);
 #endif
-            V.pos[k] = p;
-            if (last) A.points_out[v] = make_float2(p.x, p.y);
-            if (!last || banded) {
-                // (band split: the positions a launch ends with go to the slots 2, 3 of every band's mailbox, for tp_launch_band_collect)
-                const unsigned long long T = (unsigned long long)(last ? A.final_tag : pk_tag(epoch + 1u)) << 32;
-                const size_t at = ((size_t)(last ? 2u + A.final_slot : (epoch + 1u) & 1u) * A.box_stride + v) * 2;
-                const unsigned long long gx = T | __float_as_uint(p.x), gy = T | __float_as_uint(p.y);
-                if (banded) {
-                    // (what a launch ends with is a RELEASE: whoever collects it also sees the rings this workgroup wrote -- the
-                    // barriers between the phases order the other threads' ring stores before this one)
-                    if (last) __atomic_thread_fence(__ATOMIC_RELEASE);
-                    __hip_atomic_store(posbox + at, gx, PK_RLX_SYSTEM); __hip_atomic_store(posbox + at + 1, gy, PK_RLX_SYSTEM);
-                    for (int b = 0; b < A.n_peers; b++) {
-                        gu64* g = (gu64*)A.peer_box[b] + at;
-                        __hip_atomic_store(g, gx, PK_RLX_SYSTEM); __hip_atomic_store(g + 1, gy, PK_RLX_SYSTEM);
-                    }
-                } else {
-                    __hip_atomic_store(posbox + at, gx, PK_RLX_AGENT); __hip_atomic_store(posbox + at + 1, gy, PK_RLX_AGENT);
-                }
-            }
-        }
-        if (!last) {
-            for (int i = PK_THREADS - 1 - tid; i < PK_SUM_STRIDE * w.n_lines; i += PK_THREADS) V.sums[i] = 0ull;
-        }
-        PK_STAMP(5);
+        PK_STAMP(4); PK_WSTAMP(8);
+        PK_STAMP(5); PK_WSTAMP(10);
         // (no barrier here: P0 of the next grad-iter touches foreign position slots only, and its barrier orders the rest)
     }
 }
@@ -368,6 +398,9 @@ void launch_rr(const pk_args& A, dim3 g, dim3 b, size_t lds, hipStream_t s) {
 }
 }  // namespace
 
+#ifdef TPOSE_DEBUG
+int tp_persist_debug_faults(unsigned long long out[16]) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_fault), 16 * sizeof(unsigned long long)); }
+#endif
 int tp_persist_set_lds(int bytes) {
     int rc = set_lds_rr<PK_RR0>(bytes);
     if (!rc) rc = set_lds_rr<PK_RR1>(bytes);

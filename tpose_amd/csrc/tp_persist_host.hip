@@ -9,7 +9,7 @@ namespace tpctx {
 // ---- persistent grad-iter kernel: status, census, plan ------------------------------------------------------------
 #ifdef TPOSE_DEBUG  // debug flavour of the library (tools/persist_timeline.py): per-workgroup phase timestamps
 static unsigned long long* g_persist_dbg = nullptr;
-static const size_t PERSIST_DBG_WORDS = (size_t)512 * PK_DBG_ITERS * 16;
+static const size_t PERSIST_DBG_WORDS = PK_DBG_WBASE + (size_t)512 * PK_DBG_WITERS * 16 * 16;   // (room for 16 waves per workgroup)
 unsigned long long* persist_dbg_buffer(int parts, hipStream_t s) {
     if (!g_persist_dbg) { hipMalloc((void**)&g_persist_dbg, PERSIST_DBG_WORDS * 8); }
     hipMemsetAsync(g_persist_dbg, 0, PERSIST_DBG_WORDS * 8, s);
@@ -349,6 +349,14 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
     if (relerr) *relerr = rel;
     return TP_OK;
 }
+
+#ifdef TPOSE_DEBUG
+int tp_debug_persist_faults(tp_context* c, unsigned long long* out) {
+    api_guard api_lock;
+    hipStreamSynchronize(c->stream);
+    return tp_persist_debug_faults(out);
+}
+#endif
 
 #ifdef TPOSE_DEBUG
 // debug flavour only (tools/persist_timeline.py): [workgroup][grad-iter < 64][8] phase timestamps of the last persistent launch

@@ -113,7 +113,8 @@ inline int pk_lds_bytes(const pk_wg& w) {
     b += pk_align16(w.n_lines_all * 24);            // walkers
     b += pk_align16(w.n_slots * 8);                 // positions
     b += pk_align16((4 * w.n_own_v + w.n_slots) * 8);  // snapped positions: neighbours unmoved only, own slots + 4 moves
-    b += pk_align16(w.n_own_v * 8);                 // gradient
+    b += pk_align16(w.n_own_v * 16);                // gradient: per own vertex and axis {corners counted : 32, sum of their central differences : 32}
+    b += pk_align16(w.n_own_v * 4);                 // corners of every own vertex
     b += pk_align16(w.n_slots * 4);                 // vid
     b += pk_align16(w.n_edges * 4);                 // edges
     b += pk_align16(w.n_lines_all * 4);             // lines

@@ -105,22 +105,30 @@ struct tp_view {
     int W, H;
 };
 
-// Vertex stage for model-vertex `slot` of variant `i` (TDIV): displacement BEFORE x /= RATIO.
-TP_HD void tp_vertex_stage(float px, float py, int i, int slot, const tp_view& vw, int32_t& X,
-                           int32_t& Y) {
-    float Dx = 0.0f, Dy = 0.0f;
-    if (i > 0 && ((i - 1) >> 2) == slot) {
-        int k = (i - 1) & 3;
-        Dx = (k == 0) ? vw.dp : (k == 1) ? -vw.dp : 0.0f;
-        Dy = (k == 2) ? vw.dp : (k == 3) ? -vw.dp : 0.0f;
-    }
+// Vertex stage of a vertex displaced by (Dx, Dy) t-pose units (triangle.vs:66-84): displacement BEFORE x /= RATIO.
+TP_HD void tp_vertex_stage_d(float px, float py, float Dx, float Dy, const tp_view& vw, int32_t& X, int32_t& Y) {
     float tx = tp_fadd(px, Dx);
     float ty = tp_fadd(py, Dy);
-    float nx = vw.ratio == 1.0f ? tx : tp_fdiv(tx, vw.ratio);  // (x / 1 is x: square rasters skip the division)
+    float nx = tx;
+    if (vw.ratio != 1.0f) {   // (x / 1 is x: square rasters skip the division -- a branch, the same for every lane, not a select behind the division)
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("");
+#endif
+        nx = tp_fdiv(tx, vw.ratio);
+    }
     float fx = tp_fmul(tp_fadd(nx, 1.0f), vw.halfW);
     float fy = tp_fmul(tp_fsub(1.0f, ty), vw.halfH);
     X = tp_snap256(fx);
     Y = tp_snap256(fy);
+}
+// the displacement of move m (0: none, 1..4: +dp x, -dp x, +dp y, -dp y -- triangle.vs:66-78)
+TP_HD float tp_move_dx(int m, float dp) { return m == 1 ? dp : m == 2 ? -dp : 0.0f; }
+TP_HD float tp_move_dy(int m, float dp) { return m == 3 ? dp : m == 4 ? -dp : 0.0f; }
+// Vertex stage for model-vertex `slot` of variant `i` (TDIV)
+TP_HD void tp_vertex_stage(float px, float py, int i, int slot, const tp_view& vw, int32_t& X,
+                           int32_t& Y) {
+    const int m = (i > 0 && ((i - 1) >> 2) == slot) ? ((i - 1) & 3) + 1 : 0;
+    tp_vertex_stage_d(px, py, tp_move_dx(m, vw.dp), tp_move_dy(m, vw.dp), vw, X, Y);
 }
 
 TP_HD int32_t tp_floor_shr8(int32_t v) { return v >> 8; }  // arithmetic shift == floor(v/256)
