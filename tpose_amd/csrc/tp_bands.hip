@@ -27,7 +27,7 @@ size_t tp_band_mailbox_bytes(int points, int triangles) {
 int tp_band_attach(tp_context* c, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int points, int triangles, int patches_per_band) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
-    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
+    c->mutations++; c->tail_is_finish = false;   // (a retrieve no longer finds what the frame mirror holds)
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = tp_synchronize(c)) return rc;   // nothing in flight reads the mailbox or the plan
     if (n_bands <= 1) {

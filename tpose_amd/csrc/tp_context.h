@@ -172,6 +172,8 @@ struct tp_context {
     uint8_t* frame_mirror = nullptr; size_t frame_mirror_bytes = 0;
     int frame_n = 0; size_t frame_np = 0;
     uint64_t mutations = 0, ten_stamp = ~0ull, pts_stamp = ~0ull;   // (the mirror's energies / points are current while stamp == mutations)
+    bool epos_stale = false;        // persistent launches moved the vertices and left the edges' endpoint copies (`epos`) behind: filed before k_lines runs
+    bool tail_is_finish = false;    // the last thing enqueued on the stream is the small kernel behind a persistent launch: its pinned words say when the stream is done
     uint32_t epoch = 1;             // number of the next grad-iter of a persistent launch (mailbox tags)
     bool persist_unchecked = false; // persistent launches were enqueued since the status word was last read
     struct journal_entry { tp_params p; int iters; };
@@ -236,6 +238,8 @@ int enqueue_two_kernel(tp_context* c, const tp_params* p, float dp, int n);
 // tp_persist_host.hip
 int check_persist_status(tp_context* c);
 int settle_persistent(tp_context* c);
+int settle_epos(tp_context* c);   // before anything that reads `epos` (k_lines) is enqueued
+hipError_t wait_context(tp_context* c);   // wait for the context's stream
 int install_plan(tp_context* c, pk_plan& np, const float* points, int slot);
 int plan_patches(const tp_context* c);
 int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok);

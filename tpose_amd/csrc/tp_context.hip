@@ -190,7 +190,7 @@ int tp_destroy(tp_context* c) {
 int tp_set_ratio(tp_context* c, float ratio) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
-    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
+    c->mutations++; c->tail_is_finish = false;   // (a retrieve no longer finds what the frame mirror holds)
     if (!(ratio > 0.0f)) return fail(c, TP_ERR_INVALID, "RATIO must be positive");
     // (a persistent launch that gave up is replayed at the next synchronisation -- with the RATIO its grad-iters were called with)
     if (c->persist_unchecked) { HIP_TRY(c, hipSetDevice(c->device)); if (int rc = settle_persistent(c)) return rc; }
@@ -201,7 +201,7 @@ int tp_set_ratio(tp_context* c, float ratio) {
 int tp_set_dp(tp_context* c, float dp) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
-    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
+    c->mutations++; c->tail_is_finish = false;   // (a retrieve no longer finds what the frame mirror holds)
     c->dp_override = dp;  // piecewise calls only; tp_iterate takes dp from its params (part of the graph key)
     c->accumulated = c->energized = false;
     return TP_OK;
@@ -210,7 +210,7 @@ int tp_set_dp(tp_context* c, float dp) {
 int tp_set_option(tp_context* c, int option, int64_t value) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
-    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
+    c->mutations++; c->tail_is_finish = false;   // (a retrieve no longer finds what the frame mirror holds)
     switch (option) {
         case TP_OPT_PERSISTENT:
             if (value != TP_PERSIST_OFF && value != TP_PERSIST_AUTO) return fail(c, TP_ERR_INVALID, "TP_OPT_PERSISTENT: bad value %lld", (long long)value);
@@ -227,7 +227,7 @@ int tp_get_ratio(const tp_context* c, float* ratio) {
 
 static int set_image_common(tp_context* c, int slot, const void* src, size_t stride, hipMemcpyKind kind) {
     if (!c) return TP_ERR_INVALID;
-    c->mutations++;
+    c->mutations++; c->tail_is_finish = false;
     if (slot != TP_IMAGE_A && slot != TP_IMAGE_B) return fail(c, TP_ERR_INVALID, "bad image slot %d", slot);
     if (!src) return fail(c, TP_ERR_INVALID, "image pointer is NULL");
     if (stride < (size_t)c->W * 4) return fail(c, TP_ERR_INVALID, "stride %zu < 4*width", stride);
@@ -263,7 +263,7 @@ int tp_set_image_device(tp_context* c, int slot, const void* dev, size_t stride)
 int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, int NT, const int32_t* colors) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
-    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
+    c->mutations++; c->tail_is_finish = false;   // (a retrieve no longer finds what the frame mirror holds)
     if (!points || !tris || NP < 1 || NT < 1) return fail(c, TP_ERR_INVALID, "upload: bad arguments (NP=%d NT=%d)", NP, NT);
     if ((size_t)13 * NT > (size_t)TP_MAXT) return fail(c, TP_ERR_CAPACITY, "13*NT = %d exceeds MAXT = %d", 13 * NT, TP_MAXT);
     if ((size_t)NP > (size_t)TP_MAXT) return fail(c, TP_ERR_CAPACITY, "NP = %d exceeds MAXT = %d", NP, TP_MAXT);
@@ -418,18 +418,20 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
     }
     c->generation++;  // captured graphs bake NT, NP, dp and buffer addresses
     c->uploaded = true; c->accumulated = c->energized = false;
+    c->epos_stale = false;   // (k_vertex_refs' launch filed every position with its edges)
     return TP_OK;
 }
 
 int tp_accumulate(tp_context* c, int flavour, int slot) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
-    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
+    c->mutations++; c->tail_is_finish = false;   // (a retrieve no longer finds what the frame mirror holds)
     if (flavour != TP_TRIANGULATE && flavour != TP_WARP) return fail(c, TP_ERR_INVALID, "bad flavour %d", flavour);
     if (!c->uploaded) return fail(c, TP_ERR_STATE, "accumulate before upload");
     if (int rc = check_slot(c, slot)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = settle_persistent(c)) return rc;
+    if (int rc = settle_epos(c)) return rc;
     tp_launch L = make_launch(c, slot, resolve_dp(c, flavour, c->dp_override));
     tp_launch_lines(L, c->stream);
     HIP_TRY(c, hipGetLastError());
@@ -441,7 +443,7 @@ int tp_accumulate(tp_context* c, int flavour, int slot) {
 int tp_energy(tp_context* c, int flavour) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
-    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
+    c->mutations++; c->tail_is_finish = false;   // (a retrieve no longer finds what the frame mirror holds)
     if (flavour != TP_TRIANGULATE && flavour != TP_WARP) return fail(c, TP_ERR_INVALID, "bad flavour %d", flavour);
     if (!c->accumulated) return fail(c, TP_ERR_STATE, "energy before accumulate");
     if (flavour != c->acc_flavour) return fail(c, TP_ERR_STATE, "energy flavour %d differs from the accumulate pass (%d)", flavour, c->acc_flavour);
@@ -459,7 +461,7 @@ int tp_energy(tp_context* c, int flavour) {
 int tp_shift(tp_context* c, float rate) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
-    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
+    c->mutations++; c->tail_is_finish = false;   // (a retrieve no longer finds what the frame mirror holds)
     if (!c->energized) return fail(c, TP_ERR_STATE, "shift before energy");
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = settle_persistent(c)) return rc;
@@ -550,6 +552,7 @@ int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
     if (left > 0) { if (int rc = settle_persistent(c)) return rc; }
     if (n_iters == 1 && left == 1) {
         // a single frame (the schedules run them one by one and read back after each): its outputs also go to the frame mirror
+        if (int rc = settle_epos(c)) return rc;
         if (int rc = enqueue_iter(c, *p, dp, true)) return rc;
         HIP_TRY(c, hipGetLastError());
         c->ten_stamp = c->pts_stamp = c->mutations;
@@ -561,6 +564,8 @@ int enqueue_iters(tp_context* c, const tp_params* p, int n_iters) {
 
 // n grad-iters as k_lines + k_update each: whole chunks as graph replays, the rest eagerly
 int enqueue_two_kernel(tp_context* c, const tp_params* p, float dp, int left) {
+    if (left <= 0) return TP_OK;
+    if (int rc = settle_epos(c)) return rc;
     if (left >= CHUNK) {
         graph_entry* g = nullptr;
         if (int rc = chunk_graph(c, p, dp, &g)) return rc;
@@ -583,7 +588,7 @@ int tp_iterate(tp_context* c, const tp_params* p, int n_iters) {
     if (int rc = validate_params(c, p, n_iters)) return rc;
     if (n_iters == 0) return TP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    c->mutations++;
+    c->mutations++; c->tail_is_finish = false;
     return enqueue_iters(c, p, n_iters);
 }
 
@@ -601,10 +606,11 @@ int tp_prepare(tp_context* c, const tp_params* p) {
 int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* accumulate_us) {
     api_guard api_lock;
     if (!c || !accumulate_us) return TP_ERR_INVALID;
-    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
+    c->mutations++; c->tail_is_finish = false;   // (a retrieve no longer finds what the frame mirror holds)
     if (int rc = validate_params(c, p, n_iters)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = settle_persistent(c)) return rc;
+    if (int rc = settle_epos(c)) return rc;
     const float dp = resolve_dp(c, p->flavour, p->dp);
     // Eager launches enqueued back to back (no host sync in between); every k_lines dispatch
     // carries its own begin/end timestamps in an event pair.  (Timed launches record nothing when
@@ -633,10 +639,11 @@ int tp_profile_iterate(tp_context* c, const tp_params* p, int n_iters, double* a
 int tp_profile_accumulate(tp_context* c, const tp_params* p, int launches, double* accumulate_us) {
     api_guard api_lock;
     if (!c || !accumulate_us) return TP_ERR_INVALID;
-    c->mutations++;   // (a retrieve no longer finds what the frame mirror holds)
+    c->mutations++; c->tail_is_finish = false;   // (a retrieve no longer finds what the frame mirror holds)
     if (int rc = validate_params(c, p, launches)) return rc;
     if (launches < 1) return fail(c, TP_ERR_INVALID, "launches < 1");
     if (int rc = tp_synchronize(c)) return rc;
+    if (int rc = settle_epos(c)) return rc;
     const float dp = resolve_dp(c, p->flavour, p->dp);
     tp_launch L = make_launch(c, p->image_slot, dp);
     hipGraphExec_t exec = nullptr;
@@ -681,7 +688,7 @@ int tp_synchronize(tp_context* c) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, wait_stream(c->stream));
+    HIP_TRY(c, wait_context(c));
     return check_persist_status(c);
 }
 int tp_get_stream(tp_context* c, void** s) {

@@ -112,5 +112,6 @@ void tp_launch_persist(const pk_args& A, int grid, int rows, int lds_bytes, hipS
 // band split: the positions the launch ended with, from the own mailbox (every band posted there) into points_out; raises
 // status[0] when they do not arrive
 void tp_launch_band_collect(const tp_launch& L, const pk_args& A, float2* points_out, hipStream_t s);
-void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, unsigned* host_status, hipStream_t s);  // status: of the
-// launch before, or null; host_status: pinned mirror of {gave up, -, launches completed}
+void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, unsigned* host_status, int file_edges, hipStream_t s);
+void tp_launch_publish_positions(const tp_launch& L, hipStream_t s);   // every vertex files its position with its edges (`epos`)
+// (status: of the launch before, or null; host_status: pinned mirror of {gave up, -, launches completed})

@@ -686,32 +686,44 @@ void tp_launch_update(const tp_launch& L, int flavour, float rate, hipStream_t s
 // uses are not owned by any patch and keep theirs), and every vertex files its position with its edges (k_lines reads
 // endpoints by edge)
 // A launch that gave up (status[0] raised: its workgroups were not all resident, tp_context.hip) leaves everything as it was.
-__global__ void k_persist_finish(tp_launch L, const float2* points_out, unsigned* status, unsigned* host_status) {
+// file_edges: every vertex also files its position with its edges (`epos`, what k_lines reads) -- only when the two-kernel path runs
+// next; otherwise that is left to k_publish_positions, launched when it does (the dependent table reads cost 4 us of every call)
+// status[3]: a ticket counter -- the LAST block to finish counts the launch as completed and mirrors the words into pinned memory,
+// so that a host spinning on the mirror sees it only when every block's stores are out
+__global__ void k_persist_finish(tp_launch L, const float2* points_out, unsigned* status, unsigned* host_status, int file_edges) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int v = gid >> 3, lane = gid & 7;   // eight lanes per vertex: one incident edge each (the table reads are dependent ones)
-    if (status) {
-        const unsigned gave_up = status[0];
-        if (gid == 0) {
-            const unsigned done = status[2] + (gave_up ? 0u : 1u);   // (launches complete one after the other: no atomic)
-            status[2] = done;
-            if (host_status) { host_status[0] = gave_up; host_status[2] = done; }   // what the host looks at after its next wait: no copy
+    const int per = file_edges ? 8 : 1;   // lanes per vertex: with edges one incident edge each (the table reads are dependent ones)
+    const int v = gid / per, lane = gid - v * per;
+    const unsigned gave_up = status ? status[0] : 0u;
+    if (gave_up == 0u && v < L.NP) {
+        float2 p = L.points[v];
+        if (L.vtx_off[v + 1] > L.vtx_off[v]) p = points_out[v];
+        else if (v >= 4) {   // shift.cs:25-43 runs for every i in [4, NPoints): a vertex no triangle uses is still clamped
+            const float R = L.vw.ratio;
+            p.x = p.x <= -R ? -R : (p.x >= R ? R : p.x);
+            p.y = p.y <= -1.0f ? -1.0f : (p.y >= 1.0f ? 1.0f : p.y);
         }
-        if (gave_up != 0u) return;
+        // (every lane has read the old position before any lane of the vertex writes the new one: the lanes of a vertex sit in one wave)
+        if (lane == 0) L.points[v] = p;
+        if (file_edges) publish_position(L, v, p, lane, 8);
     }
-    if (v >= L.NP) return;
-    float2 p = L.points[v];
-    if (L.vtx_off[v + 1] > L.vtx_off[v]) p = points_out[v];
-    else if (v >= 4) {   // shift.cs:25-43 runs for every i in [4, NPoints): a vertex no triangle uses is still clamped
-        const float R = L.vw.ratio;
-        p.x = p.x <= -R ? -R : (p.x >= R ? R : p.x);
-        p.y = p.y <= -1.0f ? -1.0f : (p.y >= 1.0f ? 1.0f : p.y);
+    if (status) {
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(&status[3], 1u) == gridDim.x - 1u) {
+            status[3] = 0u;
+            const unsigned done = status[2] + (gave_up ? 0u : 1u);   // (launches complete one after the other)
+            status[2] = done;
+            if (host_status) { host_status[0] = gave_up; __threadfence_system(); host_status[2] = done; }   // what the host looks at: no copy
+        }
     }
-    // (every lane has read the old position before any lane of the vertex writes the new one: the eight lanes of a vertex sit in one wave)
-    if (lane == 0) L.points[v] = p;
-    publish_position(L, v, p, lane, 8);
 }
-void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, unsigned* host_status, hipStream_t s) {
-    hipLaunchKernelGGL(k_persist_finish, dim3((unsigned)((8 * L.NP + 255) / 256)), dim3(256), 0, s, L, points_out, status, host_status);
+void tp_launch_persist_finish(const tp_launch& L, const float2* points_out, unsigned* status, unsigned* host_status, int file_edges, hipStream_t s) {
+    const int threads = (file_edges ? 8 : 1) * L.NP;
+    hipLaunchKernelGGL(k_persist_finish, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, L, points_out, status, host_status, file_edges);
+}
+void tp_launch_publish_positions(const tp_launch& L, hipStream_t s) {
+    hipLaunchKernelGGL(k_publish_positions, dim3((unsigned)((L.NP + 63) / 64)), dim3(64), 0, s, L);
 }
 
 // tpose::upload colour replication (source/triangulation.hpp:633-641): col[i*NT + k] = colors[k]

@@ -3,6 +3,7 @@
 // tp_iterate call, and tp_iterate_until (the reference's frame loop up to its convergence test: software/triangulate/main.cpp:
 // 201-210, software/warp/main.cpp:226-231, source/triangulation.hpp:653-674).
 #include "tp_context.h"
+#include <atomic>
 
 namespace tpctx {
 
@@ -35,7 +36,7 @@ int check_persist_status(tp_context* c) {
     c->h_status[0] = 0u;
     c->census = -6;  // two kernels per grad-iter from now on in this context
     c->persist_failures++;
-    c->mutations++;  // (what a retrieve returns is about to change)
+    c->mutations++; c->tail_is_finish = false;  // (what a retrieve returns is about to change)
     std::vector<tp_context::journal_entry> todo(c->journal.begin() + (completed < c->journal.size() ? completed : c->journal.size()), c->journal.end());
     c->journal.clear();
     for (auto& e : todo) {
@@ -50,8 +51,34 @@ int check_persist_status(tp_context* c) {
 // that gave up is run again at the next check -- and that must be before anything that continues from its result.)
 int settle_persistent(tp_context* c) {
     if (!c->persist_unchecked) return TP_OK;
-    HIP_TRY(c, wait_stream(c->stream));
+    HIP_TRY(c, wait_context(c));
     return check_persist_status(c);
+}
+
+// the vertices' positions into the edges' endpoint copies, if persistent launches left them behind (their small finishing kernel
+// skips that: 4 us of dependent table reads per call for something only the two-kernel path reads)
+int settle_epos(tp_context* c) {
+    if (!c->epos_stale) return TP_OK;
+    c->epos_stale = false; c->tail_is_finish = false;
+    tp_launch_publish_positions(make_launch(c, 0, 0.0f), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return TP_OK;
+}
+
+// Waiting for the context's stream.  Behind a persistent launch the last thing on the stream is its small finishing kernel, whose LAST
+// block writes the count of completed launches into pinned memory: the host spins on that word (a PCIe write away from the kernel's end)
+// instead of asking the runtime (several microseconds per answer).  Anything else enqueued since: the runtime's answer.
+hipError_t wait_context(tp_context* c) {
+    if (c->tail_is_finish && c->persist_unchecked && c->h_status) {
+        const unsigned want = c->done_base + (unsigned)c->journal.size();
+        volatile unsigned* hs = c->h_status;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0;; spin++) {
+            if (hs[2] == want || hs[0] != 0u) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }
+            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;   // (a long call: block)
+        }
+    }
+    return wait_stream(c->stream);
 }
 
 // once per context: launch a full grid of the persistent kernel in census mode -- every workgroup arrives at a counter and
@@ -110,6 +137,7 @@ int install_plan(tp_context* c, pk_plan& np, const float* points, int slot) {
     G.src[1] = (const uint32_t*)(B.stage + b_wg); G.dst[1] = (uint32_t*)B.pool; G.words[1] = (uint32_t)(b_pool / 4);
     G.n = 2;
     tp_launch_copy_list(G, c->stream);
+    c->tail_is_finish = false;
     HIP_TRY(c, hipGetLastError());
     c->plan = std::move(np);
     c->plan_slot = slot;
@@ -227,7 +255,8 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
 #endif
         tp_launch_persist(A, grid, c->plan.rows_max, c->plan.lds_bytes, c->stream);
         if (banded) tp_launch_band_collect(make_launch(c, p.image_slot, dp), A, c->points_out, c->stream);
-        tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->h_status, c->stream);
+        tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->h_status, 0, c->stream);
+        c->epos_stale = true; c->tail_is_finish = true;
         c->journal.push_back({p, rings ? 0 : k});   // (a chunk of tp_iterate_until is checked by its caller: nothing to replay)
         HIP_TRY(c, hipGetLastError());
         c->epoch += (uint32_t)k;
@@ -237,6 +266,7 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         n -= k;
         if (c->iters_since_snap >= PK_CHUNK / 2) {   // the positions after this chunk, for a later maybe_replan
             const int sl = c->snap_next;
+            c->tail_is_finish = false;
             HIP_TRY(c, hipMemcpyAsync(c->snap_host[sl], c->points, sizeof(float) * 2 * (size_t)c->NP, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipEventRecord(c->snap_ev[sl], c->stream));
             c->snap_pending[sl] = true;
@@ -264,7 +294,7 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
     if (relerr) *relerr = 0.0f;
     if (max_frames == 0) return TP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    c->mutations++;
+    c->mutations++; c->tail_is_finish = false;
     if (int rc = settle_persistent(c)) return rc;
     const float dp = resolve_dp(c, p->flavour, p->dp);
     const int NT = c->NT;
@@ -295,6 +325,7 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
         if (!use || left < PK_MIN_ITERS) {
             // frame by frame on the two-kernel path: one frame, then the base energies come back
             if (int rc = host_ring((size_t)NT)) return rc;
+            if (int rc = settle_epos(c)) return rc;
             enqueue_iter(c, *p, dp);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(c->ering_host, c->ten, sizeof(int32_t) * (size_t)NT, hipMemcpyDeviceToHost, c->stream));
@@ -335,7 +366,8 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
             // back to the start of the last frame that counts, and that frame once more on the two-kernel path: it writes the
             // buffers the reference reads back (`tenergy`, `colnum`, `colacc`, `gradient`) and takes the step
             const int last = converged ? j : C - 1;
-            tp_launch_persist_finish(make_launch(c, p->image_slot, dp), pring + (size_t)last * c->NP, nullptr, nullptr, c->stream);
+            tp_launch_persist_finish(make_launch(c, p->image_slot, dp), pring + (size_t)last * c->NP, nullptr, nullptr, 1, c->stream);
+            c->epos_stale = false; c->tail_is_finish = false;
             enqueue_iter(c, *p, dp);
             HIP_TRY(c, hipGetLastError());
             break;
