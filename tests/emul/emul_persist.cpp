@@ -133,13 +133,11 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                     memcpy(&V.pos[s].x, &bx, 4); memcpy(&V.pos[s].y, &by, 4);
                 }
             // P1
-            for (int j = 0; j < 5 * w.n_own_v + (w.n_slots - w.n_own_v); j++) pk_snap_lane(w, V, vw, j);
             for (int l = 0; l < n_setup; l++) {
                 pk_walker wkr;
-                pk_setup_lane(V, vw, l, wkr);
+                V.ldir[l] = pk_setup_lane(V, vw, l, wkr);
                 V.wk[l] = wkr;
             }
-            for (int j = 0; j < 4 * w.n_corners; j++) V.coef[j] = pk_coef_lane(V, vw, j >> 2, (j & 3) + 1);
             memset(V.sums, 0, sizeof(unsigned long long) * PK_SUM_STRIDE * (size_t)w.n_lines_all);
             if (recut) {   // the wave's lanes one after the other
                 const int RRk = pk_rr_for(P.rows_max);   // tp_launch_persist's choice
@@ -214,7 +212,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                 for (int m = 1; m <= 4; m++) {
                     pk_i4 col = {0, 0, 0, 0};
                     if (flavour == 1 && ca) { const int32_t* c4 = ca + 4 * ((size_t)(4 * s + m) * NT + t); col.x = c4[0]; col.y = c4[1]; col.z = c4[2]; }
-                    const tp_moments mm = pk_coef_moments(V, V.coef[4 * k + m - 1], (cr.z & 0xffff) + m - 1, ((cr.z >> 16) & 0xffff) + m - 1, cr.w & 0xffff);
+                    const tp_moments mm = pk_corner_moments(V, (cr.z & 0xffff) + m - 1, ((cr.z >> 16) & 0xffff) + m - 1, cr.w & 0xffff, (cr.w >> 16) & 7);
                     en[m] = pk_energy(mm, flavour, col);
                     if (emit) {
                         const size_t id = (size_t)(4 * s + m) * NT + t;

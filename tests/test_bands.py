@@ -17,22 +17,29 @@ from util import RATE, case  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
+class _Box:
+    """a band's mailbox: fine-grained device memory from tp_band_mailbox_alloc (what bands on different GPUs need), freed with its context"""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.ptr = ctx, ctx.band_mailbox_alloc(nbytes)
+
+    def data_ptr(self):
+        return self.ptr
+
+
 def banded_contexts(W, H, img, imgB, pts, tris, colors, n_bands, patches):
-    import torch
     cap_p, cap_t = pts.shape[0] + 64, tris.shape[0] + 64
     nbytes = capi.band_mailbox_bytes(cap_p, cap_t)
-    boxes = [torch.zeros(nbytes // 8 + 1, dtype=torch.int64, device="cuda:0") for _ in range(n_bands)]
-    torch.cuda.synchronize()
-    ctxs = []
-    for b in range(n_bands):
-        ctx = capi.Context(0, W, H)
+    ctxs = [capi.Context(0, W, H) for _ in range(n_bands)]
+    boxes = [_Box(ctx, nbytes) for ctx in ctxs]
+    for b, ctx in enumerate(ctxs):
+        assert ctx.info(capi.INFO_BOX_FINEGRAINED) == 1
         ctx.set_image(capi.IMAGE_A, img)
         ctx.set_image(capi.IMAGE_B, imgB)
         ctx.upload(pts, tris, colors)
         ctx.band_attach(b, n_bands, [bx.data_ptr() for bx in boxes], nbytes, cap_p, cap_t, patches)
         # (the census of resident workgroups wants the device to itself: on a shared device, before any band spins in a launch)
         ctx.prepare(capi.default_params(1 if colors is not None else 0))
-        ctxs.append(ctx)
     return ctxs, boxes
 
 
@@ -119,5 +126,38 @@ def test_band_that_never_shows_up_is_survived():
     assert ctxs[0].info(9) == 1
     assert np.array_equal(ctxs[0].retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
     assert np.array_equal(ctxs[0].retrieve(capi.BUF_TENERGY), ref["ten"])
+    for ctx in ctxs:
+        ctx.close()
+
+
+def test_bands_on_two_devices():
+    """the same on TWO GPUs (skipped on a one-GPU box): band 0 on device 0, band 1 on device 1, each with its own fine-grained mailbox
+    (tp_band_mailbox_alloc) that the other device's kernel writes while this one polls it; tp_band_attach enables peer access.  The
+    oracle's bits, no launch given up (a coarse-grained mailbox would wait out its second in every launch and count as given up)."""
+    if capi.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    W, H = 300, 200
+    img, imgB, pts, tris, ratio, colors = case(W, H, (15, 5))
+    cap_p, cap_t = pts.shape[0] + 64, tris.shape[0] + 64
+    nbytes = capi.band_mailbox_bytes(cap_p, cap_t)
+    ctxs = [capi.Context(d, W, H) for d in (0, 1)]
+    boxes = [ctx.band_mailbox_alloc(nbytes) for ctx in ctxs]
+    for b, ctx in enumerate(ctxs):
+        ctx.set_image(capi.IMAGE_A, img)
+        ctx.upload(pts, tris, None)
+        ctx.band_attach(b, 2, boxes, nbytes, cap_p, cap_t, 8)
+        ctx.prepare(capi.default_params(0))
+    p = capi.default_params(0)
+    total = 0
+    for n in (6, 131, 40):
+        for ctx in ctxs:
+            ctx.iterate(p, n)
+        for ctx in ctxs:
+            ctx.synchronize()
+        total += n
+        ref = O.iterate(img, pts, tris, 0, ratio, RATE[0], total, literal=False)
+        for ctx in ctxs:
+            assert ctx.info(capi.INFO_PERSIST_FAILURES) == 0, "a band gave up: the mailboxes are not visible across the devices"
+            assert np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), ref["points"].view(np.uint32))
     for ctx in ctxs:
         ctx.close()

@@ -32,7 +32,6 @@ struct pk_view {
     unsigned long long* sums;  // [n_lines_all][PK_SUM_STRIDE] line sums (PK_SUM_WORDS of them used) {sum x | n_odd << 32, sum r | sum g << 32, sum b, q} (pk_fold_words)
     pk_walker* wk;             // [n_lines_all]
     pk_f2* pos;                // [n_slots]
-    pk_i2* snap;               // own slot k: [5 k + move]; neighbour slot s: [5 n_own_v + s - n_own_v] (unmoved)
     unsigned long long* gacc;  // [n_own_v][2] per own vertex and axis: {corners that have added their central difference this grad-iter : 32 (low),
                                // the int32 wrapping sum of those differences : 32 (high)} -- ONE returning 64-bit LDS atomic per corner and axis
                                // adds (difference << 32) | 1, and the lane whose returned count completes the vertex (vdeg) holds the whole sum:
@@ -46,7 +45,7 @@ struct pk_view {
                                // {line | chunk << 16, chunks, magic}
     pk_i4* corners;
     pk_i4* base;
-    int32_t* coef;             // [4 n_corners] (corner, move): signs of its three line sums, pk_coef_lane
+    int32_t* ldir;             // [n_lines_all] +1 / -1 / 0: the line's second endpoint lies below / above / level with its first (snapped rows)
     int32_t* flags;
 };
 
@@ -55,7 +54,6 @@ TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     V.sums = (unsigned long long*)p; p += pk_align16(w.n_lines_all * 8 * PK_SUM_STRIDE);
     V.wk = (pk_walker*)p; p += pk_align16(w.n_lines_all * 24);
     V.pos = (pk_f2*)p; p += pk_align16(w.n_slots * 8);
-    V.snap = (pk_i2*)p; p += pk_align16((4 * w.n_own_v + w.n_slots) * 8);
     V.gacc = (unsigned long long*)p; p += pk_align16(w.n_own_v * 16);
     V.vdeg = (int32_t*)p; p += pk_align16(w.n_own_v * 4);
     V.vid = (int32_t*)p; p += pk_align16(w.n_slots * 4);
@@ -65,27 +63,14 @@ TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     V.li = (int32_t*)p; p += pk_align16(w.li_cap * 12);
     V.corners = (pk_i4*)p; p += pk_align16(w.n_corners * 16);
     V.base = (pk_i4*)p; p += pk_align16(w.n_base * 16);
-    V.coef = (int32_t*)p; p += pk_align16(w.n_corners * 16);
+    V.ldir = (int32_t*)p; p += pk_align16(w.n_lines_all * 4);
     V.flags = (int32_t*)p;
-}
-
-TP_HD int pk_snap_index(const pk_wg& w, int slot, int move) {
-    return slot < w.n_own_v ? 5 * slot + move : 5 * w.n_own_v + (slot - w.n_own_v);
-}
-
-// P1a, lane j < 5 n_own_v + (n_slots - n_own_v): snapped raster position of one (slot, move)
-TP_HD void pk_snap_lane(const pk_wg& w, const pk_view& V, const tp_view& vw, int j) {
-    const int own5 = 5 * w.n_own_v;
-    const int slot = j < own5 ? j / 5 : w.n_own_v + (j - own5), move = j < own5 ? j - 5 * slot : 0;
-    const pk_f2 p = V.pos[slot];
-    int32_t X, Y;
-    tp_vertex_stage(p.x, p.y, move, 0, vw, X, Y);
-    V.snap[j].x = X; V.snap[j].y = Y;
 }
 
 // P1b, lane l < n_lines: line l = (local edge, version) -- the walker of the whole line
 // ... its endpoints displaced by (dxu, dyu) and (dxv, dyv) t-pose units (a thread's first line: worked out once per launch)
-TP_HD void pk_setup_moved(const pk_view& V, const tp_view& vw, int su, int sv, float dxu, float dyu, float dxv, float dyv, pk_walker& out) {
+// Returns which way the line runs down the raster: +1 / -1 / 0 as its second endpoint lies below / above / level with its first.
+TP_HD int pk_setup_moved(const pk_view& V, const tp_view& vw, int su, int sv, float dxu, float dyu, float dxv, float dyv, pk_walker& out) {
     const pk_f2 pu = V.pos[su], pv = V.pos[sv];
     int32_t Xa, Ya, Xb, Yb;
     tp_vertex_stage_d(pu.x, pu.y, dxu, dyu, vw, Xa, Ya);
@@ -93,15 +78,16 @@ TP_HD void pk_setup_moved(const pk_view& V, const tp_view& vw, int su, int sv, f
     tp_line ln;
     tp_setup_line(Xa, Ya, Xb, Yb, vw.H, ln);
     out.x = ln.x; out.s = ln.s; out.ra = ln.ra; out.rb = ln.rb;
+    return (Yb > Ya) - (Yb < Ya);
 }
-TP_HD void pk_setup_ends(const pk_view& V, const tp_view& vw, int su, int sv, int q, pk_walker& out) {
+TP_HD int pk_setup_ends(const pk_view& V, const tp_view& vw, int su, int sv, int q, pk_walker& out) {
     // line q: endpoint u displaced by move mu, endpoint v by move mv (tp_kernels.hip: k_lines)
     const int mu = (q >= 1 && q <= 4) ? q : 0, mv = q >= 5 ? q - 4 : 0;
-    pk_setup_moved(V, vw, su, sv, tp_move_dx(mu, vw.dp), tp_move_dy(mu, vw.dp), tp_move_dx(mv, vw.dp), tp_move_dy(mv, vw.dp), out);
+    return pk_setup_moved(V, vw, su, sv, tp_move_dx(mu, vw.dp), tp_move_dy(mu, vw.dp), tp_move_dx(mv, vw.dp), tp_move_dy(mv, vw.dp), out);
 }
-TP_HD void pk_setup_lane(const pk_view& V, const tp_view& vw, int l, pk_walker& out) {
+TP_HD int pk_setup_lane(const pk_view& V, const tp_view& vw, int l, pk_walker& out) {
     const int le = V.lines[l] & 0xffff, q = V.lines[l] >> 16;
-    pk_setup_ends(V, vw, V.edges[le] & 0xffff, (V.edges[le] >> 16) & 0xffff, q, out);
+    return pk_setup_ends(V, vw, V.edges[le] & 0xffff, (V.edges[le] >> 16) & 0xffff, q, out);
 }
 
 // x / d for the item's chunk count d (magic = floor(2^32 / d) + 1, exact for x d < 2^32; d == 1: magic 0)
@@ -429,29 +415,25 @@ TP_HD tp_moments pk_moments3(int c0, const unsigned long long* S0, int c1, const
     const tp_moments mm = {mo[0], mo[1], mo[2], mo[3], mo[4], mo[5]};
     return mm;
 }
-// P1, lane (corner k, move m): with which signs the three line sums enter the variant's moments -- from the positions alone, so
-// it is done while other lanes set the lines up, and P6 starts from the sums.  Two bits each: edge leaving the vertex | edge
-// arriving << 2 | opposite edge << 4.
-TP_HD int32_t pk_coef_lane(const pk_view& V, const tp_view& vw, int k, int m) {
-    const pk_i4 cr = V.corners[k];
-    const int s = cr.y & 3, own = (cr.y >> 2) & 0x3ff, sa = (cr.y >> 12) & 0x3ff, sb = (cr.y >> 22) & 0x3ff;
-    const int sn = s == 2 ? 0 : s + 1, sp = s == 0 ? 2 : s - 1;
-    int32_t X[3], Y[3], c[3];
-    const pk_f2 pv = V.pos[own], pa = V.pos[sa], pb = V.pos[sb];
-    tp_vertex_stage(pv.x, pv.y, m, 0, vw, X[s], Y[s]);
-    tp_vertex_stage(pa.x, pa.y, 0, 0, vw, X[sn], Y[sn]);
-    tp_vertex_stage(pb.x, pb.y, 0, 0, vw, X[sp], Y[sp]);
-    tp_variant_coeffs(X, Y, c);
-    const int cs = s == 0 ? c[0] : s == 1 ? c[1] : c[2];
-    const int cn = sn == 0 ? c[0] : sn == 1 ? c[1] : c[2];
-    const int cp = sp == 0 ? c[0] : sp == 1 ? c[1] : c[2];
-    return (cs & 3) | ((cp & 3) << 2) | ((cn & 3) << 4);
+// The signs with which three line sums enter a triangle's moments, WITHOUT its vertices (tp_raster.h: tp_variant_coeffs has them as
+// c[k] = sg * sign(Y[k+1] - Y[k]), sg the orientation of the triangle).  sign(Y[k+1] - Y[k]) is how the triangle's edge k runs down
+// the raster: the line's own direction (its set-up stored it: pk_view::ldir) -- reversed when the half-edge runs against the edge's
+// first -> second endpoint (`flip`, topology: from the plan).  And sg is whatever makes the pixel count non-negative: the count of the
+// covered pixels is the moment n, so M = sum_k sign_k W(e_k) has M_n = sg * n, and n > 0 fixes sg; n = 0: no pixel is covered, every
+// moment is 0 whichever sign (a triangle without area: its lines cancel row by row).  Nothing of this needs a vertex position, so
+// nothing between the positions and the walk computes signs any more (round 3 had three vertex stages and an orientation test per
+// corner variant there, on as many waves as the line set-up).
+TP_HD tp_moments pk_signed_moments(const pk_view& V, int l0, int l1, int l2, int flips) {
+    const unsigned long long *S0 = V.sums + (size_t)l0 * PK_SUM_STRIDE, *S1 = V.sums + (size_t)l1 * PK_SUM_STRIDE, *S2 = V.sums + (size_t)l2 * PK_SUM_STRIDE;
+    int c0 = V.ldir[l0], c1 = V.ldir[l1], c2 = V.ldir[l2];
+    c0 = (flips & 1) ? -c0 : c0; c1 = (flips & 2) ? -c1 : c1; c2 = (flips & 4) ? -c2 : c2;
+    const int64_t n = (int64_t)c0 * (int64_t)(uint32_t)S0[0] + (int64_t)c1 * (int64_t)(uint32_t)S1[0] + (int64_t)c2 * (int64_t)(uint32_t)S2[0];
+    const int sg = n < 0 ? -1 : 1;
+    return pk_moments3(c0 * sg, S0, c1 * sg, S1, c2 * sg, S2);
 }
-// P6, the same lane: the variant's moments from the three line sums (slots of the edge leaving the vertex, arriving at it, opposite)
-TP_HD tp_moments pk_coef_moments(const pk_view& V, int32_t cf, int so, int si, int sopp) {
-    const int cs = (int32_t)((uint32_t)cf << 30) >> 30, cp = (int32_t)((uint32_t)cf << 28) >> 30, cn = (int32_t)((uint32_t)cf << 26) >> 30;
-    return pk_moments3(cs, V.sums + (size_t)so * PK_SUM_STRIDE, cp, V.sums + (size_t)si * PK_SUM_STRIDE, cn, V.sums + (size_t)sopp * PK_SUM_STRIDE);
-}
+// P6, lane (corner, move): the variant's moments from the three line sums (slots of the edge leaving the vertex, arriving at it, opposite;
+// flips: leaving | arriving << 1 | opposite << 2)
+TP_HD tp_moments pk_corner_moments(const pk_view& V, int so, int si, int sopp, int flips) { return pk_signed_moments(V, so, si, sopp, flips); }
 // energy of a variant as k_update's emit_variant forms it (triangle.fs:37-43; warp: against the stored colour, :46-53)
 TP_HD int32_t pk_energy(const tp_moments& mm, int flavour, pk_i4 col) {
     return tp_wrap32(flavour == 0 ? tp_energy_triangulate(mm) : tp_energy64(mm, col.x, col.y, col.z));
@@ -460,13 +442,8 @@ TP_HD int32_t pk_energy(const tp_moments& mm, int flavour, pk_i4 col) {
 TP_HD tp_moments pk_base_moments(const pk_wg& w, const pk_view& V, int k, int& t) {
     const pk_i4 b = V.base[k];
     t = b.x;
-    const int own = b.y & 0x3ff, s1 = (b.y >> 10) & 0x3ff, s2 = (b.y >> 20) & 0x3ff;
-    int32_t X[3], Y[3], c[3];
-    const pk_i2 p0 = V.snap[pk_snap_index(w, own, 0)], p1 = V.snap[pk_snap_index(w, s1, 0)], p2 = V.snap[pk_snap_index(w, s2, 0)];
-    X[0] = p0.x; Y[0] = p0.y; X[1] = p1.x; Y[1] = p1.y; X[2] = p2.x; Y[2] = p2.y;
-    tp_variant_coeffs(X, Y, c);
-    return pk_moments3(c[0], V.sums + (size_t)(b.z & 0xffff) * PK_SUM_STRIDE, c[1], V.sums + (size_t)((b.z >> 16) & 0xffff) * PK_SUM_STRIDE,
-                       c[2], V.sums + (size_t)(b.w & 0xffff) * PK_SUM_STRIDE);
+    (void)w;
+    return pk_signed_moments(V, b.z & 0xffff, (b.z >> 16) & 0xffff, b.w & 0xffff, (b.w >> 16) & 7);
 }
 
 // P7, own vertex k with gradient (gx, gy): the shift.cs step (shift.cs:16-47).  Vertices 0..3 never move.

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         const int32_t* cr_ = A.pool + w.off_corners + 4 * (tid >> 2);
         const int m_ = tid & 3;
         my_c0 = ((cr_[2] & 0xffff) + m_) | ((((cr_[2] >> 16) & 0xffff) + m_) << 16);
-        my_c1 = (cr_[3] & 0xffff) | (((cr_[1] >> 2) & 0x3ff) << 16);
+        my_c1 = (cr_[3] & 0xffff) | (((cr_[1] >> 2) & 0x3ff) << 16) | (((cr_[3] >> 16) & 7) << 26);   // (... | flips << 26)
     }
     const char* table = reinterpret_cast<const char*>(A.px);
     // this thread's lane-item of the walk and the table records of its rows: in registers for the whole launch
@@ -186,17 +186,12 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         // ---- P1: line set-up (low threads), snapped positions (high threads), gradient reset
         for (int l = tid; l < n_setup; l += PK_THREADS) {
             pk_walker wk;
-            if (l == tid) pk_setup_moved(V, A.vw, my_ends & 0x3ff, (my_ends >> 10) & 0x3ff, my_dxu, my_dyu, my_dxv, my_dyv, wk);
-            else pk_setup_lane(V, A.vw, l, wk);
-            V.wk[l] = wk;
+            int dir;
+            if (l == tid) dir = pk_setup_moved(V, A.vw, my_ends & 0x3ff, (my_ends >> 10) & 0x3ff, my_dxu, my_dyu, my_dxv, my_dyv, wk);
+            else dir = pk_setup_lane(V, A.vw, l, wk);
+            V.wk[l] = wk; V.ldir[l] = dir;
         }
         {
-            const int nsnap = 5 * w.n_own_v + (w.n_slots - w.n_own_v);
-            // (snapped positions: only the base variants' moments read them -- the last grad-iter of a call, and every frame of tp_iterate_until)
-            if (emit || ering)
-                for (int j = PK_THREADS - 1 - tid; j < nsnap; j += PK_THREADS) pk_snap_lane(w, V, A.vw, j);
-            // (the signs of the corner variants' line sums, by the waves that set up no lines: P6 starts from the sums)
-            for (int j = tid >= PK_THREADS / 2 ? tid - PK_THREADS / 2 : tid + PK_THREADS / 2; j < 4 * w.n_corners; j += PK_THREADS) V.coef[j] = pk_coef_lane(V, A.vw, j >> 2, (j & 3) + 1);
             // (the line sums of the grad-iter before: every corner has read them by now -- the barrier behind P0 was passed)
             if (it > 0)
                 for (int i = PK_THREADS - 1 - tid; i < PK_SUM_STRIDE * w.n_lines; i += PK_THREADS) V.sums[i] = 0ull;
@@ -306,13 +301,13 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 const int4 c = A.ca[(size_t)(4 * (cq.y & 3) + m) * A.NT + cq.x];
                 col.x = c.x; col.y = c.y; col.z = c.z;
             }
-            int so, si, sopp, own;
-            if (j == tid) { so = my_c0 & 0xffff; si = (int)((unsigned)my_c0 >> 16); sopp = my_c1 & 0xffff; own = my_c1 >> 16; }
+            int so, si, sopp, own, flips;
+            if (j == tid) { so = my_c0 & 0xffff; si = (int)((unsigned)my_c0 >> 16); sopp = my_c1 & 0xffff; own = (my_c1 >> 16) & 0x3ff; flips = my_c1 >> 26; }
             else {
                 const pk_i4 cq = V.corners[k];
-                so = (cq.z & 0xffff) + m - 1; si = ((cq.z >> 16) & 0xffff) + m - 1; sopp = cq.w & 0xffff; own = (cq.y >> 2) & 0x3ff;
+                so = (cq.z & 0xffff) + m - 1; si = ((cq.z >> 16) & 0xffff) + m - 1; sopp = cq.w & 0xffff; own = (cq.y >> 2) & 0x3ff; flips = (cq.w >> 16) & 7;
             }
-            const tp_moments mm = pk_coef_moments(V, V.coef[j], so, si, sopp);
+            const tp_moments mm = pk_corner_moments(V, so, si, sopp, flips);
             const int32_t e = pk_energy(mm, A.flavour, col);
             // lanes 4k+0/1: E(+dx), E(-dx); 4k+2/3: E(+dy), E(-dy) -- the neighbour's energy by a DPP quad permute [1,0,3,2] (__shfl_xor
             // goes through the LDS crossbar: a hundred cycles on this chain)

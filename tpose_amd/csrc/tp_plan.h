@@ -74,8 +74,9 @@ struct pk_wg {
     int32_t off_vid;           // [n_slots] global vertex id
     int32_t off_edges;         // [n_edges] slot_u | slot_v << 16
     int32_t off_lines;         // [n_lines_all] local edge | version << 16
-    int32_t off_corners;       // [n_corners] {t, s | own << 2 | slot_a << 12 | slot_b << 22, out | in << 16, opp}
-    int32_t off_base;          // [n_base] {t, own | slot_1 << 10 | slot_2 << 20, line of edge 0 | edge 1 << 16, line of edge 2}
+    int32_t off_corners;       // [n_corners] {t, s | own << 2 | slot_a << 12 | slot_b << 22, out | in << 16, opp | flips << 16} -- flips: the half-edge
+                               // leaving the vertex | arriving << 1 | opposite << 2 runs against its edge's first -> second endpoint
+    int32_t off_base;          // [n_base] {t, own | slot_1 << 10 | slot_2 << 20, line of edge 0 | edge 1 << 16, line of edge 2 | flips of edges 0, 1, 2 << 16}
     int32_t lds_bytes;         // dynamic LDS of this workgroup (pk_lds_bytes)
 };
 
@@ -112,7 +113,6 @@ inline int pk_lds_bytes(const pk_wg& w) {
     b += pk_align16(w.n_lines_all * 8 * PK_SUM_STRIDE);  // line sums
     b += pk_align16(w.n_lines_all * 24);            // walkers
     b += pk_align16(w.n_slots * 8);                 // positions
-    b += pk_align16((4 * w.n_own_v + w.n_slots) * 8);  // snapped positions: neighbours unmoved only, own slots + 4 moves
     b += pk_align16(w.n_own_v * 16);                // gradient: per own vertex and axis {corners counted : 32, sum of their central differences : 32}
     b += pk_align16(w.n_own_v * 4);                 // corners of every own vertex
     b += pk_align16(w.n_slots * 4);                 // vid
@@ -122,7 +122,7 @@ inline int pk_lds_bytes(const pk_wg& w) {
     b += pk_align16(w.li_cap * 12);                 // lane-items without a thread of their own
     b += pk_align16(w.n_corners * 16);              // corners
     b += pk_align16(w.n_base * 16);                 // base variants
-    b += pk_align16(w.n_corners * 16);              // signs of the three line sums of every corner variant (this grad-iter's)
+    b += pk_align16(w.n_lines_all * 4);             // which way every line runs down the raster (this grad-iter's)
     return b + 64;                                  // flags
 }
 
@@ -350,12 +350,12 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
                 corners.push_back(t);
                 corners.push_back(s | (k << 2) | (slot(va) << 12) | (slot(vb) << 22));
                 corners.push_back(so | (si << 16));
-                corners.push_back(sopp);
+                corners.push_back(sopp | ((he_out & 1) << 16) | ((he_in & 1) << 17) | ((he_opp & 1) << 18));
                 if (s == 0) {
                     base.push_back(t);
                     base.push_back(k | (slot(va) << 10) | (slot(vb) << 20));
                     base.push_back(first[(size_t)eloc[he_out >> 1] * PK_NLINES] | (sopp << 16));
-                    base.push_back(first[(size_t)eloc[he_in >> 1] * PK_NLINES]);
+                    base.push_back(first[(size_t)eloc[he_in >> 1] * PK_NLINES] | ((he_out & 1) << 16) | ((he_opp & 1) << 17) | ((he_in & 1) << 18));
                 }
             }
         }
