@@ -219,6 +219,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the two rocprofv3 --pmc passes (traffic from profiles/)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-cache figure (five contexts cycled)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the full-contrast and all-13-variants figures")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--flavour", type=int, default=0, help="0 triangulate (metric), 1 warp")
@@ -302,6 +303,54 @@ def main():
     dt = sorted(times)[len(times) // 2]
     if dist is not None:
         dist.barrier()
+    # the same regions on SURVEY section 8(d)'s FULL-contrast raster (what rounds 1-2 timed; the reference's fixed-step descent throws
+    # vertices hundreds of pixels on it -- profiles/r04_contrast_stats.txt: 69 x the drive of the reference's photographs), and with all 13
+    # variants formed in every grad-iter (tp_iterate_until: every frame keeps its base energies for the host's convergence test, as the
+    # reference's loop reads `terr` back every frame; a tp_iterate call forms the base variants in its last grad-iter only)
+    full_ms, until_ms = None, None
+    if rank == 0 and world == 1 and not args.no_extra:
+        def regions(fn):
+            ts = []
+            for rep in range(args.repeats):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            return sorted(ts)[len(ts) // 2] / args.steps * 1e3
+        try:
+            imgF = synth.workload(W, H, NT, seed=dist_util.replica_seed(rank), contrast=1.0)[0]
+            cf = capi.Context(local_rank, W, H)
+            cf.set_image(capi.IMAGE_A, imgF)
+            if args.flavour == 1:
+                cf.set_image(capi.IMAGE_B, synth.displaced_raster(imgF))
+            cf.upload(pts, tris, colors)
+            cf.prepare(params)
+            cf.iterate(params, args.warmup)
+            cf.synchronize()
+
+            def one_full():
+                cf.iterate(params, args.steps)
+                cf.synchronize()
+            full_ms = regions(one_full)
+            cf.close()
+        except Exception as e:  # noqa: BLE001 -- an extra figure: the bench line must still appear
+            full_ms = "error: %s" % e
+        try:
+            state = {"tot": 1.0}
+            cu = capi.Context(local_rank, W, H)   # (a context of its own: its plan walks every triangle's base lines in every grad-iter)
+            cu.set_image(capi.IMAGE_A, img)
+            if args.flavour == 1:
+                cu.set_image(capi.IMAGE_B, imgB)
+            cu.upload(pts, tris, colors)
+
+            def one_until():
+                n, state["tot"], _ = cu.iterate_until(params, args.steps, 0.0, state["tot"])   # (a threshold nothing meets: exactly `steps` frames)
+                assert n == args.steps
+            for _ in range(max(1, args.warmup // max(1, args.steps))):
+                one_until()
+            until_ms = regions(one_until)
+            cu.close()
+        except Exception as e:  # noqa: BLE001
+            until_ms = "error: %s" % e
     patches, persist_iters = ctx.info(capi.INFO_PATCHES), ctx.info(capi.INFO_PERSIST_ITERS)
 
     # dominant kernel: k_persist, CHILD_ITERS grad-iters per launch, HIP events on the library's stream right after the timed
@@ -370,6 +419,12 @@ def main():
             "ms_per_step_device_note": "HIP events on the library's stream around %d more regions of the same length (median): what "
                                        "the device spent, without the host's launch and wait" % args.repeats,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step_full_contrast": full_ms,
+            "ms_per_step_full_contrast_note": "the same flags on SURVEY section 8(d)'s raster as written (uniform u8 site colours, no contrast scaling): "
+                                              "the raster of rounds 1-2; vertices fly hundreds of pixels on it, lines outgrow the rows their lanes keep",
+            "ms_per_step_all_13_variants": until_ms,
+            "ms_per_step_all_13_variants_note": "tp_iterate_until with a threshold nothing meets, the same number of frames per call: base lines walked and "
+                                                "base energies kept in EVERY grad-iter, the host's geterr over every frame, the last frame re-run to leave its buffers",
             "ms_per_step_two_kernel_path": two_kernel_ms,
             "ms_per_step_readback_every_iter": readback_ms,
             "dtype": "int64", "data": "synthetic",
@@ -379,11 +434,18 @@ def main():
                             "flavour, one replica per GPU" % (CONTRAST, "warp" if args.flavour else "triangulate"),
                 "raster": [W, H], "triangles": NT, "points": NP, "variants": 13 * NT,
                 "parallelism": "replicas x%d (no data-path collective)" % world,
-                "path": "persistent launches: %d patches (workgroups), %d grad-iters ran inside them" % (patches, persist_iters),
+                "path": "persistent launches: %d patches (workgroups), %d grad-iters ran inside them.  Inside a tp_iterate call the intermediate "
+                        "grad-iters form the 12 displaced variants of every triangle (all the step needs); the base variants (i = 0), which only "
+                        "the buffers the reference reads back need, are formed in the call's last grad-iter -- ms_per_step_all_13_variants is the "
+                        "mode that forms them every grad-iter" % (patches, persist_iters),
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "latency", "nominal_bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac_note": "algorithmic bytes (SURVEY section 8d: one read of the raster plane + indices + per-variant outputs + points) / kernel "
+                             "time / 8 TB/s -- the roofline the task prices this path against; the kernel itself is bound by latency (see "
+                             "observed_bound), its measured HBM-side traffic is `traffic`",
+                "frac_of_measured_traffic": (traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "traffic_source": traffic_source,
                 "observed_bound": "latency, not bandwidth: VALU issue inside a workgroup (the walk of the edge lines) plus one "
                                   "position hand-over between workgroups per grad-iter; the table records a lane needs stay in "

@@ -307,10 +307,36 @@ TP_HD int64_t tp_energy64(const tp_moments& m, int64_t ar, int64_t ag, int64_t a
 
 // triangulate flavour: a = ca.rgb / cn with the int32 (wrapped) sums of the reference SSBO;
 // energy 0 when cn == 0 (triangle.fs:40)
+// x / n as C truncates it (n > 0), for the three channel sums of a variant: on the device ONE 32-bit reciprocal serves all three (the
+// compiler's expansion of an int32 division builds its own each time: ~35 instructions, four of them quarter-rate multiplications, on
+// the chain between the walk and the step).  z = floor(2^32 / n) to within 2 after one Newton step on the float estimate; the quotient
+// estimate mulhi(|x|, z) is then at most 2 short, which the two remainder steps make good -- the usual unsigned expansion, shared.
+struct tp_rcp32 { uint32_t n, z; };
+TP_HD tp_rcp32 tp_rcp32_of(int32_t n) {
+    tp_rcp32 r; r.n = (uint32_t)n; r.z = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t z = (uint32_t)(__builtin_amdgcn_rcpf((float)r.n) * 4294966784.0f);   // (0x4f7ffffe: never above 2^32 / n)
+    z += __umulhi(z, (0u - r.n) * z);
+    r.z = z;
+#endif
+    return r;
+}
+TP_HD int32_t tp_div_by(int32_t x, const tp_rcp32& r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t ax = x < 0 ? 0u - (uint32_t)x : (uint32_t)x;
+    uint32_t q = __umulhi(ax, r.z), rem = ax - q * r.n;
+    if (rem >= r.n) { q++; rem -= r.n; }
+    if (rem >= r.n) q++;
+    return x < 0 ? (int32_t)(0u - q) : (int32_t)q;
+#else
+    return x / (int32_t)r.n;
+#endif
+}
 TP_HD int64_t tp_energy_triangulate(const tp_moments& m) {
     const int32_t n32 = tp_wrap32(m.n);
     if (n32 <= 0) return 0;
-    return tp_energy64(m, tp_wrap32(m.sr) / n32, tp_wrap32(m.sg) / n32, tp_wrap32(m.sb) / n32);
+    const tp_rcp32 r = tp_rcp32_of(n32);
+    return tp_energy64(m, tp_div_by(tp_wrap32(m.sr), r), tp_div_by(tp_wrap32(m.sg), r), tp_div_by(tp_wrap32(m.sb), r));
 }
 
 // =============================================================================================
