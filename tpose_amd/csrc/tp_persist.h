@@ -270,7 +270,10 @@ TP_HD int pk_walk_lane(const pk_view& V, const char* table, int pitch, int W, in
     }
     a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
     pk_rows r = pk_lane_rows(V.wk[l], c, TL, magic, pitch);
-    pk_walk_rows<4>(r, table, W, a);
+#ifndef PK_UNCACHED_BATCH
+#define PK_UNCACHED_BATCH 8    /* records requested together by a lane-item without cached records (12 would spill registers of the cached walk) */
+#endif
+    pk_walk_rows<PK_UNCACHED_BATCH>(r, table, W, a);
     return l;
 }
 
