@@ -210,6 +210,134 @@ def cold_cache_figure(capi, synth, device, params, pts, tris, flavour, planes=5,
         return {"error": str(e)}
 
 
+def pair_split_figure(capi, synth, dist_util, dist, rank, world, device, local_rank, share_gpu, steps, warmup, repeats):
+    """ONE image pair on all the GPUs of the job -- its directions (A->B, B->A: two of them from four GPUs on) each
+    split into bands of patches, one band per GPU (tp_band_attach: vertex positions cross between the bands' kernels through fine-grained
+    mailboxes mapped into every band's process; the unit being split is software/warp/main.cpp:214-283).  Every rank of the job calls
+    this; every step that can fail is followed by an agreement, so that no rank waits in a collective another one never reaches.
+    Returns a dict for rank 0's line (or {"error": ...})."""
+    import torch
+
+    def agree(ok):
+        t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=device)
+        dist.all_reduce(t)
+        return int(t.item()) == 0
+
+    D = 2 if world >= 4 else 1          # directions of the pair that run side by side
+    B = world // D                      # bands per direction
+    if B < 2 or B > 4 or B * D != world:
+        return {"error": "needs 2, 4 or 8 ranks"}
+    my_dir, my_band = rank // B, rank % B
+    err, ctx, box, mates = None, None, None, []
+    try:
+        imgA, pts, tris, he, ratio = synth.workload(W, H, NT, contrast=CONTRAST)
+        imgB = synth.displaced_raster(imgA)
+        sweep, other = (imgB, imgA) if my_dir == 0 else (imgA, imgB)   # direction 0: T(A) against image B (warp/shader/triangle.fs:49-50)
+        colors = synth.mean_colors(other, pts, tris, ratio)
+        slot = capi.IMAGE_B if my_dir == 0 else capi.IMAGE_A
+        ctx = capi.Context(local_rank, W, H)
+        ctx.set_image(slot, sweep)
+        ctx.upload(pts, tris, colors)
+        params = capi.default_params(capi.WARP)
+        params.image_slot = slot
+        cap_p, cap_t = pts.shape[0] + 64, tris.shape[0] + 64
+        nbytes = capi.band_mailbox_bytes(cap_p, cap_t)
+        box = ctx.band_mailbox_alloc(nbytes)
+        handle = ctx.band_mailbox_export(box)
+    except Exception as e:  # noqa: BLE001
+        err, handle = "set-up: %s" % e, bytes(64)
+    hs = [torch.zeros(64, dtype=torch.uint8, device=device) for _ in range(world)]
+    dist.all_gather(hs, torch.tensor(list(handle), dtype=torch.uint8, device=device))
+    if not agree(err is None):
+        return {"error": err or "another rank failed in set-up"}
+    try:
+        boxes = []
+        for b in range(B):
+            if b == my_band:
+                boxes.append(box)
+            else:
+                m = ctx.band_mailbox_import(bytes(hs[my_dir * B + b].cpu().numpy().tobytes()))
+                mates.append(m)
+                boxes.append(m)
+        # (a plan of 512 patches between the bands of a direction -- 256 when the ranks share one GPU, where more cannot be resident)
+        ppb = (256 if share_gpu else 512) // B
+        ctx.band_attach(my_band, B, boxes, nbytes, cap_p, cap_t, ppb)
+    except Exception as e:  # noqa: BLE001
+        err = "attach: %s" % e
+    if not agree(err is None):
+        return {"error": err or "another rank failed to attach"}
+    for r in range(world):   # (the census of resident workgroups wants its device to itself when ranks share one)
+        if r == rank:
+            try:
+                ctx.prepare(params)
+                ctx.synchronize()
+            except Exception as e:  # noqa: BLE001
+                err = "prepare: %s" % e
+        dist.barrier()
+    if not agree(err is None):
+        return {"error": err or "another rank failed to prepare"}
+    times = []
+    try:
+        ctx.iterate(params, warmup)
+        ctx.synchronize()
+        for rep in range(repeats):
+            dist.barrier()
+            t0 = time.perf_counter()
+            ctx.iterate(params, steps)
+            ctx.synchronize()
+            times.append(dist_util.max_over_ranks(dist, time.perf_counter() - t0, device))
+        info = {"persist_iters": ctx.info(capi.INFO_PERSIST_ITERS), "gave_up": ctx.info(capi.INFO_PERSIST_FAILURES), "patches": ctx.info(capi.INFO_PATCHES)}
+    except Exception as e:  # noqa: BLE001
+        err = "iterate: %s" % e
+    if not agree(err is None):
+        return {"error": err or "another rank failed while iterating"}
+    gave_up = torch.tensor([info["gave_up"]], dtype=torch.int64, device=device)
+    dist.all_reduce(gave_up)
+    # the same pair on ONE GPU: its directions one after the other, unsplit (rank 0, the others wait)
+    one = None
+    if rank == 0:
+        try:
+            c1 = capi.Context(local_rank, W, H)
+            c1.set_image(capi.IMAGE_B, imgB)
+            c1.set_image(capi.IMAGE_A, imgA)
+            c1.upload(pts, tris, colors)
+            c1.prepare(params)
+            c1.iterate(params, warmup)
+            c1.synchronize()
+            ts = []
+            for rep in range(repeats):
+                t0 = time.perf_counter()
+                for d in range(D):   # (the second direction costs what the first does: the same mesh against the other raster)
+                    c1.iterate(params, steps)
+                c1.synchronize()
+                ts.append(time.perf_counter() - t0)
+            one = sorted(ts)[len(ts) // 2]
+            c1.close()
+        except Exception as e:  # noqa: BLE001
+            one = None
+            err = "one-GPU leg: %s" % e
+    dist.barrier()
+    dt = sorted(times)[len(times) // 2]
+    out = {"directions": D, "bands_per_direction": B, "patches_per_band": ppb, "steps": steps,
+           "ms_per_step": dt / steps * 1e3, "value": NT * D * steps / dt, "unit": "triangles*grad-iters/s of ONE pair (warp flavour, %d direction%s)" % (D, "s" if D > 1 else ""),
+           "launches_given_up_all_ranks": int(gave_up.item()), "rank0": info,
+           "note": "one image pair on %d GPUs: %d direction(s) x %d bands of patches, positions handed over between the bands' persistent kernels "
+                   "through fine-grained mailboxes (tp_band_attach); a band that waits a second for positions gives up and every band runs the "
+                   "call whole -- launches_given_up counts that" % (world, D, B)}
+    if one:
+        out["same_pair_on_one_gpu_ms_per_step"] = one / steps * 1e3
+        out["speedup_vs_one_gpu"] = one / dt
+    if err:
+        out["warning"] = err
+    try:
+        for m in mates:
+            ctx.band_mailbox_close(m)
+        ctx.close()
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +348,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the two rocprofv3 --pmc passes (traffic from profiles/)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-cache figure (five contexts cycled)")
     ap.add_argument("--no-extra", action="store_true", help="skip the full-contrast and all-13-variants figures")
+    ap.add_argument("--no-pair-split", action="store_true", help="N > 1: skip the one-pair-on-all-GPUs figure (band split, SURVEY row e3)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--flavour", type=int, default=0, help="0 triangulate (metric), 1 warp")
@@ -387,6 +516,13 @@ def main():
     cold = None
     if rank == 0 and world == 1 and not args.no_cold:
         cold = cold_cache_figure(capi, synth, local_rank, params, pts, tris, args.flavour)
+    # N > 1: beside the replicas, ONE pair on all the GPUs (row e3) -- after the headline regions, in a context of its own
+    pair = None
+    if dist is not None and world in (2, 4, 8) and not args.no_pair_split:
+        try:
+            pair = pair_split_figure(capi, synth, dist_util, dist, rank, world, device, local_rank, args.share_gpu, args.steps, args.warmup, args.repeats)
+        except Exception as e:  # noqa: BLE001 -- an extra figure: the bench line must still appear
+            pair = {"error": str(e)}
     bytes_iter = algorithmic_bytes(W, H, NT, NP)
     # the same kernel as rocprofv3 sees it (what profiles/ holds): the roofline figure uses THIS duration when it is
     # available, so that it can be reproduced from a kernel trace; the HIP-event figure stays beside it
@@ -464,6 +600,8 @@ def main():
                 "kernel_us_samples": ev_samples,
             },
         }
+        if pair is not None:
+            line["pair_split"] = pair
         if cold is not None:
             line["cold_cache"] = cold
         if world == 1 and not args.no_cpu_baseline:

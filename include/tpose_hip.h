@@ -124,6 +124,13 @@ int tp_set_option(tp_context* ctx, int option, int64_t value);
 size_t tp_band_mailbox_bytes(int points, int triangles);
 int tp_band_mailbox_alloc(tp_context* ctx, size_t bytes, void** mailbox);
 int tp_band_mailbox_free(tp_context* ctx, void* mailbox);
+/* bands in different PROCESSES (one per GPU): a mailbox's owner exports it as an opaque 64-byte handle (hipIpcGetMemHandle), which travels
+ * by any means (a pipe, RCCL, torch.distributed); every other band imports it (hipIpcOpenMemHandle) and passes the address to
+ * tp_band_attach.  tp_band_mailbox_close unmaps an imported mailbox. */
+#define TP_MAILBOX_HANDLE_BYTES 64
+int tp_band_mailbox_export(tp_context* ctx, void* mailbox, void* handle /* [TP_MAILBOX_HANDLE_BYTES] */);
+int tp_band_mailbox_import(tp_context* ctx, const void* handle, void** mailbox);
+int tp_band_mailbox_close(tp_context* ctx, void* mailbox);
 int tp_band_attach(tp_context* ctx, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int points, int triangles,
                    int patches_per_band);
 

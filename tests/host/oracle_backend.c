@@ -181,6 +181,9 @@ int tp_band_attach(tp_context* c, int band, int n_bands, void* const* mailboxes,
 }
 int tp_band_mailbox_alloc(tp_context* c, size_t bytes, void** out) { (void)c; if (!out) return TP_ERR_INVALID; *out = calloc(bytes ? bytes : 1, 1); return *out ? TP_OK : TP_ERR_CAPACITY; }
 int tp_band_mailbox_free(tp_context* c, void* box) { (void)c; free(box); return TP_OK; }
+int tp_band_mailbox_export(tp_context* c, void* box, void* handle) { (void)c; (void)box; if (handle) memset(handle, 0, TP_MAILBOX_HANDLE_BYTES); return TP_OK; }
+int tp_band_mailbox_import(tp_context* c, const void* handle, void** box) { (void)c; (void)handle; if (box) *box = NULL; return TP_ERR_STATE; }
+int tp_band_mailbox_close(tp_context* c, void* box) { (void)c; (void)box; return TP_OK; }
 int tp_prepare(tp_context* c, const tp_params* p) { (void)c; (void)p; return TP_OK; }
 int tp_get_info(tp_context* c, int what, int64_t* value) { (void)c; (void)what; if (value) *value = 0; return TP_OK; }
 int tp_synchronize(tp_context* c) { (void)c; return TP_OK; }

@@ -147,6 +147,12 @@ def test_bench_two_ranks_on_one_gpu():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 256 and line["warmup"] == 32
     assert line["value"] > 0 and abs(line["value"] - 3000 * 256 * 2 / (line["ms_per_step"] * 256e-3)) < 1e-6 * line["value"]
     assert "cpu_baseline" not in line and line["roofline"]["nominal_bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    # beside the replicas: ONE pair on both ranks, here one direction cut into two bands, mailboxes shared between the
+    # two processes through the ABI's export / import; no launch may have given up
+    ps = line["pair_split"]
+    assert "error" not in ps, ps
+    assert ps["directions"] == 1 and ps["bands_per_direction"] == 2 and ps["launches_given_up_all_ranks"] == 0, ps
+    assert ps["rank0"]["persist_iters"] >= 256 and ps["value"] > 0 and ps["speedup_vs_one_gpu"] > 0, ps
 
 
 @pytest.mark.gpu

@@ -1,4 +1,6 @@
 mkdir -p gpurun_out
-python tools/time_big.py product ub4 > gpurun_out/r4_big2.txt 2>&1; cat gpurun_out/r4_big2.txt
-python tools/time_variants.py product ub4 > gpurun_out/r4_tv13.txt 2>&1; cat gpurun_out/r4_tv13.txt
-(timeout 600 python -m pytest tests/test_persist_sizes.py -m gpu -x -q -k "batch_size or config1") > gpurun_out/r4_t7.log 2>&1; tail -2 gpurun_out/r4_t7.log
+(timeout 900 python -m pytest tests/test_distributed.py -m gpu -x -q -k "two_ranks") > gpurun_out/r4_t8.log 2>&1; tail -15 gpurun_out/r4_t8.log
+HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 256 --warmup 32 --backend gloo --share-gpu > gpurun_out/r4_pair2.json 2> gpurun_out/r4_pair2.err; python -c "
+import json
+for l in open('gpurun_out/r4_pair2.json'):
+    if l.startswith('{'): print(json.loads(l)['pair_split'])"; tail -3 gpurun_out/r4_pair2.err

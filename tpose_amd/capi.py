@@ -24,7 +24,8 @@ SYMBOLS = [
     "tp_energy", "tp_shift", "tp_default_params", "tp_iterate", "tp_retrieve", "tp_retrieve_many", "tp_synchronize",
     "tp_get_stream", "tp_profile_iterate", "tp_profile_accumulate", "tp_get_info", "tp_selftest_walker", "tp_render",
     "tp_prepare", "tp_selftest_line", "tp_timer_start", "tp_timer_stop", "tp_iterate_until", "tp_band_mailbox_bytes",
-    "tp_band_attach", "tp_band_mailbox_alloc", "tp_band_mailbox_free",
+    "tp_band_attach", "tp_band_mailbox_alloc", "tp_band_mailbox_free", "tp_band_mailbox_export", "tp_band_mailbox_import",
+    "tp_band_mailbox_close",
 ]
 
 
@@ -168,6 +169,24 @@ class Context:
         self.lib.tp_band_mailbox_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         self._ck(self.lib.tp_band_mailbox_alloc(self.h, C.c_size_t(nbytes), C.byref(out)))
         return out.value
+
+    def band_mailbox_export(self, box):
+        """the 64-byte handle another process imports (tp_band_mailbox_export)"""
+        h = (C.c_ubyte * 64)()
+        self.lib.tp_band_mailbox_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self._ck(self.lib.tp_band_mailbox_export(self.h, C.c_void_p(box), h))
+        return bytes(h)
+
+    def band_mailbox_import(self, handle):
+        out = C.c_void_p()
+        buf = (C.c_ubyte * 64)(*handle)
+        self.lib.tp_band_mailbox_import.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        self._ck(self.lib.tp_band_mailbox_import(self.h, buf, C.byref(out)))
+        return out.value
+
+    def band_mailbox_close(self, box):
+        self.lib.tp_band_mailbox_close.argtypes = [C.c_void_p, C.c_void_p]
+        self._ck(self.lib.tp_band_mailbox_close(self.h, C.c_void_p(box)))
 
     def band_mailbox_free(self, box):
         self.lib.tp_band_mailbox_free.argtypes = [C.c_void_p, C.c_void_p]

@@ -88,6 +88,40 @@ int tp_band_mailbox_alloc(tp_context* c, size_t bytes, void** out) {
     return TP_OK;
 }
 
+int tp_band_mailbox_export(tp_context* c, void* box, void* handle) {
+    api_guard api_lock;
+    if (!c || !box || !handle) return TP_ERR_INVALID;
+    static_assert(sizeof(hipIpcMemHandle_t) <= TP_MAILBOX_HANDLE_BYTES, "the handle travels in 64 bytes");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipIpcMemHandle_t h;
+    memset(&h, 0, sizeof h);
+    HIP_TRY(c, hipIpcGetMemHandle(&h, box));
+    memset(handle, 0, TP_MAILBOX_HANDLE_BYTES);
+    memcpy(handle, &h, sizeof h);
+    return TP_OK;
+}
+
+int tp_band_mailbox_import(tp_context* c, const void* handle, void** box) {
+    api_guard api_lock;
+    if (!c || !handle || !box) return TP_ERR_INVALID;
+    *box = nullptr;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof h);
+    HIP_TRY(c, hipIpcOpenMemHandle(box, h, hipIpcMemLazyEnablePeerAccess));
+    return TP_OK;
+}
+
+int tp_band_mailbox_close(tp_context* c, void* box) {
+    api_guard api_lock;
+    if (!c) return TP_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = tp_synchronize(c)) return rc;
+    for (auto& b : c->band_box) if (b == (unsigned long long*)box) b = nullptr;
+    if (box) HIP_TRY(c, hipIpcCloseMemHandle(box));
+    return TP_OK;
+}
+
 int tp_band_mailbox_free(tp_context* c, void* box) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
