@@ -1,8 +1,8 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): everything profiles/r03_* is derived from, into gpurun_out/r03/.
+# Runs on the GPU box (gpurun): everything profiles/r04_* is derived from, into gpurun_out/r04/.
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=gpurun_out/r03
+O=gpurun_out/r04
 rm -rf $O; mkdir -p $O
 # 1. the bench line: the driver's flags, and the default flags (5 x 2048 steps)
 python bench.py --steps 20 --warmup 5 > $O/bench_20_5.json 2> $O/bench_20_5.err
@@ -13,9 +13,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt20 -o kt -- python 
 find $O -name "*kernel_trace.csv" -delete
 # 3. in-kernel timeline of the persistent kernel (debug flavour of the library): fresh mesh, and after 4000 grad-iters
 python tools/persist_timeline.py --rebuild > $O/persist_timeline.json 2> $O/persist_timeline.err
+python tools/wave_timeline.py > $O/wave_timeline.json 2>> $O/persist_timeline.err
 TPOSE_TIMELINE_AFTER=4000 python tools/persist_timeline.py > $O/persist_timeline_4000.json 2>> $O/persist_timeline.err
 # 4. persistent path against the two-kernel path and the oracle: parity and timing, other configurations
 python tools/persist_check.py > $O/persist_check.txt 2>&1
+python tools/time_big.py product > $O/time_4096.txt 2>&1
 python tools/long_parity.py > $O/long_parity.txt 2>&1
 python tools/time_variants.py product > $O/long_run_timing.txt 2>&1
 python tools/call_length.py > $O/call_length.txt 2>&1
@@ -24,9 +26,11 @@ TPOSE_PMC_TARGET=persist python tools/pmc_kernels.py $O/pmc_persist.json > /dev/
 bash tools/run_ipc_handover.sh > $O/ipc_handover.txt 2>&1
 python tools/band_timing.py > $O/band_timing_4096_12000.json 2> $O/band_timing.err
 python tools/band_timing.py 2048 3000 > $O/band_timing_2048_3000.json 2>> $O/band_timing.err
+# 5b. ONE pair on two ranks (both on this GPU: what the protocol costs between processes; the link is what a second GPU adds)
+HSA_ENABLE_IPC_MODE_LEGACY=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 2 --steps 256 --warmup 32 --backend gloo --share-gpu > $O/bench_two_ranks_one_gpu.json 2> $O/bench_two_ranks.err
 # 6. the schedules
 python tools/run_config2.py 600 > $O/config2.txt 2>&1
 python tools/run_config3.py > $O/config3.txt 2>&1
 python tools/run_batch.py --pairs 8 --iters 512 > $O/config4.json 2> $O/config4.err
 ls -la $O
-# then, in the development container: tools/copy_profiles.sh (gpurun_out/r03 -> profiles/r03_*)
+# then, in the development container: tools/copy_profiles.sh (gpurun_out/r04 -> profiles/r04_*)
