@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""The first grad-iters of a persistent launch, one by one (debug flavour): median period and phases of grad-iters 0..23 -- what a short
+call (the driver's --steps 20) pays before the launch reaches its steady state."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["TPOSE_HIP_LIB"] = os.path.join(ROOT, "tpose_amd", "variants", "libtpose_hip_debug.so")
+import numpy as np
+from tpose_amd import capi, synth
+img, pts, tris, he, ratio = synth.workload(2048, 2048, 3000, contrast=0.1)
+ctx = capi.Context(0, 2048, 2048); ctx.set_image(capi.IMAGE_A, img); ctx.upload(pts, tris, None)
+p = capi.default_params(0); ctx.iterate(p, 300); ctx.iterate(p, 40); ctx.synchronize()
+lib = ctx.lib; lib.tp_debug_dump_persist.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+buf = np.zeros(512 * 64 * 16, np.uint64); assert lib.tp_debug_dump_persist(ctx.h, buf.ctypes.data, buf.size) == 0
+st = buf.reshape(512, 64, 16)[:256, :40].astype(np.int64)
+t0 = st[:, 0, 0].min()
+print("workgroups enter grad-iter 0 within %.1f us of each other" % ((st[:, 0, 0].max() - t0) / 100.0))
+print("it  start(med, us after the first workgroup's first stamp)  period  P0  P1  P3  P6")
+for it in range(24):
+    s = np.median(st[:, it, 0] - t0) / 100.0
+    per = np.median(st[:, it + 1, 0] - st[:, it, 0]) / 100.0
+    ph = [np.median(st[:, it, k + 1] - st[:, it, k]) / 100.0 for k in range(4)]
+    print("%2d  %7.1f  %6.2f  %5.2f %5.2f %5.2f %5.2f" % (it, s, per, ph[0], ph[1], ph[2], ph[3]))
+print("grad-iters 0..19 end %.1f us after the first stamp (steady state would be %.1f)" % (np.median(st[:, 20, 0] - t0) / 100.0, 20 * np.median(st[:, 30:39, 0][:, 1:] - st[:, 30:39, 0][:, :-1]) / 100.0))

@@ -11,13 +11,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib_path = os.environ.get("TPOSE_TIMELINE_LIB") or os.path.join(ROOT, "tpose_amd", "variants", "libtpose_hip_debug.so")
+lib_path = os.environ.get("TPOSE_TIMELINE_LIB") or os.path.join(ROOT, "tpose_amd", "variants", "libtpose_hip_debugwaves.so")
 os.environ["TPOSE_HIP_LIB"] = lib_path
 from tpose_amd import build as tb  # noqa: E402
 
 if not os.path.exists(lib_path) or "--rebuild" in sys.argv:
     os.makedirs(os.path.dirname(lib_path), exist_ok=True)
-    tb.build(force=True, extra=["-DTPOSE_DEBUG"], out=lib_path)
+    tb.build(force=True, extra=["-DTPOSE_DEBUG", "-DPK_DBG_WAVES"], out=lib_path)
 import numpy as np  # noqa: E402
 
 from tpose_amd import capi, synth  # noqa: E402

@@ -104,7 +104,7 @@ struct pk_args {
     int dbg_first;
 #endif
 };
-#ifdef TPOSE_DEBUG
+#ifdef PK_DBG_BOUNDS
 int tp_persist_debug_faults(unsigned long long out[16]);   // debug flavour: table offsets beyond the table seen by k_persist
 #endif
 int tp_persist_set_lds(int bytes);  // hipFuncSetAttribute(max dynamic LDS); returns the hipError_t

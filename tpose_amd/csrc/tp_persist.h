@@ -176,12 +176,12 @@ struct pk_acc {
 
 struct pk_rec { uint64_t lo, hi; };   // one pixel record (tp_raster.h, "Pixel records")
 
-// a record of the table at byte offset `off`.  (Debug flavour of the library only: offsets beyond the table are counted, the
+// a record of the table at byte offset `off`.  (-DTPOSE_DEBUG -DPK_DBG_BOUNDS flavour of the library only -- tools/hostile_repro.py: offsets beyond the table are counted, the
 // first one is kept -- g_pk_fault = {table bytes, faults, offset, block | thread << 32} -- and the load is not made.)
-#if defined(TPOSE_DEBUG) && defined(__HIPCC__)
+#if defined(PK_DBG_BOUNDS) && defined(__HIPCC__)
 static __device__ unsigned long long g_pk_fault[16];   // (one per translation unit; the kernel's and its reader are both in tp_persist.hip)
 #endif
-#if defined(TPOSE_DEBUG) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(PK_DBG_BOUNDS) && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ pk_rec pk_load_rec(const char* table, uint32_t off) {
     if ((unsigned long long)off + 16ull > g_pk_fault[0]) {
         if (atomicAdd(&g_pk_fault[1], 1ull) == 0ull) { g_pk_fault[2] = off; g_pk_fault[3] = (unsigned long long)blockIdx.x | ((unsigned long long)threadIdx.x << 32); }
@@ -240,7 +240,7 @@ TP_HD void pk_walk_rows(pk_rows& r, const char* table, int W, pk_acc& a) {
             if (u < r.n) {
                 const uint32_t col = (uint32_t)pk_next_col(r, W);
                 sx += col;
-#if defined(TPOSE_DEBUG) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(PK_DBG_BOUNDS) && defined(__HIP_DEVICE_COMPILE__)
                 if ((unsigned long long)(r.row + (col << 4)) + 16ull > g_pk_fault[0] && atomicAdd(&g_pk_fault[14], 1ull) == 0ull)
                     g_pk_fault[15] = (unsigned long long)r.row | ((unsigned long long)(uint32_t)r.n << 32);
 #endif
@@ -343,7 +343,7 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int pitch, const c
         const int32_t col = pk_next_col(t, W) & (int32_t)on;
         if (col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
 #if !defined(PK_EXP_NOLOAD)   // timing experiments only (tools/build_variants.py); never defined in the product
-#if defined(TPOSE_DEBUG) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(PK_DBG_BOUNDS) && defined(__HIP_DEVICE_COMPILE__)
             if ((unsigned long long)(((t.row + (uint32_t)u * t.rs) & on) + ((uint32_t)col << 4)) + 16ull > g_pk_fault[0] && atomicAdd(&g_pk_fault[4], 1ull) == 0ull) {
                 g_pk_fault[5] = t.row; g_pk_fault[6] = (unsigned long long)u | ((unsigned long long)t.rs << 32); g_pk_fault[7] = (unsigned long long)(uint32_t)col | ((unsigned long long)(uint32_t)n << 32);
                 g_pk_fault[8] = (unsigned long long)(uint32_t)C.l | ((unsigned long long)(uint32_t)C.c << 32); g_pk_fault[9] = (unsigned long long)(uint32_t)C.TL | ((unsigned long long)C.magic << 32);

@@ -30,9 +30,14 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 
 #ifdef TPOSE_DEBUG
 #define PK_STAMP(k) do { if (threadIdx.x == 0 && A.dbg && it >= A.dbg_first && it < A.dbg_first + PK_DBG_ITERS) A.dbg[((size_t)blockIdx.x * PK_DBG_ITERS + (it - A.dbg_first)) * 16 + (k)] = wall_clock64(); } while (0)
-// the same per WAVE (its first lane; 16 stamps x 8 waves x PK_DBG_WITERS grad-iters per workgroup, behind the per-workgroup stamps)
+// the same per WAVE (its first lane; 16 stamps x 8 waves x PK_DBG_WITERS grad-iters per workgroup, behind the per-workgroup stamps) -- a
+// flavour of its own (-DTPOSE_DEBUG -DPK_DBG_WAVES, tools/wave_timeline.py): eleven more stamps per wave and grad-iter cost microseconds
+#ifdef PK_DBG_WAVES
 #define PK_WSTAMP(k) do { if ((threadIdx.x & 63) == 0 && A.dbg && it >= A.dbg_first && it < A.dbg_first + PK_DBG_WITERS) \
     A.dbg[PK_DBG_WBASE + (((size_t)blockIdx.x * PK_DBG_WITERS + (it - A.dbg_first)) * (PK_THREADS / 64) + (threadIdx.x >> 6)) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define PK_WSTAMP(k) do { } while (0)
+#endif
 #else
 #define PK_STAMP(k) do { } while (0)
 #define PK_WSTAMP(k) do { } while (0)
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         return;
     }
 
-#ifdef TPOSE_DEBUG
+#ifdef PK_DBG_BOUNDS
     if (tid == 0) g_pk_fault[0] = (unsigned long long)A.vw.H * (unsigned long long)A.px_pitch * 16ull;
 #endif
     // a launch behind one that gave up does nothing (tp_context.hip: the grad-iters are run again on the two-kernel path)
@@ -393,7 +398,7 @@ void launch_rr(const pk_args& A, dim3 g, dim3 b, size_t lds, hipStream_t s) {
 }
 }  // namespace
 
-#ifdef TPOSE_DEBUG
+#ifdef PK_DBG_BOUNDS
 int tp_persist_debug_faults(unsigned long long out[16]) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_fault), 16 * sizeof(unsigned long long)); }
 #endif
 int tp_persist_set_lds(int bytes) {

@@ -382,7 +382,7 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
     return TP_OK;
 }
 
-#ifdef TPOSE_DEBUG
+#ifdef PK_DBG_BOUNDS
 int tp_debug_persist_faults(tp_context* c, unsigned long long* out) {
     api_guard api_lock;
     hipStreamSynchronize(c->stream);
