@@ -1,7 +1,4 @@
-python tools/launch_profile.py 2>&1 | tail -30
-python tools/persist_timeline.py 2>/dev/null | python -c "
-import json,sys
-d=json.load(sys.stdin)
-for k,v in d.items():
-    if isinstance(v,dict): print(k, {a:b for a,b in v.items() if a in ('1','50','100','mean','P0','P1','P3','P6','P7')})
-    else: print(k, v)"
+mkdir -p gpurun_out
+(timeout 1500 python -m pytest tests -m gpu -x -q) > gpurun_out/r4_gputest4.log 2>&1; tail -3 gpurun_out/r4_gputest4.log
+for i in 1 2; do timeout 300 python bench.py --steps 20 --warmup 5 --no-cold --no-pmc --no-cpu-baseline --no-extra > gpurun_out/r4_b20.json 2>gpurun_out/r4_b20.err; python -c "
+import json; d=json.load(open('gpurun_out/r4_b20.json')); print('bench20 ms_per_step', d['ms_per_step'], 'device', d['ms_per_step_device'], 'kern/iter', d['roofline']['us_per_grad_iter'], d['timing'])"; done

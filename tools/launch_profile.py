@@ -15,6 +15,10 @@ buf = np.zeros(512 * 64 * 16, np.uint64); assert lib.tp_debug_dump_persist(ctx.h
 st = buf.reshape(512, 64, 16)[:256, :40].astype(np.int64)
 t0 = st[:, 0, 0].min()
 print("workgroups enter grad-iter 0 within %.1f us of each other" % ((st[:, 0, 0].max() - t0) / 100.0))
+e = st[:, 0, 12]
+if (e > 0).all():
+    print("kernel entry: workgroups within %.1f us of each other; tables in LDS %.2f us after entry (median), prologue over %.2f, first grad-iter begins %.2f; last workgroup's first grad-iter begins %.1f us after the first workgroup's entry"
+          % ((e.max() - e.min()) / 100.0, np.median(st[:, 0, 13] - e) / 100.0, np.median(st[:, 0, 14] - e) / 100.0, np.median(st[:, 0, 0] - e) / 100.0, (st[:, 0, 0].max() - e.min()) / 100.0))
 print("it  start(med, us after the first workgroup's first stamp)  period  P0  P1  P3  P6")
 for it in range(24):
     s = np.median(st[:, it, 0] - t0) / 100.0

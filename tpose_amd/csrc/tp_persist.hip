@@ -30,6 +30,8 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 
 #ifdef TPOSE_DEBUG
 #define PK_STAMP(k) do { if (threadIdx.x == 0 && A.dbg && it >= A.dbg_first && it < A.dbg_first + PK_DBG_ITERS) A.dbg[((size_t)blockIdx.x * PK_DBG_ITERS + (it - A.dbg_first)) * 16 + (k)] = wall_clock64(); } while (0)
+// (before the first grad-iter: into the stamps of grad-iter 0)
+#define PK_STAMP0(k) do { if (threadIdx.x == 0 && A.dbg && A.dbg_first == 0) A.dbg[(size_t)blockIdx.x * PK_DBG_ITERS * 16 + (k)] = wall_clock64(); } while (0)
 // the same per WAVE (its first lane; 16 stamps x 8 waves x PK_DBG_WITERS grad-iters per workgroup, behind the per-workgroup stamps) -- a
 // flavour of its own (-DTPOSE_DEBUG -DPK_DBG_WAVES, tools/wave_timeline.py): eleven more stamps per wave and grad-iter cost microseconds
 #ifdef PK_DBG_WAVES
@@ -40,6 +42,7 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 #endif
 #else
 #define PK_STAMP(k) do { } while (0)
+#define PK_STAMP0(k) do { } while (0)
 #define PK_WSTAMP(k) do { } while (0)
 #endif
 
@@ -100,15 +103,22 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
     // a launch behind one that gave up does nothing (tp_context.hip: the grad-iters are run again on the two-kernel path)
     // (one answer for the whole workgroup: the word may be raised while its threads look)
     if (__syncthreads_or(__hip_atomic_load(status, PK_RLX_AGENT) != 0u)) return;
+    PK_STAMP0(12);
 
-    // ---- prologue: the patch's tables and positions into LDS
+    // ---- prologue: the patch's tables and positions into LDS.  The plan lays a patch's tables out in its pool the way pk_carve lays them
+    // out in LDS -- {vid, edges, lines} and {corners, base}, every table padded to 16 bytes (tp_plan.h: put) -- so they come over as two runs
+    // of 16-byte words, normally one load per thread and all of them in flight together (six loops of dependent 4-byte loads, and the
+    // per-thread constants below read from the pool again, cost a short call 10 us before its first grad-iter; this way it is 2).
     {
         const int32_t* pool = A.pool;
-        for (int i = tid; i < w.n_slots; i += PK_THREADS) V.vid[i] = pool[w.off_vid + i];
-        for (int i = tid; i < w.n_edges; i += PK_THREADS) V.edges[i] = pool[w.off_edges + i];
-        for (int i = tid; i < w.n_lines_all; i += PK_THREADS) V.lines[i] = pool[w.off_lines + i];
-        for (int i = tid; i < 4 * w.n_corners; i += PK_THREADS) ((int32_t*)V.corners)[i] = pool[w.off_corners + i];
-        for (int i = tid; i < 4 * w.n_base; i += PK_THREADS) ((int32_t*)V.base)[i] = pool[w.off_base + i];
+        const int n_a = (pk_align16(w.n_slots * 4) + pk_align16(w.n_edges * 4) + pk_align16(w.n_lines_all * 4)) >> 4, n_b = w.n_corners + w.n_base;
+        const pk_i4* src_a = reinterpret_cast<const pk_i4*>(pool + w.off_vid);
+        const pk_i4* src_b = reinterpret_cast<const pk_i4*>(pool + w.off_corners);
+        pk_i4* dst_a = reinterpret_cast<pk_i4*>(V.vid);
+        pk_i4* dst_b = V.corners;
+        for (int i = tid; i < n_a + n_b; i += PK_THREADS) {
+            if (i < n_a) dst_a[i] = src_a[i]; else dst_b[i - n_a] = src_b[i - n_a];
+        }
         for (int i = tid; i < w.n_slots; i += PK_THREADS) {
             const float2 p = A.points[pool[w.off_vid + i]];
             V.pos[i].x = p.x; V.pos[i].y = p.y;
@@ -118,14 +128,15 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         if (tid == 0) { V.flags[0] = 0; V.flags[3] = 0; }
     }
     __syncthreads();
+    PK_STAMP0(13);
     // corners of every own vertex: the lane that brings a vertex's count to this number has seen all its central differences
-    for (int k = tid; k < w.n_corners; k += PK_THREADS) atomicAdd(&V.vdeg[(A.pool[w.off_corners + 4 * k + 1] >> 2) & 0x3ff], 1);
+    for (int k = tid; k < w.n_corners; k += PK_THREADS) atomicAdd(&V.vdeg[(V.corners[k].y >> 2) & 0x3ff], 1);
     // the stored colour of this lane's variant (warp flavour: `colacc` as uploaded, triangle.fs:49-50) never changes
     // during a launch; the first pass of the corner lanes keeps it in registers
     pk_i4 col0 = {0, 0, 0, 0};
     if (A.flavour == 1 && tid < 4 * w.n_corners) {
         const int k = tid >> 2, m = (tid & 3) + 1;
-        const int t = A.pool[w.off_corners + 4 * k], s = A.pool[w.off_corners + 4 * k + 1] & 3;
+        const int t = V.corners[k].x, s = V.corners[k].y & 3;
         const int4 c = A.ca[(size_t)(4 * s + m) * A.NT + t];
         col0.x = c.x; col0.y = c.y; col0.z = c.z; col0.w = c.w;
     }
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
     int my_ends = 0;
     float my_dxu = 0.0f, my_dyu = 0.0f, my_dxv = 0.0f, my_dyv = 0.0f;   // (... and how its endpoints are displaced)
     if (tid < w.n_lines_all) {
-        const int ln_ = A.pool[w.off_lines + tid], ed_ = A.pool[w.off_edges + (ln_ & 0xffff)];
+        const int ln_ = V.lines[tid], ed_ = V.edges[ln_ & 0xffff];
         my_ends = (ed_ & 0x3ff) | (((ed_ >> 16) & 0x3ff) << 10) | ((ln_ >> 16) << 20);
         const int q_ = ln_ >> 16, mu_ = (q_ >= 1 && q_ <= 4) ? q_ : 0, mv_ = q_ >= 5 ? q_ - 4 : 0;
         my_dxu = tp_move_dx(mu_, A.vw.dp); my_dyu = tp_move_dy(mu_, A.vw.dp); my_dxv = tp_move_dx(mv_, A.vw.dp); my_dyv = tp_move_dy(mv_, A.vw.dp);
@@ -141,10 +152,10 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
     // ... and neither do the line-sum slots of its first corner variant: edge leaving the vertex | arriving << 16; opposite | own slot << 16
     int my_c0 = 0, my_c1 = 0;
     if (tid < 4 * w.n_corners) {
-        const int32_t* cr_ = A.pool + w.off_corners + 4 * (tid >> 2);
+        const pk_i4 cr_ = V.corners[tid >> 2];
         const int m_ = tid & 3;
-        my_c0 = ((cr_[2] & 0xffff) + m_) | ((((cr_[2] >> 16) & 0xffff) + m_) << 16);
-        my_c1 = (cr_[3] & 0xffff) | (((cr_[1] >> 2) & 0x3ff) << 16) | (((cr_[3] >> 16) & 7) << 26);   // (... | flips << 26)
+        my_c0 = ((cr_.z & 0xffff) + m_) | ((((cr_.z >> 16) & 0xffff) + m_) << 16);
+        my_c1 = (cr_.w & 0xffff) | (((cr_.y >> 2) & 0x3ff) << 16) | (((cr_.w >> 16) & 7) << 26);   // (... | flips << 26)
     }
     const char* table = reinterpret_cast<const char*>(A.px);
     // this thread's lane-item of the walk and the table records of its rows: in registers for the whole launch
@@ -156,6 +167,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
     int failed = 0;
     int n_li_now = 0, n_li_all_now = 0;   // lane-items of the lines walked every grad-iter / with the last one's base lines
     __syncthreads();
+    PK_STAMP0(14);
 
     for (int it = 0; it < A.n_iters; it++) {
         const uint32_t epoch = A.epoch + (uint32_t)it, tag = pk_tag(epoch), par = epoch & 1u;
