@@ -92,8 +92,11 @@ int tp_set_dp(tp_context* ctx, float dp);
 /* Execution options (no counterpart in the reference, whose frame loop is fixed).  Results never depend on them.
  * TP_OPT_PERSISTENT: TP_PERSIST_AUTO (default) lets tp_iterate run calls of >= 4 grad-iters inside
  * persistent launches (one workgroup per patch of the mesh, K grad-iters per launch) when the device keeps a full grid
- * resident; TP_PERSIST_OFF keeps every grad-iter on the two-kernel path (k_lines + k_update). */
-enum tp_option { TP_OPT_PERSISTENT = 1 };
+ * resident; TP_PERSIST_OFF keeps every grad-iter on the two-kernel path (k_lines + k_update).
+ * TP_OPT_INJECT_GIVE_UP (tests): n > 0 makes one workgroup of the n-th persistent launch from now give up before its last grad-iter,
+ * as if the launch's workgroups had not all been resident: the launch and those behind it are run again on the two-kernel path
+ * (tp_get_info 9 counts it) and the context stops using persistent launches. */
+enum tp_option { TP_OPT_PERSISTENT = 1, TP_OPT_INJECT_GIVE_UP = 3 };
 enum { TP_PERSIST_OFF = 0, TP_PERSIST_AUTO = 1 };
 int tp_set_option(tp_context* ctx, int option, int64_t value);
 

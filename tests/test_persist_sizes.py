@@ -155,3 +155,49 @@ def test_hostile_vertex_sets_on_the_persistent_path(kind):
     else:
         assert ctx.retrieve(capi.BUF_POINTS).shape == bad.shape
     ctx.close()
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_a_launch_that_gives_up_is_run_again(flavour):
+    """A plain persistent launch finishes itself: it writes the positions it ends with into the context's second position buffer and the
+    host swaps the two.  TP_OPT_INJECT_GIVE_UP makes one workgroup of a launch give up before its LAST grad-iter -- every other workgroup
+    has written its vertices by then -- with another call already enqueued behind it: both are run again on the two-kernel path from the
+    positions the launch started with, the oracle's bits."""
+    ctx, sweep, pts, tris, ratio, colors = _setup(2048, 2048, 3000, flavour, 0.1)
+    p = capi.default_params(flavour)
+    ctx.iterate(p, 8)
+    ctx.iterate(p, 6)
+    ctx.set_option(capi.OPT_INJECT_GIVE_UP, 1)
+    ctx.iterate(p, 7)    # gives up
+    ctx.iterate(p, 5)    # behind it: does nothing
+    ctx.synchronize()
+    ref = O.iterate(sweep, pts, tris, flavour, ratio, RATE[flavour], 26, colors=colors, literal=False)
+    _compare(ctx, ref, flavour)
+    assert ctx.info(capi.INFO_PERSIST_FAILURES) == 1 and ctx.info(capi.INFO_PERSIST_LAUNCHES) == 4
+    # ... and the context carries on (two kernels per grad-iter from now on)
+    ctx.iterate(p, 9)
+    ref2 = O.iterate(sweep, ref["points"], tris, flavour, ratio, RATE[flavour], 9, colors=colors, literal=False)
+    _compare(ctx, ref2, flavour, "after the replay")
+    assert ctx.info(capi.INFO_PERSIST_LAUNCHES) == 4
+    ctx.close()
+
+
+def test_vertices_no_triangle_uses_keep_the_finishing_kernel():
+    """shift.cs clamps every vertex i >= 4, used or not: with such vertices in the upload the persistent launches keep their small
+    finishing kernel (which clamps them) instead of finishing themselves"""
+    W, H, NT, iters = 674, 449, 150, 40
+    img, pts, tris, he, ratio = synth.workload(W, H, NT, contrast=0.1)
+    pts2 = np.concatenate([pts, np.array([[3.0, 0.5], [-0.2, -7.0], [0.3, 0.3]], np.float32)])
+    n = pts.shape[0]
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts2, tris, None)
+    p = capi.default_params(0)
+    ctx.iterate(p, iters)
+    ctx.iterate(p, 7)
+    assert ctx.info(capi.INFO_PERSIST_ITERS) == iters + 7
+    ref = O.iterate(img, pts2, tris, 0, ratio, RATE[0], iters + 7, literal=False)
+    _compare(ctx, ref, 0)
+    got = ctx.retrieve(capi.BUF_POINTS)
+    assert got[n, 0] == np.float32(ratio) and got[n + 1, 1] == np.float32(-1.0) and np.array_equal(got[n + 2], pts2[n + 2])
+    ctx.close()

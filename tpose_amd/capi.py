@@ -37,7 +37,7 @@ def band_mailbox_bytes(points, triangles):
 
 
 RENDER_AVERAGE, RENDER_STORED = 0, 1
-OPT_PERSISTENT = 1
+OPT_PERSISTENT, OPT_INJECT_GIVE_UP = 1, 3
 PERSIST_OFF, PERSIST_AUTO = 0, 1
 INFO_PATCHES, INFO_PATCH_LDS, INFO_PATCH_LINES, INFO_PERSIST_LAUNCHES, INFO_PERSIST_ITERS, INFO_CENSUS, INFO_REPLANS = 2, 3, 4, 5, 6, 7, 8
 INFO_PERSIST_FAILURES, INFO_BOX_FINEGRAINED = 9, 10

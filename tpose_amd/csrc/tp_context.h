@@ -46,6 +46,7 @@ struct capture_guard {  // inside an entry point: trade the shared lock for the 
 
 struct graph_entry {
     hipGraphExec_t exec = nullptr;
+    const void* points = nullptr;   // (the position buffer the captured kernels address: the context has two, swapped by launches that finish themselves)
     tp_params params{};
     int iters = 0;
     uint64_t generation = 0;
@@ -105,6 +106,8 @@ struct tp_context {
     // persistent grad-iter kernel (tp_persist.hip): the plan of the current triangulation is built by the first
     // tp_iterate long enough to use it (not by tp_upload: schedules upload after every topology change)
     int persist_mode = TP_PERSIST_AUTO;
+    int inject_give_up = 0;         // TP_OPT_INJECT_GIVE_UP: the n-th persistent launch from now gives up (tests of the replay)
+    bool has_loose = false;         // a vertex no triangle uses (k_persist_finish clamps it; launches do not finish themselves then)
     int num_cus = 0;
     int census = 0;                 // 0 not taken, 1 every workgroup of a full grid is resident, -1 not: two-kernel path only
     int lds_attr = 0;               // dynamic LDS the kernel is currently allowed
@@ -176,7 +179,7 @@ struct tp_context {
     bool tail_is_finish = false;    // the last thing enqueued on the stream is the small kernel behind a persistent launch: its pinned words say when the stream is done
     uint32_t epoch = 1;             // number of the next grad-iter of a persistent launch (mailbox tags)
     bool persist_unchecked = false; // persistent launches were enqueued since the status word was last read
-    struct journal_entry { tp_params p; int iters; };
+    struct journal_entry { tp_params p; int iters; float2* before; };   // before: `points` when a launch that finishes itself was enqueued (else null)
     std::vector<journal_entry> journal;   // ... which ones (tp_iterate): replayed on the two-kernel path if a launch gave up
     unsigned done_base = 0;               // the device's count of completed persistent launches when the journal was last empty
     int64_t persist_failures = 0;

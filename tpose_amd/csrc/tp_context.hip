@@ -30,7 +30,7 @@ void drop_graphs(tp_context* c) {
 
 void free_triangulation(tp_context* c) {
     hipFree(c->vref); hipFree(c->vvar); c->vref = nullptr; c->vvar = nullptr;
-    hipFree(c->points); hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
+    hipFree(c->points); hipFree(c->points_out); c->points_out = nullptr; c->cap_points_out = 0; hipFree(c->tris); hipFree(c->colors); hipFree(c->vtx_off); hipFree(c->vtx_adj);
     hipFree(c->edge_uv); hipFree(c->he_edge); hipFree(c->vpos); hipFree(c->epos); hipFree(c->wline);
     hipFree(c->ten); hipFree(c->cn); hipFree(c->ca); hipFree(c->gr); hipFree(c->moments);
     c->points = nullptr; c->tris = nullptr; c->colors = nullptr; c->vtx_off = nullptr; c->vtx_adj = nullptr;
@@ -216,6 +216,10 @@ int tp_set_option(tp_context* c, int option, int64_t value) {
             if (value != TP_PERSIST_OFF && value != TP_PERSIST_AUTO) return fail(c, TP_ERR_INVALID, "TP_OPT_PERSISTENT: bad value %lld", (long long)value);
             c->persist_mode = (int)value;
             return TP_OK;
+        case TP_OPT_INJECT_GIVE_UP:
+            if (value < 0 || value > 1000000) return fail(c, TP_ERR_INVALID, "TP_OPT_INJECT_GIVE_UP: bad value %lld", (long long)value);
+            c->inject_give_up = (int)value;
+            return TP_OK;
         default: return fail(c, TP_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -280,6 +284,7 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
         free_triangulation(c);
         const int capT = NT + NT / 2 + 64, capP = NP + NP / 2 + 64;
         HIP_TRY(c, dev_alloc(&c->points, capP));
+        HIP_TRY(c, dev_alloc(&c->points_out, capP)); c->cap_points_out = (size_t)capP;   // (the two are swapped: the same size)
         HIP_TRY(c, dev_alloc(&c->gr, capP));
         HIP_TRY(c, dev_alloc(&c->vtx_off, capP + 1));
         HIP_TRY(c, dev_alloc(&c->vref, (size_t)capP * 64));
@@ -362,7 +367,8 @@ int tp_upload(tp_context* c, const float* points, int NP, const int32_t* tris, i
     // vertex -> outgoing half-edge ids (3t+s), the gather form of gradient.cs' scatter
     std::vector<int> off(NP + 1, 0), adj((size_t)3 * NT);
     for (int t = 0; t < NT; t++) for (int s = 0; s < 3; s++) off[tris[4 * t + s] + 1]++;
-    for (int v = 0; v < NP; v++) off[v + 1] += off[v];
+    c->has_loose = false;
+    for (int v = 0; v < NP; v++) { if (off[v + 1] == 0) c->has_loose = true; off[v + 1] += off[v]; }
     {
         std::vector<int> cur(off.begin(), off.end() - 1);
         for (int t = 0; t < NT; t++) for (int s = 0; s < 3; s++) adj[cur[tris[4 * t + s]]++] = 3 * t + s;
@@ -525,10 +531,10 @@ int capture_graph(tp_context* c, F&& body, hipGraphExec_t* exec) {
 // the graph of CHUNK fused grad-iters for these parameters (captured once per upload / parameter set)
 int chunk_graph(tp_context* c, const tp_params* p, float dp, graph_entry** out) {
     for (auto& e : c->graphs)
-        if (e.generation == c->generation && e.iters == CHUNK && memcmp(&e.params, p, sizeof *p) == 0) { *out = &e; return TP_OK; }
+        if (e.generation == c->generation && e.points == c->points && e.iters == CHUNK && memcmp(&e.params, p, sizeof *p) == 0) { *out = &e; return TP_OK; }
     graph_entry e;
     if (int rc = capture_graph(c, [&] { for (int k = 0; k < CHUNK; k++) enqueue_iter(c, *p, dp); }, &e.exec)) return rc;
-    e.params = *p; e.iters = CHUNK; e.generation = c->generation;
+    e.params = *p; e.iters = CHUNK; e.generation = c->generation; e.points = c->points;
     if (c->graphs.size() > 8) drop_graphs(c);
     c->graphs.push_back(e);
     *out = &c->graphs.back();

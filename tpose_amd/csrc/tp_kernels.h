@@ -98,7 +98,12 @@ struct pk_args {
     float2* peer_pring[PK_MAX_PEERS];    // ALL triangles' energies, so what a band writes into its own rings it writes into theirs
     unsigned epoch;               // number of the launch's first grad-iter (tags carry 31 bits of it)
     int n_iters;                  // < 0: census of resident workgroups instead
-    unsigned* status;             // [0] raised by a lane that gave up waiting, [1] census counter, [2] completed launches (k_persist_finish)
+    unsigned* status;             // [0] raised by a lane that gave up waiting, [1] census counter, [2] completed launches, [3] ticket counter
+    // A launch that FINISHES ITSELF (plain tp_iterate, every vertex used by a triangle): `points_out` is the context's OTHER position buffer
+    // -- the host swaps the two behind every launch -- and the last workgroup to finish counts the launch as completed and mirrors the
+    // words into pinned memory; no k_persist_finish behind it (a launch + 5 us less per call).  A launch that gives up leaves `points` whole.
+    unsigned* host_status;        // pinned mirror {gave up, -, launches completed}; null: k_persist_finish follows
+    int inject_give_up;           // tests (TP_OPT_INJECT_GIVE_UP): one workgroup gives up before the last grad-iter
 #ifdef TPOSE_DEBUG
     unsigned long long* dbg;      // [parts][PK_DBG_ITERS][16] phase timestamps of the grad-iters dbg_first ...
     int dbg_first;

@@ -708,7 +708,8 @@ __global__ void k_persist_finish(tp_launch L, const float2* points_out, unsigned
         if (file_edges) publish_position(L, v, p, lane, 8);
     }
     if (status) {
-        __threadfence();
+        // (no release here: whatever reads the positions is work on this stream, ordered behind the end of the kernel; the pinned word only
+        // spares the host a question to the runtime -- and a fence in every lane is a cache write-back per lane)
         __syncthreads();
         if (threadIdx.x == 0 && atomicAdd(&status[3], 1u) == gridDim.x - 1u) {
             status[3] = 0u;

@@ -102,7 +102,10 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
 #endif
     // a launch behind one that gave up does nothing (tp_context.hip: the grad-iters are run again on the two-kernel path)
     // (one answer for the whole workgroup: the word may be raised while its threads look)
-    if (__syncthreads_or(__hip_atomic_load(status, PK_RLX_AGENT) != 0u)) return;
+    if (__syncthreads_or(__hip_atomic_load(status, PK_RLX_AGENT) != 0u)) {
+        if (A.host_status && tid == 0 && blockIdx.x == 0) __hip_atomic_store((gu32*)A.host_status, 1u, PK_RLX_SYSTEM);
+        return;
+    }
     PK_STAMP0(12);
 
     // ---- prologue: the patch's tables and positions into LDS.  The plan lays a patch's tables out in its pool the way pk_carve lays them
@@ -194,11 +197,15 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         }
         // (a lane that gave up says so in LDS; ONE barrier, then everybody reads the word -- __syncthreads_or is a wave
         // reduction, three barriers and three dependent LDS operations: 0.2 us of every grad-iter)
+        if (A.inject_give_up && last && tid == 0 && blockIdx.x == gridDim.x / 2u) { __hip_atomic_store(status, 1u, PK_RLX_AGENT); failed = 1; }
         if (failed) V.flags[3] = 1;
         PK_WSTAMP(1);
         __syncthreads();
         PK_WSTAMP(2);
-        if (V.flags[3]) return;
+        if (V.flags[3]) {
+            if (A.host_status && tid == 0) __hip_atomic_store((gu32*)A.host_status, 1u, PK_RLX_SYSTEM);   // (nobody else will tell the host)
+            return;
+        }
         PK_STAMP(1);
         // ---- P1: line set-up (low threads), snapped positions (high threads), gradient reset
         for (int l = tid; l < n_setup; l += PK_THREADS) {
@@ -391,6 +398,20 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         PK_STAMP(4); PK_WSTAMP(8);
         PK_STAMP(5); PK_WSTAMP(10);
         // (no barrier here: P0 of the next grad-iter touches foreign position slots only, and its barrier orders the rest)
+    }
+    // ---- a launch that finishes itself: the last workgroup through here counts the launch as completed and tells the host (a pinned word it
+    // spins on).  A workgroup that gave up never takes a ticket, so a launch that reaches the full count has completed everywhere.
+    // No fences: whatever reads this launch's results is work on the same stream, ordered behind the END of the kernel (the ABI hands out no
+    // device pointers to them); the word only spares the host a question to the runtime.  (A release per workgroup is a cache write-back
+    // per workgroup: 8 us at the end of every launch -- more than the small kernel this replaces; one per lane: 47 us.)
+    if (MODE == 0 && A.host_status) {
+        __syncthreads();
+        if (tid == 0 && __hip_atomic_fetch_add(status + 3, 1u, PK_RLX_AGENT) == gridDim.x - 1u) {
+            __hip_atomic_store(status + 3, 0u, PK_RLX_AGENT);
+            const unsigned done = __hip_atomic_load(status + 2, PK_RLX_AGENT) + 1u;   // (launches complete one after the other)
+            __hip_atomic_store(status + 2, done, PK_RLX_AGENT);
+            __hip_atomic_store((gu32*)A.host_status + 2, done, PK_RLX_SYSTEM);
+        }
     }
 }
 

@@ -32,13 +32,20 @@ int check_persist_status(tp_context* c) {
     const size_t completed = (size_t)(st[2] - c->done_base);
     c->done_base = st[2];
     if (st[0] == 0u) { c->journal.clear(); return TP_OK; }
+    // (a workgroup that gives up tells the host at once; the others of its launch, and the launches behind it, are still on their way out)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemset(c->d_status, 0, sizeof(unsigned)));
+    HIP_TRY(c, hipMemset(c->d_status + 3, 0, sizeof(unsigned)));   // (the tickets of a launch that finishes itself and gave up on the way)
     c->h_status[0] = 0u;
     c->census = -6;  // two kernels per grad-iter from now on in this context
     c->persist_failures++;
     c->mutations++; c->tail_is_finish = false;  // (what a retrieve returns is about to change)
     std::vector<tp_context::journal_entry> todo(c->journal.begin() + (completed < c->journal.size() ? completed : c->journal.size()), c->journal.end());
     c->journal.clear();
+    // launches that finish themselves write the OTHER position buffer, and the host swaps the two behind each: the positions the first
+    // launch that did not complete started from are whole in the buffer it read (later launches did nothing)
+    for (auto& e : todo)
+        if (e.before) { if (c->points != e.before) std::swap(c->points, c->points_out); break; }
     for (auto& e : todo) {
         if (e.iters <= 0) continue;
         if (int rc = enqueue_two_kernel(c, &e.p, resolve_dp(c, e.p.flavour, e.p.dp), e.iters)) return rc;
@@ -253,11 +260,17 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         A.dbg = persist_dbg_buffer(c->plan.parts, c->stream);
         { const char* f = getenv("TPOSE_DBG_FIRST"); A.dbg_first = f ? atoi(f) : 0; }
 #endif
+        // a plain launch over a mesh without unused vertices finishes itself: it writes the positions it ends with into the other position
+        // buffer, its last workgroup counts it as completed, and the host swaps the buffers -- no small kernel behind it
+        const bool self = !banded && !rings && !c->has_loose && c->points_out && c->cap_points_out >= (size_t)c->NP;
+        if (self) A.host_status = c->h_status;
+        if (c->inject_give_up > 0 && --c->inject_give_up == 0) A.inject_give_up = 1;
         tp_launch_persist(A, grid, c->plan.rows_max, c->plan.lds_bytes, c->stream);
         if (banded) tp_launch_band_collect(make_launch(c, p.image_slot, dp), A, c->points_out, c->stream);
-        tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->h_status, 0, c->stream);
+        if (!self) tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->h_status, 0, c->stream);
         c->epos_stale = true; c->tail_is_finish = true;
-        c->journal.push_back({p, rings ? 0 : k});   // (a chunk of tp_iterate_until is checked by its caller: nothing to replay)
+        c->journal.push_back({p, rings ? 0 : k, self ? c->points : nullptr});   // (a chunk of tp_iterate_until is checked by its caller: nothing to replay)
+        if (self) std::swap(c->points, c->points_out);
         HIP_TRY(c, hipGetLastError());
         c->epoch += (uint32_t)k;
         c->persist_unchecked = true;
