@@ -69,10 +69,13 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
     if (W > TP_PX_MAXW) return -1;
     const int pitch = tp_px_pitch(W);
     std::vector<uint64_t> T((size_t)H * pitch * 2, 0);
+    // (... and its tiled copy; 0xCD where k_prefix_px writes nothing, so that a look-up outside the columns 0..W shows)
+    std::vector<uint64_t> TT((size_t)tp_px_tiled_rows((uint32_t)H) * pitch * 2, 0xCDCDCDCDCDCDCDCDull);
     for (int r = 0; r < H; r++) {
         uint32_t run[5] = {0, 0, 0, 0, 0};
         for (int c = 0; c <= W; c++) {
             tp_px_pack(run, &T[((size_t)r * pitch + c) * 2]);
+            tp_px_pack(run, &TT[(size_t)((tp_px_tiled_row_part((uint32_t)r, (uint32_t)pitch) + tp_px_tiled_col_part((uint32_t)c)) >> 3)]);
             if (c < W) {
                 uint32_t px;
                 memcpy(&px, img + (size_t)r * stride + 4 * (size_t)c, 4);
@@ -198,7 +201,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             }
             for (int j = S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED; j < n_li; j++) {
                 pk_acc a;
-                const int l = pk_walk_lane(V, table, pitch, W, w.n_lines_all, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.li_cap, j, a);
+                const int l = pk_walk_lane(V, table, reinterpret_cast<const char*>(TT.data()), pitch, W, w.n_lines_all, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.li_cap, j, a);
                 unsigned long long* s = V.sums + (size_t)l * PK_SUM_STRIDE;
                 unsigned long long wd[PK_SUM_WORDS];
                 pk_fold_words(a, wd);

@@ -1,5 +1,4 @@
 mkdir -p gpurun_out
-(timeout 1500 python -m pytest tests -m gpu -x -q) > gpurun_out/r4_gputest5.log 2>&1; tail -3 gpurun_out/r4_gputest5.log
-for i in 1 2; do timeout 300 python bench.py --steps 20 --warmup 5 --no-cold --no-pmc --no-cpu-baseline > gpurun_out/r4_b20.json 2>gpurun_out/r4_b20.err; python -c "
-import json; d=json.load(open('gpurun_out/r4_b20.json')); print('bench20 ms_per_step', d['ms_per_step'], 'device', d['ms_per_step_device'], 'kern/iter', d['roofline']['us_per_grad_iter'], d['timing'], d.get('ms_per_step_full_contrast'), d.get('ms_per_step_all_13_variants'))"; done
-timeout 300 python tools/call_length.py 2>&1 | head -3
+cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+timeout 900 python tools/pmc_size.py 4096 12000 > gpurun_out/r4_pmc_4096.json 2>gpurun_out/r4_pmc_4096.err; cat gpurun_out/r4_pmc_4096.json; tail -3 gpurun_out/r4_pmc_4096.err
+timeout 600 python tools/pmc_size.py 2048 3000 > gpurun_out/r4_pmc_2048.json 2>gpurun_out/r4_pmc_2048.err; cat gpurun_out/r4_pmc_2048.json

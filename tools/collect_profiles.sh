@@ -15,12 +15,15 @@ find $O -name "*kernel_trace.csv" -delete
 python tools/persist_timeline.py --rebuild > $O/persist_timeline.json 2> $O/persist_timeline.err
 python tools/wave_timeline.py > $O/wave_timeline.json 2>> $O/persist_timeline.err
 TPOSE_TIMELINE_AFTER=4000 python tools/persist_timeline.py > $O/persist_timeline_4000.json 2>> $O/persist_timeline.err
+python tools/launch_profile.py > $O/launch_profile.txt 2>> $O/persist_timeline.err   # the first grad-iters of a launch, one by one
 # 4. persistent path against the two-kernel path and the oracle: parity and timing, other configurations
 python tools/persist_check.py > $O/persist_check.txt 2>&1
 python tools/time_big.py product > $O/time_4096.txt 2>&1
 python tools/long_parity.py > $O/long_parity.txt 2>&1
 python tools/time_variants.py product > $O/long_run_timing.txt 2>&1
 python tools/call_length.py > $O/call_length.txt 2>&1
+python tools/pmc_size.py 4096 12000 > $O/pmc_traffic_4096_12000.json 2> $O/pmc_size.err   # memory-side traffic per grad-iter (separate --pmc passes)
+python tools/pmc_size.py 2048 3000 > $O/pmc_traffic_2048_3000.json 2>> $O/pmc_size.err
 TPOSE_PMC_TARGET=persist python tools/pmc_kernels.py $O/pmc_persist.json > /dev/null 2> $O/pmc_persist.err   # counters of k_persist (separate --pmc passes)
 # 5. row e3: a hand-over between two processes through an IPC-mapped granule; the band split's protocol with both bands on this device
 bash tools/run_ipc_handover.sh > $O/ipc_handover.txt 2>&1

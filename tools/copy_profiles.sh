@@ -23,4 +23,7 @@ cp $S/config4.json $D/r04_config4_batch.json
 [ -f $S/bench_two_ranks_one_gpu.json ] && grep '^{' $S/bench_two_ranks_one_gpu.json > $D/r04_bench_two_ranks_one_gpu.json
 [ -f $S/call_length.txt ] && cp $S/call_length.txt $D/r04_call_length.txt
 [ -f $S/pmc_persist.json ] && cp $S/pmc_persist.json $D/r04_pmc_persist.json
+[ -f $S/launch_profile.txt ] && cp $S/launch_profile.txt $D/r04_launch_profile.txt
+[ -f $S/pmc_traffic_4096_12000.json ] && cp $S/pmc_traffic_4096_12000.json $D/r04_pmc_traffic_4096_12000.json
+[ -f $S/pmc_traffic_2048_3000.json ] && cp $S/pmc_traffic_2048_3000.json $D/r04_pmc_traffic_2048_3000.json
 ls -la $D/r04_*

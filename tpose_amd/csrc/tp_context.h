@@ -81,6 +81,7 @@ struct tp_context {
     uint4* prefix[2] = {nullptr, nullptr};   // per-image row prefix tables
     int prefix_pitch = 0;
     uint4* px[2] = {nullptr, nullptr};     // the same in pixel records (rasters up to TP_PX_MAXW columns): persistent kernel
+    uint4* pxt[2] = {nullptr, nullptr};    // ... and tiled 4 rows x 2 columns per 128 bytes (tp_raster.h): lane-items that keep no records
     int px_pitch = 0;
     // outputs
     int32_t* ten = nullptr;

@@ -165,7 +165,7 @@ int tp_destroy(tp_context* c) {
     stop_replan_worker(c);
     drop_graphs(c);
     free_triangulation(c);
-    hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->prefix[0]); hipFree(c->prefix[1]); hipFree(c->px[0]); hipFree(c->px[1]);
+    hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->prefix[0]); hipFree(c->prefix[1]); hipFree(c->px[0]); hipFree(c->px[1]); hipFree(c->pxt[0]); hipFree(c->pxt[1]);
     hipFree(c->render_pic); hipFree(c->render_pts);
     hipFree(c->d_wg); hipFree(c->d_pool); hipFree(c->posbox); hipFree(c->points_out); hipFree(c->d_status);
     if (c->h_status) hipHostFree(c->h_status);
@@ -245,7 +245,8 @@ static int set_image_common(tp_context* c, int slot, const void* src, size_t str
     tp_launch_prefix_table(c->img[slot], c->W * 4, c->W, c->H, c->prefix_pitch, c->prefix[slot], c->stream);
     if (c->px_pitch) {  // pixel records of the same sums: what the persistent grad-iter kernel reads
         if (!c->px[slot]) HIP_TRY(c, dev_alloc(&c->px[slot], (size_t)c->H * c->px_pitch));
-        tp_launch_px_table(c->img[slot], c->W * 4, c->W, c->H, c->px_pitch, c->px[slot], c->stream);
+        if (!c->pxt[slot]) HIP_TRY(c, dev_alloc(&c->pxt[slot], (size_t)tp_px_tiled_rows((uint32_t)c->H) * c->px_pitch));
+        tp_launch_px_table(c->img[slot], c->W * 4, c->W, c->H, c->px_pitch, c->px[slot], c->pxt[slot], c->stream);
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -52,7 +52,7 @@ void tp_launch_vertex_refs(const tp_launch& L, int* vref, int* vvar, hipStream_t
 void tp_launch_replicate_colors(const tp_launch& L, hipStream_t s);
 // per-image row prefix table (tp_raster.h, "Per-image row prefix table")
 void tp_launch_prefix_table(const uint8_t* img, int pitch, int W, int H, int prefix_pitch, uint4* P, hipStream_t s);
-void tp_launch_px_table(const uint8_t* img, int pitch, int W, int H, int px_pitch, uint4* P, hipStream_t s);  // rasters up to TP_PX_MAXW columns
+void tp_launch_px_table(const uint8_t* img, int pitch, int W, int H, int px_pitch, uint4* P, uint4* P_tiled, hipStream_t s);  // rasters up to TP_PX_MAXW columns
 void tp_launch_selftest_walker(const int64_t* N0, const int32_t* step, const int32_t* d, int n, int32_t* out, hipStream_t s);
 void tp_launch_selftest_line(const int4* ends, const int* H, int n, int rows, int32_t* out, hipStream_t s);
 // several arrays copied by ONE launch, either side of which may be pinned host memory (read or written by the device across
@@ -73,6 +73,7 @@ struct pk_args {
     int parts;
     tp_view vw;
     const uint4* px;            // row prefix table of the swept image in pixel records (tp_raster.h): [H][px_pitch] 16 bytes
+    const uint4* px_tiled;      // the same records tiled 4 rows x 2 columns per 128 bytes: what lane-items without kept records read
     int px_pitch;
     const float2* points;       // positions at the start of the launch
     float2* points_out;         // positions after n_iters grad-iters (vertices of at least one triangle only)

@@ -86,7 +86,7 @@ void tp_launch_prefix_table(const uint8_t* img, int pitch, int W, int H, int pre
 
 // the same sums in pixel records (tp_raster.h, "Pixel records": 16 bytes per pixel column; rasters up to 4096 columns) --
 // what the persistent kernel reads.  One 256-thread workgroup per row; thread t owns the columns [t C, (t + 1) C)
-__global__ __launch_bounds__(256) void k_prefix_px(const uint8_t* img, int pitch, int W, int px_pitch, uint4* P) {
+__global__ __launch_bounds__(256) void k_prefix_px(const uint8_t* img, int pitch, int W, int px_pitch, uint4* P, uint4* Pt) {
     __shared__ uint32_t wave_total[4][5];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NC = W + 1;   // columns c = 0..W
@@ -119,12 +119,14 @@ __global__ __launch_bounds__(256) void k_prefix_px(const uint8_t* img, int pitch
     for (int c = c0; c < c1; c++) {
         uint64_t rec[2];
         tp_px_pack(run, rec);
-        dst[c] = make_uint4((uint32_t)rec[0], (uint32_t)(rec[0] >> 32), (uint32_t)rec[1], (uint32_t)(rec[1] >> 32));
+        const uint4 v = make_uint4((uint32_t)rec[0], (uint32_t)(rec[0] >> 32), (uint32_t)rec[1], (uint32_t)(rec[1] >> 32));
+        dst[c] = v;
+        if (Pt) Pt[(tp_px_tiled_row_part((uint32_t)row, (uint32_t)px_pitch) + tp_px_tiled_col_part((uint32_t)c)) >> 4] = v;   // (the tiled copy: tp_raster.h)
         if (c < W) px_moments5(src[c], run);
     }
 }
-void tp_launch_px_table(const uint8_t* img, int pitch, int W, int H, int px_pitch, uint4* P, hipStream_t s) {
-    hipLaunchKernelGGL(k_prefix_px, dim3((unsigned)H), dim3(256), 0, s, img, pitch, W, px_pitch, P);
+void tp_launch_px_table(const uint8_t* img, int pitch, int W, int H, int px_pitch, uint4* P, uint4* P_tiled, hipStream_t s) {
+    hipLaunchKernelGGL(k_prefix_px, dim3((unsigned)H), dim3(256), 0, s, img, pitch, W, px_pitch, P, P_tiled);
 }
 
 // ------------------------------------------------------------------------------------------------

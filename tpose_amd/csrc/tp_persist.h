@@ -205,8 +205,9 @@ TP_HD void pk_add_unpacked(uint64_t lo, uint64_t hi, pk_acc& a) {
 // pixels of each other, so what they fetch shares cache lines.  Residues are absolute (not counted from the line's first
 // row): when an endpoint crosses a pixel row, one lane of the line gains or loses a row and the others keep theirs.
 struct pk_rows { int n; int64_t x, xs; uint32_t row, rs; };
-TP_HD pk_rows pk_lane_rows(const pk_walker& ln, int c, int TL, uint32_t magic, int pitch) {
+TP_HD pk_rows pk_lane_rows(const pk_walker& ln, int c, int TL, uint32_t magic, int pitch, int* first_row = nullptr) {
     pk_rows r; r.n = 0; r.x = 0; r.xs = 0; r.row = 0; r.rs = 0;
+    if (first_row) *first_row = 0;
     if (ln.ra > ln.rb) return r;
     int d = c - (ln.ra - (int)pk_mul24(pk_div((uint32_t)ln.ra, magic), (uint32_t)TL));   // c - ra mod TL (rows and chunks < 2^13)
     d += d < 0 ? TL : 0;
@@ -218,6 +219,7 @@ TP_HD pk_rows pk_lane_rows(const pk_walker& ln, int c, int TL, uint32_t magic, i
     // (byte offsets into the table fit 32 bits: 4096 rows x 4104 records x 16 bytes < 2^29; rows, chunks < 2^13 and a row's bytes < 2^17)
     r.row = pk_mul24((uint32_t)first, (uint32_t)pitch * 16u);
     r.rs = pk_mul24((uint32_t)TL, (uint32_t)pitch * 16u);
+    if (first_row) *first_row = first;
     return r;
 }
 // crossing column of the current row, clamped to [0, W]; then one row on
@@ -256,9 +258,35 @@ TP_HD void pk_walk_rows(pk_rows& r, const char* table, int W, pk_acc& a) {
     }
 }
 
+// the same from the TILED copy of the table (tp_raster.h): rows first, first + TL, ...
+template <int B>
+TP_HD void pk_walk_rows_tiled(pk_rows& r, uint32_t row, uint32_t TL, uint32_t pitch, const char* tiled, int W, pk_acc& a) {
+    static_assert(B <= TP_PX_MAXSUM, "records added before unpacking");
+    for (; r.n > 0; r.n -= B) {
+        pk_rec d[B];
+        uint32_t sx = 0;
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            d[u].lo = 0; d[u].hi = 0;
+            if (u < r.n) {
+                const uint32_t col = (uint32_t)pk_next_col(r, W);
+                sx += col;
+                d[u] = pk_load_rec(tiled, tp_px_tiled_row_part(row, pitch) + tp_px_tiled_col_part(col));
+                row += TL;
+            }
+        }
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int u = 0; u < B; u++) { lo += d[u].lo; hi += d[u].hi; }
+        a.xs += sx;
+        pk_add_unpacked(lo, hi, a);
+    }
+}
+
 // P3, lane-item j >= PK_CACHED (a patch with more lane-items than its threads keep records for): (line l, chunk c of TL), nothing kept between
 // grad-iters.  Returns the line-sum slot, the partial sums in `a`.
-TP_HD int pk_walk_lane(const pk_view& V, const char* table, int pitch, int W, int n_lines_all, int base, int li_cap, int j, pk_acc& a) {
+// tiled: the tiled copy of the table, or null (then `table`, row-major)
+TP_HD int pk_walk_lane(const pk_view& V, const char* table, const char* tiled, int pitch, int W, int n_lines_all, int base, int li_cap, int j, pk_acc& a) {
     int l, c, TL;
     uint32_t magic;
     if (j - base < li_cap) {
@@ -269,11 +297,13 @@ TP_HD int pk_walk_lane(const pk_view& V, const char* table, int pitch, int W, in
         magic = pk_magic(TL);
     }
     a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
-    pk_rows r = pk_lane_rows(V.wk[l], c, TL, magic, pitch);
+    int first;
+    pk_rows r = pk_lane_rows(V.wk[l], c, TL, magic, pitch, &first);
 #ifndef PK_UNCACHED_BATCH
 #define PK_UNCACHED_BATCH 8    /* records requested together by a lane-item without cached records (12 would spill registers of the cached walk) */
 #endif
-    pk_walk_rows<PK_UNCACHED_BATCH>(r, table, W, a);
+    if (tiled) pk_walk_rows_tiled<PK_UNCACHED_BATCH>(r, (uint32_t)first, (uint32_t)TL, (uint32_t)pitch, tiled, W, a);
+    else pk_walk_rows<PK_UNCACHED_BATCH>(r, table, W, a);
     return l;
 }
 

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         my_c1 = (cr_.w & 0xffff) | (((cr_.y >> 2) & 0x3ff) << 16) | (((cr_.w >> 16) & 7) << 26);   // (... | flips << 26)
     }
     const char* table = reinterpret_cast<const char*>(A.px);
+    const char* tiled = reinterpret_cast<const char*>(A.px_tiled);
     // this thread's lane-item of the walk and the table records of its rows: in registers for the whole launch
     pk_lane_cache<RR> cache[PK_NI];
     gu64* posbox = (gu64*)A.posbox;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         // (lane-items beyond the cached ones: a patch with more than PK_CACHED, and the base lines of the last grad-iter)
         for (int j = (n_li_now < PK_CACHED ? n_li_now : PK_CACHED) + tid; j < n_li; j += PK_THREADS) {
             pk_acc a;
-            const int l = pk_walk_lane(V, table, A.px_pitch, A.vw.W, w.n_lines_all, n_li_now < PK_CACHED ? n_li_now : PK_CACHED, w.li_cap, j, a);
+            const int l = pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, n_li_now < PK_CACHED ? n_li_now : PK_CACHED, w.li_cap, j, a);
             fold(l, a);
         }
         PK_WSTAMP(6);

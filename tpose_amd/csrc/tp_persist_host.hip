@@ -231,7 +231,7 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         pk_args A{};
         A.wg = c->plan_dev[c->plan_slot].wg; A.pool = c->plan_dev[c->plan_slot].pool; A.parts = c->plan.parts;
         A.vw.dp = dp; A.vw.ratio = c->ratio; A.vw.halfW = 0.5f * (float)c->W; A.vw.halfH = 0.5f * (float)c->H; A.vw.W = c->W; A.vw.H = c->H;
-        A.px = c->px[p.image_slot]; A.px_pitch = c->px_pitch;
+        A.px = c->px[p.image_slot]; A.px_tiled = c->pxt[p.image_slot]; A.px_pitch = c->px_pitch;
         A.points = c->points; A.points_out = c->points_out; A.ca = c->ca;
         A.NT = c->NT; A.NP = c->NP; A.NE = c->NE;
         A.flavour = p.flavour; A.rate = p.rate;

@@ -505,6 +505,13 @@ TP_HD void tp_prefix_eval(const uint32_t rec[TP_PFX_WORDS], int32_t c, uint32_t&
 #define TP_PX_MAXW 4096
 #define TP_PX_MAXSUM 16   /* records that may be added before unpacking */
 TP_HD int32_t tp_px_pitch(int32_t W) { return (W + 1 + 7) & ~7; }   // records per row (c = 0..W): whole 128-byte lines
+// The same records a second time, TILED: a 128-byte line holds 4 rows x 2 columns instead of 8 columns of one row.  What walks a line
+// WITHOUT keeping its records (tp_persist.h: pk_walk_rows_tiled -- every record fetched again every grad-iter) reads this copy: the
+// versions of an edge cross a row within a column or two of each other and neighbouring rows a column or two further on, so a steep line's
+// 4 rows x 9 versions sit in 2-4 lines here against 4-8 in the row-major table, and lines are what such a walk is bound by.
+TP_HD uint32_t tp_px_tiled_rows(uint32_t H) { return (H + 3u) & ~3u; }
+TP_HD uint32_t tp_px_tiled_row_part(uint32_t row, uint32_t pitch) { return (row >> 2) * (pitch << 6) + ((row & 3u) << 5); }   // (pitch a multiple of 8)
+TP_HD uint32_t tp_px_tiled_col_part(uint32_t col) { return ((col & ~1u) << 6) + ((col & 1u) << 4); }
 
 // running moments m = {n_odd, r, g, b, q} of the pixels before column c -> record {low, high}
 TP_HD void tp_px_pack(const uint32_t m[5], uint64_t rec[2]) {
