@@ -292,10 +292,17 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             PK_STAMP(9);
         }
         // (lane-items beyond the cached ones: a patch with more than PK_CACHED, and the base lines of the last grad-iter)
-        for (int j = (n_li_now < PK_CACHED ? n_li_now : PK_CACHED) + tid; j < n_li; j += PK_THREADS) {
-            pk_acc a;
-            const int l = pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, n_li_now < PK_CACHED ? n_li_now : PK_CACHED, w.li_cap, j, a);
-            fold(l, a);
+        // Every other grad-iter takes them in the opposite order: what they read is the same set of lines every grad-iter and larger than the
+        // L2, so taken the same way round each time nothing of one grad-iter's reads would still be there for the next
+        {
+            const int j0 = n_li_now < PK_CACHED ? n_li_now : PK_CACHED;
+            const bool back = (it & 1) != 0;
+            for (int k = tid; k < n_li - j0; k += PK_THREADS) {
+                const int j = back ? n_li - 1 - k : j0 + k;
+                pk_acc a;
+                const int l = pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, j0, w.li_cap, j, a);
+                fold(l, a);
+            }
         }
         PK_WSTAMP(6);
         __syncthreads();
