@@ -1,12 +1,7 @@
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-(timeout 900 python -m pytest tests/test_persist_sizes.py -m gpu -x -q -k "metric_size or config1") > gpurun_out/r4_t13.log 2>&1; tail -3 gpurun_out/r4_t13.log
 for i in 1 2; do
-for e in product head; do
-unset TPOSE_HIP_LIB
-if [ $e = head ]; then export TPOSE_HIP_LIB=$PWD/tpose_amd/variants/libtpose_hip_head.so; fi
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cold --no-pmc --no-cpu-baseline --no-extra > gpurun_out/r4_b20.json 2>gpurun_out/r4_b20.err; python -c "
-import json; d=json.load(open('gpurun_out/r4_b20.json')); print('$e bench20 ms_per_step', d['ms_per_step'], 'device', d['ms_per_step_device'], 'kern/iter', d['roofline']['us_per_grad_iter'], d['timing'])"; done; done
-unset TPOSE_HIP_LIB
-python tools/time_variants.py product head
-python tools/launch_profile.py | head -8
+python tools/run_batch.py --pairs 8 --iters 512 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('product', d['triangles_iters_per_s'], d['seconds_iterating_slowest_rank'], [round(p['seconds'],4) for p in d['pairs']], [p['launches_given_up'] for p in d['pairs']])"
+done
+(timeout 900 python -m pytest tests/test_bands.py tests/test_stress.py tests/test_harness.py -m gpu -x -q) > gpurun_out/r4_t14.log 2>&1; tail -3 gpurun_out/r4_t14.log
+python tools/thread_stress.py 2>&1 | tail -3

@@ -73,7 +73,8 @@ def main():
         busy += dt
         e1 = [int(c.retrieve(capi.BUF_TENERGY)[: args.triangles].astype(np.int64).sum()) for c in ctxs]
         moved = [float(np.abs(c.retrieve(capi.BUF_POINTS) - pts).max()) for c in ctxs]
-        records.append(dict(pair=k, rank=rank, directions=mine, seconds=dt, energy_before=e0, energy_after=e1, max_vertex_shift=moved))
+        records.append(dict(pair=k, rank=rank, directions=mine, seconds=dt, energy_before=e0, energy_after=e1, max_vertex_shift=moved,
+                            launches_given_up=[c.info(capi.INFO_PERSIST_FAILURES) for c in ctxs]))
         for c in ctxs:
             c.close()
     wall = time.perf_counter() - t_all

@@ -97,6 +97,8 @@ struct tp_context {
     uint64_t generation = 1;
     std::vector<graph_entry> graphs;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool on_device = false;         // counted among its device's contexts (join_device / leave_device)
+    hipEvent_t ev_turn = nullptr;   // behind this context's last persistent launch, when other contexts share the device (tp_persist_host.hip: device turns)
     uint8_t* pinned = nullptr;   // host-pinned staging for readbacks (one synchronisation per batch)
     size_t pinned_bytes = 0;
     uint8_t* render_pic = nullptr;   // tp_render scratch (kept: the viewer renders every frame)
@@ -251,6 +253,8 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false);
 int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings = false);
 // tp_replan.hip
 int take_replan(tp_context* c);
+void join_device(tp_context* c);    // a context came to / left a device: persistent launches of the contexts of ONE device take turns
+void leave_device(tp_context* c);
 void stop_replan_worker(tp_context* c);
 int maybe_replan(tp_context* c, float dp, bool more_chunks);
 // tp_bands.hip

@@ -153,6 +153,7 @@ int tp_create(int device, int width, int height, tp_context** out) {
         tp_destroy(c);
         return rc;
     }
+    join_device(c);
     *out = c;
     return TP_OK;
 }
@@ -162,6 +163,8 @@ int tp_destroy(tp_context* c) {
     if (!c) return TP_OK;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    leave_device(c);
+    if (c->ev_turn) hipEventDestroy(c->ev_turn);
     stop_replan_worker(c);
     drop_graphs(c);
     free_triangulation(c);

@@ -216,6 +216,31 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every) {
     return TP_OK;
 }
 
+// ---- device turns.  A persistent launch wants every compute unit; two of them from two contexts of one process (the two directions of a
+// warp, a batch) may be handed out workgroup by workgroup to both at once, and then neither has its grid resident: both wait out their
+// time limit, give up and are run again on the two-kernel path (45 ms for a call; seen as one pair in eight of tools/run_batch.py taking
+// three times as long).  So while more than one context lives on a device, a persistent launch waits for the one before it, whoever
+// enqueued it: an event behind every launch, a hipStreamWaitEvent in front of the next one of another context.  Bands are exempt (they are
+// sized to be resident together), and so is the only context of its device (nothing recorded, nothing waited for).  Other processes' launches
+// are still what the give-up path is for.
+namespace {
+struct device_turn { std::mutex m; hipEvent_t last = nullptr; const tp_context* owner = nullptr; int contexts = 0; };
+device_turn g_turn[64];
+device_turn* turn_of(const tp_context* c) { return c->device >= 0 && c->device < 64 ? &g_turn[c->device] : nullptr; }
+}
+void join_device(tp_context* c) {
+    if (device_turn* T = turn_of(c)) { std::lock_guard<std::mutex> lk(T->m); T->contexts++; c->on_device = true; }
+}
+void leave_device(tp_context* c) {   // (the caller has waited for the context's stream: its event is complete)
+    if (!c->on_device) return;
+    c->on_device = false;
+    if (device_turn* T = turn_of(c)) {
+        std::lock_guard<std::mutex> lk(T->m);
+        if (T->contexts > 0) T->contexts--;
+        if (T->owner == c) { T->owner = nullptr; T->last = nullptr; }
+    }
+}
+
 // n grad-iters of the persistent kernel -- the last one writes `tenergy`, `colnum`, `colacc`, `gradient` --, then
 // `points_out` -> `points` / `epos`
 int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings) {
@@ -265,12 +290,26 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         const bool self = !banded && !rings && !c->has_loose && c->points_out && c->cap_points_out >= (size_t)c->NP;
         if (self) A.host_status = c->h_status;
         if (c->inject_give_up > 0 && --c->inject_give_up == 0) A.inject_give_up = 1;
+        device_turn* T = banded ? nullptr : turn_of(c);
+        std::unique_lock<std::mutex> turn;
+        bool shared_device = false;
+        if (T) {
+            turn = std::unique_lock<std::mutex>(T->m);
+            shared_device = T->contexts > 1;
+            if (shared_device && T->last && T->owner != c) HIP_TRY(c, hipStreamWaitEvent(c->stream, T->last, 0));
+        }
         tp_launch_persist(A, grid, c->plan.rows_max, c->plan.lds_bytes, c->stream);
         if (banded) tp_launch_band_collect(make_launch(c, p.image_slot, dp), A, c->points_out, c->stream);
         if (!self) tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->h_status, 0, c->stream);
         c->epos_stale = true; c->tail_is_finish = true;
         c->journal.push_back({p, rings ? 0 : k, self ? c->points : nullptr});   // (a chunk of tp_iterate_until is checked by its caller: nothing to replay)
         if (self) std::swap(c->points, c->points_out);
+        if (shared_device) {
+            if (!c->ev_turn) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_turn, hipEventDisableTiming));
+            HIP_TRY(c, hipEventRecord(c->ev_turn, c->stream));
+            T->last = c->ev_turn; T->owner = c;
+        }
+        if (turn.owns_lock()) turn.unlock();
         HIP_TRY(c, hipGetLastError());
         c->epoch += (uint32_t)k;
         c->persist_unchecked = true;
