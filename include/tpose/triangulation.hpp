@@ -384,6 +384,18 @@ inline void retrieve(triangulation* tr, bool base_only = false) {
 inline void retrieve_energy(triangulation* tr, bool base_only = false) {
     check(tp_retrieve(ctx, TP_BUF_TENERGY, terr, base_only ? base_entries(tr) : (size_t)13 * tr->NT), "retrieve(tenergy)");
 }
+// the base energies n triangles WOULD have at the device's current positions (vertex triples into the uploaded points; tp_evaluate_triangles):
+// what "flip, upload, computecolors, doenergy, retrieve" yields for the flipped pairs, without making them real.  false: not available
+// for this raster (beyond 4096 columns or rows) -- the caller takes the upload path
+inline bool evaluate(const std::vector<int>& vertices, std::vector<int>& energy) {
+    const int n = (int)(vertices.size() / 3);
+    energy.assign((size_t)n, 0);
+    if (n == 0) return true;
+    const int rc = tp_evaluate_triangles(ctx, swept_slot(), n, vertices.data(), energy.data(), nullptr);
+    if (rc == TP_ERR_STATE) return false;
+    check(rc, "evaluate");
+    return true;
+}
 // tcolaccbuf->retrieve(tr.NT, &tr.colors[0])
 inline void retrieve_colors(triangulation* tr) {
     check(tp_retrieve(ctx, TP_BUF_COLACC, &tr->colors[0].x, (size_t)4 * tr->NT), "retrieve(colacc)");

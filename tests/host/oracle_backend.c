@@ -184,6 +184,23 @@ int tp_band_mailbox_free(tp_context* c, void* box) { (void)c; free(box); return 
 int tp_band_mailbox_export(tp_context* c, void* box, void* handle) { (void)c; (void)box; if (handle) memset(handle, 0, TP_MAILBOX_HANDLE_BYTES); return TP_OK; }
 int tp_band_mailbox_import(tp_context* c, const void* handle, void** box) { (void)c; (void)handle; if (box) *box = NULL; return TP_ERR_STATE; }
 int tp_band_mailbox_close(tp_context* c, void* box) { (void)c; (void)box; return TP_OK; }
+/* hypothetical triangles: the oracle's single-sweep moments of a mesh made of just them, variant 0 (triangulate flavour) */
+int tp_evaluate_triangles(tp_context* c, int slot, int n, const int32_t* vertices, int32_t* energy, int32_t* count) {
+    if (n <= 0) return TP_OK;
+    int32_t* tris = (int32_t*)calloc((size_t)4 * n, 4);
+    for (int k = 0; k < n; k++) { tris[4 * k] = vertices[3 * k]; tris[4 * k + 1] = vertices[3 * k + 1]; tris[4 * k + 2] = vertices[3 * k + 2]; }
+    int64_t* mom = (int64_t*)calloc((size_t)13 * n * 6, 8);
+    int32_t* ten = (int32_t*)calloc((size_t)13 * n, 4);
+    int32_t* cn = (int32_t*)calloc((size_t)13 * n, 4);
+    int32_t* ca = (int32_t*)calloc((size_t)13 * n * 4, 4);
+    tpo_raster r = {c->img[slot], (size_t)c->W * 4, c->W, c->H};
+    tpo_moments(&r, c->points, tris, n, tpo_dp(TPO_TRIANGULATE, n), c->ratio, mom);
+    tpo_finalize(mom, n, TPO_TRIANGULATE, NULL, ten, cn, ca, NULL);
+    memcpy(energy, ten, (size_t)n * 4);
+    if (count) memcpy(count, cn, (size_t)n * 4);
+    free(tris); free(mom); free(ten); free(cn); free(ca);
+    return TP_OK;
+}
 int tp_prepare(tp_context* c, const tp_params* p) { (void)c; (void)p; return TP_OK; }
 int tp_get_info(tp_context* c, int what, int64_t* value) { (void)c; (void)what; if (value) *value = 0; return TP_OK; }
 int tp_synchronize(tp_context* c) { (void)c; return TP_OK; }

@@ -704,3 +704,47 @@ def test_frame_mirror_returns_what_the_device_holds(flavour):
     assert np.array_equal(got.view(np.uint32), ref["points"].view(np.uint32))
     assert np.array_equal(ctx.retrieve(capi.BUF_TENERGY, NT)[:NT], ref["ten"][:NT])
     ctx.close()
+
+
+@pytest.mark.parametrize("size,grid", [((300, 200), (15, 5)), ((674, 449), (10, 8))])
+def test_evaluate_triangles_is_the_base_energy(size, grid):
+    """tp_evaluate_triangles: the energy and pixel count a triangle WOULD have at the current positions equal what the sweep leaves for
+    it as a base variant -- for the triangles of the mesh (any vertex order), for triangles that are not in it (the other diagonal of a
+    quad: what the schedule's flip set asks for; checked against the oracle on a mesh that holds them), and for one without area"""
+    W, H = size
+    img, imgB, pts, tris, ratio, colors = case(W, H, grid)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts, tris, None)
+    p = capi.default_params(capi.TRIANGULATE)
+    ctx.iterate(p, 7)    # (somewhere off the grid)
+    moved = ctx.retrieve(capi.BUF_POINTS)
+    ref = O.iterate(img, moved, tris, O.TRIANGULATE, ratio, RATE[0], 1, literal=False)   # `ten`, `cn`: the sweep at `moved`
+    NT = tris.shape[0]
+    e, n = ctx.evaluate_triangles(tris[:, :3])
+    assert np.array_equal(e, ref["ten"][:NT]) and np.array_equal(n, ref["cn"][:NT])
+    e2, n2 = ctx.evaluate_triangles(tris[:, [2, 0, 1]])          # rotated
+    e3, n3 = ctx.evaluate_triangles(tris[:, [1, 0, 2]])          # mirrored
+    assert np.array_equal(e2, e) and np.array_equal(e3, e) and np.array_equal(n2, n) and np.array_equal(n3, n)
+    # the other diagonal of the quads the grid is made of: triangles (2k, 2k + 1) share an edge
+    hyp = []
+    for k in range(0, NT - 1, 2):
+        a, b = set(tris[k, :3].tolist()), set(tris[k + 1, :3].tolist())
+        shared = sorted(a & b)
+        if len(shared) != 2:
+            continue
+        pa, pb = (a - b).pop(), (b - a).pop()
+        hyp.append([pa, pb, shared[0]]); hyp.append([pb, pa, shared[1]])
+    hyp = np.array(hyp, np.int32)
+    assert hyp.shape[0] >= NT // 2
+    eh, nh = ctx.evaluate_triangles(hyp)
+    tris_h = np.zeros((hyp.shape[0], 4), np.int32); tris_h[:, :3] = hyp
+    ref_h = O.iterate(img, moved, tris_h, O.TRIANGULATE, ratio, RATE[0], 1, literal=False)
+    assert np.array_equal(eh, ref_h["ten"][: hyp.shape[0]]) and np.array_equal(nh, ref_h["cn"][: hyp.shape[0]])
+    ez, nz = ctx.evaluate_triangles(np.array([[5, 5, 9], [7, 7, 7]], np.int32))   # no area: no pixel, no energy
+    assert np.array_equal(ez, [0, 0]) and np.array_equal(nz, [0, 0])
+    # nothing of the context changed, and bad indices are refused
+    assert np.array_equal(ctx.retrieve(capi.BUF_POINTS).view(np.uint32), moved.view(np.uint32))
+    with pytest.raises(Exception):
+        ctx.evaluate_triangles(np.array([[0, 1, pts.shape[0]]], np.int32))
+    ctx.close()

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtpose_hip.so")
-SOURCES = ["tp_kernels.hip", "tp_persist.hip", "tp_context.hip", "tp_persist_host.hip", "tp_replan.hip", "tp_bands.hip", "tp_readback.hip"]
+SOURCES = ["tp_kernels.hip", "tp_persist.hip", "tp_context.hip", "tp_persist_host.hip", "tp_replan.hip", "tp_bands.hip", "tp_readback.hip", "tp_eval.hip"]
 HEADERS = ["tp_raster.h", "tp_kernels.h", "tp_plan.h", "tp_persist.h", "tp_context.h", os.path.join("..", "..", "include", "tpose_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

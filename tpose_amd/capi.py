@@ -25,7 +25,7 @@ SYMBOLS = [
     "tp_get_stream", "tp_profile_iterate", "tp_profile_accumulate", "tp_get_info", "tp_selftest_walker", "tp_render",
     "tp_prepare", "tp_selftest_line", "tp_timer_start", "tp_timer_stop", "tp_iterate_until", "tp_band_mailbox_bytes",
     "tp_band_attach", "tp_band_mailbox_alloc", "tp_band_mailbox_free", "tp_band_mailbox_export", "tp_band_mailbox_import",
-    "tp_band_mailbox_close",
+    "tp_band_mailbox_close", "tp_evaluate_triangles",
 ]
 
 
@@ -73,6 +73,7 @@ def load():
         lib.tp_set_dp.argtypes = [C.c_void_p, C.c_float]
         lib.tp_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
         lib.tp_set_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        lib.tp_evaluate_triangles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.tp_set_image_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         lib.tp_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         lib.tp_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -274,6 +275,15 @@ class Context:
         n = out.size if count is None else count
         self._ck(self.lib.tp_retrieve(self.h, what, out.ctypes.data, n))
         return out
+
+    def evaluate_triangles(self, vertices, slot=IMAGE_A):
+        """base energy and pixel count each of the triangles `vertices` (n x 3 indices into the uploaded points) would have at the
+        current positions (tp_evaluate_triangles); returns (energy, count) int32 arrays"""
+        v = np.ascontiguousarray(vertices, np.int32).reshape(-1, 3)
+        n = v.shape[0]
+        e, cnt = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self._ck(self.lib.tp_evaluate_triangles(self.h, slot, n, v.ctypes.data, e.ctypes.data, cnt.ctypes.data))
+        return e, cnt
 
     def retrieve_many(self, whats):
         """several buffers with one wait (tp_retrieve_many); returns a list of arrays"""

@@ -163,14 +163,34 @@ int main(int argc, char** argv) {
             std::sort(chosen.begin(), chosen.end(), [](const std::pair<int, float>& l, const std::pair<int, float>& r) { return l.first < r.first; });
             for (auto& h : chosen) tr.flip(h.first, 0.0f);
             const auto r1 = now();
-            tpose::upload(&tr, false);
-            const auto r2 = now();
-            tpose::computecolors();
-            tpose::doenergy();
-            tpose::retrieve_energy(&tr, !literal);
+            // The reference makes the flip set real to look at it: upload, computecolors, doenergy, read `tenergy` back -- and then at two
+            // entries per flipped edge.  A triangle's energy depends on its own pixels only, so those are the base energies of the two
+            // triangles the flip WOULD leave: evaluated on the device at its current positions (= tr.points: read back this frame), nothing
+            // uploaded (`-literal` does what the reference does; tests compare the outputs byte for byte).
+            bool evaluated = false;
+            std::vector<int> pair_energy;   // [2 i], [2 i + 1]: the two triangles of chosen[i] after its flip
+            auto r2 = now();                // (the evaluation counts as an energy pass in the timing summary, not as an upload)
+            if (!literal) {
+                std::vector<int> vs;
+                vs.reserve(chosen.size() * 6);
+                for (auto& h : chosen)
+                    for (int t : {h.first / 3, tr.halfedges[h.first] / 3})
+                        for (int k = 0; k < 3; k++) vs.push_back(tr.triangles[t][k]);
+                evaluated = tpose::evaluate(vs, pair_energy);
+            }
+            if (!evaluated) {
+                tpose::upload(&tr, false);
+                r2 = now();
+                tpose::computecolors();
+                tpose::doenergy();
+                tpose::retrieve_energy(&tr, !literal);
+            }
             const auto r3 = now();
-            for (auto& h : chosen)       // undo the flips that raised their pair's energy
-                if (tpose::terr[h.first / 3] + tpose::terr[tr.halfedges[h.first] / 3] > h.second) tr.flip(h.first, 0.0f);
+            for (size_t i = 0; i < chosen.size(); i++) {   // undo the flips that raised their pair's energy
+                const auto& h = chosen[i];
+                const int after = evaluated ? pair_energy[2 * i] + pair_energy[2 * i + 1] : tpose::terr[h.first / 3] + tpose::terr[tr.halfedges[h.first] / 3];
+                if (after > h.second) tr.flip(h.first, 0.0f);
+            }
             const auto r4 = now();
             tpose::upload(&tr, false);
             const auto r5 = now();
