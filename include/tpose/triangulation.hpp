@@ -387,13 +387,31 @@ inline void retrieve_energy(triangulation* tr, bool base_only = false) {
 // the base energies n triangles WOULD have at the device's current positions (vertex triples into the uploaded points; tp_evaluate_triangles):
 // what "flip, upload, computecolors, doenergy, retrieve" yields for the flipped pairs, without making them real.  false: not available
 // for this raster (beyond 4096 columns or rows) -- the caller takes the upload path
-inline bool evaluate(const std::vector<int>& vertices, std::vector<int>& energy) {
+// variants: empty (base variants), or one per triangle (0..12: the entry variant * NT + t of `tenergy` if the triple were triangle t)
+inline bool evaluate(const std::vector<int>& vertices, std::vector<int>& energy, const std::vector<int>& variants = std::vector<int>()) {
     const int n = (int)(vertices.size() / 3);
     energy.assign((size_t)n, 0);
     if (n == 0) return true;
-    const int rc = tp_evaluate_triangles(ctx, swept_slot(), n, vertices.data(), energy.data(), nullptr);
+    const int rc = tp_evaluate_triangles(ctx, swept_slot(), n, vertices.data(), variants.empty() ? nullptr : variants.data(), energy.data(), nullptr);
     if (rc == TP_ERR_STATE) return false;
     check(rc, "evaluate");
+    return true;
+}
+// `terr` as "upload(tr); computecolors(); doenergy(); retrieve_energy(tr, base_only = true)" would leave it -- the entries [0, NT + 2): the base
+// energies of tr's triangles and the two entries behind them (variant-major: entry e >= NT is variant e / NT of triangle e % NT) -- from
+// tp_evaluate_triangles at the device's positions, WITHOUT the upload: the device keeps the mesh it has.  false: not available.
+inline bool evaluate_mesh_energy(const triangulation* tr) {
+    const int NT = tr->NT;
+    const size_t entries = base_entries(tr);
+    std::vector<int> vs, va, e;
+    vs.reserve(entries * 3); va.reserve(entries);
+    for (size_t k = 0; k < entries; k++) {
+        const int t = (int)(k % (size_t)NT), i = (int)(k / (size_t)NT);
+        for (int j = 0; j < 3; j++) vs.push_back(tr->triangles[t][j]);
+        va.push_back(i);
+    }
+    if (!evaluate(vs, e, va)) return false;
+    for (size_t k = 0; k < entries; k++) terr[k] = e[k];
     return true;
 }
 // tcolaccbuf->retrieve(tr.NT, &tr.colors[0])

@@ -189,13 +189,15 @@ int tp_prepare(tp_context* ctx, const tp_params* p);
 /* Buffer::retrieve (triangulate/main.cpp:201-204, 221): copies `count` elements (int32 / float /
  * int64 units as listed in tp_buffer) into dst after waiting for enqueued work. */
 int tp_retrieve(tp_context* ctx, int what, void* dst, size_t count);
-/* The base energy (triangulate flavour: triangle.fs:27-43, against the triangle's own mean colour) and pixel count each of n HYPOTHETICAL
+/* The energy (triangulate flavour: triangle.fs:27-43, against the triangle's own mean colour) and pixel count each of n HYPOTHETICAL
  * triangles would have at the context's current positions on image `slot`: vertices[3k .. 3k+2] index the uploaded points; the triangles
- * need not be in the uploaded mesh, and no buffer of the context changes.  What the reference's convergence step obtains for its flip set
+ * need not be in the uploaded mesh, and no buffer of the context changes.  variants: NULL (base variants), or per triangle 0..12 -- what
+ * entry variant * NT + t of `tenergy` would hold if the triple were triangle t of the mesh (variant i > 0: vertex (i - 1) / 4 of the
+ * triple displaced by move (i - 1) % 4 + 1 of the context's dp: tp_set_dp, or the reference's law at the uploaded NT).  What the reference's convergence step obtains for its flip set
  * by flipping on the host, uploading the topology, running computecolors + doenergy over everything and reading `tenergy` back
  * (software/triangulate/main.cpp:233-306) -- a triangle's energy depends on its own pixels only.  Rasters up to 4096 columns and rows
  * (TP_ERR_STATE beyond: the caller keeps to the upload path).  count may be NULL.  Waits for the result. */
-int tp_evaluate_triangles(tp_context* ctx, int slot, int n, const int32_t* vertices, int32_t* energy, int32_t* count);
+int tp_evaluate_triangles(tp_context* ctx, int slot, int n, const int32_t* vertices, const int32_t* variants, int32_t* energy, int32_t* count);
 /* the same for n buffers with ONE wait: what[k] -> dst[k], count[k] elements.  The reference reads four
  * buffers back every frame (software/triangulate/main.cpp:201-204, warp/main.cpp:226-229); done one by one,
  * each is a blocking round trip. */

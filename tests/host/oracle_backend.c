@@ -185,7 +185,7 @@ int tp_band_mailbox_export(tp_context* c, void* box, void* handle) { (void)c; (v
 int tp_band_mailbox_import(tp_context* c, const void* handle, void** box) { (void)c; (void)handle; if (box) *box = NULL; return TP_ERR_STATE; }
 int tp_band_mailbox_close(tp_context* c, void* box) { (void)c; (void)box; return TP_OK; }
 /* hypothetical triangles: the oracle's single-sweep moments of a mesh made of just them, variant 0 (triangulate flavour) */
-int tp_evaluate_triangles(tp_context* c, int slot, int n, const int32_t* vertices, int32_t* energy, int32_t* count) {
+int tp_evaluate_triangles(tp_context* c, int slot, int n, const int32_t* vertices, const int32_t* variants, int32_t* energy, int32_t* count) {
     if (n <= 0) return TP_OK;
     int32_t* tris = (int32_t*)calloc((size_t)4 * n, 4);
     for (int k = 0; k < n; k++) { tris[4 * k] = vertices[3 * k]; tris[4 * k + 1] = vertices[3 * k + 1]; tris[4 * k + 2] = vertices[3 * k + 2]; }
@@ -194,10 +194,13 @@ int tp_evaluate_triangles(tp_context* c, int slot, int n, const int32_t* vertice
     int32_t* cn = (int32_t*)calloc((size_t)13 * n, 4);
     int32_t* ca = (int32_t*)calloc((size_t)13 * n * 4, 4);
     tpo_raster r = {c->img[slot], (size_t)c->W * 4, c->W, c->H};
-    tpo_moments(&r, c->points, tris, n, tpo_dp(TPO_TRIANGULATE, n), c->ratio, mom);
+    tpo_moments(&r, c->points, tris, n, the_dp(c, TP_TRIANGULATE), c->ratio, mom);   /* (the dp of the context's sweeps: at the UPLOADED NT) */
     tpo_finalize(mom, n, TPO_TRIANGULATE, NULL, ten, cn, ca, NULL);
-    memcpy(energy, ten, (size_t)n * 4);
-    if (count) memcpy(count, cn, (size_t)n * 4);
+    for (int k = 0; k < n; k++) {
+        const int i = variants ? variants[k] : 0;
+        energy[k] = ten[(size_t)i * n + k];
+        if (count) count[k] = cn[(size_t)i * n + k];
+    }
     free(tris); free(mom); free(ten); free(cn); free(ca);
     return TP_OK;
 }

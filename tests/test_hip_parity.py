@@ -723,6 +723,10 @@ def test_evaluate_triangles_is_the_base_energy(size, grid):
     NT = tris.shape[0]
     e, n = ctx.evaluate_triangles(tris[:, :3])
     assert np.array_equal(e, ref["ten"][:NT]) and np.array_equal(n, ref["cn"][:NT])
+    # every displaced variant: entry variant * NT + t of the sweep's buffers (the dp of the context's sweeps: the law at the uploaded NT)
+    for i in range(1, 13):
+        ei, ni = ctx.evaluate_triangles(tris[:, :3], variants=np.full(NT, i, np.int32))
+        assert np.array_equal(ei, ref["ten"][i * NT: (i + 1) * NT]) and np.array_equal(ni, ref["cn"][i * NT: (i + 1) * NT]), i
     e2, n2 = ctx.evaluate_triangles(tris[:, [2, 0, 1]])          # rotated
     e3, n3 = ctx.evaluate_triangles(tris[:, [1, 0, 2]])          # mirrored
     assert np.array_equal(e2, e) and np.array_equal(e3, e) and np.array_equal(n2, n) and np.array_equal(n3, n)

@@ -73,7 +73,7 @@ def load():
         lib.tp_set_dp.argtypes = [C.c_void_p, C.c_float]
         lib.tp_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
         lib.tp_set_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
-        lib.tp_evaluate_triangles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.tp_evaluate_triangles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.tp_set_image_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         lib.tp_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         lib.tp_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -276,13 +276,15 @@ class Context:
         self._ck(self.lib.tp_retrieve(self.h, what, out.ctypes.data, n))
         return out
 
-    def evaluate_triangles(self, vertices, slot=IMAGE_A):
+    def evaluate_triangles(self, vertices, slot=IMAGE_A, variants=None):
         """base energy and pixel count each of the triangles `vertices` (n x 3 indices into the uploaded points) would have at the
         current positions (tp_evaluate_triangles); returns (energy, count) int32 arrays"""
         v = np.ascontiguousarray(vertices, np.int32).reshape(-1, 3)
         n = v.shape[0]
         e, cnt = np.zeros(n, np.int32), np.zeros(n, np.int32)
-        self._ck(self.lib.tp_evaluate_triangles(self.h, slot, n, v.ctypes.data, e.ctypes.data, cnt.ctypes.data))
+        va = None if variants is None else np.ascontiguousarray(variants, np.int32)
+        assert va is None or va.shape == (n,)
+        self._ck(self.lib.tp_evaluate_triangles(self.h, slot, n, v.ctypes.data, None if va is None else va.ctypes.data, e.ctypes.data, cnt.ctypes.data))
         return e, cnt
 
     def retrieve_many(self, whats):

@@ -1,4 +1,4 @@
-// tp_eval.hip -- tp_evaluate_triangles: the base energy a triangle WOULD have, for triangles that are not in the uploaded mesh.
+// tp_eval.hip -- tp_evaluate_triangles: the energy a triangle WOULD have, for triangles that are not in the uploaded mesh.
 //
 // The reference's convergence step evaluates its flip set by making it real (software/triangulate/main.cpp:233-306): flip every chosen
 // edge on the host, upload the whole topology, computecolors + doenergy over every triangle and every variant, read the energies back --
@@ -13,17 +13,20 @@
 
 namespace {
 
-__global__ __launch_bounds__(64) void k_eval_triangles(tp_view vw, const float2* points, int NP, const int32_t* tri3, int n,
+// variants: null (all base variants), or per triangle 0..12 -- variant i > 0 displaces vertex (i - 1) / 4 of the triple by move (i - 1) % 4 + 1
+// of vw.dp, as the vertex stage of the sweep does (triangle.vs:66-78)
+__global__ __launch_bounds__(64) void k_eval_triangles(tp_view vw, const float2* points, int NP, const int32_t* tri3, const int32_t* variants, int n,
                                                        const char* table, int px_pitch, int32_t* energy, int32_t* count) {
     const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= n) return;
+    const int variant = variants ? variants[t] : 0;
     int32_t X[3], Y[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         int v = tri3[3 * (size_t)t + k];
         v = v < 0 ? 0 : (v >= NP ? NP - 1 : v);   // (the entry has checked them; nothing is read out of bounds whatever comes)
         const float2 p = points[v];
-        tp_vertex_stage_d(p.x, p.y, 0.0f, 0.0f, vw, X[k], Y[k]);
+        tp_vertex_stage(p.x, p.y, variant, k, vw, X[k], Y[k]);
     }
     unsigned long long S[3][PK_SUM_WORDS];
     int dir[3];
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(64) void k_eval_triangles(tp_view vw, const float2*
 
 using namespace tpctx;
 
-extern "C" int tp_evaluate_triangles(tp_context* c, int slot, int n, const int32_t* vertices, int32_t* energy, int32_t* count) {
+extern "C" int tp_evaluate_triangles(tp_context* c, int slot, int n, const int32_t* vertices, const int32_t* variants, int32_t* energy, int32_t* count) {
     api_guard api_lock;
     if (!c) return TP_ERR_INVALID;
     if (n < 0 || (n > 0 && (!vertices || !energy))) return fail(c, TP_ERR_INVALID, "evaluate_triangles: bad arguments");
@@ -72,11 +75,13 @@ extern "C" int tp_evaluate_triangles(tp_context* c, int slot, int n, const int32
     if (!c->px_pitch || !c->px[slot]) return fail(c, TP_ERR_STATE, "evaluate_triangles: no pixel-record table of image %d (no image yet, or a raster beyond %d columns or rows)", slot, TP_PX_MAXW);
     for (int k = 0; k < 3 * n; k++)
         if (vertices[k] < 0 || vertices[k] >= c->NP) return fail(c, TP_ERR_INVALID, "evaluate_triangles: vertex %d of triangle %d is %d (NP=%d)", k % 3, k / 3, vertices[k], c->NP);
+    for (int k = 0; variants && k < n; k++)
+        if (variants[k] < 0 || variants[k] > 12) return fail(c, TP_ERR_INVALID, "evaluate_triangles: variant %d of triangle %d", variants[k], k);
     if (n == 0) return TP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = settle_persistent(c)) return rc;   // (the positions are those behind everything called so far)
-    // one pinned block {vertices in | energies, counts out} and its device twin, grown as needed
-    const size_t words = (size_t)5 * n;
+    // one pinned block {vertices, variants in | energies, counts out} and its device twin, grown as needed
+    const size_t words = (size_t)6 * n;
     if (words > c->eval_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->eval_host) hipHostFree(c->eval_host);
@@ -88,21 +93,24 @@ extern "C" int tp_evaluate_triangles(tp_context* c, int slot, int n, const int32
         c->eval_cap = cap;
     }
     memcpy(c->eval_host, vertices, sizeof(int32_t) * 3 * (size_t)n);
+    if (variants) memcpy(c->eval_host + 3 * (size_t)n, variants, sizeof(int32_t) * (size_t)n);
     tp_copy_list G{};   // (small: one kernel fetches the list across the link, another writes the answers back -- no copy commands)
-    G.src[0] = (const uint32_t*)c->eval_host; G.dst[0] = (uint32_t*)c->eval_dev; G.words[0] = (uint32_t)(3 * (size_t)n); G.n = 1;
+    G.src[0] = (const uint32_t*)c->eval_host; G.dst[0] = (uint32_t*)c->eval_dev; G.words[0] = (uint32_t)((variants ? 4 : 3) * (size_t)n); G.n = 1;
     tp_launch_copy_list(G, c->stream);
     tp_view vw;
-    vw.dp = 0.0f; vw.ratio = c->ratio; vw.halfW = 0.5f * (float)c->W; vw.halfH = 0.5f * (float)c->H; vw.W = c->W; vw.H = c->H;
-    int32_t* d_out = c->eval_dev + 3 * (size_t)n;
-    hipLaunchKernelGGL(k_eval_triangles, dim3((unsigned)n), dim3(64), 0, c->stream, vw, (const float2*)c->points, c->NP, (const int32_t*)c->eval_dev, n,
+    vw.dp = resolve_dp(c, TP_TRIANGULATE, c->dp_override);   // (the dp of the context's sweeps: tp_set_dp, or the reference's law at the uploaded NT)
+    vw.ratio = c->ratio; vw.halfW = 0.5f * (float)c->W; vw.halfH = 0.5f * (float)c->H; vw.W = c->W; vw.H = c->H;
+    int32_t* d_out = c->eval_dev + 4 * (size_t)n;
+    hipLaunchKernelGGL(k_eval_triangles, dim3((unsigned)n), dim3(64), 0, c->stream, vw, (const float2*)c->points, c->NP, (const int32_t*)c->eval_dev,
+                       variants ? (const int32_t*)(c->eval_dev + 3 * (size_t)n) : (const int32_t*)nullptr, n,
                        reinterpret_cast<const char*>(c->px[slot]), c->px_pitch, d_out, d_out + n);
     tp_copy_list B{};
-    B.src[0] = (const uint32_t*)d_out; B.dst[0] = (uint32_t*)(c->eval_host + 3 * (size_t)n); B.words[0] = (uint32_t)(2 * (size_t)n); B.n = 1;
+    B.src[0] = (const uint32_t*)d_out; B.dst[0] = (uint32_t*)(c->eval_host + 4 * (size_t)n); B.words[0] = (uint32_t)(2 * (size_t)n); B.n = 1;
     tp_launch_copy_list(B, c->stream);
     c->tail_is_finish = false;
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, wait_stream(c->stream));
-    memcpy(energy, c->eval_host + 3 * (size_t)n, sizeof(int32_t) * (size_t)n);
-    if (count) memcpy(count, c->eval_host + 4 * (size_t)n, sizeof(int32_t) * (size_t)n);
+    memcpy(energy, c->eval_host + 4 * (size_t)n, sizeof(int32_t) * (size_t)n);
+    if (count) memcpy(count, c->eval_host + 5 * (size_t)n, sizeof(int32_t) * (size_t)n);
     return TP_OK;
 }

@@ -104,7 +104,7 @@ int main(int argc, char** argv) {
         const auto t1 = now();
         t_device += secs(t0, t1);
 
-        bool updated = false;
+        bool updated = false, device_stale = false;
         if (tpose::geterr(&tr) < 1E-4) {
             if (exportlist.empty() || tr.NT > maxtris) { done = true; break; }
             if (tr.NT >= exportlist.back()) {
@@ -192,11 +192,18 @@ int main(int argc, char** argv) {
                 if (after > h.second) tr.flip(h.first, 0.0f);
             }
             const auto r4 = now();
-            tpose::upload(&tr, false);
-            const auto r5 = now();
-            tpose::computecolors();
-            tpose::doenergy();
-            tpose::retrieve_energy(&tr, !literal);
+            // ... and the energies of the mesh the flips left -- the reference's second "upload, computecolors, doenergy, read back": the same
+            // NT + 2 entries from the device without making the mesh real there.  The device then holds the mesh of before the flips until
+            // the upload at the end of this frame (a split follows almost always); if none comes, the mesh goes up there on its own.
+            auto r5 = r4;
+            if (evaluated && tpose::evaluate_mesh_energy(&tr)) device_stale = true;
+            else {
+                tpose::upload(&tr, false);
+                r5 = now();
+                tpose::computecolors();
+                tpose::doenergy();
+                tpose::retrieve_energy(&tr, !literal);
+            }
             const auto r6 = now();
             t_rank += secs(r0, r1) + secs(r3, r4); t_upload += secs(r1, r2) + secs(r4, r5); t_energy += secs(r2, r3) + secs(r5, r6);
 
@@ -232,7 +239,10 @@ int main(int argc, char** argv) {
             tpose::upload(&tr, false);
             tpose::computecolors();  // a new topology: the sweep cannot ride the next frame's fused sequence
             fresh = true;            // (upload drops the device lists; keep the reference's order of calls)
+        } else if (device_stale) {
+            tpose::upload(&tr, false);   // (flips the device has not seen, and nothing else changed: the next frame's fused sequence needs them)
         }
+        device_stale = false;
         t_loops += secs(t2, t3);
         t_reup += secs(t3, now());
     }
