@@ -164,9 +164,20 @@ struct triangulation {
         const vec2 A = points[org(ha)], B = points[org(hb)], C = points[apex(ha)], D = points[apex(hb)];
         if (ccw(A, C, D) == ccw(B, C, D) || ccw(A, B, C) == ccw(A, B, D)) return false;  // diagonals must cross
 
-        const float aa = angle(ha), ab = angle(hb);
-        if (aa + ab < minangle) return false;
-        if (aa <= 1E-8 || ab <= 1E-8) return false;
+        if (minangle <= 0.0f) {
+            // (the schedule's flip set: no bound on the angles' sum, only "neither angle is zero".  acos(x) of a float is 0 for x == 1 and at
+            // least acos(1 - 2^-24) = 3.5e-4 below it, and NaN -- which passes `<= 1E-8` as false -- above: no arc cosine needed to decide)
+            auto zero = [&](int h) {
+                const vec2 u = points[org(h)] - points[apex(h)], w = points[dst(h)] - points[apex(h)];
+                if (length(u) == 0 || length(w) == 0) return true;
+                return dot(u, w) / length(u) / length(w) == 1.0f;
+            };
+            if (zero(ha) || zero(hb)) return false;
+        } else {
+            const float aa = angle(ha), ab = angle(hb);
+            if (aa + ab < minangle) return false;
+            if (aa <= 1E-8 || ab <= 1E-8) return false;
+        }
 
         // the four outer half-edges around the quad, and the two triangles' labels, before the flip
         const int a1 = halfedges[3 * ta + (ja + 1) % 3], a2 = halfedges[3 * ta + (ja + 2) % 3];

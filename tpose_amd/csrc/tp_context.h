@@ -97,7 +97,7 @@ struct tp_context {
     uint64_t generation = 1;
     std::vector<graph_entry> graphs;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int32_t* eval_host = nullptr; int32_t* eval_dev = nullptr; size_t eval_cap = 0;   // tp_evaluate_triangles: {vertices | energies, counts}, pinned and device (words)
+    int32_t* eval_host = nullptr; size_t eval_cap = 0;   // tp_evaluate_triangles: {vertices, variants | energies, counts}, pinned (words)
     bool on_device = false;         // counted among its device's contexts (join_device / leave_device)
     hipEvent_t ev_turn = nullptr;   // behind this context's last persistent launch, when other contexts share the device (tp_persist_host.hip: device turns)
     uint8_t* pinned = nullptr;   // host-pinned staging for readbacks (one synchronisation per batch)

@@ -182,7 +182,6 @@ int tp_destroy(tp_context* c) {
         if (c->snap_ev[k]) hipEventDestroy(c->snap_ev[k]);
     }
     if (c->eval_host) hipHostFree(c->eval_host);
-    hipFree(c->eval_dev);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->up_pinned) hipHostFree(c->up_pinned);
     if (c->ev0) hipEventDestroy(c->ev0);

@@ -80,33 +80,26 @@ extern "C" int tp_evaluate_triangles(tp_context* c, int slot, int n, const int32
     if (n == 0) return TP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = settle_persistent(c)) return rc;   // (the positions are those behind everything called so far)
-    // one pinned block {vertices, variants in | energies, counts out} and its device twin, grown as needed
+    // one pinned block {vertices, variants in | energies, counts out}, grown as needed: the kernel reads its list and writes its answers
+    // across the link itself (a few words per wave) -- one launch and one wait per call, no copies
     const size_t words = (size_t)6 * n;
     if (words > c->eval_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->eval_host) hipHostFree(c->eval_host);
-        hipFree(c->eval_dev);
-        c->eval_host = nullptr; c->eval_dev = nullptr; c->eval_cap = 0;
+        c->eval_host = nullptr; c->eval_cap = 0;
         const size_t cap = words + words / 2 + 1024;
         HIP_TRY(c, hipHostMalloc((void**)&c->eval_host, cap * sizeof(int32_t), hipHostMallocDefault));
-        HIP_TRY(c, dev_alloc(&c->eval_dev, cap));
         c->eval_cap = cap;
     }
     memcpy(c->eval_host, vertices, sizeof(int32_t) * 3 * (size_t)n);
     if (variants) memcpy(c->eval_host + 3 * (size_t)n, variants, sizeof(int32_t) * (size_t)n);
-    tp_copy_list G{};   // (small: one kernel fetches the list across the link, another writes the answers back -- no copy commands)
-    G.src[0] = (const uint32_t*)c->eval_host; G.dst[0] = (uint32_t*)c->eval_dev; G.words[0] = (uint32_t)((variants ? 4 : 3) * (size_t)n); G.n = 1;
-    tp_launch_copy_list(G, c->stream);
     tp_view vw;
     vw.dp = resolve_dp(c, TP_TRIANGULATE, c->dp_override);   // (the dp of the context's sweeps: tp_set_dp, or the reference's law at the uploaded NT)
     vw.ratio = c->ratio; vw.halfW = 0.5f * (float)c->W; vw.halfH = 0.5f * (float)c->H; vw.W = c->W; vw.H = c->H;
-    int32_t* d_out = c->eval_dev + 4 * (size_t)n;
-    hipLaunchKernelGGL(k_eval_triangles, dim3((unsigned)n), dim3(64), 0, c->stream, vw, (const float2*)c->points, c->NP, (const int32_t*)c->eval_dev,
-                       variants ? (const int32_t*)(c->eval_dev + 3 * (size_t)n) : (const int32_t*)nullptr, n,
-                       reinterpret_cast<const char*>(c->px[slot]), c->px_pitch, d_out, d_out + n);
-    tp_copy_list B{};
-    B.src[0] = (const uint32_t*)d_out; B.dst[0] = (uint32_t*)(c->eval_host + 4 * (size_t)n); B.words[0] = (uint32_t)(2 * (size_t)n); B.n = 1;
-    tp_launch_copy_list(B, c->stream);
+    int32_t* out = c->eval_host + 4 * (size_t)n;
+    hipLaunchKernelGGL(k_eval_triangles, dim3((unsigned)n), dim3(64), 0, c->stream, vw, (const float2*)c->points, c->NP, (const int32_t*)c->eval_host,
+                       variants ? (const int32_t*)(c->eval_host + 3 * (size_t)n) : (const int32_t*)nullptr, n,
+                       reinterpret_cast<const char*>(c->px[slot]), c->px_pitch, out, out + n);
     c->tail_is_finish = false;
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, wait_stream(c->stream));

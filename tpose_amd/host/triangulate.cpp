@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
 
     long frame = 0;
     bool done = false;
-    double t_device = 0, t_converged = 0, t_loops = 0, t_rank = 0, t_upload = 0, t_energy = 0, t_reup = 0;  // where the wall time goes (stderr, with "seconds")
+    double t_device = 0, t_converged = 0, t_loops = 0, t_flip = 0, t_rank = 0, t_upload = 0, t_energy = 0, t_reup = 0;  // where the wall time goes (stderr, with "seconds")
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     while (!done && frame < maxframes) {
@@ -123,13 +123,18 @@ int main(int argc, char** argv) {
             const auto r0 = now();
             // (the order is that of a stable sort by descending energy: a stable radix sort on the float's bits, which order
             // like the values for the non-negative sums at hand; ties stay in insertion order, 3t + k ascending)
-            std::vector<std::pair<int, float>> ranked, spare;
+            // (... and the two half-edges of an edge carry the same energy, so the later one never survives the `unique` below: the
+            // shortcut path does not insert it in the first place -- half the entries to sort; the buffers live across the steps)
+            static std::vector<std::pair<int, float>> ranked, spare;
+            static std::vector<uint32_t> count;
+            ranked.clear();
             ranked.reserve(tr.triangles.size() * 3);
             bool radix_ok = !literal;
             for (int t = 0; t < (int)tr.triangles.size(); t++)
                 for (int k = 0; k < 3; k++) {
                     const int w = tr.halfedges[3 * t + k];
                     if (w < 0) continue;
+                    if (!literal && w < 3 * t + k) continue;
                     const float e = tpose::terr[t] + tpose::terr[w / 3];
                     radix_ok = radix_ok && e >= 0.0f;   // (false for negative sums, -0 and NaN alike: the comparison sort then)
                     ranked.emplace_back(3 * t + k, e == 0.0f ? 0.0f : e);
@@ -138,7 +143,7 @@ int main(int argc, char** argv) {
                 spare.resize(ranked.size());
                 for (int pass = 0; pass < 3; pass++) {   // digits of 11, 11 and 10 bits, least significant first, descending
                     const int shift = 11 * pass, bits = pass == 2 ? 10 : 11;
-                    std::vector<uint32_t> count((size_t)1 << bits, 0);
+                    count.assign((size_t)1 << bits, 0);
                     auto digit = [&](float e) { uint32_t b; memcpy(&b, &e, 4); return ((~b) >> shift) & ((1u << bits) - 1u); };
                     for (auto& r : ranked) count[digit(r.second)]++;
                     uint32_t run = 0;
@@ -150,8 +155,10 @@ int main(int argc, char** argv) {
                 std::stable_sort(ranked.begin(), ranked.end(), [](const std::pair<int, float>& l, const std::pair<int, float>& r) { return l.second > r.second; });
             }
             ranked.erase(std::unique(ranked.begin(), ranked.end(), [](const std::pair<int, float>& l, const std::pair<int, float>& r) { return l.second == r.second; }), ranked.end());
-            std::vector<char> locked(tr.halfedges.size(), 0);  // half-edges whose triangle already takes part in a flip
-            std::vector<std::pair<int, float>> chosen;          // half-edge -> pair energy before the flip, by half-edge (the reference's std::map order)
+            static std::vector<char> locked;                    // half-edges whose triangle already takes part in a flip
+            locked.assign(tr.halfedges.size(), 0);
+            static std::vector<std::pair<int, float>> chosen;   // half-edge -> pair energy before the flip, by half-edge (the reference's std::map order)
+            chosen.clear();
             for (auto& h : ranked) {
                 if (locked[h.first]) continue;
                 const int w = tr.halfedges[h.first];
@@ -161,8 +168,10 @@ int main(int argc, char** argv) {
                 for (int k = 0; k < 3; k++) { locked[3 * (h.first / 3) + k] = 1; locked[3 * (w / 3) + k] = 1; }
             }
             std::sort(chosen.begin(), chosen.end(), [](const std::pair<int, float>& l, const std::pair<int, float>& r) { return l.first < r.first; });
+            const auto r0b = now();
             for (auto& h : chosen) tr.flip(h.first, 0.0f);
             const auto r1 = now();
+            t_flip += secs(r0b, r1);
             // The reference makes the flip set real to look at it: upload, computecolors, doenergy, read `tenergy` back -- and then at two
             // entries per flipped edge.  A triangle's energy depends on its own pixels only, so those are the base energies of the two
             // triangles the flip WOULD leave: evaluated on the device at its current positions (= tr.points: read back this frame), nothing
@@ -192,6 +201,7 @@ int main(int argc, char** argv) {
                 if (after > h.second) tr.flip(h.first, 0.0f);
             }
             const auto r4 = now();
+            t_flip += secs(r3, r4);
             // ... and the energies of the mesh the flips left -- the reference's second "upload, computecolors, doenergy, read back": the same
             // NT + 2 entries from the device without making the mesh real there.  The device then holds the mesh of before the flips until
             // the upload at the end of this frame (a split follows almost always); if none comes, the mesh goes up there on its own.
@@ -250,7 +260,7 @@ int main(int argc, char** argv) {
               << (nlevels - (int)exportlist.size()) << std::endl;
     std::cerr << "frame device calls + readbacks " << t_device << " s, convergence steps (flip set, split) " << t_converged
               << " s, per-frame host loops (prune, angle, collapse) " << t_loops << " s, re-upload + computecolors after a change " << t_reup << " s" << std::endl;
-    std::cerr << "inside the convergence steps: ranking + flips " << t_rank << " s, uploads " << t_upload << " s, computecolors + doenergy + read-back "
+    std::cerr << "inside the convergence steps: ranking + flips " << t_rank << " s (the flips and flip-backs themselves " << t_flip << "), uploads " << t_upload << " s, computecolors + doenergy + read-back "
               << t_energy << " s" << std::endl;
     std::cerr << "seconds " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
     tpose::quit();
