@@ -201,3 +201,31 @@ def test_vertices_no_triangle_uses_keep_the_finishing_kernel():
     got = ctx.retrieve(capi.BUF_POINTS)
     assert got[n, 0] == np.float32(ratio) and got[n + 1, 1] == np.float32(-1.0) and np.array_equal(got[n + 2], pts2[n + 2])
     ctx.close()
+
+
+def test_two_contexts_on_one_device_take_turns():
+    """Two contexts of one process with persistent launches of both pending at once (the two directions of a warp, a batch): each launch
+    wants every compute unit, so they take turns on the device (an event behind each, a wait in front of the next context's) instead of
+    being handed out half a grid each and waiting out their time limit.  No launch gives up, and both follow the oracle."""
+    W = H = 2048
+    ctxs, refs = [], []
+    for seed in (11, 12):
+        img, pts, tris, he, ratio = synth.workload(W, H, 3000, seed=seed, contrast=0.1)
+        c = capi.Context(0, W, H)
+        c.set_image(capi.IMAGE_A, img)
+        c.upload(pts, tris, None)
+        ctxs.append(c)
+        refs.append((img, pts, tris, ratio))
+    p = capi.default_params(0)
+    for c in ctxs:
+        c.prepare(p)
+    total = 0
+    for n in (9, 6, 11, 5, 8, 7):          # enqueued alternately, nobody waits in between
+        for c in ctxs:
+            c.iterate(p, n)
+        total += n
+    for c, (img, pts, tris, ratio) in zip(ctxs, refs):
+        ref = O.iterate(img, pts, tris, 0, ratio, RATE[0], total, literal=False)
+        _compare(c, ref, 0)
+        assert c.info(capi.INFO_PERSIST_FAILURES) == 0 and c.info(capi.INFO_PERSIST_ITERS) == total
+        c.close()
