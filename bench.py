@@ -277,18 +277,27 @@ def pair_split_figure(capi, synth, dist_util, dist, rank, world, device, local_r
     if not agree(err is None):
         return {"error": err or "another rank failed to prepare"}
     times = []
-    try:
-        ctx.iterate(params, warmup)
+    info = {"persist_iters": 0, "gave_up": 0, "patches": 0}
+
+    def guarded(fn):   # (a rank whose call fails still takes part in every collective of the loop below)
+        nonlocal err
+        if err is None:
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001
+                err = "iterate: %s" % e
+
+    def step(n):
+        ctx.iterate(params, n)
         ctx.synchronize()
-        for rep in range(repeats):
-            dist.barrier()
-            t0 = time.perf_counter()
-            ctx.iterate(params, steps)
-            ctx.synchronize()
-            times.append(dist_util.max_over_ranks(dist, time.perf_counter() - t0, device))
-        info = {"persist_iters": ctx.info(capi.INFO_PERSIST_ITERS), "gave_up": ctx.info(capi.INFO_PERSIST_FAILURES), "patches": ctx.info(capi.INFO_PATCHES)}
-    except Exception as e:  # noqa: BLE001
-        err = "iterate: %s" % e
+
+    guarded(lambda: step(warmup))
+    for rep in range(repeats):
+        dist.barrier()
+        t0 = time.perf_counter()
+        guarded(lambda: step(steps))
+        times.append(dist_util.max_over_ranks(dist, time.perf_counter() - t0, device))
+    guarded(lambda: info.update(persist_iters=ctx.info(capi.INFO_PERSIST_ITERS), gave_up=ctx.info(capi.INFO_PERSIST_FAILURES), patches=ctx.info(capi.INFO_PATCHES)))
     if not agree(err is None):
         return {"error": err or "another rank failed while iterating"}
     gave_up = torch.tensor([info["gave_up"]], dtype=torch.int64, device=device)

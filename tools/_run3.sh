@@ -1,4 +1,2 @@
-mkdir -p gpurun_out
-(timeout 1800 python -m pytest tests -m gpu -x -q) > gpurun_out/r4_gputest6.log 2>&1; tail -3 gpurun_out/r4_gputest6.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-bash tools/collect_profiles.sh > gpurun_out/collect_r04.log 2>&1; tail -2 gpurun_out/collect_r04.log
+python tools/wave_timeline.py --rebuild > gpurun_out/r04/wave_timeline.json 2> gpurun_out/wave.err; tail -3 gpurun_out/wave.err; wc -c gpurun_out/r04/wave_timeline.json
+(timeout 600 python -m pytest tests/test_persist_sizes.py -m gpu -x -q -k "take_turns") 2>&1 | tail -3

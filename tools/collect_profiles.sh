@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt20 -o kt -- python 
 find $O -name "*kernel_trace.csv" -delete
 # 3. in-kernel timeline of the persistent kernel (debug flavour of the library): fresh mesh, and after 4000 grad-iters
 python tools/persist_timeline.py --rebuild > $O/persist_timeline.json 2> $O/persist_timeline.err
-python tools/wave_timeline.py > $O/wave_timeline.json 2>> $O/persist_timeline.err
+python tools/wave_timeline.py --rebuild > $O/wave_timeline.json 2>> $O/persist_timeline.err
 TPOSE_TIMELINE_AFTER=4000 python tools/persist_timeline.py > $O/persist_timeline_4000.json 2>> $O/persist_timeline.err
 python tools/launch_profile.py > $O/launch_profile.txt 2>> $O/persist_timeline.err   # the first grad-iters of a launch, one by one
 # 4. persistent path against the two-kernel path and the oracle: parity and timing, other configurations
