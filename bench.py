@@ -29,6 +29,7 @@ NT = 3000
 DOMINANT = "k_persist"  # the kernel the roofline figure is about: K grad-iters per launch
 CONTRAST = 0.1          # photograph-like contrast of the synthetic raster (tpose_amd/synth.py: workload)
 CHILD_ITERS = 256       # grad-iters per k_persist launch in the profiler passes
+CHILD_LAUNCHES = 16     # ... and launches per pass: the first 4096 grad-iters of the descent (the span the default warm-up and first timed regions cover)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -125,12 +126,12 @@ def live_pmc_traffic(timeout_s=150):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return int((2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]) * 1024), \
-        "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 4 launches of %d grad-iters each), 2 x FETCH + WRITE, KB" % CHILD_ITERS
+        "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, %d launches of %d grad-iters each), 2 x FETCH + WRITE, KB" % (CHILD_LAUNCHES, CHILD_ITERS)
 
 
 def live_kernel_trace(timeout_s=150):
     """Average duration of the kernels as rocprofv3 sees them: `rocprofv3 --kernel-trace --stats` over a child run of this
-    script (4 launches of CHILD_ITERS grad-iters of the same workload).  Returns ({kernel: avg_us}, note) or (None, reason)."""
+    script (CHILD_LAUNCHES launches of CHILD_ITERS grad-iters of the same workload).  Returns ({kernel: avg_us}, note) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -163,7 +164,7 @@ def live_kernel_trace(timeout_s=150):
                 # one of the launches is the census of resident workgroups (the same kernel, a few microseconds): leave it out
                 ns, calls = ns - a["min"], calls - 1
             out[name] = {"avg_us": ns / calls / 1e3, "calls": calls}
-        return out, "live: rocprofv3 --kernel-trace --stats over 4 launches of %d grad-iters (child run)" % CHILD_ITERS
+        return out, "live: rocprofv3 --kernel-trace --stats over %d launches of %d grad-iters (child run)" % (CHILD_LAUNCHES, CHILD_ITERS)
     except Exception as e:  # noqa: BLE001 -- measurement is best effort, the bench line must still appear
         return None, "kernel trace: %s" % e
     finally:
@@ -410,7 +411,7 @@ def main():
 
     if args.pmc_child or args.trace_child:  # what the profiler passes sample: fused grad-iters, nothing else
         ctx.prepare(params)
-        for _ in range(4):
+        for _ in range(CHILD_LAUNCHES):
             ctx.iterate(params, CHILD_ITERS)
         ctx.synchronize()
         ctx.close()
@@ -599,8 +600,8 @@ def main():
                 "kernel": DOMINANT, "kernel_us": kern_us, "grad_iters_per_launch": CHILD_ITERS,
                 "us_per_grad_iter": kern_us / CHILD_ITERS,
                 "algorithmic_bytes": bytes_iter * CHILD_ITERS, "algorithmic_bytes_per_grad_iter": bytes_iter,
-                "kernel_timing": ("average duration in a rocprofv3 --kernel-trace --stats pass over a child run (4 launches of "
-                                  "%d grad-iters), collected by this command" % CHILD_ITERS if trace and DOMINANT in trace else
+                "kernel_timing": ("average duration in a rocprofv3 --kernel-trace --stats pass over a child run (%d launches of "
+                                  "%d grad-iters: the first %d of the descent), collected by this command" % (CHILD_LAUNCHES, CHILD_ITERS, CHILD_LAUNCHES * CHILD_ITERS) if trace and DOMINANT in trace else
                                   "HIP events (kernel trace unavailable: %s)" % trace_note),
                 "kernel_trace_us": trace,
                 "kernel_us_hip_events": kern_us_events,

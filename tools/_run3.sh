@@ -1,2 +1,6 @@
-python tools/wave_timeline.py --rebuild > gpurun_out/r04/wave_timeline.json 2> gpurun_out/wave.err; tail -3 gpurun_out/wave.err; wc -c gpurun_out/r04/wave_timeline.json
-(timeout 600 python -m pytest tests/test_persist_sizes.py -m gpu -x -q -k "take_turns") 2>&1 | tail -3
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 600 python bench.py --no-cpu-baseline > gpurun_out/r4_bdef.json 2>gpurun_out/r4_bdef.err; python -c "
+import json; d=json.load(open('gpurun_out/r4_bdef.json')); r=d['roofline']; print('bench ms_per_step', d['ms_per_step'], 'frac', r['frac'], r['us_per_grad_iter'], r['traffic'], r['kernel_timing'])"
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r4_b20.json 2>gpurun_out/r4_b20.err; python -c "
+import json; d=json.load(open('gpurun_out/r4_b20.json')); r=d['roofline']; print('bench20 ms_per_step', d['ms_per_step'], 'frac', r['frac'], r['us_per_grad_iter'], r['traffic'])"

@@ -2,7 +2,7 @@
 """Per-kernel hardware counters of the headline workload: runs `rocprofv3 --pmc <counters>` (counters only, no trace
 domains; one pass per group) over tools/time_acc.py and prints the per-launch average of every counter for every
 kernel.  Needs an MI355X.   python tools/pmc_kernels.py [out.json]
-TPOSE_PMC_TARGET=persist: over `bench.py --pmc-child` instead (4 persistent launches of 256 grad-iters on the bench's raster; the
+TPOSE_PMC_TARGET=persist: over `bench.py --pmc-child` instead (16 persistent launches of 256 grad-iters on the bench's raster; the
 census launch -- the same kernel, a few microseconds -- is left out of k_persist's averages)."""
 import csv
 import glob
