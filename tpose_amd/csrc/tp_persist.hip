@@ -400,9 +400,6 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 A.ten[t] = pk_energy(mm, A.flavour, col); A.cn[t] = tp_wrap32(mm.n);
             }
         }
-#if defined(PK_EXP_C1_ENDBAR)
-        __syncthreads();
-#endif
         PK_STAMP(4); PK_WSTAMP(8);
         PK_STAMP(5); PK_WSTAMP(10);
         // (no barrier here: P0 of the next grad-iter touches foreign position slots only, and its barrier orders the rest)
