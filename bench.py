@@ -29,6 +29,7 @@ NT = 3000
 DOMINANT = "k_persist"  # the kernel the roofline figure is about: K grad-iters per launch
 CONTRAST = 0.1          # photograph-like contrast of the synthetic raster (tpose_amd/synth.py: workload)
 CHILD_ITERS = 256       # grad-iters per k_persist launch in the profiler passes
+PAIR_SPLIT_DEADLINE_S = 240   # the one-pair-on-all-GPUs figure runs under this deadline (bench.py --gpus N)
 CHILD_LAUNCHES = 16     # ... and launches per pass: the first 4096 grad-iters of the descent (the span the default warm-up and first timed regions cover)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -526,13 +527,6 @@ def main():
     cold = None
     if rank == 0 and world == 1 and not args.no_cold:
         cold = cold_cache_figure(capi, synth, local_rank, params, pts, tris, args.flavour)
-    # N > 1: beside the replicas, ONE pair on all the GPUs (row e3) -- after the headline regions, in a context of its own
-    pair = None
-    if dist is not None and world in (2, 4, 8) and not args.no_pair_split:
-        try:
-            pair = pair_split_figure(capi, synth, dist_util, dist, rank, world, device, local_rank, args.share_gpu, args.steps, args.warmup, args.repeats)
-        except Exception as e:  # noqa: BLE001 -- an extra figure: the bench line must still appear
-            pair = {"error": str(e)}
     bytes_iter = algorithmic_bytes(W, H, NT, NP)
     # the same kernel as rocprofv3 sees it (what profiles/ holds): the roofline figure uses THIS duration when it is
     # available, so that it can be reproduced from a kernel trace; the HIP-event figure stays beside it
@@ -552,6 +546,7 @@ def main():
         ctx.synchronize()
         traffic, traffic_source = live_pmc_traffic()
 
+    line = None
     if rank == 0:
         line = {
             "metric": "triangles*grad-iters/sec at 2048^2/3000 tris; HBM GB/s vs roofline",
@@ -610,12 +605,39 @@ def main():
                 "kernel_us_samples": ev_samples,
             },
         }
-        if pair is not None:
-            line["pair_split"] = pair
         if cold is not None:
             line["cold_cache"] = cold
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(img if args.flavour == 0 else imgB, pts, tris, ratio)
+    # N > 1: beside the replicas, ONE pair on all the GPUs (row e3) -- LAST, in a context of its own, with the headline already in hand:
+    # it has only ever run with its ranks sharing one GPU, so it runs under a deadline -- if any rank is stuck in it (a collective another
+    # rank never reaches, a mailbox that cannot be mapped across devices), rank 0 prints the line without the figure and every rank leaves.
+    if dist is not None and world in (2, 4, 8) and not args.no_pair_split:
+        import threading
+        printed = threading.Lock()
+
+        def give_up():
+            if not printed.acquire(blocking=False):
+                return
+            if rank == 0 and line is not None:
+                line["pair_split"] = {"error": "no answer within %d s: a rank is stuck in the band split; left out" % PAIR_SPLIT_DEADLINE_S}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(PAIR_SPLIT_DEADLINE_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            pair = pair_split_figure(capi, synth, dist_util, dist, rank, world, device, local_rank, args.share_gpu, args.steps, args.warmup, args.repeats)
+        except Exception as e:  # noqa: BLE001 -- an extra figure: the bench line must still appear
+            pair = {"error": str(e)}
+        watchdog.cancel()
+        if not printed.acquire(blocking=False):
+            time.sleep(60)   # (the watchdog is printing: it ends the process)
+            return
+        if line is not None and pair is not None:
+            line["pair_split"] = pair
+    if line is not None:
         print(json.dumps(line), flush=True)
 
     ctx.close()

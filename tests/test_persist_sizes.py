@@ -229,3 +229,41 @@ def test_two_contexts_on_one_device_take_turns():
         _compare(c, ref, 0)
         assert c.info(capi.INFO_PERSIST_FAILURES) == 0 and c.info(capi.INFO_PERSIST_ITERS) == total
         c.close()
+
+
+@pytest.mark.parametrize("first", [1, 2])
+def test_a_small_mesh_whose_early_launch_gives_up(first):
+    """tools/run_batch.py in the small (512^2, 150 triangles, warp flavour, two contexts of one process): the FIRST or second persistent
+    launch of a context gives up; the calls are run again and the energies and positions are the oracle's -- also for a read-back right
+    behind the call that gave up (round 4: such a read-back returned what the buffers held BEFORE the replay; seen once as a two-rank batch
+    whose `energy_before` was 0)"""
+    W = H = 512
+    img, pts, tris, he, ratio = synth.workload(W, H, 150, seed=4001)
+    imgB = synth.displaced_raster(img)
+    colors = synth.mean_colors(img, pts, tris, ratio)
+    ctxs = []
+    for k in range(2):
+        c = capi.Context(0, W, H)
+        c.set_image(capi.IMAGE_A, img); c.set_image(capi.IMAGE_B, imgB)
+        c.upload(pts, tris, colors)
+        ctxs.append(c)
+    p = capi.default_params(capi.WARP)
+    ctxs[0].set_option(capi.OPT_INJECT_GIVE_UP, first)
+    for c in ctxs:
+        c.iterate(p, 16)
+    # (read back right behind the call, nothing waited for in between: the read-back itself finds the launch that gave up, has its call run
+    # again and must then return what THAT left -- tools/run_batch.py's `energy_before`)
+    e0 = [c.retrieve(capi.BUF_TENERGY)[:150].astype(np.int64).sum() for c in ctxs]
+    ref16 = O.iterate(imgB, pts, tris, 1, ratio, RATE[1], 16, colors=colors, literal=False)
+    assert all(e == ref16["ten"][:150].astype(np.int64).sum() for e in e0), e0
+    for c in ctxs:
+        c.iterate(p, 48)
+    for c in ctxs:
+        c.synchronize()
+    ref = O.iterate(imgB, pts, tris, 1, ratio, RATE[1], 64, colors=colors, literal=False)
+    for k, c in enumerate(ctxs):
+        _compare(c, ref, 1, "context %d" % k)
+        assert c.retrieve(capi.BUF_TENERGY)[:150].astype(np.int64).sum() < e0[k]
+    assert ctxs[0].info(capi.INFO_PERSIST_FAILURES) == 1 and ctxs[1].info(capi.INFO_PERSIST_FAILURES) == 0
+    for c in ctxs:
+        c.close()

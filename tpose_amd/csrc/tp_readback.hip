@@ -92,33 +92,41 @@ int tp_retrieve_many(tp_context* c, int n, const int* what, void* const* dst, co
     }
     std::vector<const void*> src(n);
     std::vector<size_t> bytes(n), off(n);
-    size_t total = 0;
-    for (int k = 0; k < n; k++) {
-        if (!dst[k] && count[k]) return fail(c, TP_ERR_INVALID, "retrieve: dst is NULL");
-        if (int rc = buffer_source(c, what[k], count[k], &src[k], &bytes[k])) return rc;
-        off[k] = total;
-        total += (bytes[k] + 255) & ~(size_t)255;
-    }
-    if (total > c->pinned_bytes) {
-        if (c->pinned) hipHostFree(c->pinned);
-        c->pinned = nullptr; c->pinned_bytes = 0;
-        HIP_TRY(c, hipHostMalloc((void**)&c->pinned, total + total / 2, hipHostMallocDefault));
-        c->pinned_bytes = total + total / 2;
-    }
     // everything rides the context's stream behind the enqueued work: ONE wait for the whole batch.  Small batches (the
     // per-frame read-backs of the schedules) are written into the pinned buffer by one kernel instead of one copy command each
-    if (n <= TP_COPY_MAX && total <= ((size_t)4 << 20)) {
-        tp_copy_list G{};
-        for (int k = 0; k < n; k++)
-            if (bytes[k]) { G.src[G.n] = (const uint32_t*)src[k]; G.dst[G.n] = (uint32_t*)(c->pinned + off[k]); G.words[G.n] = (uint32_t)(bytes[k] / 4); G.n++; }
-        tp_launch_copy_list(G, c->stream);
-        HIP_TRY(c, hipGetLastError());
-    } else {
-        for (int k = 0; k < n; k++)
-            if (bytes[k]) HIP_TRY(c, hipMemcpyAsync(c->pinned + off[k], src[k], bytes[k], hipMemcpyDeviceToHost, c->stream));
-    }
-    HIP_TRY(c, wait_stream(c->stream));
+    auto copy_all = [&]() -> int {
+        size_t total = 0;
+        for (int k = 0; k < n; k++) {
+            if (!dst[k] && count[k]) return fail(c, TP_ERR_INVALID, "retrieve: dst is NULL");
+            if (int rc = buffer_source(c, what[k], count[k], &src[k], &bytes[k])) return rc;
+            off[k] = total;
+            total += (bytes[k] + 255) & ~(size_t)255;
+        }
+        if (total > c->pinned_bytes) {
+            if (c->pinned) hipHostFree(c->pinned);
+            c->pinned = nullptr; c->pinned_bytes = 0;
+            HIP_TRY(c, hipHostMalloc((void**)&c->pinned, total + total / 2, hipHostMallocDefault));
+            c->pinned_bytes = total + total / 2;
+        }
+        if (n <= TP_COPY_MAX && total <= ((size_t)4 << 20)) {
+            tp_copy_list G{};
+            for (int k = 0; k < n; k++)
+                if (bytes[k]) { G.src[G.n] = (const uint32_t*)src[k]; G.dst[G.n] = (uint32_t*)(c->pinned + off[k]); G.words[G.n] = (uint32_t)(bytes[k] / 4); G.n++; }
+            tp_launch_copy_list(G, c->stream);
+            HIP_TRY(c, hipGetLastError());
+        } else {
+            for (int k = 0; k < n; k++)
+                if (bytes[k]) HIP_TRY(c, hipMemcpyAsync(c->pinned + off[k], src[k], bytes[k], hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_TRY(c, wait_stream(c->stream));
+        return TP_OK;
+    };
+    const int64_t failures = c->persist_failures;
+    if (int rc = copy_all()) return rc;
     if (int rc = check_persist_status(c)) return rc;
+    // a persistent launch ahead of the copy had given up: its calls were run again just now, and what the copy took is from before that
+    // (the positions may even live in the other buffer by now) -- once more
+    if (c->persist_failures != failures) { if (int rc = copy_all()) return rc; }
     for (int k = 0; k < n; k++) {
         if (bytes[k]) memcpy(dst[k], c->pinned + off[k], bytes[k]);
         else if (what[k] == TP_BUF_PENERGY) memset(dst[k], 0, count[k] * 4);
