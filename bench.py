@@ -29,7 +29,7 @@ NT = 3000
 DOMINANT = "k_persist"  # the kernel the roofline figure is about: K grad-iters per launch
 CONTRAST = 0.1          # photograph-like contrast of the synthetic raster (tpose_amd/synth.py: workload)
 CHILD_ITERS = 256       # grad-iters per k_persist launch in the profiler passes
-PAIR_SPLIT_DEADLINE_S = 240   # the one-pair-on-all-GPUs figure runs under this deadline (bench.py --gpus N)
+PAIR_SPLIT_DEADLINE_S = 150   # the one-pair-on-all-GPUs figure runs under this deadline (bench.py --gpus N)
 CHILD_LAUNCHES = 16     # ... and launches per pass: the first 4096 grad-iters of the descent (the span the default warm-up and first timed regions cover)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
