@@ -60,6 +60,7 @@ void tp_launch_selftest_line(const int4* ends, const int* H, int n, int rows, in
 #define TP_COPY_MAX 8
 struct tp_copy_list { const uint32_t* src[TP_COPY_MAX]; uint32_t* dst[TP_COPY_MAX]; uint32_t words[TP_COPY_MAX]; int n; };
 void tp_launch_copy_list(const tp_copy_list& G, hipStream_t s);
+void tp_launch_frame_sums(const int32_t* ering, int C, int NT, float* out, hipStream_t s);   // out: device-visible (pinned) float[C]
 void tp_launch_render(const tp_launch& L, const float2* pts, int source, void* out, int out_pitch_px, hipStream_t s);
 
 // ---- persistent grad-iter kernel (tp_persist.hip): K grad-iters per launch, one workgroup per patch of the mesh

@@ -497,6 +497,21 @@ __global__ __launch_bounds__(256) void k_copy_list(tp_copy_list G) {
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < G.words[k]; i += gridDim.x * 256u) dst[i] = src[i];
     }
 }
+// tp_iterate_until: geterr's float32 sum of a frame's base energies, ascending t (source/triangulation.hpp:653-674), for the C frames of a
+// chunk -- one lane per frame.  A frame's sum is ONE chain of NT dependent additions in the reference's order (float addition does not
+// reassociate), but the frames do not depend on each other: 256 chains side by side here instead of 3 MB across the link and 8 at a
+// time on the host.  Written straight into the pinned buffer the host tests from.
+__global__ __launch_bounds__(64) void k_frame_sums(const int32_t* ering, int C, int NT, float* out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= C) return;
+    const int32_t* e = ering + (size_t)j * NT;
+    float newerr = 0.0f;
+    for (int i = 0; i < NT; i++) { float err = 0.0f; err += (float)e[i]; newerr += err; }
+    out[j] = newerr;
+}
+void tp_launch_frame_sums(const int32_t* ering, int C, int NT, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_frame_sums, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, ering, C, NT, out);
+}
 void tp_launch_copy_list(const tp_copy_list& G, hipStream_t s) {
     uint32_t most = 0;
     for (int k = 0; k < G.n; k++) most = G.words[k] > most ? G.words[k] : most;
