@@ -498,19 +498,39 @@ __global__ __launch_bounds__(256) void k_copy_list(tp_copy_list G) {
     }
 }
 // tp_iterate_until: geterr's float32 sum of a frame's base energies, ascending t (source/triangulation.hpp:653-674), for the C frames of a
-// chunk -- one lane per frame.  A frame's sum is ONE chain of NT dependent additions in the reference's order (float addition does not
-// reassociate), but the frames do not depend on each other: 256 chains side by side here instead of 3 MB across the link and 8 at a
-// time on the host.  Written straight into the pinned buffer the host tests from.
+// chunk.  A frame's sum is ONE chain of NT dependent additions in the reference's order (float addition does not reassociate), but the
+// frames do not depend on each other: one wave per frame here instead of 3 MB across the link and eight chains at a time on the host.
+// The wave fetches 512 energies at a time, coalesced (the next 512 are on their way while these are added), and every lane runs the same
+// chain over them, element after element out of the lanes' registers.  Written straight into the pinned buffer the host tests from.
 __global__ __launch_bounds__(64) void k_frame_sums(const int32_t* ering, int C, int NT, float* out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.x, lane = threadIdx.x;
     if (j >= C) return;
     const int32_t* e = ering + (size_t)j * NT;
-    float newerr = 0.0f;
-    for (int i = 0; i < NT; i++) { float err = 0.0f; err += (float)e[i]; newerr += err; }
-    out[j] = newerr;
+    auto fetch = [&](int base, float v[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int i = base + 64 * k + lane; v[k] = i < NT ? (float)e[i] : 0.0f; }
+    };
+    float newerr = 0.0f, cur[8], nxt[8];
+    fetch(0, cur);
+    for (int base = 0; base < NT; base += 512) {
+        if (base + 512 < NT) fetch(base + 512, nxt);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int left = NT - (base + 64 * k);   // (the same for every lane)
+            if (left >= 64) {
+#pragma unroll
+                for (int l = 0; l < 64; l++) { float err = 0.0f; err += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[k]), l)); newerr += err; }
+            } else {
+                for (int l = 0; l < left; l++) { float err = 0.0f; err += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[k]), l)); newerr += err; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+    }
+    if (lane == 0) out[j] = newerr;
 }
 void tp_launch_frame_sums(const int32_t* ering, int C, int NT, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_frame_sums, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, ering, C, NT, out);
+    hipLaunchKernelGGL(k_frame_sums, dim3((unsigned)C), dim3(64), 0, s, ering, C, NT, out);
 }
 void tp_launch_copy_list(const tp_copy_list& G, hipStream_t s) {
     uint32_t most = 0;

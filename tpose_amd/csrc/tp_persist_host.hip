@@ -420,9 +420,11 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
         const float2* pring = shared ? band_pring(c, c->band) + (size_t)c->ring_half * (PK_RING_FRAMES / 2) * (size_t)c->NP : c->pring;
         if (int rc = host_ring((size_t)256 * NT)) return rc;   // (for the longest chunk at once: freeing pinned memory waits for the device)
         if (int rc = enqueue_persistent(c, *p, dp, C, true)) return rc;
-        // the frames' sums: on the device for a context on its own (one chain per lane, written into the pinned buffer); a band split's rings
-        // are the bands' shared mailboxes, read back and summed on the host as before
-        if (!shared) tp_launch_frame_sums(ering, C, NT, (float*)c->ering_host, c->stream);
+        // the frames' sums: on the device for the long chunks of a context on its own (one wave per frame, written into the pinned buffer:
+        // 256 frames of 3000 energies are 3 MB across the link and 0.1 ms of host additions otherwise); short chunks and a band split's
+        // rings (the bands' shared mailboxes) are read back and summed on the host -- a launch more would cost a short chunk more than it saves
+        const bool device_sums = !shared && C >= 64;
+        if (device_sums) tp_launch_frame_sums(ering, C, NT, (float*)c->ering_host, c->stream);
         else HIP_TRY(c, hipMemcpyAsync(c->ering_host, ering, sizeof(int32_t) * (size_t)C * NT, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, wait_stream(c->stream));
@@ -431,7 +433,7 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
             if (int rc = check_persist_status(c)) return rc;
             if (c->persist_failures != fails) { use = false; continue; }   // the chunk gave up (nothing changed): frame by frame from here
         }
-        if (shared) chunk_sums(c->ering_host, C);
+        if (!device_sums) chunk_sums(c->ering_host, C);
         else sums.assign((const float*)c->ering_host, (const float*)c->ering_host + C);
         int j = 0;
         for (; j < C; j++) {
