@@ -19,6 +19,9 @@ e = st[:, 0, 12]
 if (e > 0).all():
     print("kernel entry: workgroups within %.1f us of each other; tables in LDS %.2f us after entry (median), prologue over %.2f, first grad-iter begins %.2f; last workgroup's first grad-iter begins %.1f us after the first workgroup's entry"
           % ((e.max() - e.min()) / 100.0, np.median(st[:, 0, 13] - e) / 100.0, np.median(st[:, 0, 14] - e) / 100.0, np.median(st[:, 0, 0] - e) / 100.0, (st[:, 0, 0].max() - e.min()) / 100.0))
+if (st[:, 0, 6] > 0).all() and (st[:, 0, 7] > 0).all():
+    print("grad-iter 0, P1 in parts (us, medians): line set-up + barrier %.2f, the cut of the lines on one wave + barrier %.2f, lane-item table + the lanes' items + barrier %.2f"
+          % (np.median(st[:, 0, 6] - st[:, 0, 1]) / 100.0, np.median(st[:, 0, 7] - st[:, 0, 6]) / 100.0, np.median(st[:, 0, 2] - st[:, 0, 7]) / 100.0))
 print("it  start(med, us after the first workgroup's first stamp)  period  P0  P1  P3  P6")
 for it in range(24):
     s = np.median(st[:, it, 0] - t0) / 100.0

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         PK_WSTAMP(3);
         __syncthreads();
         PK_WSTAMP(4);
+        PK_STAMP(6);
         if (recut) {
             if (tid < 64) {
                 // (the first cut of a launch always counts as a change: every thread's lane-items are decided there -- also in a patch
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 if (tid == 0) { V.flags[1] = changed; V.flags[2] = rpl; }
             }
             __syncthreads();
+            PK_STAMP(7);
             n_li_now = V.cut[w.n_lines]; n_li_all_now = V.cut[w.n_lines_all];
             if (V.flags[1]) {
                 for (int l = tid; l < w.n_lines_all; l += PK_THREADS) pk_list_line(V, l, n_li_now < PK_CACHED ? n_li_now : PK_CACHED, w.li_cap);
