@@ -95,7 +95,8 @@ int tp_set_dp(tp_context* ctx, float dp);
  * resident; TP_PERSIST_OFF keeps every grad-iter on the two-kernel path (k_lines + k_update).
  * TP_OPT_INJECT_GIVE_UP (tests): n > 0 makes one workgroup of the n-th persistent launch from now give up before its last grad-iter,
  * as if the launch's workgroups had not all been resident: the launch and those behind it are run again on the two-kernel path
- * (tp_get_info 9 counts it) and the context stops using persistent launches. */
+ * (tp_get_info 9 counts it) and the context keeps to the two-kernel path for a while (0.2 s; longer after every further give-up, for good
+ * after the fourth). */
 enum tp_option { TP_OPT_PERSISTENT = 1, TP_OPT_INJECT_GIVE_UP = 3 };
 enum { TP_PERSIST_OFF = 0, TP_PERSIST_AUTO = 1 };
 int tp_set_option(tp_context* ctx, int option, int64_t value);

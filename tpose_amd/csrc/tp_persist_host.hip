@@ -23,7 +23,7 @@ unsigned long long* persist_dbg_buffer(int parts, hipStream_t s) {
 // the same GPU at that moment (the census only shows that a full grid fits an otherwise idle device).  A launch that
 // gives up changes nothing: `points` is only written by the small kernel behind it, which does nothing once the status
 // word is raised, and so do all later persistent launches.  So the grad-iters of the launches that did not complete are
-// run again here, on the two-kernel path, and the context stops using persistent launches.
+// run again here, on the two-kernel path, and the context stops using persistent launches for a while.
 int check_persist_status(tp_context* c) {
     if (!c->persist_unchecked || !c->d_status) return TP_OK;
     c->persist_unchecked = false;
@@ -37,8 +37,12 @@ int check_persist_status(tp_context* c) {
     HIP_TRY(c, hipMemset(c->d_status, 0, sizeof(unsigned)));
     HIP_TRY(c, hipMemset(c->d_status + 3, 0, sizeof(unsigned)));   // (the tickets of a launch that finishes itself and gave up on the way)
     c->h_status[0] = 0u;
-    c->census = -6;  // two kernels per grad-iter from now on in this context
+    // two kernels per grad-iter from now on -- for a while: a collision with somebody else's launch is a transient thing, and the
+    // two-kernel path is three times slower.  Persistent launches are tried again 0.2 s later (0.8, 3.2, 12.8 s after the next ones; a
+    // context whose launches keep giving up -- a device it really shares -- stays on the two-kernel path after the fourth).
+    c->census = -6;
     c->persist_failures++;
+    c->persist_retry_at = std::chrono::steady_clock::now() + std::chrono::milliseconds(200ll << (2 * (c->persist_failures < 4 ? c->persist_failures - 1 : 3)));
     c->mutations++; c->tail_is_finish = false;  // (what a retrieve returns is about to change)
     std::vector<tp_context::journal_entry> todo(c->journal.begin() + (completed < c->journal.size() ? completed : c->journal.size()), c->journal.end());
     c->journal.clear();
@@ -176,6 +180,8 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every) {
     if (c->n_bands > 1) base_every = true;
     if (c->persist_mode == TP_PERSIST_OFF || !c->px_pitch) return TP_OK;  // (rasters beyond 4096 columns or rows have no pixel-record table)
     if (int rc = take_census(c)) return rc;
+    if (c->census == -6 && c->n_bands == 1 && c->persist_failures <= 4 && std::chrono::steady_clock::now() >= c->persist_retry_at)
+        c->census = 1;   // (the census itself had passed: a launch gave up later, check_persist_status)
     if (c->census != 1) return TP_OK;
     if (c->plan_generation == c->generation && base_every && !c->plan_base_every) {
         // the plan of this triangulation does not walk the base lines in every grad-iter yet: cut it again (from the
