@@ -96,6 +96,10 @@ hipError_t wait_context(tp_context* c) {
 // waits for all the others.  If that times out, workgroups of such a grid are not resident together on this device
 // (CU masking, another process) and hand-overs inside a launch would never complete: the context keeps to two kernels.
 int take_census(tp_context* c) {
+    // (a census that timed out says the device was busy at that moment -- another process's grid -- not that a full grid never fits:
+    // once more a second later, and once more four seconds after that; each try that fails costs its 30 ms)
+    if ((c->census == -4 || c->census == -5) && c->census_retries < 2 && c->journal.empty() &&
+        std::chrono::steady_clock::now() >= c->persist_retry_at) { c->census = 0; c->census_retries++; }
     if (c->census != 0) return TP_OK;
     c->census = -1;
     if (c->num_cus < 1) return TP_OK;
@@ -118,7 +122,10 @@ int take_census(tp_context* c) {
     HIP_TRY(c, hipMemset(c->d_status, 0, 4 * sizeof(unsigned)));
     c->done_base = 0;
     if (st[0] == 0u && st[1] == (unsigned)full) c->census = 1;
-    else c->census = -4 - (int)(st[0] != 0u);
+    else {
+        c->census = -4 - (int)(st[0] != 0u);
+        c->persist_retry_at = std::chrono::steady_clock::now() + std::chrono::milliseconds(c->census_retries == 0 ? 1000 : 4000);
+    }
     return TP_OK;
 }
 
