@@ -727,6 +727,13 @@ def test_evaluate_triangles_is_the_base_energy(size, grid):
     for i in range(1, 13):
         ei, ni = ctx.evaluate_triangles(tris[:, :3], variants=np.full(NT, i, np.int32))
         assert np.array_equal(ei, ref["ten"][i * NT: (i + 1) * NT]) and np.array_equal(ni, ref["cn"][i * NT: (i + 1) * NT]), i
+    # ... and with tp_set_dp in force: the displaced variants follow it
+    ctx.set_dp(0.02)
+    ref_dp = O.iterate(img, moved, tris, O.TRIANGULATE, ratio, RATE[0], 1, dp_=0.02, literal=False)
+    for i in (1, 6, 12):
+        ei, ni = ctx.evaluate_triangles(tris[:, :3], variants=np.full(NT, i, np.int32))
+        assert np.array_equal(ei, ref_dp["ten"][i * NT: (i + 1) * NT]) and np.array_equal(ni, ref_dp["cn"][i * NT: (i + 1) * NT]), ("dp", i)
+    ctx.set_dp(0.0)
     e2, n2 = ctx.evaluate_triangles(tris[:, [2, 0, 1]])          # rotated
     e3, n3 = ctx.evaluate_triangles(tris[:, [1, 0, 2]])          # mirrored
     assert np.array_equal(e2, e) and np.array_equal(e3, e) and np.array_equal(n2, n) and np.array_equal(n3, n)
