@@ -252,6 +252,13 @@ int tp_selftest_walker(tp_context* ctx, const int64_t* N0, const int32_t* step, 
  * column (not clamped to the raster) of `rows` consecutive rows from the first, from the one set-up of the line. */
 int tp_selftest_line(tp_context* ctx, const int32_t* ends, const int32_t* H, int n, int rows, int32_t* out);
 
+/* device self-test of the arithmetic between a patch's line sums and a variant's energy as k_persist runs it (round 5: packed 64-bit
+ * words, float reciprocal with a remainder fix) beside the general 64-bit form (triangle.fs:37-43 / warp :46-53 from exact moments).
+ * Case k: sums[12k ..] = three lines x four words {n | n_odd << 32, sum r | sum g << 32, sum b, q}; meta[8k ..] = the lines' directions
+ * (+1 / -1 / 0), flip bits, flavour, stored colour r, g, b.  out[10k ..] = n, n_odd, sum r, sum g, sum b, q low, q high (packed form),
+ * energy (packed form), energy (general form), 1 when the six moments of the two forms agree. */
+int tp_selftest_variant(tp_context* ctx, const uint64_t* sums, const int32_t* meta, int n, int32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

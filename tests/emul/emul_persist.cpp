@@ -32,6 +32,68 @@ extern "C" int emul_magic_check() {
     return bad;
 }
 
+// The packed form of a variant's moments and energy (tp_persist.h: pk_signed_packed, pk_energy_var) against the general 64-bit form
+// (pk_signed_moments, pk_energy) on made-up line sums: M = the moments of a covered pixel set (up to 2^24 pixels), three line sums with
+// W_a + W_b - W_c = M under random signs, orientations, flips, level lines and orders; fields at their limits.  Returns mismatches.
+extern "C" int emul_packed_check(uint64_t seed, int trials) {
+    auto rnd = [&]() { seed += 0x9e3779b97f4a7c15ull; uint64_t z = seed; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); };
+    std::vector<char> lds(4096, 0);
+    pk_view V;
+    V.sums = (unsigned long long*)lds.data();
+    V.ldir = (int32_t*)(lds.data() + 2048);
+    int bad = 0;
+    for (int trial = 0; trial < trials; trial++) {
+        // M: n pixels, every field somewhere between 0 and its bound (often AT the bound)
+        const int kind = (int)(rnd() % 8);
+        uint64_t n = kind == 0 ? 0 : kind == 1 ? (1ull << 24) : kind == 2 ? (1ull << 23) : kind == 3 ? (1ull << 23) - 1 : kind == 4 ? 1 + rnd() % 4000 : rnd() % ((1ull << 24) + 1);
+        // ... of two colours (a real pixel set: sum |I - a|^2 >= 0 for every a), often black or white
+        auto colour = [&](uint64_t c[3]) { const int k = (int)(rnd() % 4); for (int i = 0; i < 3; i++) c[i] = k == 0 ? 255 : k == 1 ? 0 : rnd() % 256; };
+        uint64_t c1[3], c2[3];
+        colour(c1); colour(c2);
+        const uint64_t n1 = (rnd() & 1) ? n : (n ? rnd() % (n + 1) : 0), n2 = n - n1;
+        const uint64_t o1 = (c1[0] + c1[1] + c1[2]) & 1, o2 = (c2[0] + c2[1] + c2[2]) & 1;
+        uint64_t M[6] = {n, n1 * o1 + n2 * o2, n1 * c1[0] + n2 * c2[0], n1 * c1[1] + n2 * c2[1], n1 * c1[2] + n2 * c2[2],
+                         n1 * (c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]) + n2 * (c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2])};
+        // X, Y >= 0 so that W_a = M + X, W_b = Y, W_c = X + Y stay inside a line sum's fields (n, n_odd <= 2^24; r, g < 2^32)
+        uint64_t Wa[6], Wb[6], Wc[6];
+        const uint64_t cap[6] = {1ull << 24, 1ull << 24, (1ull << 32) - 1, (1ull << 32) - 1, (1ull << 32), 1ull << 42};
+        for (int f = 0; f < 6; f++) {
+            const uint64_t room = cap[f] - M[f];
+            const uint64_t X = room ? rnd() % (room / 2 + 1) : 0, Y = room ? rnd() % (room / 2 + 1) : 0;
+            Wa[f] = M[f] + X; Wb[f] = Y; Wc[f] = X + Y;
+        }
+        // lines in a random order; the negative one by its direction or by its flip bit; the whole triangle maybe the other way round
+        const uint64_t* W3[3] = {Wa, Wb, Wc};
+        int sign[3] = {1, 1, -1};
+        if (rnd() & 1) for (int k = 0; k < 3; k++) sign[k] = -sign[k];
+        int perm[3] = {0, 1, 2};
+        for (int k = 2; k > 0; k--) { const int j = (int)(rnd() % (k + 1)); const int t_ = perm[k]; perm[k] = perm[j]; perm[j] = t_; }
+        int flips = 0, slot[3];
+        for (int k = 0; k < 3; k++) {
+            const int src = perm[k];
+            slot[k] = k * 3 + (int)(rnd() % 3);   // (three different slots)
+            unsigned long long* S = V.sums + (size_t)slot[k] * PK_SUM_STRIDE;
+            const uint64_t* Wk = W3[src];
+            const bool zero = Wk[0] == 0 && Wk[1] == 0 && Wk[2] == 0 && Wk[3] == 0 && Wk[4] == 0 && Wk[5] == 0;
+            S[0] = Wk[0] | (Wk[1] << 32); S[1] = Wk[2] | (Wk[3] << 32); S[2] = Wk[4]; S[3] = Wk[5];
+            const int fl = (int)(rnd() & 1);
+            flips |= fl << k;
+            V.ldir[slot[k]] = (zero && (rnd() & 1)) ? 0 : (fl ? -sign[src] : sign[src]);   // (a line without rows may be level)
+        }
+        for (int flavour = 0; flavour < 2; flavour++) {
+            pk_i4 col = {(int32_t)(rnd() % 256), (int32_t)(rnd() % 256), (int32_t)(rnd() % 256), 0};
+            if (flavour == 1 && rnd() % 4 == 0) col.y = (int32_t)rnd();   // (a caller's colour outside a byte: the general form)
+            const pk_var v = pk_signed_packed(V, slot[0], slot[1], slot[2], flips);
+            const tp_moments mm = pk_signed_moments(V, slot[0], slot[1], slot[2], flips);
+            const bool same = mm.n == (int64_t)v.n && mm.nodd == (int64_t)v.nodd && mm.sr == (int64_t)v.r && mm.sg == (int64_t)v.g && mm.sb == (int64_t)v.b && mm.q == (int64_t)v.q &&
+                              (uint64_t)mm.n == M[0] && (uint64_t)mm.q == M[5];
+            bad += !same;
+            bad += pk_energy_var(v, flavour, col) != pk_energy(mm, flavour, col);
+        }
+    }
+    return bad;
+}
+
 // Band split (tp_band_attach): band `band` of `n_bands` replays the patches [band, band + 1) * parts / n_bands only; after every
 // grad-iter `exchange` is handed the mailbox slot array its patches just posted into ({tag : 32, float : 32} granules, two per
 // vertex) and the tag of the new positions, and brings in the other bands' posts (tests: torch.distributed all_gather).
@@ -215,12 +277,17 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                 for (int m = 1; m <= 4; m++) {
                     pk_i4 col = {0, 0, 0, 0};
                     if (flavour == 1 && ca) { const int32_t* c4 = ca + 4 * ((size_t)(4 * s + m) * NT + t); col.x = c4[0]; col.y = c4[1]; col.z = c4[2]; }
-                    const tp_moments mm = pk_corner_moments(V, (cr.z & 0xffff) + m - 1, ((cr.z >> 16) & 0xffff) + m - 1, cr.w & 0xffff, (cr.w >> 16) & 7);
-                    en[m] = pk_energy(mm, flavour, col);
+                    const pk_var mv = pk_signed_packed(V, (cr.z & 0xffff) + m - 1, ((cr.z >> 16) & 0xffff) + m - 1, cr.w & 0xffff, (cr.w >> 16) & 7);
+                    en[m] = pk_energy_var(mv, flavour, col);
+                    {   // (the general form of both, which the packed one replaces)
+                        const tp_moments mm = pk_corner_moments(V, (cr.z & 0xffff) + m - 1, ((cr.z >> 16) & 0xffff) + m - 1, cr.w & 0xffff, (cr.w >> 16) & 7);
+                        if (mm.n != (int64_t)mv.n || mm.nodd != (int64_t)mv.nodd || mm.sr != (int64_t)mv.r || mm.sg != (int64_t)mv.g || mm.sb != (int64_t)mv.b ||
+                            mm.q != (int64_t)mv.q || pk_energy(mm, flavour, col) != en[m]) return -5;
+                    }
                     if (emit) {
                         const size_t id = (size_t)(4 * s + m) * NT + t;
-                        if (flavour == 0) { ca_out[4 * id] = tp_wrap32(mm.sr); ca_out[4 * id + 1] = tp_wrap32(mm.sg); ca_out[4 * id + 2] = tp_wrap32(mm.sb); ca_out[4 * id + 3] = 0; }
-                        ten[id] = en[m]; cn[id] = tp_wrap32(mm.n);
+                        if (flavour == 0) { ca_out[4 * id] = (int32_t)mv.r; ca_out[4 * id + 1] = (int32_t)mv.g; ca_out[4 * id + 2] = (int32_t)mv.b; ca_out[4 * id + 3] = 0; }
+                        ten[id] = en[m]; cn[id] = (int32_t)mv.n;
                     }
                 }
                 V.gacc[2 * own] += pk_gacc_word((uint32_t)en[1] - (uint32_t)en[2]);       // (the kernel: one returning LDS atomic each)
@@ -229,11 +296,11 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             if (emit)
                 for (int k = 0; k < w.n_base; k++) {
                     int t;
-                    const tp_moments mm = pk_base_moments(w, V, k, t);
+                    const pk_var mv = pk_base_var(V, k, t);
                     pk_i4 col = {0, 0, 0, 0};
                     if (flavour == 1 && ca) { col.x = ca[4 * t]; col.y = ca[4 * t + 1]; col.z = ca[4 * t + 2]; }
-                    if (flavour == 0) { ca_out[4 * t] = tp_wrap32(mm.sr); ca_out[4 * t + 1] = tp_wrap32(mm.sg); ca_out[4 * t + 2] = tp_wrap32(mm.sb); ca_out[4 * t + 3] = 0; }
-                    ten[t] = pk_energy(mm, flavour, col); cn[t] = tp_wrap32(mm.n);
+                    if (flavour == 0) { ca_out[4 * t] = (int32_t)mv.r; ca_out[4 * t + 1] = (int32_t)mv.g; ca_out[4 * t + 2] = (int32_t)mv.b; ca_out[4 * t + 3] = 0; }
+                    ten[t] = pk_energy_var(mv, flavour, col); cn[t] = (int32_t)mv.n;
                 }
             // P7: posts go to the OTHER parity of the mailbox, so workgroups replayed later in this sweep still read this
             // grad-iter's positions
@@ -333,6 +400,39 @@ extern "C" int emul_plan_patches(const float* points, int NP, const int32_t* tri
         const pk_wg& w = P.wg[p];
         int32_t* o = out + 8 * p;
         o[0] = w.n_own_v; o[1] = w.n_slots; o[2] = w.n_edges; o[3] = w.n_lines; o[4] = w.n_li; o[5] = w.n_corners; o[6] = w.rows; o[7] = w.lds_bytes;
+    }
+    return P.parts;
+}
+
+// per-patch share of EARLY lines (tools/plan_stats.py): lines whose two endpoints are both the patch's own vertices -- what a workgroup can
+// set up and walk before its neighbours' positions arrive.  out[4p ..] = {lines, early lines, rows of all lines, rows of the early ones}
+extern "C" int emul_plan_early(const float* points, int NP, const int32_t* tris, int NT, int W, int H, float ratio, float dp_px,
+                               int max_parts, int lds_limit, int32_t* out, int cap) {
+    std::map<std::pair<int, int>, int> eid;
+    std::vector<int32_t> edge_uv, he_edge(3 * (size_t)NT);
+    for (int t = 0; t < NT; t++)
+        for (int k = 0; k < 3; k++) {
+            const int o = tris[4 * t + k], d = tris[4 * t + (k + 1) % 3];
+            const std::pair<int, int> key(o < d ? o : d, o < d ? d : o);
+            auto it = eid.find(key);
+            if (it == eid.end()) { it = eid.emplace(key, (int)(edge_uv.size() / 2)).first; edge_uv.push_back(key.first); edge_uv.push_back(key.second); }
+            he_edge[3 * t + k] = it->second * 2 + (o != key.first ? 1 : 0);
+        }
+    pk_plan P;
+    pk_build_plan(NP, NT, tris, points, (int)(edge_uv.size() / 2), edge_uv.data(), he_edge.data(), W, H, ratio, dp_px, max_parts, lds_limit, P);
+    if (!P.ok) return -1;
+    for (int p = 0; p < P.parts && p < cap; p++) {
+        const pk_wg& w = P.wg[p];
+        int32_t* o = out + 4 * p;
+        o[0] = w.n_lines; o[1] = 0; o[2] = 0; o[3] = 0;
+        for (int l = 0; l < w.n_lines; l++) {
+            const int ln = P.pool[w.off_lines + l], ed = P.pool[w.off_edges + (ln & 0xffff)];
+            const int su = ed & 0xffff, sv = (ed >> 16) & 0xffff;
+            const int vu = P.pool[w.off_vid + su], vv = P.pool[w.off_vid + sv];
+            const int rows = (int)(fabsf(points[2 * vu + 1] - points[2 * vv + 1]) * 0.5f * (float)H) + 1;
+            const bool early = su < w.n_own_v && sv < w.n_own_v;
+            o[1] += early; o[2] += rows; o[3] += early ? rows : 0;
+        }
     }
     return P.parts;
 }

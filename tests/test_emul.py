@@ -378,3 +378,10 @@ def test_persistent_patch_without_vertices(emp):
     ref = O.iterate(img, bad, tris, 0, ratio, 0.00005, 2, literal=False)
     assert np.array_equal(p.view(np.uint32), ref["points"].view(np.uint32))
     assert np.array_equal(stats_out["ten"], ref["ten"])
+
+
+def test_packed_variant_moments_and_energy_equal_the_general_form(emp):
+    """round 5: P6 sums the line sums as packed words and takes the energy in 24/32-bit arithmetic (tp_persist.h: pk_signed_packed,
+    pk_energy_var); the general 64-bit form is the reference here -- random and extreme fields, both flavours, colours outside a byte"""
+    emp.emul_packed_check.argtypes = [C.c_uint64, C.c_int]
+    assert emp.emul_packed_check(12345, 200000) == 0

@@ -759,3 +759,63 @@ def test_evaluate_triangles_is_the_base_energy(size, grid):
     with pytest.raises(Exception):
         ctx.evaluate_triangles(np.array([[0, 1, pts.shape[0]]], np.int32))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_packed_variant_arithmetic_on_the_device():
+    """round 5: P6 of k_persist sums line sums as packed 64-bit words and takes the channel averages through one float reciprocal with a
+    remainder fix (tp_persist.h: pk_signed_packed, pk_energy_var).  On the device, against the general 64-bit form and against Python integers:
+    pixel sets of two colours up to 2^24 pixels, averages that divide exactly (255 n / n), one below and one above, both flavours."""
+    rng = np.random.default_rng(5)
+    n_cases = 200000
+    n = rng.integers(0, (1 << 24) + 1, n_cases).astype(np.int64)
+    n[:20000] = rng.integers(1, 5000, 20000)
+    n[20000:20010] = [0, 1, 2, (1 << 23) - 1, 1 << 23, (1 << 23) + 1, 1 << 24, (1 << 24) - 1, 3, 255]
+    c1 = rng.integers(0, 256, (n_cases, 3)).astype(np.int64); c2 = rng.integers(0, 256, (n_cases, 3)).astype(np.int64)
+    c1[::7] = 255; c2[::11] = 0; c2[::13] = 255
+    n1 = (rng.random(n_cases) * (n + 1)).astype(np.int64)
+    n1[::5] = n[::5]                 # one colour: the average divides exactly
+    n1[1::5] = np.maximum(n[1::5] - 1, 0)   # ... one pixel short of it
+    n2 = n - n1
+    odd1, odd2 = c1.sum(1) & 1, c2.sum(1) & 1
+    M = np.stack([n, n1 * odd1 + n2 * odd2, n1 * c1[:, 0] + n2 * c2[:, 0], n1 * c1[:, 1] + n2 * c2[:, 1], n1 * c1[:, 2] + n2 * c2[:, 2],
+                  n1 * (c1 ** 2).sum(1) + n2 * (c2 ** 2).sum(1)], 1)
+    # three lines with Wa + Wb - Wc = M (fields inside a line sum's: n, n_odd <= 2^24; r, g < 2^32)
+    cap = np.array([1 << 24, 1 << 24, (1 << 32) - 1, (1 << 32) - 1, 1 << 32, 1 << 42], np.int64)
+    room = cap[None, :] - M
+    X = (rng.random(M.shape) * (room // 2 + 1)).astype(np.int64); Y = (rng.random(M.shape) * (room // 2 + 1)).astype(np.int64)
+    Ws = [M + X, Y, X + Y]
+    sign = np.array([1, 1, -1])[None, :] * np.where(rng.random(n_cases) < 0.5, 1, -1)[:, None]
+    perm = np.argsort(rng.random((n_cases, 3)), 1)
+    flips_bits = rng.integers(0, 2, (n_cases, 3))
+    sums = np.zeros((n_cases, 3, 4), np.uint64)
+    meta = np.zeros((n_cases, 8), np.int32)
+    for k in range(3):
+        Wk = np.choose(perm[:, k][:, None], [Ws[0], Ws[1], Ws[2]])
+        sk = np.take_along_axis(sign, perm[:, k][:, None], 1)[:, 0]
+        sums[:, k, 0] = (Wk[:, 0] | (Wk[:, 1] << 32)).astype(np.uint64); sums[:, k, 1] = (Wk[:, 2] | (Wk[:, 3] << 32)).astype(np.uint64)
+        sums[:, k, 2] = Wk[:, 4].astype(np.uint64); sums[:, k, 3] = Wk[:, 5].astype(np.uint64)
+        meta[:, k] = np.where(flips_bits[:, k] == 1, -sk, sk)
+        meta[:, 3] |= (flips_bits[:, k] << k).astype(np.int32)
+    meta[:, 4] = rng.integers(0, 2, n_cases)
+    meta[:, 5:8] = rng.integers(0, 256, (n_cases, 3))
+    wild = (rng.random(n_cases) < 0.1) & (meta[:, 4] == 1)
+    meta[wild, 6] = rng.integers(-2**31, 2**31, int(wild.sum()))   # a caller's colour outside a byte: the general form
+    ctx = capi.Context(0, 64, 64)
+    out = ctx.selftest_variant(sums, meta)
+    ctx.close()
+    assert np.all(out[:, 9] == 1)
+    got = out[:, :5].astype(np.int64) & 0xffffffff
+    assert np.array_equal(got, M[:, :5])
+    assert np.array_equal((out[:, 5].astype(np.int64) & 0xffffffff) | ((out[:, 6].astype(np.int64) & 0xffffffff) << 32), M[:, 5])
+    assert np.array_equal(out[:, 7], out[:, 8])
+    # ... and what the reference computes (triangle.fs:37-43), in Python integers, for the cases no int32 of it wraps in
+    tri = np.nonzero((meta[:, 4] == 0) & (n > 0) & (n < (1 << 23)))[0][:20000]
+    for i in tri[:: max(1, len(tri) // 3000)]:
+        nn, no, sr, sg, sb, q = (int(x) for x in M[i])
+        a = (sr // nn, sg // nn, sb // nn)
+        a2 = a[0] ** 2 + a[1] ** 2 + a[2] ** 2
+        S = q - 2 * (a[0] * sr + a[1] * sg + a[2] * sb) + nn * a2
+        nodd = nn - no if a2 & 1 else no
+        want = ((S - nodd) // 2) & 0xffffffff
+        assert (int(out[i, 7]) & 0xffffffff) == want, (i, M[i])

@@ -25,7 +25,7 @@ SYMBOLS = [
     "tp_get_stream", "tp_profile_iterate", "tp_profile_accumulate", "tp_get_info", "tp_selftest_walker", "tp_render",
     "tp_prepare", "tp_selftest_line", "tp_timer_start", "tp_timer_stop", "tp_iterate_until", "tp_band_mailbox_bytes",
     "tp_band_attach", "tp_band_mailbox_alloc", "tp_band_mailbox_free", "tp_band_mailbox_export", "tp_band_mailbox_import",
-    "tp_band_mailbox_close", "tp_evaluate_triangles",
+    "tp_band_mailbox_close", "tp_evaluate_triangles", "tp_selftest_variant",
 ]
 
 
@@ -97,6 +97,7 @@ def load():
         lib.tp_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.tp_prepare.argtypes = [C.c_void_p, C.POINTER(Params)]
         lib.tp_selftest_line.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.tp_selftest_variant.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -237,6 +238,15 @@ class Context:
         out = np.zeros((ends.shape[0], rows + 2), np.int32)
         self._ck(self.lib.tp_selftest_line(self.h, ends.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p),
                                            ends.shape[0], rows, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def selftest_variant(self, sums, meta):
+        """sums uint64[n,3,4] line sums, meta int32[n,8] {dir x3, flips, flavour, r, g, b} -> int32[n,10] (tp_selftest_variant)"""
+        sums = np.ascontiguousarray(sums, np.uint64)
+        meta = np.ascontiguousarray(meta, np.int32)
+        out = np.zeros((meta.shape[0], 10), np.int32)
+        self._ck(self.lib.tp_selftest_variant(self.h, sums.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p), meta.shape[0],
+                                              out.ctypes.data_as(C.c_void_p)))
         return out
 
     def profile_iterate(self, params, n):

@@ -62,9 +62,53 @@ __global__ __launch_bounds__(64) void k_eval_triangles(tp_view vw, const float2*
     }
 }
 
+// tp_selftest_variant: the packed form of a variant's moments and energy (tp_persist.h: pk_signed_packed, pk_energy_var -- what P6 of
+// k_persist runs, float reciprocal and all) beside the general 64-bit form, on line sums the caller made up
+__global__ void k_selftest_variant(const unsigned long long* sums, const int32_t* meta, int n, int32_t* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long S[3 * PK_SUM_STRIDE];
+    int32_t dir[3];
+    for (int k = 0; k < 3; k++) {
+        for (int q = 0; q < PK_SUM_WORDS; q++) S[k * PK_SUM_STRIDE + q] = sums[((size_t)i * 3 + k) * PK_SUM_WORDS + q];
+        dir[k] = meta[8 * (size_t)i + k];
+    }
+    pk_view V;
+    V.sums = S; V.ldir = dir;
+    const int flips = meta[8 * (size_t)i + 3], flavour = meta[8 * (size_t)i + 4];
+    const pk_i4 col = {meta[8 * (size_t)i + 5], meta[8 * (size_t)i + 6], meta[8 * (size_t)i + 7], 0};
+    const pk_var v = pk_signed_packed(V, 0, 1, 2, flips);
+    const tp_moments mm = pk_signed_moments(V, 0, 1, 2, flips);
+    int32_t* o = out + 10 * (size_t)i;
+    o[0] = (int32_t)v.n; o[1] = (int32_t)v.nodd; o[2] = (int32_t)v.r; o[3] = (int32_t)v.g; o[4] = (int32_t)v.b; o[5] = (int32_t)(uint32_t)v.q; o[6] = (int32_t)(uint32_t)(v.q >> 32);
+    o[7] = pk_energy_var(v, flavour, col);
+    o[8] = pk_energy(mm, flavour, col);
+    o[9] = mm.n == (int64_t)v.n && mm.nodd == (int64_t)v.nodd && mm.sr == (int64_t)v.r && mm.sg == (int64_t)v.g && mm.sb == (int64_t)v.b && mm.q == (int64_t)v.q;
+}
+
 }  // namespace
 
 using namespace tpctx;
+
+extern "C" int tp_selftest_variant(tp_context* c, const uint64_t* sums, const int32_t* meta, int n, int32_t* out) {
+    api_guard api_lock;
+    if (!c || !sums || !meta || !out || n < 0) return TP_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long* ds = nullptr; int32_t *dm = nullptr, *dout = nullptr;
+    hipError_t e = dev_alloc(&ds, (size_t)n * 12);   // (one exit: the buffers are freed on every path)
+    if (e == hipSuccess) e = dev_alloc(&dm, (size_t)n * 8);
+    if (e == hipSuccess) e = dev_alloc(&dout, (size_t)n * 10);
+    if (e == hipSuccess) e = hipMemcpy(ds, sums, sizeof(uint64_t) * 12 * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dm, meta, sizeof(int32_t) * 8 * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n > 0) {
+        hipLaunchKernelGGL(k_selftest_variant, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ds, dm, n, dout);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(int32_t) * 10 * (size_t)n, hipMemcpyDeviceToHost);
+    hipFree(ds); hipFree(dm); hipFree(dout);
+    if (e != hipSuccess) return fail(c, TP_ERR_HIP, "selftest_variant: %s", hipGetErrorString(e));
+    return TP_OK;
+}
 
 extern "C" int tp_evaluate_triangles(tp_context* c, int slot, int n, const int32_t* vertices, const int32_t* variants, int32_t* energy, int32_t* count) {
     api_guard api_lock;

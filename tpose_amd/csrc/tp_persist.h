@@ -479,6 +479,78 @@ TP_HD tp_moments pk_base_moments(const pk_wg& w, const pk_view& V, int k, int& t
     return pk_signed_moments(V, b.z & 0xffff, (b.z >> 16) & 0xffff, b.w & 0xffff, (b.w >> 16) & 7);
 }
 
+// ---- P6 in packed words (round 5).  pk_signed_moments + pk_energy above are the GENERAL form: eighteen 64-bit products by -1 / 0 / +1 and
+// 64-bit moments throughout -- on this part ~100 quarter-rate multiplications on the one wave per SIMD that forms corners, 0.9 us of every
+// grad-iter between the walk and the step.  The same values come out of the line sums AS THEY LIE IN LDS:
+//   * a line whose direction is 0 has no rows, its sums are 0, so it may take either sign: every line enters as +w or -w;
+//   * sum_k (+-w_k) of the packed words {n | n_odd << 32, r | g << 32, b, q} is taken modulo 2^64 -- (w ^ s) + (s & 1) per negated word, the
+//     +1s gathered into one addend -- and equals A_lo + 2^32 A_hi (mod 2^64) for the two field sums A_lo, A_hi, whatever borrows ran
+//     through the middle;
+//   * the orientation is the sign of the field n = the low half of word 0 as an int32 (|n| <= 3 x 2^24); negating all four words once more
+//     leaves M_lo + 2^32 M_hi with both halves the moments of the covered pixels: >= 0 and < 2^32 (at most 2^24 pixels of 255), so the halves
+//     ARE the fields.  b fits 32 bits for the same reason; only q needs 64.
+// The energy then has a fast lane: fewer than 2^23 pixels (no int32 sum of the reference can have wrapped, so the channel averages are
+// 0..255) and, warp flavour, a stored colour in 0..255 -- averages by one float reciprocal and a remainder fix (exact), the rest in 24- and
+// 32-bit multiplications.  Anything else (a variant of 8 M pixels, a caller's colour outside a byte) takes the general form, lane by lane.
+// tests/emul compares the two forms on random and extreme line sums.
+struct pk_var { uint32_t n, nodd, r, g, b; uint64_t q; };
+TP_HD pk_var pk_signed_packed(const pk_view& V, int l0, int l1, int l2, int flips) {
+    const unsigned long long *S0 = V.sums + (size_t)l0 * PK_SUM_STRIDE, *S1 = V.sums + (size_t)l1 * PK_SUM_STRIDE, *S2 = V.sums + (size_t)l2 * PK_SUM_STRIDE;
+    const int d0 = V.ldir[l0], d1 = V.ldir[l1], d2 = V.ldir[l2];
+    const uint64_t s0 = ((d0 < 0) != ((flips & 1) != 0)) ? ~0ull : 0ull, s1 = ((d1 < 0) != ((flips & 2) != 0)) ? ~0ull : 0ull,
+                   s2 = ((d2 < 0) != ((flips & 4) != 0)) ? ~0ull : 0ull;
+    const uint64_t ones = (s0 & 1ull) + (s1 & 1ull) + (s2 & 1ull);
+    uint64_t z[PK_SUM_WORDS];
+#pragma unroll
+    for (int q = 0; q < PK_SUM_WORDS; q++) z[q] = (S0[q] ^ s0) + (S1[q] ^ s1) + (S2[q] ^ s2) + ones;
+    const uint64_t sg = (int32_t)(uint32_t)z[0] < 0 ? ~0ull : 0ull;
+#pragma unroll
+    for (int q = 0; q < PK_SUM_WORDS; q++) z[q] = (z[q] ^ sg) + (sg & 1ull);
+    pk_var v;
+    v.n = (uint32_t)z[0]; v.nodd = (uint32_t)(z[0] >> 32); v.r = (uint32_t)z[1]; v.g = (uint32_t)(z[1] >> 32); v.b = (uint32_t)z[2]; v.q = z[3];
+    return v;
+}
+// floor(x / n) for x < 2^31, 0 < n < 2^23, x <= 255 n: the float quotient is within 1e-4 of the real one, so its truncation is at most one
+// off either way and the remainder says which
+TP_HD uint32_t pk_avg(uint32_t x, uint32_t n, float rn) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t a = (uint32_t)__fmul_rn((float)x, rn);
+    const int32_t rem = (int32_t)(x - __umul24(a, n));
+    a = rem < 0 ? a - 1u : ((uint32_t)rem >= n ? a + 1u : a);
+    return a;
+#else
+    (void)rn;
+    return x / n;
+#endif
+}
+TP_HD int32_t pk_energy_var(const pk_var& v, int flavour, pk_i4 col) {
+    const bool fast = v.n < (1u << 23) && (flavour == 0 || (((uint32_t)col.x | (uint32_t)col.y | (uint32_t)col.z) < 256u));
+    if (fast) {
+        uint32_t ar, ag, ab;
+        if (flavour == 0) {
+            if (v.n == 0u) return 0;   // triangle.fs:40
+#if defined(__HIP_DEVICE_COMPILE__)
+            const float rn = __builtin_amdgcn_rcpf((float)v.n);
+#else
+            const float rn = 0.0f;
+#endif
+            ar = pk_avg(v.r, v.n, rn); ag = pk_avg(v.g, v.n, rn); ab = pk_avg(v.b, v.n, rn);
+        } else { ar = (uint32_t)col.x; ag = (uint32_t)col.y; ab = (uint32_t)col.z; }
+        const uint32_t a2 = pk_mul24(ar, ar) + pk_mul24(ag, ag) + pk_mul24(ab, ab);
+        const uint64_t dot = (uint64_t)ar * v.r + (uint64_t)ag * v.g + (uint64_t)ab * v.b;
+        const uint64_t S = v.q + (uint64_t)v.n * a2 - 2ull * dot;                  // sum |I - a|^2 >= 0
+        const uint32_t nodd = (a2 & 1u) ? v.n - v.nodd : v.nodd;                   // ... of which so many are odd
+        return (int32_t)(uint32_t)((S - nodd) >> 1);
+    }
+    const tp_moments mm = {(int64_t)v.n, (int64_t)v.nodd, (int64_t)v.r, (int64_t)v.g, (int64_t)v.b, (int64_t)v.q};
+    return pk_energy(mm, flavour, col);
+}
+TP_HD pk_var pk_base_var(const pk_view& V, int k, int& t) {
+    const pk_i4 b = V.base[k];
+    t = b.x;
+    return pk_signed_packed(V, b.z & 0xffff, (b.z >> 16) & 0xffff, b.w & 0xffff, (b.w >> 16) & 7);
+}
+
 // P7, own vertex k with gradient (gx, gy): the shift.cs step (shift.cs:16-47).  Vertices 0..3 never move.
 // one coordinate of it: clamped to [-bound, bound] (and its gradient dropped) BEFORE the step (shift.cs:25-45); bound = RATIO for x, 1 for y
 TP_HD float pk_step_axis(float p, int32_t g, float bound, float rate) {

@@ -182,6 +182,11 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         const int n_lines = emit ? w.n_lines_all : w.n_lines, n_setup = recut ? w.n_lines_all : n_lines;
         PK_STAMP(0); PK_WSTAMP(0);
         // ---- P0: positions of the neighbouring vertices this patch uses (the first grad-iter of a launch read `points`)
+        // (One request per granule in flight, issued by the lanes that have just finished the corners: round 5 measured the alternatives -- the
+        // idle last wave polling from the end of its walk on, two or four requests in flight, a 16-byte load per vertex, a cache line or
+        // 256 bytes per vertex, a pause before the first poll -- and every one that adds requests makes the hand-over SLOWER (4.75 -> 5.0 /
+        // 5.3 / 5.6 us per grad-iter); the others change nothing.  tools/handover_bench.hip: 0.93 us per hand-over, the store's trip to the
+        // memory side plus the load's, whatever the layout.)
         if (it > 0) {
             for (int s = w.n_own_v + tid; s < w.n_slots; s += PK_THREADS) {
                 gu64* g = posbox + ((size_t)par * A.box_stride + V.vid[s]) * 2;
@@ -312,10 +317,10 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         if (ering && !emit) {   // tp_iterate_until: the energy of the base variants, frame by frame (the plan walks their lines every grad-iter)
             for (int k = tid; k < w.n_base; k += PK_THREADS) {
                 int t;
-                const tp_moments mm = pk_base_moments(w, V, k, t);
+                const pk_var mv = pk_base_var(V, k, t);
                 pk_i4 col = {0, 0, 0, 0};
                 if (A.flavour == 1) { const int4 c = A.ca[t]; col.x = c.x; col.y = c.y; col.z = c.z; }
-                const int32_t en = pk_energy(mm, A.flavour, col);
+                const int32_t en = pk_energy_var(mv, A.flavour, col);
                 const size_t at = (size_t)it * A.NT + t;
                 if (banded) {
                     __hip_atomic_store((gu32*)ering + at, (unsigned)en, PK_RLX_SYSTEM);
@@ -336,21 +341,39 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 col.x = c.x; col.y = c.y; col.z = c.z;
             }
             int so, si, sopp, own, flips;
-            if (j == tid) { so = my_c0 & 0xffff; si = (int)((unsigned)my_c0 >> 16); sopp = my_c1 & 0xffff; own = (my_c1 >> 16) & 0x3ff; flips = my_c1 >> 26; }
+            if (j == tid) {
+                // (decoded here, every grad-iter: hoisted out of the loop the slot addresses and flip masks take a dozen registers from the walk,
+                // and the two that no longer fit come back from scratch memory right on the chain between the corners and the step)
+                int c0_ = my_c0, c1_ = my_c1;
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(c0_), "+v"(c1_));
+#endif
+                so = c0_ & 0xffff; si = (int)((unsigned)c0_ >> 16); sopp = c1_ & 0xffff; own = (c1_ >> 16) & 0x3ff; flips = c1_ >> 26;
+            }
             else {
                 const pk_i4 cq = V.corners[k];
                 so = (cq.z & 0xffff) + m - 1; si = ((cq.z >> 16) & 0xffff) + m - 1; sopp = cq.w & 0xffff; own = (cq.y >> 2) & 0x3ff; flips = (cq.w >> 16) & 7;
             }
-            const tp_moments mm = pk_corner_moments(V, so, si, sopp, flips);
-            const int32_t e = pk_energy(mm, A.flavour, col);
+            const pk_var mv = pk_signed_packed(V, so, si, sopp, flips);
+#ifdef PK_DBG_WAVES
+            if (j == tid) { asm volatile("" :: "v"(mv.n), "v"(mv.q)); PK_WSTAMP(11); }
+#endif
+#if defined(PK_EXP_OLDP6)   // timing experiments only (tools/build_variants.py): the general 64-bit form
+            const int32_t e = pk_energy(pk_corner_moments(V, so, si, sopp, flips), A.flavour, col);
+#else
+            const int32_t e = pk_energy_var(mv, A.flavour, col);
+#endif
             // lanes 4k+0/1: E(+dx), E(-dx); 4k+2/3: E(+dy), E(-dy) -- the neighbour's energy by a DPP quad permute [1,0,3,2] (__shfl_xor
             // goes through the LDS crossbar: a hundred cycles on this chain)
+#ifdef PK_DBG_WAVES
+            if (j == tid) { asm volatile("" :: "v"(e)); PK_WSTAMP(12); }
+#endif
             const uint32_t d = (uint32_t)e - (uint32_t)__builtin_amdgcn_mov_dpp(e, 0xB1, 0xF, 0xF, true);
             if (emit) {
                 const pk_i4 cr = V.corners[k];   // the variant's outputs in the reference's layout, id = i NT + t (triangle.vs:47-48)
                 const size_t id = (size_t)(4 * (cr.y & 3) + m) * A.NT + cr.x;
-                if (A.flavour == 0) A.ca_out[id] = make_int4(tp_wrap32(mm.sr), tp_wrap32(mm.sg), tp_wrap32(mm.sb), 0);
-                A.ten[id] = e; A.cn[id] = tp_wrap32(mm.n);
+                if (A.flavour == 0) A.ca_out[id] = make_int4((int32_t)mv.r, (int32_t)mv.g, (int32_t)mv.b, 0);
+                A.ten[id] = e; A.cn[id] = (int32_t)mv.n;
             }
             // ---- P7, by the lane that completes an axis of a vertex.  Lanes 4k + 0 / 4k + 2 add the corner's x / y difference to the vertex's
             // accumulator of that axis with ONE returning atomic, (difference << 32) | 1: the lane whose returned count is the vertex's last
@@ -361,6 +384,9 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 const int ax = (j >> 1) & 1;   // 0: x, 1: y
                 unsigned long long* acc = V.gacc + 2 * own + ax;
                 const unsigned long long old = atomicAdd(acc, pk_gacc_word(d));
+#ifdef PK_DBG_WAVES
+                if (j == tid) { asm volatile("" :: "v"(old)); PK_WSTAMP(13); }
+#endif
                 if ((uint32_t)old + 1u == (uint32_t)V.vdeg[own]) {
                     const int32_t g = (int32_t)((uint32_t)(old >> 32) + d);
                     *acc = 0ull;   // (for the next grad-iter: every corner of the vertex has added to it)
@@ -395,11 +421,11 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         if (emit) {   // base variants (i = 0) of the triangles whose first vertex this patch owns
             for (int k = tid; k < w.n_base; k += PK_THREADS) {
                 int t;
-                const tp_moments mm = pk_base_moments(w, V, k, t);
+                const pk_var mv = pk_base_var(V, k, t);
                 pk_i4 col = {0, 0, 0, 0};
                 if (A.flavour == 1) { const int4 c = A.ca[t]; col.x = c.x; col.y = c.y; col.z = c.z; }
-                if (A.flavour == 0) A.ca_out[t] = make_int4(tp_wrap32(mm.sr), tp_wrap32(mm.sg), tp_wrap32(mm.sb), 0);
-                A.ten[t] = pk_energy(mm, A.flavour, col); A.cn[t] = tp_wrap32(mm.n);
+                if (A.flavour == 0) A.ca_out[t] = make_int4((int32_t)mv.r, (int32_t)mv.g, (int32_t)mv.b, 0);
+                A.ten[t] = pk_energy_var(mv, A.flavour, col); A.cn[t] = (int32_t)mv.n;
             }
         }
         PK_STAMP(4); PK_WSTAMP(8);
