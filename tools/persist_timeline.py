@@ -67,4 +67,33 @@ period = (st[:, IT - 1, 0] - st[:, 8, 0]) / 100.0 / (IT - 1 - 8)
 out["grad-iter period"] = {"mean": round(float(period.mean()), 3), "min": round(float(period.min()), 3), "max": round(float(period.max()), 3)}
 start = (st[:, 0, 0] - st[:, 0, 0].min()) / 100.0
 out["workgroup start spread"] = round(float(start.max()), 2)
+# who sets the pace: per workgroup, the median over grad-iters of its own chain (P1 + P3 + P6: everything but the wait for positions)
+chain = (sel[:, :, 1:2] * 0 + (sel[:, :, 5] - sel[:, :, 1])[:, :, None])[:, :, 0] / 100.0   # stamp 1 (positions in) -> stamp 5 (end of the grad-iter)
+cm = np.median(chain, axis=1)
+p3 = np.median((sel[:, :, 3] - sel[:, :, 2]) / 100.0, axis=1)
+order = np.argsort(-cm)
+out["chain P1..P7 per workgroup, median over grad-iters"] = {str(q): round(float(np.percentile(cm, q)), 2) for q in (0, 10, 50, 90, 100)}
+out["P3 per workgroup, median over grad-iters"] = {str(q): round(float(np.percentile(p3, q)), 2) for q in (0, 10, 50, 90, 100)}
+p3a = np.median((sel[:, :, 8] - sel[:, :, 2]) / 100.0, axis=1); p3b = np.median((sel[:, :, 9] - sel[:, :, 8]) / 100.0, axis=1); p3e = np.median((sel[:, :, 3] - sel[:, :, 9]) / 100.0, axis=1)
+p1 = np.median((sel[:, :, 2] - sel[:, :, 1]) / 100.0, axis=1); p6 = np.median((sel[:, :, 5] - sel[:, :, 3]) / 100.0, axis=1)
+out["slowest workgroups (block: chain, P1, P3 = scan + sums + barrier, P6)"] = {str(int(b)): [round(float(v[b]), 2) for v in (cm, p1, p3, p3a, p3b, p3e, p6)] for b in order[:12]}
+out["fastest workgroups (block: chain, P1, P3 = scan + sums + barrier, P6)"] = {str(int(b)): [round(float(v[b]), 2) for v in (cm, p1, p3, p3a, p3b, p3e, p6)] for b in order[-6:]}
+try:
+    pp = np.zeros((512, 8), np.int32)
+    # (what the plan says about the slowest: own vertices, slots, edges, lines, lane-items, corners, rows per lane -- CPU replay of the planner)
+    import subprocess
+    so = os.path.join(ROOT, "tests", "_build", "libtp_emul_persist_tl.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-o", so, os.path.join(ROOT, "tests", "emul", "emul_persist.cpp")])
+    emp = ctypes.CDLL(so)
+    dp_px = 0.05 / (1 + 4 * tris.shape[0] / 3000.0) * H / 2
+    n = emp.emul_plan_patches(pts.ctypes.data_as(ctypes.c_void_p), pts.shape[0], tris.ctypes.data_as(ctypes.c_void_p), tris.shape[0], W, H, ctypes.c_float(ratio), ctypes.c_float(dp_px),
+                              parts, 160 * 1024 - 512, pp.ctypes.data_as(ctypes.c_void_p), 512)
+    def patch_of_block(b): return (b & 7) * (parts >> 3) + (b >> 3) if parts % 8 == 0 else b
+    out["plan of the slowest (block: own vertices, slots, edges, lines, lane-items, corners, rows per lane)"] = {str(int(b)): [int(x) for x in pp[patch_of_block(int(b))][:7]] for b in order[:12]}
+    out["plan of the fastest"] = {str(int(b)): [int(x) for x in pp[patch_of_block(int(b))][:7]] for b in order[-6:]}
+except Exception as e:  # noqa: BLE001
+    out["plan of the slowest"] = "unavailable: %s" % e
+# P3 of every grad-iter, max over workgroups: spikes are the grad-iters in which lines are cut again
+out["P3 max over workgroups by grad-iter"] = [round(float(v), 2) for v in ((sel[:, :, 3] - sel[:, :, 2]) / 100.0).max(axis=0)]
 print(json.dumps(out, indent=1))

@@ -300,7 +300,8 @@ TP_HD int pk_walk_lane(const pk_view& V, const char* table, const char* tiled, i
     int first;
     pk_rows r = pk_lane_rows(V.wk[l], c, TL, magic, pitch, &first);
 #ifndef PK_UNCACHED_BATCH
-#define PK_UNCACHED_BATCH 8    /* records requested together by a lane-item without cached records (12 would spill registers of the cached walk) */
+#define PK_UNCACHED_BATCH 4    /* records requested together by a lane-item without cached records (8 measured the same at 4096^2 in round 4, and its 32 registers in flight
+                                  are what decides whether the kernel fits three waves per SIMD with 16 rows per lane) */
 #endif
     if (tiled) pk_walk_rows_tiled<PK_UNCACHED_BATCH>(r, (uint32_t)first, (uint32_t)TL, (uint32_t)pitch, tiled, W, a);
     else pk_walk_rows<PK_UNCACHED_BATCH>(r, table, W, a);

@@ -77,7 +77,7 @@ __device__ __forceinline__ int patch_of_block(int b, int parts) {
 template <int RR, int MODE>
 __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_THREADS / 256, PK_THREADS / 256))) void k_persist(pk_args A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
     const int part = A.part0 + patch_of_block((int)blockIdx.x, (int)gridDim.x);
     const pk_wg w = A.wg[part];
     pk_view V;
@@ -173,7 +173,15 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
     __syncthreads();
     PK_STAMP0(14);
 
+    // the mailbox slot of the first foreign vertex this lane polls (its number is a table look-up the poll would otherwise start with)
+    const int my_vid = w.n_own_v + tid < w.n_slots ? V.vid[w.n_own_v + tid] : 0;
     for (int it = 0; it < A.n_iters; it++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // Nothing derived from the thread's number is kept across grad-iters: left alone, the compiler hoists some forty addresses out of
+        // this loop, and with them the kernel needs 253 registers where 167 do -- the difference between two waves per SIMD and three.
+        // (What a chain would wait for -- the polled vertex, the first line's ends, the first corner's slots -- is kept by name, above.)
+        asm volatile("" : "+v"(tid));
+#endif
         const uint32_t epoch = A.epoch + (uint32_t)it, tag = pk_tag(epoch), par = epoch & 1u;
         // the last grad-iter of a call that wants the reference's buffers also walks the base lines of the base variants
         const bool last = it + 1 == A.n_iters, emit = last && A.emit;
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         // memory side plus the load's, whatever the layout.)
         if (it > 0) {
             for (int s = w.n_own_v + tid; s < w.n_slots; s += PK_THREADS) {
-                gu64* g = posbox + ((size_t)par * A.box_stride + V.vid[s]) * 2;
+                gu64* g = posbox + ((size_t)par * A.box_stride + (s < w.n_own_v + PK_THREADS ? my_vid : V.vid[s])) * 2;
                 spin_state st = {0u, 0ull};
                 unsigned long long a, b;
                 for (;;) {

@@ -33,18 +33,22 @@
 #define PK_SUM_STRIDE 5         /* ... and the words from one line's sums to the next: at 4 (32 bytes) the lines a wave folds into fall on
                                    8 of the 32 LDS banks; at 5 they spread over all of them */
 #endif
+/* Threads per workgroup and lane-items per thread (round 5: 768 x 1, three waves per SIMD; rounds 3-4: 512 x 2).  The register file holds
+   the same number of table records either way, but a wave walks at the LATENCY of its own instruction stream -- the row of a walk is one
+   chain of dependent instructions (shift, clamp, mask, compare, branch, address, load) -- so what fills a SIMD is waves, not work per wave:
+   two waves of 24 rows keep the VALU ~70 % busy, three of 14-16 rows ~85 % (profiles/r05_experiments.txt). */
 #ifndef PK_THREADS
-#define PK_THREADS 512
+#define PK_THREADS 768
 #endif
 #ifndef PK_WG_PER_CU
-#define PK_WG_PER_CU 1        /* workgroups (patches) per compute unit: PK_THREADS x this = 512 threads, two waves per SIMD */
+#define PK_WG_PER_CU 1        /* workgroups (patches) per compute unit */
 #endif
 #ifndef PK_NI
-#define PK_NI 2                /* lane-items of the walk a thread keeps table records for, in registers */
+#define PK_NI 1                /* lane-items of the walk a thread keeps table records for, in registers */
 #endif
 #define PK_CACHED (PK_THREADS * PK_NI)
 #ifndef PK_ROWS_PER_LANE
-#define PK_ROWS_PER_LANE 12  /* table records a lane of the walk keeps in registers: the most rows per lane */
+#define PK_ROWS_PER_LANE 16  /* table records a lane of the walk keeps in registers: the most rows per lane */
 #endif
 /* the instantiations of the kernel: rows a lane keeps records for (fewer rows, fewer registers and less straight-line code) */
 #define PK_RR0 (PK_ROWS_PER_LANE * 2 / 3)
