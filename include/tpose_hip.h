@@ -237,7 +237,8 @@ int tp_render(tp_context* ctx, int source, const float* points, uint8_t* dst_rgb
  * 5 = persistent launches so far, 6 = grad-iters run inside them, 7 = census (1 a full grid is resident, -1 not,
  * 0 not taken yet; below -1: why not), 8 = plans cut again during long descents (vertices had drifted from where the plan saw
  * them), 9 = persistent launches that gave up waiting and were run again on the two-kernel path, 10 = this band's mailbox came
- * from tp_band_mailbox_alloc (fine-grained memory) */
+ * from tp_band_mailbox_alloc (fine-grained memory), 11 = persistent launches that started from what the launch before them left (the cut of the
+ * patches' lines and the lanes' lane-items: same plan, image and dp -- a launch after tp_upload, tp_set_image or tp_set_dp never does) */
 int tp_get_info(tp_context* ctx, int what, int64_t* value);
 
 /* device self-test of the exact span walker (tp_raster.h): for each (N0, step, d), the 32 values

@@ -279,3 +279,50 @@ def test_a_small_mesh_whose_early_launch_gives_up(first):
     assert ctxs[0].info(capi.INFO_PERSIST_FAILURES) == 1 and ctxs[1].info(capi.INFO_PERSIST_FAILURES) == 0
     for c in ctxs:
         c.close()
+
+
+def test_warm_launches_start_from_the_last_cut_and_never_after_an_upload_image_or_dp():
+    """round 5: a persistent launch leaves the cut of its patches' lines and its threads' lane-items for the next launch on the same plan
+    (tp_persist.hip, "carry"), which then neither counts chunks nor searches in its first grad-iter; its first grad-iter also fetches every
+    record from the tiled copy of the table.  Same bits across warm launches (calls of 5, 7, 60 and 9 grad-iters: the lines are cut again
+    INSIDE the third, 64 grad-iters after the first cut), and a launch behind tp_upload, tp_set_image or tp_set_dp is never warm."""
+    W, H, NT = 640, 480, 3000
+    img, pts, tris, he, ratio = synth.workload(W, H, NT, contrast=0.3)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts, tris, None)
+    p = capi.default_params(0)
+    ref_pts, warm = pts, 0
+    for k, n in enumerate((5, 7, 60, 9)):
+        ctx.iterate(p, n)
+        ref = O.iterate(img, ref_pts, tris, 0, ratio, RATE[0], n, literal=False)
+        _compare(ctx, ref, 0, "call %d" % k)
+        ref_pts = ref["points"]
+        assert ctx.info(capi.INFO_WARM_LAUNCHES) == warm + (1 if k > 0 else 0), k
+        warm = ctx.info(capi.INFO_WARM_LAUNCHES)
+    assert ctx.info(capi.INFO_PERSIST_FAILURES) == 0 and ctx.info(capi.INFO_PERSIST_ITERS) == 81
+    # a new image: the next launch cuts for itself, the one behind it is warm again
+    img2 = np.ascontiguousarray(img[::-1])
+    ctx.set_image(capi.IMAGE_A, img2)
+    ctx.iterate(p, 6)
+    assert ctx.info(capi.INFO_WARM_LAUNCHES) == warm
+    ref = O.iterate(img2, ref_pts, tris, 0, ratio, RATE[0], 6, literal=False)
+    _compare(ctx, ref, 0, "after tp_set_image"); ref_pts = ref["points"]
+    ctx.iterate(p, 6)
+    assert ctx.info(capi.INFO_WARM_LAUNCHES) == warm + 1
+    warm += 1
+    ref = O.iterate(img2, ref_pts, tris, 0, ratio, RATE[0], 6, literal=False)
+    _compare(ctx, ref, 0, "warm on the new image"); ref_pts = ref["points"]
+    # tp_set_dp
+    ctx.set_dp(0.02)
+    ctx.iterate(p, 5)
+    assert ctx.info(capi.INFO_WARM_LAUNCHES) == warm
+    ref = O.iterate(img2, ref_pts, tris, 0, ratio, RATE[0], 5, literal=False)
+    _compare(ctx, ref, 0, "after tp_set_dp"); ref_pts = ref["points"]
+    # tp_upload of the moved mesh
+    ctx.upload(ref_pts, tris, None)
+    ctx.iterate(p, 5)
+    assert ctx.info(capi.INFO_WARM_LAUNCHES) == warm
+    ref = O.iterate(img2, ref_pts, tris, 0, ratio, RATE[0], 5, literal=False)
+    _compare(ctx, ref, 0, "after tp_upload")
+    ctx.close()

@@ -40,7 +40,7 @@ RENDER_AVERAGE, RENDER_STORED = 0, 1
 OPT_PERSISTENT, OPT_INJECT_GIVE_UP = 1, 3
 PERSIST_OFF, PERSIST_AUTO = 0, 1
 INFO_PATCHES, INFO_PATCH_LDS, INFO_PATCH_LINES, INFO_PERSIST_LAUNCHES, INFO_PERSIST_ITERS, INFO_CENSUS, INFO_REPLANS = 2, 3, 4, 5, 6, 7, 8
-INFO_PERSIST_FAILURES, INFO_BOX_FINEGRAINED = 9, 10
+INFO_PERSIST_FAILURES, INFO_BOX_FINEGRAINED, INFO_WARM_LAUNCHES = 9, 10, 11
 
 
 class Params(C.Structure):

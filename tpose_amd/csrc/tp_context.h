@@ -129,6 +129,15 @@ struct tp_context {
     struct plan_buf { pk_wg* wg = nullptr; int32_t* pool = nullptr; size_t cap_wg = 0, cap_pool = 0; uint8_t* stage = nullptr; size_t cap_stage = 0; };
     plan_buf plan_dev[2];
     int plan_slot = 0;
+    // What a persistent launch hands to the next one on the same plan (tp_persist.hip, "carry"): per workgroup the cut of its lines into lane
+    // chunks, the lane-items of its threads and how long ago the lines were last cut -- a launch that finds them does not cut and search again
+    // (3 us of a short call's first grad-iter).  Tagged: a new plan, image or dp gets a new tag, and words that carry another are ignored.
+    int32_t* carry = nullptr; size_t cap_carry = 0;
+    int carry_stride = 0;
+    uint32_t carry_tag = 0, carry_seq = 0;
+    float carry_dp = -1.0f; int carry_slot = -1;   // what the launches under the current tag were called with
+    int64_t warm_launches = 0;       // (tp_get_info 11: persistent launches enqueued with a carry of the same tag behind them)
+    bool carry_written = false;      // a launch with the current tag has been enqueued: the next one finds its carry
     std::vector<float> plan_points;           // positions the current plan was cut from
     float* snap_host[2] = {nullptr, nullptr};  // pinned: positions after a chunk
     size_t snap_cap = 0;
@@ -250,6 +259,7 @@ int settle_persistent(tp_context* c);
 int settle_epos(tp_context* c);   // before anything that reads `epos` (k_lines) is enqueued
 hipError_t wait_context(tp_context* c);   // wait for the context's stream
 int install_plan(tp_context* c, pk_plan& np, const float* points, int slot);
+void drop_carry(tp_context* c);   // what the last launch left for the next is not to be used (a new plan, image or dp)
 int plan_patches(const tp_context* c);
 int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok);
 int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false);

@@ -170,7 +170,7 @@ int tp_destroy(tp_context* c) {
     free_triangulation(c);
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->prefix[0]); hipFree(c->prefix[1]); hipFree(c->px[0]); hipFree(c->px[1]); hipFree(c->pxt[0]); hipFree(c->pxt[1]);
     hipFree(c->render_pic); hipFree(c->render_pts);
-    hipFree(c->d_wg); hipFree(c->d_pool); hipFree(c->posbox); hipFree(c->points_out); hipFree(c->d_status);
+    hipFree(c->d_wg); hipFree(c->d_pool); hipFree(c->posbox); hipFree(c->points_out); hipFree(c->d_status); hipFree(c->carry);
     if (c->h_status) hipHostFree(c->h_status);
     if (c->frame_mirror) hipHostFree(c->frame_mirror);
     hipFree(c->ering); hipFree(c->pring);
@@ -207,6 +207,7 @@ int tp_set_dp(tp_context* c, float dp) {
     if (!c) return TP_ERR_INVALID;
     c->mutations++; c->tail_is_finish = false;   // (a retrieve no longer finds what the frame mirror holds)
     c->dp_override = dp;  // piecewise calls only; tp_iterate takes dp from its params (part of the graph key)
+    drop_carry(c);        // (the next persistent launch cuts its lines itself)
     c->accumulated = c->energized = false;
     return TP_OK;
 }
@@ -256,6 +257,7 @@ static int set_image_common(tp_context* c, int slot, const void* src, size_t str
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_img[slot] = true;
     c->accumulated = c->energized = false;
+    drop_carry(c);   // (the next persistent launch cuts its lines itself)
     return TP_OK;
 }
 
@@ -777,6 +779,7 @@ int tp_get_info(tp_context* c, int what, int64_t* value) {
         case 8: *value = c->replans; return TP_OK;
         case 9: *value = c->persist_failures; return TP_OK;
         case 10: *value = c->box_finegrained ? 1 : 0; return TP_OK;
+        case 11: *value = c->warm_launches; return TP_OK;
         default: return fail(c, TP_ERR_INVALID, "unknown info %d", what);
     }
 }

@@ -106,6 +106,10 @@ struct pk_args {
     // words into pinned memory; no k_persist_finish behind it (a launch + 5 us less per call).  A launch that gives up leaves `points` whole.
     unsigned* host_status;        // pinned mirror {gave up, -, launches completed}; null: k_persist_finish follows
     int inject_give_up;           // tests (TP_OPT_INJECT_GIVE_UP): one workgroup gives up before the last grad-iter
+    // carry: [parts][carry_stride] words a launch leaves for the next one on the same plan -- {tag, grad-iters since the lines were cut, rows per
+    // lane, lane-items, lane-items with the base lines, -, -, -}, the cut (first lane-item of every line), every thread's lane-item {line, chunk,
+    // chunks}; null: none.  A workgroup whose words carry carry_tag starts from them (tp_persist.hip)
+    int32_t* carry; int carry_stride; unsigned carry_tag; int carry_cut_cap;
 #ifdef TPOSE_DEBUG
     unsigned long long* dbg;      // [parts][PK_DBG_ITERS][16] phase timestamps of the grad-iters dbg_first ...
     int dbg_first;

@@ -389,6 +389,30 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int pitch, const c
     }
     return n;
 }
+// step 1 in the FIRST grad-iter of a launch: nothing is cached yet, every row of every lane is fetched -- from the TILED copy of the table
+// (4 rows x 2 columns per 128-byte line: the chunks of a line and the versions of an edge share lines there; the row-major table gives
+// every record a line of its own, a million lines per launch at 2048^2 / 3000 and 15 us of a 20-step call).  No comparison, no branch; the
+// address arithmetic of the tiled form costs this one grad-iter ~7 instructions per row and the others nothing.
+template <int RR, int R>
+TP_HD int pk_walk_fill(pk_lane_cache<R>& C, const pk_view& V, int pitch, const char* tiled, int W) {
+    static_assert(RR <= R && RR <= 32, "one bit per row");
+    pk_rows t;
+    int first = 0;
+    if (C.TL == 0) { t.n = 0; t.x = 0; t.xs = 0; t.row = 0; t.rs = 0; }
+    else t = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch, &first);
+    const uint32_t live = t.n >= 32 ? 0xffffffffu : ((1u << t.n) - 1u);
+    C.row0 = t.row;
+    uint32_t row = (uint32_t)first;
+#pragma unroll
+    for (int u = 0; u < RR; u++) {
+        const uint32_t on = 0u - ((live >> u) & 1u);
+        const int32_t col = pk_next_col(t, W) & (int32_t)on;
+        C.rec[u] = pk_load_rec(tiled, (tp_px_tiled_row_part(row, (uint32_t)pitch) & on) + tp_px_tiled_col_part((uint32_t)col));
+        C.col[u] = col;
+        row += (uint32_t)C.TL;
+    }
+    return t.n;
+}
 // step 2: the line's partial sums of this lane (the crossing columns are the cached ones by now: they are added up here,
 // behind the fetches).  n: the lane's rows, from step 1
 template <int RR, int R>

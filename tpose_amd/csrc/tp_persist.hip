@@ -26,6 +26,9 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 #define PK_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define PK_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 #define PK_TIMEOUT_TICKS 3000000ull  // 30 ms of the 100 MHz wall clock (a hand-over takes microseconds)
+#ifndef PK_EXP_NOFILL
+#define PK_EXP_NOFILL 0   /* timing experiments only: 1 = the first grad-iter of a launch fetches like every other (row-major table, compare first) */
+#endif
 #define PK_TIMEOUT_BANDS 100000000ull  // 1 s when other processes take part (their launches start when their hosts get to it)
 
 #ifdef TPOSE_DEBUG
@@ -107,6 +110,18 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         return;
     }
     PK_STAMP0(12);
+    // carry (below): requested first, so that the words are on their way while the tables come over
+    int32_t* const carry = A.carry && w.n_lines_all + 1 <= A.carry_cut_cap ? A.carry + (size_t)part * (size_t)A.carry_stride : nullptr;
+    int32_t cy_hdr[5] = {0, 0, 0, 0, 0}, cy_item[PK_NI][3], cy_cut = 0;
+    if (carry) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) cy_hdr[q] = carry[q];
+#pragma unroll
+        for (int i = 0; i < PK_NI; i++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) cy_item[i][q] = carry[8 + A.carry_cut_cap + 3 * (tid + i * PK_THREADS) + q];
+        if (tid <= w.n_lines_all) cy_cut = carry[8 + tid];
+    }
 
     // ---- prologue: the patch's tables and positions into LDS.  The plan lays a patch's tables out in its pool the way pk_carve lays them
     // out in LDS -- {vid, edges, lines} and {corners, base}, every table padded to 16 bytes (tp_plan.h: put) -- so they come over as two runs
@@ -175,6 +190,32 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
 
     // the mailbox slot of the first foreign vertex this lane polls (its number is a table look-up the poll would otherwise start with)
     const int my_vid = w.n_own_v + tid < w.n_slots ? V.vid[w.n_own_v + tid] : 0;
+    // ---- carry: what the launch before this one left for it (same plan, image, dp -- the tag says so): the cut of the patch's lines, this
+    // thread's lane-item, the rows per lane and how long ago the lines were cut.  A launch that finds them neither counts chunks nor searches
+    // for its lane-items in its first grad-iter (1.2 + 1.5 us of a short call), and cuts again when the lines are due, not at its start.
+    int age0 = 0;
+    bool warm = carry && (unsigned)cy_hdr[0] == A.carry_tag;
+    if (warm) {
+        age0 = cy_hdr[1] & (PK_RECUT - 1);
+        warm = age0 != 0;   // (due at once: the first grad-iter cuts as a cold launch does)
+        if (!warm) age0 = 0;
+    }
+    if (warm) {
+        if (tid <= w.n_lines_all) V.cut[tid] = cy_cut;
+        for (int i = tid + PK_THREADS; i <= w.n_lines_all; i += PK_THREADS) V.cut[i] = carry[8 + i];
+        if (tid == 0) { V.flags[1] = 0; V.flags[2] = cy_hdr[2]; }
+        n_li_now = cy_hdr[3]; n_li_all_now = cy_hdr[4];
+#pragma unroll
+        for (int i = 0; i < PK_NI; i++) {
+            const int lc = cy_item[i][0], TL = cy_item[i][1];
+            cache[i].l = lc & 0xffff; cache[i].c = (int)((unsigned)lc >> 16); cache[i].TL = TL; cache[i].magic = (uint32_t)cy_item[i][2];
+            cache[i].row0 = TL ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int u = 0; u < RR; u++) { cache[i].col[u] = TL ? -1 : 0; cache[i].rec[u].lo = 0; cache[i].rec[u].hi = 0; }
+        }
+        // (the table of the lane-items no thread keeps records for -- the patch's overflow, and the last grad-iter's base lines -- is listed
+        // behind the first barrier of the first grad-iter, where the cut is visible to everybody)
+    }
     for (int it = 0; it < A.n_iters; it++) {
 #if defined(__HIP_DEVICE_COMPILE__)
         // Nothing derived from the thread's number is kept across grad-iters: left alone, the compiler hoists some forty addresses out of
@@ -186,7 +227,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         // the last grad-iter of a call that wants the reference's buffers also walks the base lines of the base variants
         const bool last = it + 1 == A.n_iters, emit = last && A.emit;
         // every PK_RECUT grad-iters the patch looks at the chunks of its lines again (tp_persist.h, pk_recut_line)
-        const bool recut = (it & (PK_RECUT - 1)) == 0;
+        const bool recut = ((it + age0) & (PK_RECUT - 1)) == 0;   // (age0: grad-iters since the cut a warm launch inherited)
         const int n_lines = emit ? w.n_lines_all : w.n_lines, n_setup = recut ? w.n_lines_all : n_lines;
         PK_STAMP(0); PK_WSTAMP(0);
         // ---- P0: positions of the neighbouring vertices this patch uses (the first grad-iter of a launch read `points`)
@@ -248,11 +289,16 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         __syncthreads();
         PK_WSTAMP(4);
         PK_STAMP(6);
+        if (warm && it == 0) {
+            const int j0 = n_li_now < PK_CACHED ? n_li_now : PK_CACHED;
+            for (int l = tid; l < w.n_lines_all; l += PK_THREADS) pk_list_line(V, l, j0, w.li_cap);
+            __syncthreads();
+        }
         if (recut) {
             if (tid < 64) {
                 // (the first cut of a launch always counts as a change: every thread's lane-items are decided there -- also in a patch
                 // without lines, whose threads would otherwise walk whatever their registers held)
-                int changed = it == 0 ? 1 : 0, rpl = it == 0 ? w.rows : V.flags[2];
+                int changed = it == 0 ? 1 : 0, rpl = it == 0 ? w.rows : V.flags[2];   // (a warm launch never cuts in its first grad-iter)
                 bool first = it == 0;
                 for (;;) {
                     int every;
@@ -296,7 +342,8 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         {
             int rows[PK_NI];
 #pragma unroll
-            for (int i = 0; i < PK_NI; i++) rows[i] = pk_walk_pass<RR>(cache[i], V, A.px_pitch, table, A.vw.W);
+            for (int i = 0; i < PK_NI; i++)
+                rows[i] = (it == 0 && tiled && !PK_EXP_NOFILL) ? pk_walk_fill<RR>(cache[i], V, A.px_pitch, tiled, A.vw.W) : pk_walk_pass<RR>(cache[i], V, A.px_pitch, table, A.vw.W);
             PK_STAMP(8); PK_WSTAMP(5);
 #pragma unroll
             for (int i = 0; i < PK_NI; i++) {
@@ -439,6 +486,20 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         PK_STAMP(4); PK_WSTAMP(8);
         PK_STAMP(5); PK_WSTAMP(10);
         // (no barrier here: P0 of the next grad-iter touches foreign position slots only, and its barrier orders the rest)
+    }
+    // ---- carry for the next launch on this plan (no fence: it is work on the same stream, ordered behind the end of this kernel)
+    if (carry) {
+        __syncthreads();
+        for (int i = tid; i <= w.n_lines_all; i += PK_THREADS) carry[8 + i] = V.cut[i];
+#pragma unroll
+        for (int i = 0; i < PK_NI; i++) {
+            int32_t* e = carry + 8 + A.carry_cut_cap + 3 * (tid + i * PK_THREADS);
+            e[0] = (cache[i].l & 0xffff) | (cache[i].c << 16); e[1] = cache[i].TL; e[2] = (int32_t)cache[i].magic;
+        }
+        if (tid == 0) {
+            carry[1] = (A.n_iters + age0) & (PK_RECUT - 1); carry[2] = V.flags[2]; carry[3] = n_li_now; carry[4] = n_li_all_now;
+            carry[0] = (int32_t)A.carry_tag;
+        }
     }
     // ---- a launch that finishes itself: the last workgroup through here counts the launch as completed and tells the host (a pinned word it
     // spins on).  A workgroup that gave up never takes a ticket, so a launch that reaches the full count has completed everywhere.

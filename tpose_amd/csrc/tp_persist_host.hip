@@ -161,8 +161,27 @@ int install_plan(tp_context* c, pk_plan& np, const float* points, int slot) {
     c->plan_slot = slot;
     c->plan_points.assign(points, points + 2 * (size_t)c->NP);
     c->iters_since_cut = 0;
+    {   // room for what the launches on this plan hand to each other, under a tag of its own
+        int most = 0;
+        for (const pk_wg& w : c->plan.wg) most = std::max(most, w.n_lines_all);
+        const int cut_cap = (most + 1 + 3) & ~3;
+        c->carry_stride = 8 + cut_cap + 3 * PK_THREADS;
+        const size_t words = (size_t)c->plan.parts * (size_t)c->carry_stride;
+        if (words > c->cap_carry) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));   // (an earlier launch may still be writing the old one)
+            hipFree(c->carry); c->carry = nullptr; c->cap_carry = 0;
+            const size_t n = words + words / 4 + 1024;
+            HIP_TRY(c, dev_alloc(&c->carry, n));
+            c->cap_carry = n;
+        }
+        // (cleared for every plan: the words of another plan's layout are anything -- a lane-item's chunk count where this layout keeps a
+        // tag --, and no tag is 0)
+        HIP_TRY(c, hipMemsetAsync(c->carry, 0, words * sizeof(int32_t), c->stream));
+        drop_carry(c);
+    }
     return TP_OK;
 }
+void drop_carry(tp_context* c) { c->carry_tag = ++c->carry_seq ? c->carry_seq : ++c->carry_seq; c->carry_written = false; }
 int plan_patches(const tp_context* c) { return c->n_bands > 1 ? c->n_bands * c->band_patches : c->num_cus * PK_WG_PER_CU; }
 
 // cut a plan from `points` and install it in plan buffer `slot`.  c->plan is replaced only when the new plan is usable.
@@ -284,6 +303,12 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
             A.final_slot = (unsigned)(c->band_seq++ & 1);
         }
         A.epoch = c->epoch; A.n_iters = k; A.status = c->d_status;
+        if (c->carry && c->carry_stride > 0) {
+            if (dp != c->carry_dp || p.image_slot != c->carry_slot) { drop_carry(c); c->carry_dp = dp; c->carry_slot = p.image_slot; }   // (another dp or image than the launch before)
+            A.carry = c->carry; A.carry_stride = c->carry_stride; A.carry_tag = c->carry_tag; A.carry_cut_cap = c->carry_stride - 8 - 3 * PK_THREADS;
+            if (c->carry_written) c->warm_launches++;
+            c->carry_written = true;
+        }
         A.emit = n == k && !rings; A.ten = c->ten; A.cn = c->cn; A.ca_out = c->ca; A.gr = c->gr;
         if (rings && !banded_rings(c)) { A.ering = c->ering; A.pring = c->pring; }
         if (rings && banded_rings(c)) {
