@@ -93,10 +93,10 @@ int tp_set_dp(tp_context* ctx, float dp);
  * TP_OPT_PERSISTENT: TP_PERSIST_AUTO (default) lets tp_iterate run calls of >= 4 grad-iters inside
  * persistent launches (one workgroup per patch of the mesh, K grad-iters per launch) when the device keeps a full grid
  * resident; TP_PERSIST_OFF keeps every grad-iter on the two-kernel path (k_lines + k_update).
- * TP_OPT_INJECT_GIVE_UP (tests): n > 0 makes one workgroup of the n-th persistent launch from now give up before its last grad-iter,
+ * TP_OPT_INJECT_GIVE_UP (tests; refused unless TPOSE_ALLOW_FAULT_INJECTION is set in the environment): n > 0 makes one workgroup of the n-th persistent launch from now give up before its last grad-iter,
  * as if the launch's workgroups had not all been resident: the launch and those behind it are run again on the two-kernel path
- * (tp_get_info 9 counts it) and the context keeps to the two-kernel path for a while (0.2 s; longer after every further give-up, for good
- * after the fourth). */
+ * (tp_get_info 9 counts it) and the context keeps to the two-kernel path for a while: 0.2 s, then 0.8, 3.2 and 12.8 s while give-ups come in a
+ * row (64 launches that complete end a row); never for good -- tp_get_info 12 says how long is left. */
 enum tp_option { TP_OPT_PERSISTENT = 1, TP_OPT_INJECT_GIVE_UP = 3 };
 enum { TP_PERSIST_OFF = 0, TP_PERSIST_AUTO = 1 };
 int tp_set_option(tp_context* ctx, int option, int64_t value);
@@ -203,10 +203,12 @@ int tp_evaluate_triangles(tp_context* ctx, int slot, int n, const int32_t* verti
  * buffers back every frame (software/triangulate/main.cpp:201-204, warp/main.cpp:226-229); done one by one,
  * each is a blocking round trip. */
 int tp_retrieve_many(tp_context* ctx, int n, const int* what, void* const* dst, const size_t* count);
+/* tp_synchronize waits for everything the LIBRARY has enqueued for this context.  Work a caller puts on the stream of tp_get_stream
+ * itself is not covered: wait for that with the HIP runtime (hipStreamSynchronize). */
 int tp_synchronize(tp_context* ctx);
 
-/* measurement hooks (bench.py): the HIP stream the kernels run on; a pair of HIP events on that stream around whatever is
- * enqueued between the two calls (tp_timer_stop waits for the second event and returns the time between them) */
+/* measurement hooks (bench.py): the HIP stream the kernels run on (foreign work on it: see tp_synchronize); a pair of HIP events on that
+ * stream around whatever is enqueued between the two calls (tp_timer_stop waits for the second event and returns the time between them) */
 int tp_get_stream(tp_context* ctx, void** hip_stream);
 int tp_timer_start(tp_context* ctx);
 int tp_timer_stop(tp_context* ctx, double* elapsed_us);
@@ -238,7 +240,8 @@ int tp_render(tp_context* ctx, int source, const float* points, uint8_t* dst_rgb
  * 0 not taken yet; below -1: why not), 8 = plans cut again during long descents (vertices had drifted from where the plan saw
  * them), 9 = persistent launches that gave up waiting and were run again on the two-kernel path, 10 = this band's mailbox came
  * from tp_band_mailbox_alloc (fine-grained memory), 11 = persistent launches that started from what the launch before them left (the cut of the
- * patches' lines and the lanes' lane-items: same plan, image and dp -- a launch after tp_upload, tp_set_image or tp_set_dp never does) */
+ * patches' lines and the lanes' lane-items: same plan, image and dp -- a launch after tp_upload, tp_set_image or tp_set_dp never does),
+ * 12 = milliseconds until persistent launches are tried again after one gave up (0: in use) */
 int tp_get_info(tp_context* ctx, int what, int64_t* value);
 
 /* device self-test of the exact span walker (tp_raster.h): for each (N0, step, d), the 32 values

@@ -326,3 +326,46 @@ def test_warm_launches_start_from_the_last_cut_and_never_after_an_upload_image_o
     ref = O.iterate(img2, ref_pts, tris, 0, ratio, RATE[0], 5, literal=False)
     _compare(ctx, ref, 0, "after tp_upload")
     ctx.close()
+
+
+def test_an_ageing_descent_under_the_oracle():
+    """Ageing in the driver-run suite: 640 x 480 / 3000 triangles at three times the reference's rate, 2100 grad-iters in calls of mixed
+    lengths -- the lines are cut again every 64 grad-iters (32 times), launches hand their cuts to each other (warm launches), vertices drift
+    far enough for the host to cut new plans -- and after EVERY call all four buffers and the float32 positions are the oracle's, 0 ulp."""
+    W, H, NT = 640, 480, 3000
+    img, pts, tris, he, ratio = synth.workload(W, H, NT, contrast=0.3)
+    ctx = capi.Context(0, W, H)
+    ctx.set_image(capi.IMAGE_A, img)
+    ctx.upload(pts, tris, None)
+    rate = np.float32(3.0) * np.float32(RATE[0])
+    p = capi.default_params(0, rate=float(rate))
+    calls = [20, 257, 600, 33, 700, 5, 64, 421]
+    assert sum(calls) == 2100
+    ref_pts = pts
+    for k, n in enumerate(calls):
+        ctx.iterate(p, n)
+        ref = O.iterate(img, ref_pts, tris, 0, ratio, float(rate), n, literal=False)
+        _compare(ctx, ref, 0, "call %d (%d grad-iters)" % (k, n))
+        ref_pts = ref["points"]
+    assert ctx.info(capi.INFO_PERSIST_ITERS) == 2100 and ctx.info(capi.INFO_PERSIST_FAILURES) == 0
+    assert ctx.info(capi.INFO_REPLANS) >= 1, "no plan was cut again: the mesh did not drift"
+    assert ctx.info(capi.INFO_WARM_LAUNCHES) >= 3
+    moved = np.abs((ref_pts - pts) * np.array([W / 2 / ratio, H / 2], np.float32)).max()
+    assert moved > 4.0, moved
+    ctx.close()
+
+
+def test_sixteen_grad_iters_from_an_old_state_at_the_metric_size():
+    """2048^2 / 3000: 4096 grad-iters on the device (re-cuts, re-plans, chunked launches), then the positions go to the oracle and 16 more
+    grad-iters in two calls are compared -- the state the benchmark's long calls run in, not the fresh one"""
+    ctx, sweep, pts, tris, ratio, colors = _setup(2048, 2048, 3000, 0, 0.1)
+    p = capi.default_params(0)
+    ctx.iterate(p, 4096)
+    old = ctx.retrieve(capi.BUF_POINTS)
+    assert not np.array_equal(old, pts)
+    ctx.iterate(p, 9)
+    ctx.iterate(p, 7)
+    ref = O.iterate(sweep, old, tris, 0, ratio, RATE[0], 16, literal=False)
+    _compare(ctx, ref, 0, "16 grad-iters behind 4096")
+    assert ctx.info(capi.INFO_PERSIST_ITERS) == 4096 + 16 and ctx.info(capi.INFO_PERSIST_FAILURES) == 0
+    ctx.close()

@@ -196,6 +196,8 @@ struct tp_context {
     std::vector<journal_entry> journal;   // ... which ones (tp_iterate): replayed on the two-kernel path if a launch gave up
     unsigned done_base = 0;               // the device's count of completed persistent launches when the journal was last empty
     int64_t persist_failures = 0;
+    int persist_streak = 0;                  // give-ups in a row (64 completed launches end a row): what the wait before the next try grows with
+    int64_t completed_since_give_up = 0;
     int census_retries = 0;         // a census that timed out (the device was busy with somebody else's grid) is taken again, twice at most
     std::chrono::steady_clock::time_point persist_retry_at{};   // after a launch gave up: when persistent launches are tried again
     int64_t persist_launches = 0, persist_iters = 0;

@@ -223,6 +223,8 @@ int tp_set_option(tp_context* c, int option, int64_t value) {
             return TP_OK;
         case TP_OPT_INJECT_GIVE_UP:
             if (value < 0 || value > 1000000) return fail(c, TP_ERR_INVALID, "TP_OPT_INJECT_GIVE_UP: bad value %lld", (long long)value);
+            // (a fault injection for tests: a client cannot send a production context to the slow path with it)
+            if (value > 0 && !getenv("TPOSE_ALLOW_FAULT_INJECTION")) return fail(c, TP_ERR_INVALID, "TP_OPT_INJECT_GIVE_UP needs TPOSE_ALLOW_FAULT_INJECTION in the environment");
             c->inject_give_up = (int)value;
             return TP_OK;
         default: return fail(c, TP_ERR_INVALID, "unknown option %d", option);
@@ -780,6 +782,11 @@ int tp_get_info(tp_context* c, int what, int64_t* value) {
         case 9: *value = c->persist_failures; return TP_OK;
         case 10: *value = c->box_finegrained ? 1 : 0; return TP_OK;
         case 11: *value = c->warm_launches; return TP_OK;
+        case 12: {   // milliseconds until persistent launches are tried again after a give-up (0: they are in use, or were never possible here)
+            const auto now = std::chrono::steady_clock::now();
+            *value = c->census == -6 && c->persist_retry_at > now ? (int64_t)std::chrono::duration_cast<std::chrono::milliseconds>(c->persist_retry_at - now).count() + 1 : 0;
+            return TP_OK;
+        }
         default: return fail(c, TP_ERR_INVALID, "unknown info %d", what);
     }
 }

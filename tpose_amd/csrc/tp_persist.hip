@@ -26,6 +26,12 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 #define PK_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define PK_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 #define PK_TIMEOUT_TICKS 3000000ull  // 30 ms of the 100 MHz wall clock (a hand-over takes microseconds)
+#ifndef PK_RECUT_ON_DEMAND
+#define PK_RECUT_ON_DEMAND 0   /* (measured: while a cut that changes one line moves every lane-item behind it, cutting more often costs more than the rows it saves) */
+#endif
+#ifndef PK_RECUT_MIN_GAP
+#define PK_RECUT_MIN_GAP 4    /* grad-iters between two cuts of a patch's lines, at least */
+#endif
 #ifndef PK_EXP_NOFILL
 #define PK_EXP_NOFILL 0   /* timing experiments only: 1 = the first grad-iter of a launch fetches like every other (row-major table, compare first) */
 #endif
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
     // ---- carry: what the launch before this one left for it (same plan, image, dp -- the tag says so): the cut of the patch's lines, this
     // thread's lane-item, the rows per lane and how long ago the lines were cut.  A launch that finds them neither counts chunks nor searches
     // for its lane-items in its first grad-iter (1.2 + 1.5 us of a short call), and cuts again when the lines are due, not at its start.
-    int age0 = 0;
+    int age0 = 0, last_cut = 0;
     bool warm = carry && (unsigned)cy_hdr[0] == A.carry_tag;
     if (warm) {
         age0 = cy_hdr[1] & (PK_RECUT - 1);
@@ -227,7 +233,12 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         // the last grad-iter of a call that wants the reference's buffers also walks the base lines of the base variants
         const bool last = it + 1 == A.n_iters, emit = last && A.emit;
         // every PK_RECUT grad-iters the patch looks at the chunks of its lines again (tp_persist.h, pk_recut_line)
-        const bool recut = ((it + age0) & (PK_RECUT - 1)) == 0;   // (age0: grad-iters since the cut a warm launch inherited)
+        // ... and at once when a lane has found more rows than it keeps records for (a line outgrew its chunks: those rows are fetched again every
+        // grad-iter, a memory latency or two inside the sums of its wave, until the lines are cut again -- on a raster of three times the
+        // contrast a tenth of the patches spent 2.4 us of every grad-iter waiting for such a wave; profiles/r05_experiments.txt)
+        const bool recut = ((it + age0) & (PK_RECUT - 1)) == 0 ||   // (age0: grad-iters since the cut a warm launch inherited)
+                           (PK_RECUT_ON_DEMAND && it > 0 && it - last_cut >= PK_RECUT_MIN_GAP && __hip_atomic_load(&V.flags[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0);
+        if (recut) last_cut = it;
         const int n_lines = emit ? w.n_lines_all : w.n_lines, n_setup = recut ? w.n_lines_all : n_lines;
         PK_STAMP(0); PK_WSTAMP(0);
         // ---- P0: positions of the neighbouring vertices this patch uses (the first grad-iter of a launch read `points`)
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                     rpl++; first = true;   // (more lane-items than lanes keep records for: a row more per lane)
                 }
                 changed = __any(changed);
-                if (tid == 0) { V.flags[1] = changed; V.flags[2] = rpl; }
+                if (tid == 0) { V.flags[1] = changed; V.flags[2] = rpl; V.flags[8] = 0; }
             }
             __syncthreads();
             PK_STAMP(7);
@@ -349,6 +360,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             for (int i = 0; i < PK_NI; i++) {
                 pk_acc a;
                 pk_walk_sum<RR>(cache[i], rows[i], V, A.px_pitch, table, A.vw.W, a);
+                if (rows[i] > RR) V.flags[8] = 1;   // (the lines want cutting again)
                 fold(cache[i].l, a);
             }
             PK_STAMP(9);

@@ -31,19 +31,30 @@ int check_persist_status(tp_context* c) {
     const unsigned st[3] = {c->h_status[0], 0u, c->h_status[2]};
     const size_t completed = (size_t)(st[2] - c->done_base);
     c->done_base = st[2];
-    if (st[0] == 0u) { c->journal.clear(); return TP_OK; }
+    if (st[0] == 0u) {
+        // (a run of launches that completed ends the streak: give-ups hours apart -- another process briefly on the device -- are each
+        // the first of their own, not steps towards the longest wait)
+        c->completed_since_give_up += (int64_t)c->journal.size();
+        if (c->completed_since_give_up >= 64) c->persist_streak = 0;
+        c->journal.clear();
+        return TP_OK;
+    }
     // (a workgroup that gives up tells the host at once; the others of its launch, and the launches behind it, are still on their way out)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemset(c->d_status, 0, sizeof(unsigned)));
     HIP_TRY(c, hipMemset(c->d_status + 3, 0, sizeof(unsigned)));   // (the tickets of a launch that finishes itself and gave up on the way)
     c->h_status[0] = 0u;
     // two kernels per grad-iter from now on -- for a while: a collision with somebody else's launch is a transient thing, and the
-    // two-kernel path is three times slower.  Persistent launches are tried again 0.2 s later (0.8, 3.2, 12.8 s after the next ones; a
-    // context whose launches keep giving up -- a device it really shares -- stays on the two-kernel path after the fourth).
+    // two-kernel path is three times slower.  Persistent launches are tried again 0.2 s later -- 0.8, 3.2, then every 12.8 s while the give-ups
+    // come in a row (a device the context really shares); 64 launches that complete start the count afresh.  Never for good.
     c->census = -6;
     c->persist_failures++;
-    c->persist_retry_at = std::chrono::steady_clock::now() + std::chrono::milliseconds(200ll << (2 * (c->persist_failures < 4 ? c->persist_failures - 1 : 3)));
+    c->persist_streak++; c->completed_since_give_up = 0;
+    c->persist_retry_at = std::chrono::steady_clock::now() + std::chrono::milliseconds(200ll << (2 * (c->persist_streak < 4 ? c->persist_streak - 1 : 3)));
     c->mutations++; c->tail_is_finish = false;  // (what a retrieve returns is about to change)
+    // (snapshots taken behind launches that did nothing hold a half-written buffer: no plan is cut from them)
+    c->snap_pending[0] = c->snap_pending[1] = false; c->iters_since_snap = 0;
+    if (c->worker) { std::lock_guard<std::mutex> lk(c->worker->m); c->worker->superseded = true; }
     std::vector<tp_context::journal_entry> todo(c->journal.begin() + (completed < c->journal.size() ? completed : c->journal.size()), c->journal.end());
     c->journal.clear();
     // launches that finish themselves write the OTHER position buffer, and the host swaps the two behind each: the positions the first
@@ -206,7 +217,7 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every) {
     if (c->n_bands > 1) base_every = true;
     if (c->persist_mode == TP_PERSIST_OFF || !c->px_pitch) return TP_OK;  // (rasters beyond 4096 columns or rows have no pixel-record table)
     if (int rc = take_census(c)) return rc;
-    if (c->census == -6 && c->n_bands == 1 && c->persist_failures <= 4 && std::chrono::steady_clock::now() >= c->persist_retry_at)
+    if (c->census == -6 && c->n_bands == 1 && std::chrono::steady_clock::now() >= c->persist_retry_at)
         c->census = 1;   // (the census itself had passed: a launch gave up later, check_persist_status)
     if (c->census != 1) return TP_OK;
     if (c->plan_generation == c->generation && base_every && !c->plan_base_every) {
