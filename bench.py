@@ -29,6 +29,7 @@ NT = 3000
 DOMINANT = "k_persist"  # the kernel the roofline figure is about: K grad-iters per launch
 CONTRAST = 0.1          # photograph-like contrast of the synthetic raster (tpose_amd/synth.py: workload)
 CHILD_ITERS = 256       # grad-iters per k_persist launch in the profiler passes
+LONG_RUN = 131072       # grad-iters of the ageing figure (ms_per_step_long_run)
 PAIR_SPLIT_DEADLINE_S = 150   # the one-pair-on-all-GPUs figure runs under this deadline (bench.py --gpus N)
 CHILD_LAUNCHES = 16     # ... and launches per pass: the first 4096 grad-iters of the descent (the span the default warm-up and first timed regions cover)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -304,6 +305,8 @@ def pair_split_figure(capi, synth, dist_util, dist, rank, world, device, local_r
         return {"error": err or "another rank failed while iterating"}
     gave_up = torch.tensor([info["gave_up"]], dtype=torch.int64, device=device)
     dist.all_reduce(gave_up)
+    fine = torch.tensor([1 if ctx.info(capi.INFO_BOX_FINEGRAINED) == 1 else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(fine)   # (ranks whose band mailbox is fine-grained memory: all of them, or bands on different devices cannot see each other's posts)
     # the same pair on ONE GPU: its directions one after the other, unsplit (rank 0, the others wait)
     one = None
     if rank == 0:
@@ -331,7 +334,7 @@ def pair_split_figure(capi, synth, dist_util, dist, rank, world, device, local_r
     dt = sorted(times)[len(times) // 2]
     out = {"directions": D, "bands_per_direction": B, "patches_per_band": ppb, "steps": steps,
            "ms_per_step": dt / steps * 1e3, "value": NT * D * steps / dt, "unit": "triangles*grad-iters/s of ONE pair (warp flavour, %d direction%s)" % (D, "s" if D > 1 else ""),
-           "launches_given_up_all_ranks": int(gave_up.item()), "rank0": info,
+           "launches_given_up_all_ranks": int(gave_up.item()), "mailbox_fine_grained": int(fine.item()) == world, "rank0": info,
            "note": "one image pair on %d GPUs: %d direction(s) x %d bands of patches, positions handed over between the bands' persistent kernels "
                    "through fine-grained mailboxes (tp_band_attach); a band that waits a second for positions gives up and every band runs the "
                    "call whole -- launches_given_up counts that" % (world, D, B)}
@@ -441,13 +444,17 @@ def main():
         ctx.iterate(params, args.steps)
         dev_us.append(ctx.timer_stop())   # (waits for the end of the region on the library's stream)
     dt = sorted(times)[len(times) // 2]
+    ranks_in_collective = 1
     if dist is not None:
         dist.barrier()
+        one_each = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(one_each)   # (SUM over the process group -- RCCL when the driver launches this: how many ranks really took part)
+        ranks_in_collective = int(one_each.item())
     # the same regions on SURVEY section 8(d)'s FULL-contrast raster (what rounds 1-2 timed; the reference's fixed-step descent throws
     # vertices hundreds of pixels on it -- profiles/r04_contrast_stats.txt: 69 x the drive of the reference's photographs), and with all 13
     # variants formed in every grad-iter (tp_iterate_until: every frame keeps its base energies for the host's convergence test, as the
     # reference's loop reads `terr` back every frame; a tp_iterate call forms the base variants in its last grad-iter only)
-    full_ms, until_ms = None, None
+    full_ms, until_ms, by_contrast, full_kernel_us, long_run = None, None, None, None, None
     if rank == 0 and world == 1 and not args.no_extra:
         def regions(fn):
             ts = []
@@ -456,24 +463,36 @@ def main():
                 fn()
                 ts.append(time.perf_counter() - t0)
             return sorted(ts)[len(ts) // 2] / args.steps * 1e3
-        try:
-            imgF = synth.workload(W, H, NT, seed=dist_util.replica_seed(rank), contrast=1.0)[0]
-            cf = capi.Context(local_rank, W, H)
-            cf.set_image(capi.IMAGE_A, imgF)
-            if args.flavour == 1:
-                cf.set_image(capi.IMAGE_B, synth.displaced_raster(imgF))
-            cf.upload(pts, tris, colors)
-            cf.prepare(params)
-            cf.iterate(params, args.warmup)
-            cf.synchronize()
-
-            def one_full():
-                cf.iterate(params, args.steps)
+        by_contrast, full_kernel_us = {}, None
+        for cval in (0.14, 0.3, 1.0):
+            try:
+                imgF = synth.workload(W, H, NT, seed=dist_util.replica_seed(rank), contrast=cval)[0]
+                cf = capi.Context(local_rank, W, H)
+                cf.set_image(capi.IMAGE_A, imgF)
+                if args.flavour == 1:
+                    cf.set_image(capi.IMAGE_B, synth.displaced_raster(imgF))
+                cf.upload(pts, tris, colors)
+                cf.prepare(params)
+                cf.iterate(params, args.warmup)
                 cf.synchronize()
-            full_ms = regions(one_full)
-            cf.close()
-        except Exception as e:  # noqa: BLE001 -- an extra figure: the bench line must still appear
-            full_ms = "error: %s" % e
+
+                def one_full():
+                    cf.iterate(params, args.steps)
+                    cf.synchronize()
+                by_contrast["%.2f" % cval] = regions(one_full)
+                if cval == 1.0:
+                    full_ms = by_contrast["1.00"]
+                    evs = []
+                    for _ in range(3):   # the dominant kernel on this raster: one launch of CHILD_ITERS grad-iters between HIP events
+                        cf.timer_start()
+                        cf.iterate(params, CHILD_ITERS)
+                        evs.append(cf.timer_stop())
+                    full_kernel_us = sorted(evs)[1]
+                cf.close()
+            except Exception as e:  # noqa: BLE001 -- an extra figure: the bench line must still appear
+                by_contrast["%.2f" % cval] = "error: %s" % e
+                if cval == 1.0:
+                    full_ms = "error: %s" % e
         try:
             state = {"tot": 1.0}
             cu = capi.Context(local_rank, W, H)   # (a context of its own: its plan walks every triangle's base lines in every grad-iter)
@@ -520,6 +539,24 @@ def main():
         ctx.retrieve_many([capi.BUF_TENERGY, capi.BUF_PENERGY, capi.BUF_COLNUM, capi.BUF_POINTS])
     readback_ms = (time.perf_counter() - t0) / 256 * 1e3
     ctx.set_persistent(True)
+    # how the figure ages: LONG_RUN grad-iters more on the same context (calls of 4096), the last LONG_RUN / 4 of them timed
+    if rank == 0 and world == 1 and not args.no_extra:
+        try:
+            ctx.prepare(params)
+            done = 0
+            while done < LONG_RUN * 3 // 4:
+                ctx.iterate(params, 4096); done += 4096
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            n_timed = 0
+            while done < LONG_RUN:
+                ctx.iterate(params, 4096); done += 4096; n_timed += 4096
+            ctx.synchronize()
+            long_run = {"ms_per_step": (time.perf_counter() - t0) / n_timed * 1e3, "grad_iters_before": done - n_timed, "grad_iters_timed": n_timed,
+                        "plans_cut_again": ctx.info(capi.INFO_REPLANS), "launches_given_up": ctx.info(capi.INFO_PERSIST_FAILURES),
+                        "note": "the same context after the timed regions: calls of 4096 grad-iters until %d have run, the last quarter host-timed" % LONG_RUN}
+        except Exception as e:  # noqa: BLE001
+            long_run = {"error": str(e)}
     # SURVEY section 8d caveat (iii): the same calls over more tables than the 256 MB Infinity Cache holds -- five contexts
     # (five rasters: 5 x 118 MB of raster + tables), one call each in turn, against the same loop on ONE context.  What a
     # cold table costs the persistent path is the first grad-iter of a launch (every lane fetches its records) and the
@@ -550,9 +587,13 @@ def main():
     if rank == 0:
         line = {
             "metric": "triangles*grad-iters/sec at 2048^2/3000 tris; HBM GB/s vs roofline",
+            "metric_conditions": "value: contrast x%.2f raster, tp_iterate calls of `steps` grad-iters whose intermediate grad-iters form the 12 displaced "
+                                 "variants (the base variants in the call's last one); like-for-like with the reference's loop shape: "
+                                 "ms_per_step_all_13_variants; on SURVEY 8(d)'s raster as written: ms_per_step_full_contrast" % CONTRAST,
             "value": NT * args.steps * world / dt,
             "unit": "triangles*grad-iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ranks_in_collective": ranks_in_collective, "collective_backend": (args.backend if dist is not None else None),
             "ms_per_step": dt / args.steps * 1e3,
             "timing": "median of %d timed regions of %d steps; ms_per_step of each: %s" % (
                 len(times), args.steps, ", ".join("%.5f" % (t / args.steps * 1e3) for t in times)),
@@ -563,6 +604,14 @@ def main():
             "ms_per_step_full_contrast": full_ms,
             "ms_per_step_full_contrast_note": "the same flags on SURVEY section 8(d)'s raster as written (uniform u8 site colours, no contrast scaling): "
                                               "the raster of rounds 1-2; vertices fly hundreds of pixels on it, lines outgrow the rows their lanes keep",
+            "ms_per_step_by_contrast": dict({"%.2f" % CONTRAST: dt / args.steps * 1e3}, **(by_contrast or {})),
+            "ms_per_step_by_contrast_note": "the same flags on the same raster at other contrasts about mid-grey (1.00 = SURVEY section 8(d)'s raster as written): the "
+                                            "kernel keeps a lane's table records in registers and re-fetches a row only when its crossing column changes, so it is "
+                                            "fastest when vertices move a fraction of a pixel per grad-iter; at higher contrast the fixed-step descent moves them "
+                                            "further, more rows are re-fetched and lines outgrow the rows their lanes keep between two cuts",
+            "roofline_frac_full_contrast": (algorithmic_bytes(W, H, NT, NP) * CHILD_ITERS / (full_kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if full_kernel_us else None,
+            "roofline_frac_full_contrast_note": "the dominant kernel on SURVEY section 8(d)'s raster as written: one launch of %d grad-iters between HIP events, algorithmic bytes / time / 8 TB/s" % CHILD_ITERS,
+            "ms_per_step_long_run": long_run,
             "ms_per_step_all_13_variants": until_ms,
             "ms_per_step_all_13_variants_note": "tp_iterate_until with a threshold nothing meets, the same number of frames per call: base lines walked and "
                                                 "base energies kept in EVERY grad-iter, the host's geterr over every frame, the last frame re-run to leave its buffers",
@@ -637,6 +686,9 @@ def main():
             return
         if line is not None and pair is not None:
             line["pair_split"] = pair
+            # (for whoever reads a SCALE line without having seen the run: what makes the one-pair figure mean something, at the top level)
+            line["pair_split_launches_given_up_all_ranks"] = pair.get("launches_given_up_all_ranks")
+            line["pair_split_mailbox_fine_grained"] = pair.get("mailbox_fine_grained")
     if line is not None:
         print(json.dumps(line), flush=True)
 

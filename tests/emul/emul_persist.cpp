@@ -262,12 +262,16 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                 for (int q = 0; q < PK_SUM_WORDS; q++) s[q] += wd[q];
             }
             for (int j = S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED; j < n_li; j++) {
-                pk_acc a;
-                const int l = pk_walk_lane(V, table, reinterpret_cast<const char*>(TT.data()), pitch, W, w.n_lines_all, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.li_cap, j, a);
-                unsigned long long* s = V.sums + (size_t)l * PK_SUM_STRIDE;
-                unsigned long long wd[PK_SUM_WORDS];
-                pk_fold_words(a, wd);
-                for (int q = 0; q < PK_SUM_WORDS; q++) s[q] += wd[q];
+                // (every other lane-item in four parts on four "lanes", as the kernel walks them when a patch has few: the same sums)
+                const int parts = (j & 1) ? 4 : 1;
+                for (int part = 0; part < parts; part++) {
+                    pk_acc a;
+                    const int l = pk_walk_lane(V, table, reinterpret_cast<const char*>(TT.data()), pitch, W, w.n_lines_all, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.li_cap, j, a, part, parts);
+                    unsigned long long* s = V.sums + (size_t)l * PK_SUM_STRIDE;
+                    unsigned long long wd[PK_SUM_WORDS];
+                    pk_fold_words(a, wd);
+                    for (int q = 0; q < PK_SUM_WORDS; q++) s[q] += wd[q];
+                }
             }
             // P6
             for (int k = 0; k < w.n_corners; k++) {

@@ -153,6 +153,10 @@ def test_bench_two_ranks_on_one_gpu():
     assert "error" not in ps, ps
     assert ps["directions"] == 1 and ps["bands_per_direction"] == 2 and ps["launches_given_up_all_ranks"] == 0, ps
     assert ps["rank0"]["persist_iters"] >= 256 and ps["value"] > 0 and ps["speedup_vs_one_gpu"] > 0, ps
+    # what makes a SCALE line checkable by itself: every rank took part in a SUM all-reduce, no band gave a launch up, every band's
+    # mailbox is fine-grained memory -- at the top level of the line
+    assert line["ranks_in_collective"] == 2 and line["collective_backend"] == "gloo"
+    assert line["pair_split_launches_given_up_all_ranks"] == 0 and line["pair_split_mailbox_fine_grained"] is True and ps["mailbox_fine_grained"] is True
 
 
 @pytest.mark.gpu

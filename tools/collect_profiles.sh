@@ -1,8 +1,8 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): everything profiles/r04_* is derived from, into gpurun_out/r04/.
+# Runs on the GPU box (gpurun): everything profiles/r05_* is derived from, into gpurun_out/r05/.
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=gpurun_out/r04
+O=gpurun_out/r05
 rm -rf $O; mkdir -p $O
 # 1. the bench line: the driver's flags, and the default flags (5 x 2048 steps)
 python bench.py --steps 20 --warmup 5 > $O/bench_20_5.json 2> $O/bench_20_5.err
@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt20 -o kt -- python 
 find $O -name "*kernel_trace.csv" -delete
 # 3. in-kernel timeline of the persistent kernel (debug flavour of the library): fresh mesh, and after 4000 grad-iters
 python tools/persist_timeline.py --rebuild > $O/persist_timeline.json 2> $O/persist_timeline.err
-python tools/wave_timeline.py --rebuild > $O/wave_timeline.json 2>> $O/persist_timeline.err
+TPOSE_WAVES=12 python tools/wave_timeline.py --rebuild > $O/wave_timeline.json 2>> $O/persist_timeline.err
 TPOSE_TIMELINE_AFTER=4000 python tools/persist_timeline.py > $O/persist_timeline_4000.json 2>> $O/persist_timeline.err
 python tools/launch_profile.py > $O/launch_profile.txt 2>> $O/persist_timeline.err   # the first grad-iters of a launch, one by one
 # 4. persistent path against the two-kernel path and the oracle: parity and timing, other configurations
@@ -22,6 +22,7 @@ python tools/time_big.py product > $O/time_4096.txt 2>&1
 python tools/long_parity.py > $O/long_parity.txt 2>&1
 python tools/time_variants.py product > $O/long_run_timing.txt 2>&1
 python tools/call_length.py > $O/call_length.txt 2>&1
+python tools/contrast_sweep.py > $O/contrast_sweep.txt 2>&1
 python tools/pmc_size.py 4096 12000 > $O/pmc_traffic_4096_12000.json 2> $O/pmc_size.err   # memory-side traffic per grad-iter (separate --pmc passes)
 python tools/pmc_size.py 2048 3000 > $O/pmc_traffic_2048_3000.json 2>> $O/pmc_size.err
 TPOSE_PMC_TARGET=persist python tools/pmc_kernels.py $O/pmc_persist.json > /dev/null 2> $O/pmc_persist.err   # counters of k_persist (separate --pmc passes)
@@ -36,4 +37,4 @@ python tools/run_config2.py 600 > $O/config2.txt 2>&1
 python tools/run_config3.py > $O/config3.txt 2>&1
 python tools/run_batch.py --pairs 8 --iters 512 > $O/config4.json 2> $O/config4.err
 ls -la $O
-# then, in the development container: tools/copy_profiles.sh (gpurun_out/r04 -> profiles/r04_*)
+# then, in the development container: tools/copy_profiles.sh (gpurun_out/r05 -> profiles/r05_*)

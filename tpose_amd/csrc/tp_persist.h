@@ -283,10 +283,18 @@ TP_HD void pk_walk_rows_tiled(pk_rows& r, uint32_t row, uint32_t TL, uint32_t pi
     }
 }
 
+#ifndef PK_UNCACHED_BATCH
+#define PK_UNCACHED_BATCH 4    /* records requested together by a lane-item without cached records (8 measured the same at 4096^2 in round 4, and its 32 registers in flight
+                                  are what decides whether the kernel fits three waves per SIMD with 16 rows per lane) */
+#endif
 // P3, lane-item j >= PK_CACHED (a patch with more lane-items than its threads keep records for): (line l, chunk c of TL), nothing kept between
 // grad-iters.  Returns the line-sum slot, the partial sums in `a`.
 // tiled: the tiled copy of the table, or null (then `table`, row-major)
-TP_HD int pk_walk_lane(const pk_view& V, const char* table, const char* tiled, int pitch, int W, int n_lines_all, int base, int li_cap, int j, pk_acc& a) {
+// part / parts: this call takes the rows [part B, (part + 1) B) of the lane-item, B = PK_UNCACHED_BATCH (the last part: all that is left) -- a
+// lane-item of 14 rows walked by ONE lane is four memory latencies in a row; its four parts on four lanes are one (the kernel has idle lanes
+// whenever a patch has few such lane-items: a mesh a hundred thousand grad-iters old, whose lines have grown beyond what the threads keep)
+TP_HD int pk_walk_lane(const pk_view& V, const char* table, const char* tiled, int pitch, int W, int n_lines_all, int base, int li_cap, int j, pk_acc& a,
+                       int part = 0, int parts = 1) {
     int l, c, TL;
     uint32_t magic;
     if (j - base < li_cap) {
@@ -299,10 +307,12 @@ TP_HD int pk_walk_lane(const pk_view& V, const char* table, const char* tiled, i
     a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
     int first;
     pk_rows r = pk_lane_rows(V.wk[l], c, TL, magic, pitch, &first);
-#ifndef PK_UNCACHED_BATCH
-#define PK_UNCACHED_BATCH 4    /* records requested together by a lane-item without cached records (8 measured the same at 4096^2 in round 4, and its 32 registers in flight
-                                  are what decides whether the kernel fits three waves per SIMD with 16 rows per lane) */
-#endif
+    if (parts > 1) {
+        const int skip = part * PK_UNCACHED_BATCH;
+        if (skip >= r.n) return l;   // (nothing left for this part)
+        r.n -= skip; r.x = (int64_t)((uint64_t)r.x + (uint64_t)skip * (uint64_t)r.xs); r.row += (uint32_t)skip * r.rs; first += skip * TL;
+        if (part + 1 < parts && r.n > PK_UNCACHED_BATCH) r.n = PK_UNCACHED_BATCH;
+    }
     if (tiled) pk_walk_rows_tiled<PK_UNCACHED_BATCH>(r, (uint32_t)first, (uint32_t)TL, (uint32_t)pitch, tiled, W, a);
     else pk_walk_rows<PK_UNCACHED_BATCH>(r, table, W, a);
     return l;

@@ -32,6 +32,9 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 #ifndef PK_RECUT_MIN_GAP
 #define PK_RECUT_MIN_GAP 4    /* grad-iters between two cuts of a patch's lines, at least */
 #endif
+#ifndef PK_UNCACHED_PARTS
+#define PK_UNCACHED_PARTS 4   /* lanes that share a lane-item without cached records when a patch has few of those */
+#endif
 #ifndef PK_EXP_NOFILL
 #define PK_EXP_NOFILL 0   /* timing experiments only: 1 = the first grad-iter of a launch fetches like every other (row-major table, compare first) */
 #endif
@@ -371,10 +374,14 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         {
             const int j0 = n_li_now < PK_CACHED ? n_li_now : PK_CACHED;
             const bool back = (it & 1) != 0;
-            for (int k = tid; k < n_li - j0; k += PK_THREADS) {
-                const int j = back ? n_li - 1 - k : j0 + k;
+            const int extra = n_li - j0;
+            // few of them: every lane-item in PK_UNCACHED_PARTS parts on as many lanes (one memory latency instead of four in a row)
+            const int parts = extra * PK_UNCACHED_PARTS <= PK_THREADS ? PK_UNCACHED_PARTS : 1;
+            for (int k = tid; k < extra * parts; k += PK_THREADS) {
+                const int kk = parts > 1 ? k / PK_UNCACHED_PARTS : k, part = parts > 1 ? k % PK_UNCACHED_PARTS : 0;
+                const int j = back ? n_li - 1 - kk : j0 + kk;
                 pk_acc a;
-                const int l = pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, j0, w.li_cap, j, a);
+                const int l = pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, j0, w.li_cap, j, a, part, parts);
                 fold(l, a);
             }
         }
@@ -537,11 +544,22 @@ int set_lds_rr(int bytes) {
     if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist<RR, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     return rc;
 }
+// TPOSE_COOPERATIVE=1 (experiment, round 5): hipLaunchCooperativeKernel instead of a plain launch -- the runtime then checks that the grid can be
+// resident at once and sends it through the device's cooperative queue.  Measured and not made the default: profiles/r05_experiments.txt.
+bool cooperative() { static const bool on = [] { const char* e = getenv("TPOSE_COOPERATIVE"); return e && e[0] == '1'; }(); return on; }
+template <typename K>
+void launch_one(K kernel, const pk_args& A, dim3 g, dim3 b, size_t lds, hipStream_t s) {
+    if (cooperative()) {
+        pk_args copy = A;
+        void* args[] = {(void*)&copy};
+        (void)hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), g, b, args, (unsigned)lds, s);
+    } else hipLaunchKernelGGL(kernel, g, b, lds, s, A);
+}
 template <int RR>
 void launch_rr(const pk_args& A, dim3 g, dim3 b, size_t lds, hipStream_t s) {
-    if (A.n_peers > 0) hipLaunchKernelGGL((k_persist<RR, 2>), g, b, lds, s, A);
-    else if (A.ering || A.pring) hipLaunchKernelGGL((k_persist<RR, 1>), g, b, lds, s, A);
-    else hipLaunchKernelGGL((k_persist<RR, 0>), g, b, lds, s, A);
+    if (A.n_peers > 0) launch_one(k_persist<RR, 2>, A, g, b, lds, s);
+    else if (A.ering || A.pring) launch_one(k_persist<RR, 1>, A, g, b, lds, s);
+    else launch_one(k_persist<RR, 0>, A, g, b, lds, s);
 }
 }  // namespace
 
