@@ -179,6 +179,8 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
         for (int s = 0; s < w.n_slots; s++) { V.pos[s].x = points[2 * V.vid[s]]; V.pos[s].y = points[2 * V.vid[s] + 1]; }
         S[p].cache.resize(PK_CACHED);
         memset((void*)S[p].cache.data(), 0xCD, sizeof(S[p].cache[0]) * S[p].cache.size());   // (registers hold anything when a kernel starts)
+        for (auto& C : S[p].cache) pk_slot_clear(C);   // (... but no slot has a lane-item before the first cut: the kernel's prologue)
+        for (int sl = 0; sl < PK_CACHED; sl++) V.st[sl] = -1;
     }
     std::vector<unsigned long long> posbox((size_t)2 * NP * 2, 0);
     const char* table = reinterpret_cast<const char*>(T.data());
@@ -204,31 +206,51 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                 V.wk[l] = wkr;
             }
             memset(V.sums, 0, sizeof(unsigned long long) * PK_SUM_STRIDE * (size_t)w.n_lines_all);
-            if (recut) {   // the wave's lanes one after the other
+            if (recut) {   // the four passes of a cut (tp_persist.h, "SLOTS"): the wave's lanes / the slots one after the other
                 const int RRk = pk_rr_for(P.rows_max);   // tp_launch_persist's choice
-                int changed = it == 0 ? 1 : 0, sum[64];
+                int changed = 0;
                 int rpl = it == 0 ? w.rows : S[p].rpl;
                 bool first = it == 0;
                 for (;;) {
-                    int every = 0, run = 0;
-                    for (int lane = 0; lane < 64; lane++) {
-                        int ev;
-                        sum[lane] = pk_recut_count(V, w.n_lines_all, w.n_lines, lane, 64, rpl, first, changed, ev);
-                        every += ev;
-                    }
-                    for (int lane = 0; lane < 64; lane++) { pk_recut_write(V, w.n_lines_all, lane, 64, run); run += sum[lane]; }
+                    int every = 0;
+                    changed = 0;
+                    for (int lane = 0; lane < 64; lane++) every += pk_cut_want(V, w.n_lines_all, w.n_lines, lane, 64, rpl, first, changed);
                     if (every <= PK_CACHED || rpl >= RRk) break;
                     rpl++; first = true;
                 }
                 S[p].rpl = rpl;
-                S[p].n_li = V.cut[w.n_lines]; S[p].n_li_all = V.cut[w.n_lines_all];
-                if (changed)
-                    for (int l = 0; l < w.n_lines_all; l++) pk_list_line(V, l, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.li_cap);
-                if (changed)
-                    for (int j = 0; j < PK_CACHED; j++)
-                        pk_cache_init(S[p].cache[j], V, j, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.n_lines_all, it == 0);
+                if (!changed) for (int lane = 0; lane < 64; lane++) pk_cut_forget(V, w.n_lines_all, lane, 64);
+                if (changed) {
+                    int n_free = 0;
+                    for (int sl = 0; sl < PK_CACHED; sl++)
+                        if (pk_slot_release(S[p].cache[sl], V)) {
+                            if (first) V.freel[pk_place_of_slot(sl)] = sl; else V.freel[n_free] = sl;
+                            n_free++;
+                        }
+                    if (first && n_free != PK_CACHED) return -7;
+                    int base = 0, need[64], unc[64], off = 0;
+                    for (int lane = 0; lane < 64; lane++) need[lane] = pk_cut_need(V, w.n_lines_all, w.n_lines, lane, 64);
+                    for (int lane = 0; lane < 64; lane++) { unc[lane] = pk_cut_alloc(V, w.n_lines_all, w.n_lines, lane, 64, base, n_free); base += need[lane]; }
+                    for (int lane = 0; lane < 64; lane++) { pk_cut_write(V, w.n_lines_all, lane, 64, off); off += unc[lane]; }
+                    for (int sl = 0; sl < PK_CACHED; sl++) pk_slot_take(S[p].cache[sl], V, sl);
+                    for (int sl = 0; sl < PK_CACHED; sl++) if (V.st[sl] != -1) return -8;   // (a lane-item handed to a slot that was not free)
+                    for (int l = 0; l < w.n_lines_all; l++) pk_list_line(V, l, w.li_cap);
+                    // every chunk of every line walked every grad-iter belongs to exactly one slot, or to the uncached lane-items
+                    std::vector<int> seen;
+                    for (int l = 0; l < w.n_lines; l++) {
+                        if (V.nc[l] < 0 || V.nc[l] > V.tl[l]) return -9;
+                        seen.assign((size_t)V.tl[l], 0);
+                        for (int sl = 0; sl < PK_CACHED; sl++) {
+                            const auto& C = S[p].cache[sl];
+                            if (C.TL != 0 && C.l == l) { if (C.TL != V.tl[l] || C.c < 0 || C.c >= V.nc[l] || seen[(size_t)C.c]) return -10; seen[(size_t)C.c] = 1; }
+                        }
+                        for (int c = 0; c < V.nc[l]; c++) if (!seen[(size_t)c]) return -11;
+                    }
+                }
+                S[p].n_li = V.cut[w.n_lines]; S[p].n_li_all = V.cut[w.n_lines_all];   // (the UNCACHED lane-items)
                 if (g_recuts) g_recuts[0] += changed;
             }
+            for (size_t i = 0; i < (size_t)PK_SUM_STRIDE * (size_t)w.n_lines_all; i++) if (V.sums[i] != 0ull) return -12;   // (the cut's scratch left in a line's sums)
             const int n_li = emit ? S[p].n_li_all : S[p].n_li;
             for (int k = 0; k < w.n_own_v; k++) { V.gacc[2 * k] = 0ull; V.gacc[2 * k + 1] = 0ull; }
             // P3
@@ -261,12 +283,12 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                 pk_fold_words(a, wd);
                 for (int q = 0; q < PK_SUM_WORDS; q++) s[q] += wd[q];
             }
-            for (int j = S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED; j < n_li; j++) {
+            for (int j = 0; j < n_li; j++) {   // the lane-items without a slot
                 // (every other lane-item in four parts on four "lanes", as the kernel walks them when a patch has few: the same sums)
                 const int parts = (j & 1) ? 4 : 1;
                 for (int part = 0; part < parts; part++) {
                     pk_acc a;
-                    const int l = pk_walk_lane(V, table, reinterpret_cast<const char*>(TT.data()), pitch, W, w.n_lines_all, S[p].n_li < PK_CACHED ? S[p].n_li : PK_CACHED, w.li_cap, j, a, part, parts);
+                    const int l = pk_walk_lane(V, table, reinterpret_cast<const char*>(TT.data()), pitch, W, w.n_lines_all, 0, w.li_cap, j, a, part, parts);
                     unsigned long long* s = V.sums + (size_t)l * PK_SUM_STRIDE;
                     unsigned long long wd[PK_SUM_WORDS];
                     pk_fold_words(a, wd);

@@ -40,13 +40,18 @@ struct pk_view {
     int32_t* vid;              // static tables, copied from the plan's pool at the start of the launch
     int32_t* edges;
     int32_t* lines;
-    int32_t* cut;              // [n_lines_all + 1] first lane-item of every line; the last entry: how many there are
-    int32_t* li;               // [li_cap][3] the lane-items from `base` = min(lane-items walked every grad-iter, PK_CACHED) on:
-                               // {line | chunk << 16, chunks, magic}
+    int32_t* cut;              // [n_lines_all + 1] first of every line's lane-items that have NO thread of their own (the uncached ones: chunks nc .. tl - 1;
+                               // lines walked every grad-iter first, then the last grad-iter's base lines); the last entry: how many there are
+    int32_t* tl;               // [n_lines_all] chunks of every line, as last cut
+    int32_t* nc;               // [n_lines_all] ... of which the chunks [0, nc) belong to a thread (a slot) that keeps their records
+    int32_t* st;               // [PK_CACHED] while the lines are cut again: line | chunk << 16 handed to a free slot, -1 none
+    int32_t* freel;            // [PK_CACHED] while the lines are cut again: the free slots
+    int32_t* li;               // [li_cap][3] the first li_cap uncached lane-items: {line | chunk << 16, chunks, magic}
     pk_i4* corners;
     pk_i4* base;
     int32_t* ldir;             // [n_lines_all] +1 / -1 / 0: the line's second endpoint lies below / above / level with its first (snapped rows)
     int32_t* flags;
+    char* stage;               // [PK_STAGE_ROWS][waves][64] table records on their way from memory straight into LDS (tp_persist.hip, P3)
 };
 
 TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
@@ -60,11 +65,16 @@ TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     V.edges = (int32_t*)p; p += pk_align16(w.n_edges * 4);
     V.lines = (int32_t*)p; p += pk_align16(w.n_lines_all * 4);
     V.cut = (int32_t*)p; p += pk_align16((w.n_lines_all + 1) * 4);
+    V.tl = (int32_t*)p; p += pk_align16(w.n_lines_all * 4);
+    V.nc = (int32_t*)p; p += pk_align16(w.n_lines_all * 4);
+    V.st = (int32_t*)p; p += pk_align16(PK_CACHED * 4);
+    V.freel = (int32_t*)p; p += pk_align16(PK_CACHED * 4);
     V.li = (int32_t*)p; p += pk_align16(w.li_cap * 12);
     V.corners = (pk_i4*)p; p += pk_align16(w.n_corners * 16);
     V.base = (pk_i4*)p; p += pk_align16(w.n_base * 16);
     V.ldir = (int32_t*)p; p += pk_align16(w.n_lines_all * 4);
-    V.flags = (int32_t*)p;
+    V.flags = (int32_t*)p; p += 64;
+    V.stage = p;
 }
 
 // P1b, lane l < n_lines: line l = (local edge, version) -- the walker of the whole line
@@ -109,64 +119,103 @@ TP_HD uint32_t pk_mul24(uint32_t a, uint32_t b) {
 }
 TP_HD uint32_t pk_magic(int d) { return d == 1 ? 0u : (uint32_t)(4294967296.0 / (double)d) + 1u; }
 
-// ---- The chunks of a patch's lines.  A line of r rows is walked by ceil((r + slack) / rows-per-lane) lanes (its chunks,
-// consecutive lane-items); lines grow and shrink while the descent runs, so the workgroup counts again every PK_RECUT
-// grad-iters, from the walkers of the grad-iter at hand -- on the device, with nothing from the host.  A line keeps its
-// chunks while it still fits them and has not shrunk by a lane's worth (every change of one line moves the lane-items of
-// all the lines behind it, and every lane then fetches its records again).  How lines are cut never changes a sum.
-// A patch whose lines have grown into more lane-items than its threads keep records for takes a row more per lane.
-// One wave does it: lane i takes the lines [i B, (i + 1) B), B = ceil(n / lanes) -- pk_recut_count: chunks of each into
-// `tl` scratch (the lines' sum slots, zeroed again by pk_recut_write), their sum returned; the caller's prefix sum over
-// lanes gives `offset`; pk_recut_write: first lane-item of each.
+// ---- The chunks of a patch's lines, and who walks them.  A line of r rows is walked by ceil((r + slack) / rows-per-lane) lanes (its chunks);
+// lines grow and shrink while the descent runs, so the workgroup counts again every PK_RECUT grad-iters (and when a lane finds more rows
+// than it keeps records for), from the walkers of the grad-iter at hand -- on the device, with nothing from the host.  A line keeps its
+// chunks while it still fits them and has not shrunk by a lane's worth.  How lines are cut never changes a sum.
+//
+// Round 5: SLOTS.  A thread's cached lane-item is a slot; rounds 3-4 numbered lane-items by a prefix sum over the lines, so one line that
+// gained a chunk moved the lane-items of every line behind it, every thread behind it fetched its 14 records again, and a cut that changed
+// anything cost ~10 us (which is why cutting more often, or on demand, never paid).  Now a line OWNS slots: a cut frees the slots of the
+// lines whose chunk count changed (their rows change lanes: those records are gone anyway) and hands free slots to the chunks that want
+// one -- nobody else's lane-item moves.  tl[l] = chunks of line l, nc[l] = how many of them (chunks 0 .. nc - 1) have a slot; the others,
+// and the base lines only the last grad-iter of a call walks, are the UNCACHED lane-items, numbered by a prefix sum (`cut`) and walked
+// without kept records.  Four passes with workgroup barriers between them:
+//   A  one wave, lane i takes the lines [i B, (i + 1) B):  what every line wants now -> scratch {want, changed} (the line's sum slot)
+//   B  every slot:  a slot whose line changed gives its lane-item up; every free slot files itself in `freel`
+//   C  the wave again:  free slots to the chunks that want one (prefix sum over the lines), `st[slot]` = line | chunk << 16; tl, nc, cut
+//   D  every slot:  a free slot that was handed a lane-item takes it (records to be fetched); the table of uncached lane-items
+// A patch whose lines want more slots than there are takes a row more per lane (everything is cut afresh then).
 TP_HD int pk_recut_line(const pk_view& V, int l, int rpl, bool first) {
     const pk_walker& k = V.wk[l];
     const int rows = k.ra > k.rb ? 0 : k.rb - k.ra + 1;
     const int fresh = pk_chunks(rows, rpl);
     if (first) return fresh;
-    const int old = V.cut[l + 1] - V.cut[l];
+    const int old = V.tl[l];
     return (rows + 1 <= old * rpl && old <= fresh + 1) ? old : fresh;
 }
-TP_HD int pk_recut_count(const pk_view& V, int n, int n_every, int lane, int lanes, int rpl, bool first, int& changed, int& sum_every) {
+// pass A.  Returns the chunks the lines walked every grad-iter want together.
+TP_HD int pk_cut_want(const pk_view& V, int n, int n_every, int lane, int lanes, int rpl, bool first, int& changed) {
     const int B = (n + lanes - 1) / lanes;
-    int sum = 0;
-    sum_every = 0;   // ... of the lines walked every grad-iter, [0, n_every)
+    int every = 0;
     for (int l = lane * B; l < n && l < (lane + 1) * B; l++) {
         const int t = pk_recut_line(V, l, rpl, first);
-        changed |= first || t != V.cut[l + 1] - V.cut[l];
-        V.sums[PK_SUM_STRIDE * (size_t)l] = (unsigned long long)t;
-        sum += t;
-        sum_every += l < n_every ? t : 0;
+        const bool ch = first || t != V.tl[l];
+        changed |= ch ? 1 : 0;
+        V.sums[PK_SUM_STRIDE * (size_t)l] = (unsigned long long)(uint32_t)t | (ch ? 1ull << 32 : 0ull);
+        every += l < n_every ? t : 0;
     }
-    return sum;
+    return every;
 }
-TP_HD void pk_recut_write(const pk_view& V, int n, int lane, int lanes, int offset) {
+// ... when no line changed: the scratch is the lines' sum slots, which the walk adds to
+TP_HD void pk_cut_forget(const pk_view& V, int n, int lane, int lanes) {
     const int B = (n + lanes - 1) / lanes;
+    for (int l = lane * B; l < n && l < (lane + 1) * B; l++) V.sums[PK_SUM_STRIDE * (size_t)l] = 0ull;
+}
+TP_HD bool pk_cut_line_changed(const pk_view& V, int l) { return ((V.sums[PK_SUM_STRIDE * (size_t)l] >> 32) & 1ull) != 0ull; }
+// pass C, first half: the slots the lane's lines ask for (a changed line all its chunks, an unchanged one those it has no slot for)
+TP_HD int pk_cut_need(const pk_view& V, int n, int n_every, int lane, int lanes) {
+    const int B = (n + lanes - 1) / lanes;
+    int need = 0;
+    for (int l = lane * B; l < n && l < (lane + 1) * B && l < n_every; l++)
+        need += pk_cut_line_changed(V, l) ? (int)(uint32_t)V.sums[PK_SUM_STRIDE * (size_t)l] : V.tl[l] - V.nc[l];
+    return need;
+}
+// ... second half: `base` = slots asked for by the lanes before this one, n_free = free slots filed in pass B.  Returns the lane's uncached chunks.
+TP_HD int pk_cut_alloc(const pk_view& V, int n, int n_every, int lane, int lanes, int base, int n_free) {
+    const int B = (n + lanes - 1) / lanes;
+    int unc = 0;
     for (int l = lane * B; l < n && l < (lane + 1) * B; l++) {
-        V.cut[l] = offset;
-        offset += (int)V.sums[PK_SUM_STRIDE * (size_t)l];
+        const int want = (int)(uint32_t)V.sums[PK_SUM_STRIDE * (size_t)l];
+        if (pk_cut_line_changed(V, l)) { V.tl[l] = want; V.nc[l] = 0; }
         V.sums[PK_SUM_STRIDE * (size_t)l] = 0ull;
+        if (l < n_every) {
+            const int need = V.tl[l] - V.nc[l];
+            int k = n_free - base;
+            k = k < 0 ? 0 : (k > need ? need : k);
+            for (int i = 0; i < k; i++) V.st[V.freel[base + i]] = l | ((V.nc[l] + i) << 16);
+            V.nc[l] += k;
+            base += need;
+        }
+        unc += V.tl[l] - V.nc[l];
     }
+    return unc;
+}
+// ... and the prefix sum of the uncached chunks: `offset` = those of the lanes before this one
+TP_HD void pk_cut_write(const pk_view& V, int n, int lane, int lanes, int offset) {
+    const int B = (n + lanes - 1) / lanes;
+    for (int l = lane * B; l < n && l < (lane + 1) * B; l++) { V.cut[l] = offset; offset += V.tl[l] - V.nc[l]; }
     if (lane == lanes - 1) V.cut[n] = offset;   // (the last lane's lines are the last ones, or it has none and its offset is the total)
 }
-// after a re-cut, lane l < n_lines_all: the line's lane-items from `base` on into the table
-TP_HD void pk_list_line(const pk_view& V, int l, int base, int li_cap) {
+// after a cut, lane l < n_lines_all: the line's uncached lane-items into the table
+TP_HD void pk_list_line(const pk_view& V, int l, int li_cap) {
     const int j0 = V.cut[l], j1 = V.cut[l + 1];
-    if (j1 <= base) return;
-    const int TL = j1 - j0;
+    if (j1 <= j0 || j0 >= li_cap) return;
+    const int TL = V.tl[l], c0 = TL - (j1 - j0);
     const int32_t magic = (int32_t)pk_magic(TL);
-    for (int j = j0 < base ? base : j0; j < j1 && j - base < li_cap; j++) {
-        int32_t* e = V.li + 3 * (size_t)(j - base);
-        e[0] = l | ((j - j0) << 16); e[1] = TL; e[2] = magic;
+    for (int j = j0; j < j1 && j < li_cap; j++) {
+        int32_t* e = V.li + 3 * (size_t)j;
+        e[0] = l | ((c0 + j - j0) << 16); e[1] = TL; e[2] = magic;
     }
 }
-// lane-item j -> (line l, chunk c of TL): the line whose run of lane-items holds j
+// uncached lane-item j -> (line l, chunk c of TL): the line whose run of uncached lane-items holds j
 TP_HD void pk_find_item(const pk_view& V, int n_lines_all, int j, int& l, int& c, int& TL) {
     int lo = 0, hi = n_lines_all;   // cut[lo] <= j < cut[hi]
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (V.cut[mid] <= j) lo = mid; else hi = mid;
     }
-    l = lo; c = j - V.cut[lo]; TL = V.cut[lo + 1] - V.cut[lo];
+    l = lo; TL = V.tl[lo]; c = TL - (V.cut[lo + 1] - V.cut[lo]) + (j - V.cut[lo]);
 }
 
 struct pk_acc {
@@ -334,21 +383,30 @@ struct pk_lane_cache {
     int32_t col[R];         // crossing column of rec[u]; -1: nothing cached
     pk_rec rec[R];
 };
-// Which lane-item cached slot j (thread j mod PK_THREADS, its item j / PK_THREADS) takes: the chunks of a line are
-// consecutive lane-items, and consecutive lanes of a wave take lane-items 16 apart, so that the lanes of one LDS atomic
-// fold different lines (the same line from adjacent lanes serialises the instruction)
-TP_HD int pk_item_of_slot(int j) { return (j & 63) * (PK_CACHED / 64) + (j >> 6); }
+// A slot (a thread's cached lane-item) through a cut of the lines -- passes B and D above.
+// Where a slot stands in the order the free list is filled in when EVERYTHING is cut afresh (a launch without a carry, a row more per
+// lane): the chunks of a line take consecutive places, and consecutive places are lanes 64 / (PK_CACHED / 64) apart ... so that the lanes
+// of one LDS atomic fold different lines (the same line from adjacent lanes serialises the instruction)
+TP_HD int pk_place_of_slot(int s) { return (s & 63) * (PK_CACHED / 64) + (s >> 6); }
+// (A slot's records and columns are never touched here: a slot that changes hands gets a first row that matches nothing -- row0 = ~0 -- and
+// the walk's own "the line's first row moved" path drops its columns and fetches; a slot without a lane-item has no rows, its columns
+// read 0 and its records the table's all-zero record.  Loops over a slot's 16 rows in three more places cost the kernel 160 registers.)
 template <int R>
-TP_HD void pk_cache_init(pk_lane_cache<R>& C, const pk_view& V, int slot, int n_li, int n_lines_all, bool fresh) {
-    const int j = pk_item_of_slot(slot);
-    const bool live = j < n_li;
-    int l = 0, c = 0, TL = 0;   // (0 chunks: a thread without a lane-item -- no rows, ever)
-    if (live) pk_find_item(V, n_lines_all, j, l, c, TL);
-    if (!fresh && l == C.l && c == C.c && TL == C.TL) return;   // the same rows of the same line as before: its records stay
-    C.l = l; C.c = c; C.TL = TL; C.magic = live ? pk_magic(TL) : 0u;
-    C.row0 = live ? 0xffffffffu : 0u;
-#pragma unroll
-    for (int u = 0; u < R; u++) { C.col[u] = live ? -1 : 0; C.rec[u].lo = 0; C.rec[u].hi = 0; }
+TP_HD void pk_slot_clear(pk_lane_cache<R>& C) { C.l = 0; C.c = 0; C.TL = 0; C.magic = 0u; C.row0 = 0xffffffffu; }
+// pass B: true when the slot is free after it (it had no lane-item, or its line is cut differently now)
+template <int R>
+TP_HD bool pk_slot_release(pk_lane_cache<R>& C, const pk_view& V) {
+    if (C.TL != 0 && pk_cut_line_changed(V, C.l)) pk_slot_clear(C);
+    return C.TL == 0;
+}
+// pass D
+template <int R>
+TP_HD void pk_slot_take(pk_lane_cache<R>& C, const pk_view& V, int s) {
+    const int e = V.st[s];
+    if (e < 0) return;
+    V.st[s] = -1;
+    C.l = e & 0xffff; C.c = e >> 16; C.TL = V.tl[C.l]; C.magic = pk_magic(C.TL);
+    C.row0 = 0xffffffffu;
 }
 // The walk of a cached lane-item in two steps, so that a thread can run each step for all its lane-items before the next
 // (the fetches of all of them are in flight while the sums begin).  RR <= R: how many of the R cached rows the lanes of this

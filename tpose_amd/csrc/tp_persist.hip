@@ -32,6 +32,9 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 #ifndef PK_RECUT_MIN_GAP
 #define PK_RECUT_MIN_GAP 4    /* grad-iters between two cuts of a patch's lines, at least */
 #endif
+#ifndef PK_STAGED
+#define PK_STAGED 1   /* the few uncached lane-items of a patch have their records requested into LDS before the cached walk */
+#endif
 #ifndef PK_UNCACHED_PARTS
 #define PK_UNCACHED_PARTS 4   /* lanes that share a lane-item without cached records when a patch has few of those */
 #endif
@@ -57,6 +60,8 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 #define PK_STAMP0(k) do { } while (0)
 #define PK_WSTAMP(k) do { } while (0)
 #endif
+
+static_assert(PK_UNCACHED_BATCH == PK_STAGE_ROWS, "a staged part is one batch of an uncached lane-item");
 
 namespace {
 
@@ -121,15 +126,17 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
     PK_STAMP0(12);
     // carry (below): requested first, so that the words are on their way while the tables come over
     int32_t* const carry = A.carry && w.n_lines_all + 1 <= A.carry_cut_cap ? A.carry + (size_t)part * (size_t)A.carry_stride : nullptr;
-    int32_t cy_hdr[5] = {0, 0, 0, 0, 0}, cy_item[PK_NI][3], cy_cut = 0;
+    int32_t cy_hdr[5] = {0, 0, 0, 0, 0}, cy_item[PK_NI][3], cy_cut[3] = {0, 0, 0};
     if (carry) {
 #pragma unroll
         for (int q = 0; q < 5; q++) cy_hdr[q] = carry[q];
 #pragma unroll
         for (int i = 0; i < PK_NI; i++)
 #pragma unroll
-            for (int q = 0; q < 3; q++) cy_item[i][q] = carry[8 + A.carry_cut_cap + 3 * (tid + i * PK_THREADS) + q];
-        if (tid <= w.n_lines_all) cy_cut = carry[8 + tid];
+            for (int q = 0; q < 3; q++) cy_item[i][q] = carry[8 + 3 * A.carry_cut_cap + 3 * (tid + i * PK_THREADS) + q];
+        if (tid <= w.n_lines_all)
+#pragma unroll
+            for (int q = 0; q < 3; q++) cy_cut[q] = carry[8 + q * A.carry_cut_cap + tid];   // (tl, nc, cut)
     }
 
     // ---- prologue: the patch's tables and positions into LDS.  The plan lays a patch's tables out in its pool the way pk_carve lays them
@@ -152,7 +159,8 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         }
         for (int i = tid; i < PK_SUM_STRIDE * w.n_lines_all; i += PK_THREADS) V.sums[i] = 0ull;
         for (int k = tid; k < w.n_own_v; k += PK_THREADS) { V.gacc[2 * k] = 0ull; V.gacc[2 * k + 1] = 0ull; V.vdeg[k] = 0; }
-        if (tid == 0) { V.flags[0] = 0; V.flags[3] = 0; }
+        if (tid < 16) V.flags[tid] = 0;   // ([3]: a lane gave up; [8]: the lines want cutting again; [9]: free slots filed while they are)
+        for (int i = tid; i < PK_CACHED; i += PK_THREADS) V.st[i] = -1;
     }
     __syncthreads();
     PK_STAMP0(13);
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
     int32_t* const ering = MODE == 0 ? nullptr : A.ering;
     float2* const pring = MODE == 0 ? nullptr : A.pring;
     int failed = 0;
-    int n_li_now = 0, n_li_all_now = 0;   // lane-items of the lines walked every grad-iter / with the last one's base lines
+    int n_unc_now = 0, n_unc_all_now = 0;   // lane-items WITHOUT a slot: of the lines walked every grad-iter / with the last one's base lines
     __syncthreads();
     PK_STAMP0(14);
 
@@ -210,20 +218,25 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         if (!warm) age0 = 0;
     }
     if (warm) {
-        if (tid <= w.n_lines_all) V.cut[tid] = cy_cut;
-        for (int i = tid + PK_THREADS; i <= w.n_lines_all; i += PK_THREADS) V.cut[i] = carry[8 + i];
+        if (tid < w.n_lines_all) { V.tl[tid] = cy_cut[0]; V.nc[tid] = cy_cut[1]; }
+        if (tid <= w.n_lines_all) V.cut[tid] = cy_cut[2];
+        for (int i = tid + PK_THREADS; i <= w.n_lines_all; i += PK_THREADS) {
+            if (i < w.n_lines_all) { V.tl[i] = carry[8 + i]; V.nc[i] = carry[8 + A.carry_cut_cap + i]; }
+            V.cut[i] = carry[8 + 2 * A.carry_cut_cap + i];
+        }
         if (tid == 0) { V.flags[1] = 0; V.flags[2] = cy_hdr[2]; }
-        n_li_now = cy_hdr[3]; n_li_all_now = cy_hdr[4];
+        n_unc_now = cy_hdr[3]; n_unc_all_now = cy_hdr[4];
 #pragma unroll
         for (int i = 0; i < PK_NI; i++) {
             const int lc = cy_item[i][0], TL = cy_item[i][1];
             cache[i].l = lc & 0xffff; cache[i].c = (int)((unsigned)lc >> 16); cache[i].TL = TL; cache[i].magic = (uint32_t)cy_item[i][2];
-            cache[i].row0 = TL ? 0xffffffffu : 0u;
-#pragma unroll
-            for (int u = 0; u < RR; u++) { cache[i].col[u] = TL ? -1 : 0; cache[i].rec[u].lo = 0; cache[i].rec[u].hi = 0; }
+            cache[i].row0 = 0xffffffffu;   // (matches no row: the first walk drops the columns and fetches)
         }
         // (the table of the lane-items no thread keeps records for -- the patch's overflow, and the last grad-iter's base lines -- is listed
         // behind the first barrier of the first grad-iter, where the cut is visible to everybody)
+    } else {
+#pragma unroll
+        for (int i = 0; i < PK_NI; i++) pk_slot_clear(cache[i]);   // (no slot has a lane-item before the first cut)
     }
     for (int it = 0; it < A.n_iters; it++) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -304,43 +317,64 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         PK_WSTAMP(4);
         PK_STAMP(6);
         if (warm && it == 0) {
-            const int j0 = n_li_now < PK_CACHED ? n_li_now : PK_CACHED;
-            for (int l = tid; l < w.n_lines_all; l += PK_THREADS) pk_list_line(V, l, j0, w.li_cap);
+            for (int l = tid; l < w.n_lines_all; l += PK_THREADS) pk_list_line(V, l, w.li_cap);
             __syncthreads();
         }
         if (recut) {
+            // pass A (tp_persist.h, "SLOTS"): what every line wants now
             if (tid < 64) {
-                // (the first cut of a launch always counts as a change: every thread's lane-items are decided there -- also in a patch
-                // without lines, whose threads would otherwise walk whatever their registers held)
-                int changed = it == 0 ? 1 : 0, rpl = it == 0 ? w.rows : V.flags[2];   // (a warm launch never cuts in its first grad-iter)
+                // (the first cut of a launch without a carry cuts everything afresh: every slot's lane-item is decided there)
+                int changed = 0, rpl = it == 0 ? w.rows : V.flags[2];   // (a warm launch never cuts in its first grad-iter)
                 bool first = it == 0;
                 for (;;) {
-                    int every;
-                    const int sum = pk_recut_count(V, w.n_lines_all, w.n_lines, tid, 64, rpl, first, changed, every);
-                    int incl = sum;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); incl += tid >= d ? o : 0; }
+                    changed = 0;
+                    int every = pk_cut_want(V, w.n_lines_all, w.n_lines, tid, 64, rpl, first, changed);
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) every += __shfl_xor(every, d);
-                    pk_recut_write(V, w.n_lines_all, tid, 64, incl - sum);
                     if (every <= PK_CACHED || rpl >= RR) break;
-                    rpl++; first = true;   // (more lane-items than lanes keep records for: a row more per lane)
+                    rpl++; first = true;   // (more chunks than slots: a row more per lane, everything afresh)
                 }
-                changed = __any(changed);
-                if (tid == 0) { V.flags[1] = changed; V.flags[2] = rpl; V.flags[8] = 0; }
+                changed = __any(changed) ? (first ? 2 : 1) : 0;
+                if (!changed) pk_cut_forget(V, w.n_lines_all, tid, 64);
+                if (tid == 0) { V.flags[1] = changed; V.flags[2] = rpl; V.flags[8] = 0; V.flags[9] = changed == 2 ? PK_CACHED : 0; }
             }
             __syncthreads();
             PK_STAMP(7);
-            n_li_now = V.cut[w.n_lines]; n_li_all_now = V.cut[w.n_lines_all];
-            if (V.flags[1]) {
-                for (int l = tid; l < w.n_lines_all; l += PK_THREADS) pk_list_line(V, l, n_li_now < PK_CACHED ? n_li_now : PK_CACHED, w.li_cap);
+            const int how = V.flags[1];   // 0: no line changed, 1: some did, 2: everything is cut afresh
+            if (how) {
+                // pass B: slots of changed lines are given up; every free slot files itself (afresh: in the order that keeps a line's chunks apart)
 #pragma unroll
-                for (int i = 0; i < PK_NI; i++)
-                    pk_cache_init(cache[i], V, tid + i * PK_THREADS, n_li_now < PK_CACHED ? n_li_now : PK_CACHED, w.n_lines_all, it == 0);
-                __syncthreads();   // (the table of the other lane-items is read by other threads than wrote it)
+                for (int i = 0; i < PK_NI; i++) {
+                    const int sl = tid + i * PK_THREADS;
+                    if (pk_slot_release(cache[i], V)) {
+                        if (how == 2) V.freel[pk_place_of_slot(sl)] = sl;
+                        else V.freel[__hip_atomic_fetch_add(&V.flags[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = sl;
+                    }
+                }
+                __syncthreads();
+                // pass C: free slots to the chunks that want one; the uncached lane-items numbered
+                if (tid < 64) {
+                    const int n_free = V.flags[9];
+                    const int need = pk_cut_need(V, w.n_lines_all, w.n_lines, tid, 64);
+                    int incl = need;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); incl += tid >= d ? o : 0; }
+                    const int unc = pk_cut_alloc(V, w.n_lines_all, w.n_lines, tid, 64, incl - need, n_free);
+                    int uincl = unc;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(uincl, d); uincl += tid >= d ? o : 0; }
+                    pk_cut_write(V, w.n_lines_all, tid, 64, uincl - unc);
+                }
+                __syncthreads();
+                // pass D: the slots that were handed a lane-item take it; the table of the uncached ones
+#pragma unroll
+                for (int i = 0; i < PK_NI; i++) pk_slot_take(cache[i], V, tid + i * PK_THREADS);
+                for (int l = tid; l < w.n_lines_all; l += PK_THREADS) pk_list_line(V, l, w.li_cap);
+                __syncthreads();   // (the table is read by other threads than wrote it)
             }
+            n_unc_now = V.cut[w.n_lines]; n_unc_all_now = V.cut[w.n_lines_all];
         }
-        const int n_li = emit ? n_li_all_now : n_li_now;
+        const int n_unc = emit ? n_unc_all_now : n_unc_now;
         PK_STAMP(2);
         // ---- P3: walk -- one table record per (line, row); chunks of a line meet in LDS
         auto fold = [&](int l, const pk_acc& a) {
@@ -352,6 +386,48 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 for (int q = 0; q < PK_SUM_WORDS; q++) atomicAdd(&s[q], wd[q]);
             }
         };
+        // Lane-items WITHOUT a slot (a patch with more chunks than slots; the base lines of a call's last grad-iter), every other grad-iter
+        // in the opposite order (the same set of lines every grad-iter and larger than the L2: taken the same way round each time nothing
+        // of one grad-iter's reads would still be there for the next).  When a patch has few of them each is cut into PK_UNCACHED_PARTS
+        // parts of PK_STAGE_ROWS rows on as many lanes, and the records of a part are requested BEFORE the lane walks its cached rows --
+        // straight into LDS (global_load ... lds: no registers to keep them in; round 5) -- and summed behind that walk: their memory
+        // latency, which used to stand at the end of the walk of every such patch (1.5-2.4 us of every grad-iter on an aged mesh or a
+        // raster of higher contrast, and of every call's last grad-iter), runs beside the cached walk instead.
+        const bool back = (it & 1) != 0;
+        const int extra = n_unc;
+        const int parts = extra * PK_UNCACHED_PARTS <= PK_THREADS ? PK_UNCACHED_PARTS : 1;
+        int st_l = -1, st_n = 0, st_rest = 0;   // the staged part of this lane: line-sum slot, records on their way, rows beyond them (walked later)
+        uint32_t st_sx = 0u;
+        typedef __attribute__((address_space(3))) char lds_char;
+        lds_char* const stage = (lds_char*)V.stage + (size_t)(tid >> 6) * 1024u;   // (+ u * PK_THREADS * 16: one 1 KB run per wave and record)
+        if (PK_STAGED && parts > 1 && tiled && tid < extra * parts) {
+            const int kk = tid / PK_UNCACHED_PARTS, part = tid % PK_UNCACHED_PARTS;
+            const int j = back ? extra - 1 - kk : kk;
+            int l, c, TL;
+            uint32_t magic;
+            if (j < w.li_cap) { const int32_t* e = V.li + 3 * (size_t)j; l = e[0] & 0xffff; c = e[0] >> 16; TL = e[1]; magic = (uint32_t)e[2]; }
+            else { pk_find_item(V, w.n_lines_all, j, l, c, TL); magic = pk_magic(TL); }
+            int first;
+            pk_rows r = pk_lane_rows(V.wk[l], c, TL, magic, A.px_pitch, &first);
+            const int skip = part * PK_STAGE_ROWS;
+            st_l = l;
+            if (skip < r.n) {
+                r.n -= skip; r.x = (int64_t)((uint64_t)r.x + (uint64_t)skip * (uint64_t)r.xs); first += skip * TL;
+                st_n = r.n < PK_STAGE_ROWS ? r.n : PK_STAGE_ROWS;
+                st_rest = part + 1 == PK_UNCACHED_PARTS ? r.n - st_n : 0;   // (a lane-item of more than parts x rows: its last part walks the rest)
+                uint32_t row = (uint32_t)first;
+#pragma unroll
+                for (int u = 0; u < PK_STAGE_ROWS; u++) {
+                    if (u < st_n) {
+                        const uint32_t col = (uint32_t)pk_next_col(r, A.vw.W);
+                        st_sx += col;
+                        const char* src = tiled + tp_px_tiled_row_part(row, (uint32_t)A.px_pitch) + tp_px_tiled_col_part(col);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(stage + (size_t)u * (PK_THREADS * 16u)), 16, 0, 0);
+                        row += (uint32_t)TL;
+                    }
+                }
+            }
+        }
         // (each step for both lane-items of the thread before the next step: their fetches are in flight together)
         {
             int rows[PK_NI];
@@ -368,20 +444,32 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             }
             PK_STAMP(9);
         }
-        // (lane-items beyond the cached ones: a patch with more than PK_CACHED, and the base lines of the last grad-iter)
-        // Every other grad-iter takes them in the opposite order: what they read is the same set of lines every grad-iter and larger than the
-        // L2, so taken the same way round each time nothing of one grad-iter's reads would still be there for the next
-        {
-            const int j0 = n_li_now < PK_CACHED ? n_li_now : PK_CACHED;
-            const bool back = (it & 1) != 0;
-            const int extra = n_li - j0;
-            // few of them: every lane-item in PK_UNCACHED_PARTS parts on as many lanes (one memory latency instead of four in a row)
-            const int parts = extra * PK_UNCACHED_PARTS <= PK_THREADS ? PK_UNCACHED_PARTS : 1;
+        if (PK_STAGED && parts > 1 && tiled) {
+            if (st_l >= 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the records requested above have landed in LDS)
+                pk_acc a;
+                a.xs = st_sx; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
+                uint64_t lo = 0, hi = 0;
+                const char* mine = V.stage + (size_t)(tid >> 6) * 1024u + (size_t)(tid & 63) * 16u;
+#pragma unroll
+                for (int u = 0; u < PK_STAGE_ROWS; u++)
+                    if (u < st_n) { const pk_rec d = *reinterpret_cast<const pk_rec*>(mine + (size_t)u * (PK_THREADS * 16u)); lo += d.lo; hi += d.hi; }
+                pk_add_unpacked(lo, hi, a);
+                if (st_rest > 0) {   // (rare: the rows beyond the parts, walked the slow way)
+                    const int kk = tid / PK_UNCACHED_PARTS;
+                    const int j = back ? extra - 1 - kk : kk;
+                    pk_acc b;
+                    pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, 0, w.li_cap, j, b, PK_UNCACHED_PARTS, PK_UNCACHED_PARTS + 1);
+                    a.xs += b.xs; a.nodd += b.nodd; a.r += b.r; a.g += b.g; a.b += b.b; a.q += b.q;
+                }
+                fold(st_l, a);
+            }
+        } else {
             for (int k = tid; k < extra * parts; k += PK_THREADS) {
                 const int kk = parts > 1 ? k / PK_UNCACHED_PARTS : k, part = parts > 1 ? k % PK_UNCACHED_PARTS : 0;
-                const int j = back ? n_li - 1 - kk : j0 + kk;
+                const int j = back ? extra - 1 - kk : kk;
                 pk_acc a;
-                const int l = pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, j0, w.li_cap, j, a, part, parts);
+                const int l = pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, 0, w.li_cap, j, a, part, parts);
                 fold(l, a);
             }
         }
@@ -509,14 +597,17 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
     // ---- carry for the next launch on this plan (no fence: it is work on the same stream, ordered behind the end of this kernel)
     if (carry) {
         __syncthreads();
-        for (int i = tid; i <= w.n_lines_all; i += PK_THREADS) carry[8 + i] = V.cut[i];
+        for (int i = tid; i <= w.n_lines_all; i += PK_THREADS) {
+            if (i < w.n_lines_all) { carry[8 + i] = V.tl[i]; carry[8 + A.carry_cut_cap + i] = V.nc[i]; }
+            carry[8 + 2 * A.carry_cut_cap + i] = V.cut[i];
+        }
 #pragma unroll
         for (int i = 0; i < PK_NI; i++) {
-            int32_t* e = carry + 8 + A.carry_cut_cap + 3 * (tid + i * PK_THREADS);
+            int32_t* e = carry + 8 + 3 * A.carry_cut_cap + 3 * (tid + i * PK_THREADS);
             e[0] = (cache[i].l & 0xffff) | (cache[i].c << 16); e[1] = cache[i].TL; e[2] = (int32_t)cache[i].magic;
         }
         if (tid == 0) {
-            carry[1] = (A.n_iters + age0) & (PK_RECUT - 1); carry[2] = V.flags[2]; carry[3] = n_li_now; carry[4] = n_li_all_now;
+            carry[1] = (A.n_iters + age0) & (PK_RECUT - 1); carry[2] = V.flags[2]; carry[3] = n_unc_now; carry[4] = n_unc_all_now;
             carry[0] = (int32_t)A.carry_tag;
         }
     }

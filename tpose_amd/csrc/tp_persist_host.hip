@@ -176,7 +176,7 @@ int install_plan(tp_context* c, pk_plan& np, const float* points, int slot) {
         int most = 0;
         for (const pk_wg& w : c->plan.wg) most = std::max(most, w.n_lines_all);
         const int cut_cap = (most + 1 + 3) & ~3;
-        c->carry_stride = 8 + cut_cap + 3 * PK_THREADS;
+        c->carry_stride = 8 + 3 * cut_cap + 3 * PK_CACHED;   // {header, chunks / slots / first uncached lane-item of every line, every slot's lane-item}
         const size_t words = (size_t)c->plan.parts * (size_t)c->carry_stride;
         if (words > c->cap_carry) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));   // (an earlier launch may still be writing the old one)
@@ -316,7 +316,7 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         A.epoch = c->epoch; A.n_iters = k; A.status = c->d_status;
         if (c->carry && c->carry_stride > 0) {
             if (dp != c->carry_dp || p.image_slot != c->carry_slot) { drop_carry(c); c->carry_dp = dp; c->carry_slot = p.image_slot; }   // (another dp or image than the launch before)
-            A.carry = c->carry; A.carry_stride = c->carry_stride; A.carry_tag = c->carry_tag; A.carry_cut_cap = c->carry_stride - 8 - 3 * PK_THREADS;
+            A.carry = c->carry; A.carry_stride = c->carry_stride; A.carry_tag = c->carry_tag; A.carry_cut_cap = (c->carry_stride - 8 - 3 * PK_CACHED) / 3;
             if (c->carry_written) c->warm_launches++;
             c->carry_written = true;
         }

@@ -54,6 +54,8 @@
 #define PK_RR0 (PK_ROWS_PER_LANE * 2 / 3)
 #define PK_RR1 (PK_ROWS_PER_LANE * 5 / 6)
 #define PK_RR2 (PK_ROWS_PER_LANE * 11 / 12)
+#define PK_STAGE_ROWS 4        /* table records a lane may have on their way into LDS while it walks its cached rows */
+#define PK_STAGE_BYTES (PK_STAGE_ROWS * PK_THREADS * 16)
 #define PK_MAX_SLOTS 1023    /* position slots of a workgroup (10-bit fields of the corner records) */
 #define PK_MAX_TL 4095       /* chunks per line */
 #ifndef PK_SLACK_ROWS
@@ -122,7 +124,10 @@ inline int pk_lds_bytes(const pk_wg& w) {
     b += pk_align16(w.n_slots * 4);                 // vid
     b += pk_align16(w.n_edges * 4);                 // edges
     b += pk_align16(w.n_lines_all * 4);             // lines
-    b += pk_align16((w.n_lines_all + 1) * 4);       // first lane-item of every line (and the total)
+    b += pk_align16((w.n_lines_all + 1) * 4);       // first lane-item WITHOUT a thread of its own of every line (and the total)
+    b += 2 * pk_align16(w.n_lines_all * 4);         // chunks of every line; how many of them have a thread (slot) of their own
+    b += 2 * pk_align16(PK_CACHED * 4);             // while the lines are cut again: the lane-item handed to a slot; the free slots
+    b += PK_STAGE_BYTES;                            // records of uncached lane-items on their way (global_load ... lds), tp_persist.hip
     b += pk_align16(w.li_cap * 12);                 // lane-items without a thread of their own
     b += pk_align16(w.n_corners * 16);              // corners
     b += pk_align16(w.n_base * 16);                 // base variants
