@@ -221,16 +221,27 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                 S[p].rpl = rpl;
                 if (!changed) for (int lane = 0; lane < 64; lane++) pk_cut_forget(V, w.n_lines_all, lane, 64);
                 if (changed) {
-                    int n_free = 0;
+                    int n_free = 0, unc[64], off = 0;
                     for (int sl = 0; sl < PK_CACHED; sl++)
-                        if (pk_slot_release(S[p].cache[sl], V)) {
-                            if (first) V.freel[pk_place_of_slot(sl)] = sl; else V.freel[n_free] = sl;
-                            n_free++;
-                        }
+                        if (pk_slot_release(S[p].cache[sl], V, first)) { if (!first) V.freel[n_free] = sl; n_free++; }
                     if (first && n_free != PK_CACHED) return -7;
-                    int base = 0, need[64], unc[64], off = 0;
-                    for (int lane = 0; lane < 64; lane++) need[lane] = pk_cut_need(V, w.n_lines_all, w.n_lines, lane, 64);
-                    for (int lane = 0; lane < 64; lane++) { unc[lane] = pk_cut_alloc(V, w.n_lines_all, w.n_lines, lane, 64, base, n_free); base += need[lane]; }
+                    if (first) {   // chunk-major, slot = place
+                        for (int lane = 0; lane < 64; lane++) pk_cut_fresh_begin(V, w.n_lines_all, lane, 64);
+                        int base = 0;
+                        for (int c = 0;; c++) {
+                            int k[64], total = 0;
+                            for (int lane = 0; lane < 64; lane++) { k[lane] = pk_cut_level_count(V, w.n_lines, lane, 64, w.n_lines_all, c); total += k[lane]; }
+                            if (total == 0) break;
+                            int run = base;
+                            for (int lane = 0; lane < 64; lane++) { pk_cut_level_assign(V, w.n_lines, lane, 64, w.n_lines_all, c, run, PK_CACHED); run += k[lane]; }
+                            base += total;
+                        }
+                        for (int lane = 0; lane < 64; lane++) unc[lane] = pk_cut_fresh_done(V, w.n_lines_all, lane, 64);
+                    } else {
+                        int base = 0, need[64];
+                        for (int lane = 0; lane < 64; lane++) need[lane] = pk_cut_need(V, w.n_lines_all, w.n_lines, lane, 64);
+                        for (int lane = 0; lane < 64; lane++) { unc[lane] = pk_cut_alloc(V, w.n_lines_all, w.n_lines, lane, 64, base, n_free); base += need[lane]; }
+                    }
                     for (int lane = 0; lane < 64; lane++) { pk_cut_write(V, w.n_lines_all, lane, 64, off); off += unc[lane]; }
                     for (int sl = 0; sl < PK_CACHED; sl++) pk_slot_take(S[p].cache[sl], V, sl);
                     for (int sl = 0; sl < PK_CACHED; sl++) if (V.st[sl] != -1) return -8;   // (a lane-item handed to a slot that was not free)

@@ -163,13 +163,55 @@ TP_HD void pk_cut_forget(const pk_view& V, int n, int lane, int lanes) {
     for (int l = lane * B; l < n && l < (lane + 1) * B; l++) V.sums[PK_SUM_STRIDE * (size_t)l] = 0ull;
 }
 TP_HD bool pk_cut_line_changed(const pk_view& V, int l) { return ((V.sums[PK_SUM_STRIDE * (size_t)l] >> 32) & 1ull) != 0ull; }
-// pass C, first half: the slots the lane's lines ask for (a changed line all its chunks, an unchanged one those it has no slot for)
+// A changed line KEEPS the slots of the chunks it still has (chunk c < what it wants now: the slot stays where it is, only its rows change
+// lanes -- pk_slot_release) and asks for the others; an unchanged line asks for the chunks it has no slot for.
+TP_HD int pk_cut_line_need(const pk_view& V, int l) {
+    if (!pk_cut_line_changed(V, l)) return V.tl[l] - V.nc[l];
+    const int want = (int)(uint32_t)V.sums[PK_SUM_STRIDE * (size_t)l];
+    return want - (V.nc[l] < want ? V.nc[l] : want);
+}
+// pass C, first half: the slots the lane's lines ask for
 TP_HD int pk_cut_need(const pk_view& V, int n, int n_every, int lane, int lanes) {
     const int B = (n + lanes - 1) / lanes;
     int need = 0;
-    for (int l = lane * B; l < n && l < (lane + 1) * B && l < n_every; l++)
-        need += pk_cut_line_changed(V, l) ? (int)(uint32_t)V.sums[PK_SUM_STRIDE * (size_t)l] : V.tl[l] - V.nc[l];
+    for (int l = lane * B; l < n && l < (lane + 1) * B && l < n_every; l++) need += pk_cut_line_need(V, l);
     return need;
+}
+// EVERYTHING afresh (a launch without a carry; a row more per lane): slots are handed out CHUNK-MAJOR -- the chunks 0 of all lines, then
+// the chunks 1, ... -- so that the lanes of a wave walk the same chunk of consecutive lines: the versions of one edge, whose rows are the
+// same and whose crossing columns lie within a few pixels of each other.  Their table records then share cache lines (a row's records: 8 to
+// a 128-byte line), and a wave's load touches a third of the lines it touches when its lanes sit lane-items apart -- which is what a patch
+// whose vertices move fast is bound by (every row stale: one L1 look-up per lane and row; profiles/r05_experiments.txt).  And the lanes of
+// one LDS atomic still fold different lines.  Level c: how many of the lane's lines want a chunk c ...
+TP_HD int pk_cut_level_count(const pk_view& V, int n_every, int lane, int lanes, int n, int c) {
+    const int B = (n + lanes - 1) / lanes;
+    int k = 0;
+    for (int l = lane * B; l < n && l < (lane + 1) * B && l < n_every; l++) k += (int)(uint32_t)V.sums[PK_SUM_STRIDE * (size_t)l] > c ? 1 : 0;
+    return k;
+}
+// ... and their slots: first + 0, 1, ... while there are slots (every slot is free: slot = place)
+TP_HD void pk_cut_level_assign(const pk_view& V, int n_every, int lane, int lanes, int n, int c, int first, int n_slots) {
+    const int B = (n + lanes - 1) / lanes;
+    for (int l = lane * B; l < n && l < (lane + 1) * B && l < n_every; l++)
+        if ((int)(uint32_t)V.sums[PK_SUM_STRIDE * (size_t)l] > c) {
+            if (first < n_slots) { V.st[first] = l | (c << 16); V.nc[l] = c + 1; }
+            first++;
+        }
+}
+// ... and then tl, and the uncached chunks of the lane's lines (pk_cut_write numbers them)
+TP_HD int pk_cut_fresh_done(const pk_view& V, int n, int lane, int lanes) {
+    const int B = (n + lanes - 1) / lanes;
+    int unc = 0;
+    for (int l = lane * B; l < n && l < (lane + 1) * B; l++) {
+        V.tl[l] = (int)(uint32_t)V.sums[PK_SUM_STRIDE * (size_t)l];
+        V.sums[PK_SUM_STRIDE * (size_t)l] = 0ull;
+        unc += V.tl[l] - V.nc[l];
+    }
+    return unc;
+}
+TP_HD void pk_cut_fresh_begin(const pk_view& V, int n, int lane, int lanes) {
+    const int B = (n + lanes - 1) / lanes;
+    for (int l = lane * B; l < n && l < (lane + 1) * B; l++) V.nc[l] = 0;
 }
 // ... second half: `base` = slots asked for by the lanes before this one, n_free = free slots filed in pass B.  Returns the lane's uncached chunks.
 TP_HD int pk_cut_alloc(const pk_view& V, int n, int n_every, int lane, int lanes, int base, int n_free) {
@@ -177,7 +219,7 @@ TP_HD int pk_cut_alloc(const pk_view& V, int n, int n_every, int lane, int lanes
     int unc = 0;
     for (int l = lane * B; l < n && l < (lane + 1) * B; l++) {
         const int want = (int)(uint32_t)V.sums[PK_SUM_STRIDE * (size_t)l];
-        if (pk_cut_line_changed(V, l)) { V.tl[l] = want; V.nc[l] = 0; }
+        if (pk_cut_line_changed(V, l)) { V.tl[l] = want; V.nc[l] = V.nc[l] < want ? V.nc[l] : want; }   // (the chunks below both counts kept their slots)
         V.sums[PK_SUM_STRIDE * (size_t)l] = 0ull;
         if (l < n_every) {
             const int need = V.tl[l] - V.nc[l];
@@ -384,9 +426,7 @@ struct pk_lane_cache {
     pk_rec rec[R];
 };
 // A slot (a thread's cached lane-item) through a cut of the lines -- passes B and D above.
-// Where a slot stands in the order the free list is filled in when EVERYTHING is cut afresh (a launch without a carry, a row more per
-// lane): the chunks of a line take consecutive places, and consecutive places are lanes 64 / (PK_CACHED / 64) apart ... so that the lanes
-// of one LDS atomic fold different lines (the same line from adjacent lanes serialises the instruction)
+// where a slot stands in the free list when everything is cut afresh the OTHER way (PK_CHUNK_MAJOR 0: a line's chunks on lanes 64 / (slots / 64) apart)
 TP_HD int pk_place_of_slot(int s) { return (s & 63) * (PK_CACHED / 64) + (s >> 6); }
 // (A slot's records and columns are never touched here: a slot that changes hands gets a first row that matches nothing -- row0 = ~0 -- and
 // the walk's own "the line's first row moved" path drops its columns and fetches; a slot without a lane-item has no rows, its columns
@@ -394,9 +434,15 @@ TP_HD int pk_place_of_slot(int s) { return (s & 63) * (PK_CACHED / 64) + (s >> 6
 template <int R>
 TP_HD void pk_slot_clear(pk_lane_cache<R>& C) { C.l = 0; C.c = 0; C.TL = 0; C.magic = 0u; C.row0 = 0xffffffffu; }
 // pass B: true when the slot is free after it (it had no lane-item, or its line is cut differently now)
+// (afresh: every slot is given up; otherwise a slot whose chunk its line still has stays that chunk's, with the line's new count)
 template <int R>
-TP_HD bool pk_slot_release(pk_lane_cache<R>& C, const pk_view& V) {
-    if (C.TL != 0 && pk_cut_line_changed(V, C.l)) pk_slot_clear(C);
+TP_HD bool pk_slot_release(pk_lane_cache<R>& C, const pk_view& V, bool afresh) {
+    if (afresh) pk_slot_clear(C);
+    else if (C.TL != 0 && pk_cut_line_changed(V, C.l)) {
+        const int want = (int)(uint32_t)V.sums[PK_SUM_STRIDE * (size_t)C.l];
+        if (C.c < want) { C.TL = want; C.magic = pk_magic(want); C.row0 = 0xffffffffu; }
+        else pk_slot_clear(C);
+    }
     return C.TL == 0;
 }
 // pass D

@@ -32,14 +32,20 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 #ifndef PK_RECUT_MIN_GAP
 #define PK_RECUT_MIN_GAP 4    /* grad-iters between two cuts of a patch's lines, at least */
 #endif
+#ifndef PK_CHUNK_MAJOR
+#define PK_CHUNK_MAJOR 0   /* 1: a cut of everything hands slots out chunk-major (tp_persist.h) -- measured: 5 % faster on the full-contrast raster, 2 % slower on
+                             the bench's; 0: line by line, a line's chunks on lanes far apart */
+#endif
 #ifndef PK_STAGED
-#define PK_STAGED 1   /* the few uncached lane-items of a patch have their records requested into LDS before the cached walk */
+#define PK_STAGED 0   /* 1: the few uncached lane-items of a patch have their records requested into LDS before the cached walk -- built, bit-exact,
+                        and measured to change nothing (the patches it was meant for are bound by the number of record fetches, not by
+                        their latency); costs four registers */
 #endif
 #ifndef PK_UNCACHED_PARTS
 #define PK_UNCACHED_PARTS 4   /* lanes that share a lane-item without cached records when a patch has few of those */
 #endif
 #ifndef PK_EXP_NOFILL
-#define PK_EXP_NOFILL 0   /* timing experiments only: 1 = the first grad-iter of a launch fetches like every other (row-major table, compare first) */
+#define PK_EXP_NOFILL 0   /* 1 = the first grad-iter of a launch fetches like every other (row-major table, compare first) */
 #endif
 #define PK_TIMEOUT_BANDS 100000000ull  // 1 s when other processes take part (their launches start when their hosts get to it)
 
@@ -336,30 +342,46 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 }
                 changed = __any(changed) ? (first ? 2 : 1) : 0;
                 if (!changed) pk_cut_forget(V, w.n_lines_all, tid, 64);
-                if (tid == 0) { V.flags[1] = changed; V.flags[2] = rpl; V.flags[8] = 0; V.flags[9] = changed == 2 ? PK_CACHED : 0; }
+                if (tid == 0) { V.flags[1] = changed; V.flags[2] = rpl; V.flags[8] = 0; V.flags[9] = 0; }
             }
             __syncthreads();
             PK_STAMP(7);
             const int how = V.flags[1];   // 0: no line changed, 1: some did, 2: everything is cut afresh
             if (how) {
-                // pass B: slots of changed lines are given up; every free slot files itself (afresh: in the order that keeps a line's chunks apart)
+                // pass B: a slot whose line dropped its chunk is given up (afresh: every slot); every free slot files itself
 #pragma unroll
-                for (int i = 0; i < PK_NI; i++) {
-                    const int sl = tid + i * PK_THREADS;
-                    if (pk_slot_release(cache[i], V)) {
-                        if (how == 2) V.freel[pk_place_of_slot(sl)] = sl;
-                        else V.freel[__hip_atomic_fetch_add(&V.flags[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = sl;
+                for (int i = 0; i < PK_NI; i++)
+                    if (pk_slot_release(cache[i], V, how == 2)) {
+                        if (how != 2) V.freel[__hip_atomic_fetch_add(&V.flags[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = tid + i * PK_THREADS;
+                        else if (!PK_CHUNK_MAJOR) V.freel[pk_place_of_slot(tid + i * PK_THREADS)] = tid + i * PK_THREADS;
                     }
-                }
                 __syncthreads();
                 // pass C: free slots to the chunks that want one; the uncached lane-items numbered
                 if (tid < 64) {
-                    const int n_free = V.flags[9];
-                    const int need = pk_cut_need(V, w.n_lines_all, w.n_lines, tid, 64);
-                    int incl = need;
+                    int unc;
+                    if (how == 2 && PK_CHUNK_MAJOR) {   // chunk-major: the chunks 0 of all lines, then the chunks 1, ... (slot = place)
+                        pk_cut_fresh_begin(V, w.n_lines_all, tid, 64);
+                        int base = 0;
+                        for (int c = 0;; c++) {
+                            const int k = pk_cut_level_count(V, w.n_lines, tid, 64, w.n_lines_all, c);
+                            int incl = k;
 #pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); incl += tid >= d ? o : 0; }
-                    const int unc = pk_cut_alloc(V, w.n_lines_all, w.n_lines, tid, 64, incl - need, n_free);
+                            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); incl += tid >= d ? o : 0; }
+                            const int total = __shfl(incl, 63);
+                            if (total == 0) break;
+                            pk_cut_level_assign(V, w.n_lines, tid, 64, w.n_lines_all, c, base + incl - k, PK_CACHED);
+                            base += total;
+                        }
+                        unc = pk_cut_fresh_done(V, w.n_lines_all, tid, 64);
+                    } else {
+                        if (how == 2) pk_cut_fresh_begin(V, w.n_lines_all, tid, 64);   // (no chunk keeps a slot)
+                        const int n_free = how == 2 ? PK_CACHED : V.flags[9];
+                        const int need = pk_cut_need(V, w.n_lines_all, w.n_lines, tid, 64);
+                        int incl = need;
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); incl += tid >= d ? o : 0; }
+                        unc = pk_cut_alloc(V, w.n_lines_all, w.n_lines, tid, 64, incl - need, n_free);
+                    }
                     int uincl = unc;
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(uincl, d); uincl += tid >= d ? o : 0; }
