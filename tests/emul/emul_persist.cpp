@@ -168,7 +168,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
     std::vector<part_state> S((size_t)P.parts);
     for (int p = 0; p < P.parts; p++) {
         const pk_wg& w = P.wg[p];
-        S[p].lds.assign((size_t)w.lds_bytes, 0);
+        S[p].lds.assign((size_t)w.lds_bytes, (char)0xA5);   // (LDS holds anything when a kernel starts; the prologue clears what it must)
         pk_view& V = S[p].V;
         pk_carve(S[p].lds.data(), w, V);
         memcpy(V.vid, &P.pool[w.off_vid], sizeof(int32_t) * w.n_slots);
@@ -219,6 +219,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                     rpl++; first = true;
                 }
                 S[p].rpl = rpl;
+                if (first) changed = 1;   // (a patch without lines still gets its empty tables written)
                 if (!changed) for (int lane = 0; lane < 64; lane++) pk_cut_forget(V, w.n_lines_all, lane, 64);
                 if (changed) {
                     int n_free = 0, unc[64], off = 0;

@@ -388,7 +388,11 @@ TP_HD int pk_walk_lane(const pk_view& V, const char* table, const char* tiled, i
                        int part = 0, int parts = 1) {
     int l, c, TL;
     uint32_t magic;
+#ifdef PK_EXP_NOLI
+    if (false) {
+#else
     if (j - base < li_cap) {
+#endif
         const int32_t* e = V.li + 3 * (size_t)(j - base);
         l = e[0] & 0xffff; c = e[0] >> 16; TL = e[1]; magic = (uint32_t)e[2];
     } else {   // (the patch's lines have outgrown the table)

@@ -340,7 +340,9 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                     if (every <= PK_CACHED || rpl >= RR) break;
                     rpl++; first = true;   // (more chunks than slots: a row more per lane, everything afresh)
                 }
-                changed = __any(changed) ? (first ? 2 : 1) : 0;
+                // (afresh counts as a change whatever the lines say: a patch WITHOUT lines -- a crowded mesh leaves some -- must still get its
+                // (empty) tables written, or its threads walk whatever the LDS held: found by config 3's coarsest level, 2 runs in 3)
+                changed = first ? 2 : (__any(changed) ? 1 : 0);
                 if (!changed) pk_cut_forget(V, w.n_lines_all, tid, 64);
                 if (tid == 0) { V.flags[1] = changed; V.flags[2] = rpl; V.flags[8] = 0; V.flags[9] = 0; }
             }

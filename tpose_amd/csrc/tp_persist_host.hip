@@ -314,7 +314,8 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
             A.final_slot = (unsigned)(c->band_seq++ & 1);
         }
         A.epoch = c->epoch; A.n_iters = k; A.status = c->d_status;
-        if (c->carry && c->carry_stride > 0) {
+        static const bool no_carry = getenv("TPOSE_NO_CARRY") != nullptr;   // (debugging: every launch cuts for itself)
+        if (c->carry && c->carry_stride > 0 && !no_carry) {
             if (dp != c->carry_dp || p.image_slot != c->carry_slot) { drop_carry(c); c->carry_dp = dp; c->carry_slot = p.image_slot; }   // (another dp or image than the launch before)
             A.carry = c->carry; A.carry_stride = c->carry_stride; A.carry_tag = c->carry_tag; A.carry_cut_cap = (c->carry_stride - 8 - 3 * PK_CACHED) / 3;
             if (c->carry_written) c->warm_launches++;
