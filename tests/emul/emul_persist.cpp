@@ -289,7 +289,22 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             }
             for (int j = 0; j < PK_CACHED; j++) {   // the cached slots (a slot without a lane-item walks nothing)
                 pk_acc a;
-                pk_walk_cached<PK_ROWS_PER_LANE>(S[p].cache[j], V, table, pitch, W, a);
+                if (w.lds_rows) pk_walk_cached<PK_ROWS_PER_LANE, PK_LDS_ROWS>(S[p].cache[j], V, j, table, pitch, W, a);
+                else pk_walk_cached<PK_ROWS_PER_LANE, 0>(S[p].cache[j], V, j, table, pitch, W, a);
+                if (S[p].cache[j].TL != 0) {   // what the slot keeps now -- in registers and in LDS -- is the record of every row's CURRENT crossing column
+                    const auto& C = S[p].cache[j];
+                    pk_rows r = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
+                    const int n = r.n;
+                    if (C.row0 != r.row) return -13;
+                    for (int u = 0; u < PK_ROWS_PER_LANE + w.lds_rows; u++) {
+                        const uint32_t col = u < n ? (uint32_t)pk_next_col(r, W) : 0u;
+                        const uint32_t off = (u < n ? r.row + (uint32_t)u * r.rs : 0u) + (col << 4);
+                        const int v = u - PK_ROWS_PER_LANE;
+                        const uint32_t have = v < 0 ? (uint32_t)C.col[u] : (uint32_t)V.lcol[(size_t)j * PK_LDS_ROWS + v];
+                        const void* rec = v < 0 ? (const void*)&C.rec[u] : (const void*)(V.lrec + 16 * ((size_t)v * PK_CACHED + j));
+                        if (have != col || memcmp(rec, table + off, 16) != 0) return -14;
+                    }
+                }
                 unsigned long long* s = V.sums + (size_t)S[p].cache[j].l * PK_SUM_STRIDE;
                 unsigned long long wd[PK_SUM_WORDS];
                 pk_fold_words(a, wd);

@@ -7,7 +7,11 @@ from tpose_amd import capi, synth
 contrast=float(os.environ.get("TPOSE_CONTRAST","0.3"))
 img, pts, tris, he, ratio = synth.workload(2048, 2048, 3000, contrast=contrast)
 ctx = capi.Context(0, 2048, 2048); ctx.set_image(capi.IMAGE_A, img); ctx.upload(pts, tris, None)
-p = capi.default_params(0); ctx.iterate(p, 1024); ctx.iterate(p, 130); ctx.synchronize()
+p = capi.default_params(0)
+age = int(os.environ.get("TPOSE_AGE", "1024"))
+while age > 0:
+    ctx.iterate(p, min(age, 4096)); age -= 4096
+ctx.iterate(p, 130); ctx.synchronize()
 lib = ctx.lib; lib.tp_debug_dump_persist.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 parts = ctx.info(capi.INFO_PATCHES)
 IT, WIT, WAVES = 64, 32, 12
@@ -19,10 +23,12 @@ st = buf[base: base + parts * WIT * WAVES * 16].reshape(parts, WIT, WAVES, 16).a
 dur = (st[:, 8:, :, 6].max(axis=2) - st[:, 8:, :, 4].min(axis=2)) / 100.0
 med = np.median(dur, axis=1)
 order = np.argsort(-med)
-names = {4: "P1 barrier", 5: "pass", 6: "folded", 7: "P3 barrier"}
+names = {4: "P1 barrier", 14: "LDS pass", 5: "pass", 15: "sums", 6: "folded", 7: "P3 barrier"}
 for b in list(order[:3]) + [order[-1]]:
     it = 12
     t0 = st[b, it, :, 4].min()
     print("block", b, "median P3 %.2f" % med[b])
-    for k in (4, 5, 6, 7):
+    for k in (4, 14, 5, 15, 6, 7):
         print("   %-10s" % names[k], " ".join("%5.2f" % ((st[b, it, w, k] - t0) / 100.0) for w in range(WAVES)))
+    note = st[b, it, :, 9]
+    print("   lanes with more rows than records", " ".join("%d" % (v & 0xffff) for v in note), "| lane-items without a slot: in LDS %d, beyond %d" % (note[0] >> 32, (note[0] >> 16) & 0xffff))

@@ -41,6 +41,7 @@ OPT_PERSISTENT, OPT_INJECT_GIVE_UP = 1, 3
 PERSIST_OFF, PERSIST_AUTO = 0, 1
 INFO_PATCHES, INFO_PATCH_LDS, INFO_PATCH_LINES, INFO_PERSIST_LAUNCHES, INFO_PERSIST_ITERS, INFO_CENSUS, INFO_REPLANS = 2, 3, 4, 5, 6, 7, 8
 INFO_PERSIST_FAILURES, INFO_BOX_FINEGRAINED, INFO_WARM_LAUNCHES = 9, 10, 11
+INFO_RETRY_MS, INFO_PLAN_ROWS = 12, 13
 
 
 class Params(C.Structure):

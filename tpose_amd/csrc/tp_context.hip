@@ -787,6 +787,7 @@ int tp_get_info(tp_context* c, int what, int64_t* value) {
             *value = c->census == -6 && c->persist_retry_at > now ? (int64_t)std::chrono::duration_cast<std::chrono::milliseconds>(c->persist_retry_at - now).count() + 1 : 0;
             return TP_OK;
         }
+        case 13: *value = (c->plan_generation == c->generation && c->plan.ok) ? c->plan.rows_max : 0; return TP_OK;
         default: return fail(c, TP_ERR_INVALID, "unknown info %d", what);
     }
 }

@@ -51,7 +51,9 @@ struct pk_view {
     pk_i4* base;
     int32_t* ldir;             // [n_lines_all] +1 / -1 / 0: the line's second endpoint lies below / above / level with its first (snapped rows)
     int32_t* flags;
-    char* stage;               // [PK_STAGE_ROWS][waves][64] table records on their way from memory straight into LDS (tp_persist.hip, P3)
+    // rows PK_ROWS_PER_LANE .. PK_ROWS_MAX - 1 of every slot's lane-item, when the plan has them (pk_wg::lds_rows; pk_walk_lds_rows)
+    char* lrec;                // [PK_LDS_ROWS][PK_CACHED] table records (a wave's 64 slots side by side: they arrive by global_load ... lds)
+    uint16_t* lcol;            // [PK_CACHED][PK_LDS_ROWS] the crossing column each belongs to (a slot's four in one 64-bit word)
 };
 
 TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
@@ -74,7 +76,8 @@ TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     V.base = (pk_i4*)p; p += pk_align16(w.n_base * 16);
     V.ldir = (int32_t*)p; p += pk_align16(w.n_lines_all * 4);
     V.flags = (int32_t*)p; p += 64;
-    V.stage = p;
+    V.lrec = p; p += (size_t)w.lds_rows * 16 * PK_CACHED;
+    V.lcol = (uint16_t*)p;
 }
 
 // P1b, lane l < n_lines: line l = (local edge, version) -- the walker of the whole line
@@ -465,9 +468,38 @@ TP_HD void pk_slot_take(pk_lane_cache<R>& C, const pk_view& V, int s) {
 // step 1: every row's crossing column, once; a row whose column has left its cached record is fetched right there (loads
 // are issued, not waited for).  Returns the rows of the lane.  (Round 3 began with a scan that only compared, and a second
 // walk that fetched when anything in the WAVE was stale -- which is nearly always: one pass is 0.3 us per grad-iter less.)
-template <int RR, int R>
-TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int pitch, const char* table, int W) {
-    static_assert(RR <= R && RR <= 32, "one bit per row");
+// rows RR .. RR + RL - 1 of slot s's lane-item: their records live in LDS (round 5), everything else as for the rows in registers -- what is
+// summed is the record of the row's current crossing column, a row is fetched when that column has changed (`moved`: all of them).  t: the
+// walk behind row RR - 1.  Stale records are requested straight into LDS (global_load ... lds: a wave's 64 slots side by side).
+TP_HD void pk_lds_fetch(const char* src, char* wave_run, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)wave_run, 16, 0, 0);
+#else
+    memcpy(wave_run + 16 * (size_t)lane, src, 16);
+#endif
+}
+template <int RR, int RL>
+TP_HD void pk_walk_lds_rows(const pk_view& V, int s, pk_rows& t, uint32_t live, bool moved, const char* table, int W) {
+    static_assert(RL == 0 || RL == 4, "a slot's crossing columns in LDS are one 64-bit word");
+    if (RL == 0) return;
+    uint64_t* const word = reinterpret_cast<uint64_t*>(V.lcol) + s;
+    uint64_t pc = *word;
+    char* const run = V.lrec + 16 * (size_t)(s & ~63);
+#pragma unroll
+    for (int u = 0; u < RL; u++) {
+        const uint32_t on = 0u - ((live >> (RR + u)) & 1u);
+        const uint32_t col = (uint32_t)pk_next_col(t, W) & on;
+        if (moved || col != (uint32_t)((pc >> (16 * u)) & 0xffffu)) {
+            pk_lds_fetch(table + (((t.row + (uint32_t)(RR + u) * t.rs) & on) + (col << 4)), run + 16 * (size_t)u * PK_CACHED, s & 63);
+            pc = (pc & ~(0xffffull << (16 * u))) | ((uint64_t)col << (16 * u));
+        }
+    }
+    *word = pc;
+}
+template <int RR, int RL, int R>
+TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, const char* table, int W) {
+    static_assert(RR <= R && RR + RL <= 32, "one bit per row");
     pk_rows t;
     if (C.TL == 0) { t.n = 0; t.x = 0; t.xs = 0; t.row = 0; t.rs = 0; }
     else t = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
@@ -505,15 +537,17 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int pitch, const c
             C.col[u] = col;
         }
     }
+    pk_walk_lds_rows<RR, RL>(V, s, t, live, moved, table, W);
     return n;
 }
 // step 1 in the FIRST grad-iter of a launch: nothing is cached yet, every row of every lane is fetched -- from the TILED copy of the table
 // (4 rows x 2 columns per 128-byte line: the chunks of a line and the versions of an edge share lines there; the row-major table gives
 // every record a line of its own, a million lines per launch at 2048^2 / 3000 and 15 us of a 20-step call).  No comparison, no branch; the
-// address arithmetic of the tiled form costs this one grad-iter ~7 instructions per row and the others nothing.
-template <int RR, int R>
-TP_HD int pk_walk_fill(pk_lane_cache<R>& C, const pk_view& V, int pitch, const char* tiled, int W) {
-    static_assert(RR <= R && RR <= 32, "one bit per row");
+// address arithmetic of the tiled form costs this one grad-iter ~7 instructions per row and the others nothing.  (Rows kept in LDS: from
+// the row-major table, as when the first row has moved.)
+template <int RR, int RL, int R>
+TP_HD int pk_walk_fill(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, const char* tiled, const char* table, int W) {
+    static_assert(RR <= R && RR + RL <= 32, "one bit per row");
     pk_rows t;
     int first = 0;
     if (C.TL == 0) { t.n = 0; t.x = 0; t.xs = 0; t.row = 0; t.rs = 0; }
@@ -521,6 +555,7 @@ TP_HD int pk_walk_fill(pk_lane_cache<R>& C, const pk_view& V, int pitch, const c
     const uint32_t live = t.n >= 32 ? 0xffffffffu : ((1u << t.n) - 1u);
     C.row0 = t.row;
     uint32_t row = (uint32_t)first;
+    const int n = t.n;
 #pragma unroll
     for (int u = 0; u < RR; u++) {
         const uint32_t on = 0u - ((live >> u) & 1u);
@@ -529,12 +564,14 @@ TP_HD int pk_walk_fill(pk_lane_cache<R>& C, const pk_view& V, int pitch, const c
         C.col[u] = col;
         row += (uint32_t)C.TL;
     }
-    return t.n;
+    pk_walk_lds_rows<RR, RL>(V, s, t, live, true, table, W);
+    return n;
 }
 // step 2: the line's partial sums of this lane (the crossing columns are the cached ones by now: they are added up here,
-// behind the fetches).  n: the lane's rows, from step 1
-template <int RR, int R>
-TP_HD void pk_walk_sum(const pk_lane_cache<R>& C, int n, const pk_view& V, int pitch, const char* table, int W, pk_acc& a) {
+// behind the fetches -- on the device behind a wait for the requests into LDS, if there are rows there).  n: the lane's rows, from step 1
+template <int RR, int RL, int R>
+TP_HD void pk_walk_sum(const pk_lane_cache<R>& C, int n, const pk_view& V, int s, int pitch, const char* table, int W, pk_acc& a) {
+    static_assert(RL <= TP_PX_MAXSUM, "records added before unpacking");
     a.xs = 0; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
 #pragma unroll
     for (int u = 0; u < RR; u++) a.xs += (uint32_t)C.col[u];
@@ -545,17 +582,28 @@ TP_HD void pk_walk_sum(const pk_lane_cache<R>& C, int n, const pk_view& V, int p
         for (int u = u0; u < RR && u < u0 + TP_PX_MAXSUM; u++) { lo += C.rec[u].lo; hi += C.rec[u].hi; }
         pk_add_unpacked(lo, hi, a);
     }
-    if (n > RR) {   // the line has grown beyond the rows this workgroup's lanes keep (its rows are worked out again here, in
-                    // the rare case, so that nothing of step 1 but `n` stays in registers across the fetches)
+    if (RL > 0) {
+        const uint64_t pc = reinterpret_cast<const uint64_t*>(V.lcol)[s];
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int u = 0; u < RL; u++) {
+            a.xs += (uint32_t)((pc >> (16 * u)) & 0xffffu);
+            const pk_rec d = *reinterpret_cast<const pk_rec*>(V.lrec + 16 * ((size_t)u * PK_CACHED + s));
+            lo += d.lo; hi += d.hi;
+        }
+        pk_add_unpacked(lo, hi, a);
+    }
+    if (n > RR + RL) {   // the line has grown beyond the rows this workgroup's lanes keep (its rows are worked out again here, in
+                         // the rare case, so that nothing of step 1 but `n` stays in registers across the fetches)
         pk_rows r = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
-        r.n -= RR; r.x = (int64_t)((uint64_t)r.x + (uint64_t)RR * (uint64_t)r.xs); r.row += (uint32_t)RR * r.rs;
+        r.n -= RR + RL; r.x = (int64_t)((uint64_t)r.x + (uint64_t)(RR + RL) * (uint64_t)r.xs); r.row += (uint32_t)(RR + RL) * r.rs;
         pk_walk_rows<4>(r, table, W, a);
     }
 }
-template <int RR, int R>
-TP_HD void pk_walk_cached(pk_lane_cache<R>& C, const pk_view& V, const char* table, int pitch, int W, pk_acc& a) {
-    const int n = pk_walk_pass<RR>(C, V, pitch, table, W);
-    pk_walk_sum<RR>(C, n, V, pitch, table, W, a);
+template <int RR, int RL, int R>
+TP_HD void pk_walk_cached(pk_lane_cache<R>& C, const pk_view& V, int s, const char* table, int pitch, int W, pk_acc& a) {
+    const int n = pk_walk_pass<RR, RL>(C, V, s, pitch, table, W);
+    pk_walk_sum<RR, RL>(C, n, V, s, pitch, table, W, a);
 }
 
 // tag of grad-iter `epoch`: never 0 (a cleared mailbox matches nothing), and no two grad-iters of a context's life share one

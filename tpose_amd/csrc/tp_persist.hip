@@ -36,11 +36,6 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 #define PK_CHUNK_MAJOR 0   /* 1: a cut of everything hands slots out chunk-major (tp_persist.h) -- measured: 5 % faster on the full-contrast raster, 2 % slower on
                              the bench's; 0: line by line, a line's chunks on lanes far apart */
 #endif
-#ifndef PK_STAGED
-#define PK_STAGED 0   /* 1: the few uncached lane-items of a patch have their records requested into LDS before the cached walk -- built, bit-exact,
-                        and measured to change nothing (the patches it was meant for are bound by the number of record fetches, not by
-                        their latency); costs four registers */
-#endif
 #ifndef PK_UNCACHED_PARTS
 #define PK_UNCACHED_PARTS 4   /* lanes that share a lane-item without cached records when a patch has few of those */
 #endif
@@ -58,16 +53,20 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 #ifdef PK_DBG_WAVES
 #define PK_WSTAMP(k) do { if ((threadIdx.x & 63) == 0 && A.dbg && it >= A.dbg_first && it < A.dbg_first + PK_DBG_WITERS) \
     A.dbg[PK_DBG_WBASE + (((size_t)blockIdx.x * PK_DBG_WITERS + (it - A.dbg_first)) * (PK_THREADS / 64) + (threadIdx.x >> 6)) * 16 + (k)] = wall_clock64(); } while (0)
+// (a figure instead of the clock, from the wave's first lane)
+#define PK_WNOTE(k, v) do { if ((threadIdx.x & 63) == 0 && A.dbg && it >= A.dbg_first && it < A.dbg_first + PK_DBG_WITERS) \
+    A.dbg[PK_DBG_WBASE + (((size_t)blockIdx.x * PK_DBG_WITERS + (it - A.dbg_first)) * (PK_THREADS / 64) + (threadIdx.x >> 6)) * 16 + (k)] = (unsigned long long)(v); } while (0)
 #else
 #define PK_WSTAMP(k) do { } while (0)
+#define PK_WNOTE(k, v) do { } while (0)
 #endif
 #else
 #define PK_STAMP(k) do { } while (0)
 #define PK_STAMP0(k) do { } while (0)
 #define PK_WSTAMP(k) do { } while (0)
+#define PK_WNOTE(k, v) do { } while (0)
 #endif
 
-static_assert(PK_UNCACHED_BATCH == PK_STAGE_ROWS, "a staged part is one batch of an uncached lane-item");
 
 namespace {
 
@@ -97,8 +96,9 @@ __device__ __forceinline__ int patch_of_block(int b, int parts) {
 // MODE: 0 a plain tp_iterate, 1 with the rings of tp_iterate_until, 2 a band of a split descent (rings decided at run time).
 // (One kernel for all three kept a dozen pointers of the rare cases in scalar registers -- 130 of them spilled to vector
 // lanes -- and cost every grad-iter of the common case 0.3 us.)
-template <int RR, int MODE>
+template <int RT, int MODE>
 __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_THREADS / 256, PK_THREADS / 256))) void k_persist(pk_args A) {
+    constexpr int RR = RT > PK_ROWS_PER_LANE ? PK_ROWS_PER_LANE : RT, RL = RT - RR;   // rows per lane whose records live in registers / in LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tid = threadIdx.x;
     const int part = A.part0 + patch_of_block((int)blockIdx.x, (int)gridDim.x);
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                     int every = pk_cut_want(V, w.n_lines_all, w.n_lines, tid, 64, rpl, first, changed);
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) every += __shfl_xor(every, d);
-                    if (every <= PK_CACHED || rpl >= RR) break;
+                    if (every <= PK_CACHED || rpl >= RT) break;
                     rpl++; first = true;   // (more chunks than slots: a row more per lane, everything afresh)
                 }
                 // (afresh counts as a change whatever the lines say: a patch WITHOUT lines -- a crowded mesh leaves some -- must still get its
@@ -413,89 +413,36 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         // Lane-items WITHOUT a slot (a patch with more chunks than slots; the base lines of a call's last grad-iter), every other grad-iter
         // in the opposite order (the same set of lines every grad-iter and larger than the L2: taken the same way round each time nothing
         // of one grad-iter's reads would still be there for the next).  When a patch has few of them each is cut into PK_UNCACHED_PARTS
-        // parts of PK_STAGE_ROWS rows on as many lanes, and the records of a part are requested BEFORE the lane walks its cached rows --
-        // straight into LDS (global_load ... lds: no registers to keep them in; round 5) -- and summed behind that walk: their memory
-        // latency, which used to stand at the end of the walk of every such patch (1.5-2.4 us of every grad-iter on an aged mesh or a
-        // raster of higher contrast, and of every call's last grad-iter), runs beside the cached walk instead.
+        // parts on as many lanes: one memory latency instead of four in a row.
         const bool back = (it & 1) != 0;
         const int extra = n_unc;
         const int parts = extra * PK_UNCACHED_PARTS <= PK_THREADS ? PK_UNCACHED_PARTS : 1;
-        int st_l = -1, st_n = 0, st_rest = 0;   // the staged part of this lane: line-sum slot, records on their way, rows beyond them (walked later)
-        uint32_t st_sx = 0u;
-        typedef __attribute__((address_space(3))) char lds_char;
-        lds_char* const stage = (lds_char*)V.stage + (size_t)(tid >> 6) * 1024u;   // (+ u * PK_THREADS * 16: one 1 KB run per wave and record)
-        if (PK_STAGED && parts > 1 && tiled && tid < extra * parts) {
-            const int kk = tid / PK_UNCACHED_PARTS, part = tid % PK_UNCACHED_PARTS;
-            const int j = back ? extra - 1 - kk : kk;
-            int l, c, TL;
-            uint32_t magic;
-            if (j < w.li_cap) { const int32_t* e = V.li + 3 * (size_t)j; l = e[0] & 0xffff; c = e[0] >> 16; TL = e[1]; magic = (uint32_t)e[2]; }
-            else { pk_find_item(V, w.n_lines_all, j, l, c, TL); magic = pk_magic(TL); }
-            int first;
-            pk_rows r = pk_lane_rows(V.wk[l], c, TL, magic, A.px_pitch, &first);
-            const int skip = part * PK_STAGE_ROWS;
-            st_l = l;
-            if (skip < r.n) {
-                r.n -= skip; r.x = (int64_t)((uint64_t)r.x + (uint64_t)skip * (uint64_t)r.xs); first += skip * TL;
-                st_n = r.n < PK_STAGE_ROWS ? r.n : PK_STAGE_ROWS;
-                st_rest = part + 1 == PK_UNCACHED_PARTS ? r.n - st_n : 0;   // (a lane-item of more than parts x rows: its last part walks the rest)
-                uint32_t row = (uint32_t)first;
-#pragma unroll
-                for (int u = 0; u < PK_STAGE_ROWS; u++) {
-                    if (u < st_n) {
-                        const uint32_t col = (uint32_t)pk_next_col(r, A.vw.W);
-                        st_sx += col;
-                        const char* src = tiled + tp_px_tiled_row_part(row, (uint32_t)A.px_pitch) + tp_px_tiled_col_part(col);
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(stage + (size_t)u * (PK_THREADS * 16u)), 16, 0, 0);
-                        row += (uint32_t)TL;
-                    }
-                }
-            }
-        }
         // (each step for both lane-items of the thread before the next step: their fetches are in flight together)
         {
             int rows[PK_NI];
 #pragma unroll
             for (int i = 0; i < PK_NI; i++)
-                rows[i] = (it == 0 && tiled && !PK_EXP_NOFILL) ? pk_walk_fill<RR>(cache[i], V, A.px_pitch, tiled, A.vw.W) : pk_walk_pass<RR>(cache[i], V, A.px_pitch, table, A.vw.W);
+                rows[i] = (it == 0 && tiled && !PK_EXP_NOFILL) ? pk_walk_fill<RR, RL>(cache[i], V, tid + i * PK_THREADS, A.px_pitch, tiled, table, A.vw.W)
+                                                                : pk_walk_pass<RR, RL>(cache[i], V, tid + i * PK_THREADS, A.px_pitch, table, A.vw.W);
             PK_STAMP(8); PK_WSTAMP(5);
+            if (RL > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the records requested into LDS have landed: the compiler does not count those)
 #pragma unroll
             for (int i = 0; i < PK_NI; i++) {
                 pk_acc a;
-                pk_walk_sum<RR>(cache[i], rows[i], V, A.px_pitch, table, A.vw.W, a);
-                if (rows[i] > RR) V.flags[8] = 1;   // (the lines want cutting again)
+                pk_walk_sum<RR, RL>(cache[i], rows[i], V, tid + i * PK_THREADS, A.px_pitch, table, A.vw.W, a);
+                if (rows[i] > RT) V.flags[8] = 1;   // (the lines want cutting again)
                 fold(cache[i].l, a);
             }
-            PK_STAMP(9);
+            PK_STAMP(9); PK_WSTAMP(15);
+            // (how many of the wave's lanes have more rows than records | lane-items without a slot beyond those in LDS << 16 | those in LDS << 32)
+            PK_WNOTE(9, (unsigned long long)__popcll(__ballot(rows[0] > RT)) | ((unsigned long long)extra << 16));
         }
-        if (PK_STAGED && parts > 1 && tiled) {
-            if (st_l >= 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the records requested above have landed in LDS)
-                pk_acc a;
-                a.xs = st_sx; a.nodd = 0; a.r = 0; a.g = 0; a.b = 0; a.q = 0;
-                uint64_t lo = 0, hi = 0;
-                const char* mine = V.stage + (size_t)(tid >> 6) * 1024u + (size_t)(tid & 63) * 16u;
-#pragma unroll
-                for (int u = 0; u < PK_STAGE_ROWS; u++)
-                    if (u < st_n) { const pk_rec d = *reinterpret_cast<const pk_rec*>(mine + (size_t)u * (PK_THREADS * 16u)); lo += d.lo; hi += d.hi; }
-                pk_add_unpacked(lo, hi, a);
-                if (st_rest > 0) {   // (rare: the rows beyond the parts, walked the slow way)
-                    const int kk = tid / PK_UNCACHED_PARTS;
-                    const int j = back ? extra - 1 - kk : kk;
-                    pk_acc b;
-                    pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, 0, w.li_cap, j, b, PK_UNCACHED_PARTS, PK_UNCACHED_PARTS + 1);
-                    a.xs += b.xs; a.nodd += b.nodd; a.r += b.r; a.g += b.g; a.b += b.b; a.q += b.q;
-                }
-                fold(st_l, a);
-            }
-        } else {
-            for (int k = tid; k < extra * parts; k += PK_THREADS) {
-                const int kk = parts > 1 ? k / PK_UNCACHED_PARTS : k, part = parts > 1 ? k % PK_UNCACHED_PARTS : 0;
-                const int j = back ? extra - 1 - kk : kk;
-                pk_acc a;
-                const int l = pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, 0, w.li_cap, j, a, part, parts);
-                fold(l, a);
-            }
+        for (int k = tid; k < extra * parts; k += PK_THREADS) {
+            const int kk = parts > 1 ? k / PK_UNCACHED_PARTS : k, part = parts > 1 ? k % PK_UNCACHED_PARTS : 0;
+            const int j = back ? extra - 1 - kk : kk;
+            pk_acc a;
+            const int l = pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, 0, w.li_cap, j, a, part, parts);
+            fold(l, a);
         }
         PK_WSTAMP(6);
         __syncthreads();
@@ -686,6 +633,7 @@ int tp_persist_set_lds(int bytes) {
     if (!rc) rc = set_lds_rr<PK_RR1>(bytes);
     if (!rc) rc = set_lds_rr<PK_RR2>(bytes);
     if (!rc) rc = set_lds_rr<PK_ROWS_PER_LANE>(bytes);
+    if (!rc) rc = set_lds_rr<PK_ROWS_MAX>(bytes);
     return rc;
 }
 // rows: the most rows per lane of any patch of the plan (pk_plan::rows_max); the census passes PK_ROWS_PER_LANE
@@ -695,7 +643,8 @@ void tp_launch_persist(const pk_args& A, int grid, int rows, int lds_bytes, hipS
         case PK_RR0: launch_rr<PK_RR0>(A, g, b, (size_t)lds_bytes, s); break;
         case PK_RR1: launch_rr<PK_RR1>(A, g, b, (size_t)lds_bytes, s); break;
         case PK_RR2: launch_rr<PK_RR2>(A, g, b, (size_t)lds_bytes, s); break;
-        default: launch_rr<PK_ROWS_PER_LANE>(A, g, b, (size_t)lds_bytes, s); break;
+        case PK_ROWS_PER_LANE: launch_rr<PK_ROWS_PER_LANE>(A, g, b, (size_t)lds_bytes, s); break;
+        default: launch_rr<PK_ROWS_MAX>(A, g, b, (size_t)lds_bytes, s); break;   // (rows beyond the registers in LDS: the plan has made the room)
     }
 }
 

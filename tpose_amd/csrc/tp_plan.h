@@ -54,8 +54,12 @@
 #define PK_RR0 (PK_ROWS_PER_LANE * 2 / 3)
 #define PK_RR1 (PK_ROWS_PER_LANE * 5 / 6)
 #define PK_RR2 (PK_ROWS_PER_LANE * 11 / 12)
-#define PK_STAGE_ROWS 4        /* table records a lane may have on their way into LDS while it walks its cached rows */
-#define PK_STAGE_BYTES (PK_STAGE_ROWS * PK_THREADS * 16)
+/* Rows per lane beyond the registers (round 5): a plan whose patches need more than PK_ROWS_PER_LANE rows per lane -- an aged mesh: its lines have
+   grown -- takes up to PK_LDS_ROWS more, and every thread keeps the records of those rows of its lane-item in LDS (tp_persist.h, pk_walk_lds_rows):
+   a row more in the same walk costs a seventh of what a lane-item more does */
+#define PK_LDS_ROWS 4
+#define PK_ROWS_MAX (PK_ROWS_PER_LANE + PK_LDS_ROWS)
+#define PK_LDS_ROW_BYTES (PK_THREADS * PK_NI * (16 + 2))   /* per row: a record and its crossing column for every thread */
 #define PK_MAX_SLOTS 1023    /* position slots of a workgroup (10-bit fields of the corner records) */
 #define PK_MAX_TL 4095       /* chunks per line */
 #ifndef PK_SLACK_ROWS
@@ -84,6 +88,7 @@ struct pk_wg {
                                // leaving the vertex | arriving << 1 | opposite << 2 runs against its edge's first -> second endpoint
     int32_t off_base;          // [n_base] {t, own | slot_1 << 10 | slot_2 << 20, line of edge 0 | edge 1 << 16, line of edge 2 | flips of edges 0, 1, 2 << 16}
     int32_t lds_bytes;         // dynamic LDS of this workgroup (pk_lds_bytes)
+    int32_t lds_rows;          // rows per lane whose records live in LDS: 0, or PK_LDS_ROWS when some patch of the plan takes more than PK_ROWS_PER_LANE (the same for every patch)
 };
 
 struct pk_plan {
@@ -108,7 +113,7 @@ struct pk_plan {
 PK_HD int pk_align16(int v) { return (v + 15) & ~15; }
 // the instantiation that runs a plan whose patches take at most `rows` rows per lane: one row more than the plan's where
 // there is one (a line that has grown by a chunk's worth of rows since the plan was cut still fits the records its lanes keep)
-PK_HD int pk_rr_for(int rows) { return rows < PK_RR0 ? PK_RR0 : rows < PK_RR1 ? PK_RR1 : rows < PK_RR2 ? PK_RR2 : PK_ROWS_PER_LANE; }
+PK_HD int pk_rr_for(int rows) { return rows < PK_RR0 ? PK_RR0 : rows < PK_RR1 ? PK_RR1 : rows < PK_RR2 ? PK_RR2 : rows <= PK_ROWS_PER_LANE ? PK_ROWS_PER_LANE : PK_ROWS_MAX; }
 // chunks of a line of `rows` pixel rows when a lane takes `rpl` of them
 PK_HD int pk_chunks(int rows, int rpl) {
     const int t = (rows + PK_SLACK_ROWS + rpl - 1) / rpl;
@@ -127,12 +132,12 @@ inline int pk_lds_bytes(const pk_wg& w) {
     b += pk_align16((w.n_lines_all + 1) * 4);       // first lane-item WITHOUT a thread of its own of every line (and the total)
     b += 2 * pk_align16(w.n_lines_all * 4);         // chunks of every line; how many of them have a thread (slot) of their own
     b += 2 * pk_align16(PK_CACHED * 4);             // while the lines are cut again: the lane-item handed to a slot; the free slots
-    b += PK_STAGE_BYTES;                            // records of uncached lane-items on their way (global_load ... lds), tp_persist.hip
     b += pk_align16(w.li_cap * 12);                 // lane-items without a thread of their own
     b += pk_align16(w.n_corners * 16);              // corners
     b += pk_align16(w.n_base * 16);                 // base variants
     b += pk_align16(w.n_lines_all * 4);             // which way every line runs down the raster (this grad-iter's)
-    return b + 64;                                  // flags
+    b += 64;                                        // flags
+    return b + w.lds_rows * PK_LDS_ROW_BYTES;       // records and crossing columns of the rows beyond the registers
 }
 
 namespace pk_detail {
@@ -174,7 +179,7 @@ inline void rcb(std::vector<rcb_vertex>& a, int lo, int hi, int p0, int p1, std:
 // base_every: the base lines of every triangle are walked in every grad-iter (not only in the last one of a call).
 inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* points, int NE, const int32_t* edge_uv,
                           const int32_t* he_edge, int W, int H, float ratio, float dp_px, int max_parts, int lds_limit,
-                          pk_plan& P, bool base_every = false) {
+                          pk_plan& P, bool base_every = false, int rows_cap = PK_ROWS_MAX) {
     P = pk_plan();
     if (NT < 1 || NE < 1 || max_parts < 1) { P.why = "empty triangulation"; return; }
     auto EU = [&](int e) { return edge_uv[2 * (size_t)e] & 0x3fffffff; };
@@ -312,11 +317,15 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
         };
         auto active = [&](int le, int q) { return (emask[le] & (q == 0 ? 1 : q <= 4 ? 2 : 4)) != 0; };
         int rpl = 4;
-        for (; rpl < PK_ROWS_PER_LANE; rpl++) {
+        for (; rpl < rows_cap; rpl++) {
             long n = 0;
             for (int le = 0; le < w.n_edges; le++)
                 for (int q = 0; q < PK_NLINES; q++) if (active(le, q)) n += chunks(le, q, rpl);
             if (n <= PK_CACHED - PK_CACHED / 64) break;   // (a little room: lines grow and shrink while the descent runs)
+            // (rows beyond the registers cost every patch of the plan 0.35 us per grad-iter, lane-items without a slot cost the patch that
+            // has them twice that: the step from PK_ROWS_PER_LANE up is taken when the chunks do not fit at all)
+            // (... and this count runs a row or two per line ahead of the workgroup's own: 3 % more chunks than slots still fit there)
+            if (rpl == PK_ROWS_PER_LANE && n <= PK_CACHED + PK_CACHED / 32) break;
         }
         w.rows = rpl;
         int n_li = 0;
@@ -389,5 +398,14 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
         P.work_max = std::max(P.work_max, work); P.work_mean += work / parts;
     }
     if (P.lds_bytes > lds_limit) { P.why = "a patch does not fit the LDS"; return; }
+    if (P.rows_max > PK_ROWS_PER_LANE) {   // rows beyond the registers: in LDS, if the tables leave the room -- or the plan again without them
+        if (P.lds_bytes + PK_LDS_ROWS * PK_LDS_ROW_BYTES > lds_limit) {
+            P = pk_plan();
+            pk_build_plan(NP, NT, tris, points, NE, edge_uv, he_edge, W, H, ratio, dp_px, max_parts, lds_limit, P, base_every, PK_ROWS_PER_LANE);
+            return;
+        }
+        P.lds_bytes = 0;
+        for (auto& w : P.wg) { w.lds_rows = PK_LDS_ROWS; w.lds_bytes = pk_lds_bytes(w); P.lds_bytes = std::max(P.lds_bytes, w.lds_bytes); }
+    }
     P.ok = true;
 }
