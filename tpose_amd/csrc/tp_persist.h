@@ -522,6 +522,13 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
     const int n = t.n;
 #pragma unroll
     for (int u = 0; u < RR; u++) {
+#if defined(PK_PRIO) && defined(__HIP_DEVICE_COMPILE__)
+        // a wave that is behind its SIMD's other waves is issued first: the hardware's oldest-first order lets the youngest of three finish alone
+        if (u == 0) __builtin_amdgcn_s_setprio(3);
+        else if (u == PK_PRIO) __builtin_amdgcn_s_setprio(2);
+        else if (u == 2 * PK_PRIO) __builtin_amdgcn_s_setprio(1);
+        else if (u == 3 * PK_PRIO) __builtin_amdgcn_s_setprio(0);
+#endif
         const uint32_t on = 0u - ((live >> u) & 1u);
         const int32_t col = pk_next_col(t, W) & (int32_t)on;
         if (col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
