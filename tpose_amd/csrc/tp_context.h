@@ -99,6 +99,8 @@ struct tp_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int32_t* eval_host = nullptr; size_t eval_cap = 0;   // tp_evaluate_triangles: {vertices, variants | energies, counts}, pinned (words)
     bool on_device = false;         // counted among its device's contexts (join_device / leave_device)
+    hipEvent_t ev_tail = nullptr;   // a marker behind a single frame (tp_iterate), polled by the frame's read-back
+    uint64_t tail_mark = ~0ull;     // the value of `mutations` when ev_tail was recorded as the LAST thing on the stream (a single frame)
     hipEvent_t ev_turn = nullptr;   // behind this context's last persistent launch, when other contexts share the device (tp_persist_host.hip: device turns)
     uint8_t* pinned = nullptr;   // host-pinned staging for readbacks (one synchronisation per batch)
     size_t pinned_bytes = 0;

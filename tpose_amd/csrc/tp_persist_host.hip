@@ -354,11 +354,13 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         c->epos_stale = true; c->tail_is_finish = true;
         c->journal.push_back({p, rings ? 0 : k, self ? c->points : nullptr});   // (a chunk of tp_iterate_until is checked by its caller: nothing to replay)
         if (self) std::swap(c->points, c->points_out);
-        if (shared_device) {
-            if (!c->ev_turn) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_turn, hipEventDisableTiming));
-            HIP_TRY(c, hipEventRecord(c->ev_turn, c->stream));
-            T->last = c->ev_turn; T->owner = c;
-        }
+        // A marker behind every launch (round 5): the runtime raises a completion signal for the LAST command of a stream only when somebody
+        // asks -- a caller's hipStreamSynchronize / hipDeviceSynchronize behind a bare kernel submits a barrier packet of its own and waits
+        // for the round trip (13.6 us behind a 20-step launch; 6.4 with the marker already queued: tools/host_call_cost.py).  0.6 us of
+        // host time per launch.  It is also what another context's launch waits for when the device is shared (device turns, above).
+        if (!c->ev_turn) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_turn, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->ev_turn, c->stream));
+        if (shared_device) { T->last = c->ev_turn; T->owner = c; }
         if (turn.owns_lock()) turn.unlock();
         HIP_TRY(c, hipGetLastError());
         c->epoch += (uint32_t)k;

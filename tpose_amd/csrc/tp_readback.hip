@@ -75,7 +75,8 @@ int tp_retrieve_many(tp_context* c, int n, const int* what, void* const* dst, co
         return true;
     };
     if (mirrored()) {
-        HIP_TRY(c, wait_stream(c->stream));
+        if (c->ev_tail && c->tail_mark == c->mutations) HIP_TRY(c, wait_event(c->ev_tail));   // (the marker behind the frame: tp_iterate)
+        else HIP_TRY(c, wait_stream(c->stream));
         if (int rc = check_persist_status(c)) return rc;
         if (mirrored()) {   // (still: nothing had to be run again)
             const int32_t* ten = (const int32_t*)c->frame_mirror;
