@@ -498,13 +498,11 @@ TP_HD void pk_walk_lds_rows(const pk_view& V, int s, pk_rows& t, uint32_t live, 
     *word = pc;
 }
 template <int RR, int RL, int R>
-TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, const char* table, int W, const char* tiled = nullptr) {
+TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, const char* table, int W) {
     static_assert(RR <= R && RR + RL <= 32, "one bit per row");
     pk_rows t;
-    int first = 0;
     if (C.TL == 0) { t.n = 0; t.x = 0; t.xs = 0; t.row = 0; t.rs = 0; }
-    else t = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch, &first);
-    (void)first;
+    else t = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
     const uint32_t live = t.n >= 32 ? 0xffffffffu : ((1u << t.n) - 1u);   // bit u: row u exists
     const bool moved = t.row != C.row0;   // another first row: every record is another row's (an endpoint crossed a pixel row)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -522,13 +520,6 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
     const int n = t.n;
 #pragma unroll
     for (int u = 0; u < RR; u++) {
-#if defined(PK_PRIO) && defined(__HIP_DEVICE_COMPILE__)
-        // a wave that is behind its SIMD's other waves is issued first: the hardware's oldest-first order lets the youngest of three finish alone
-        if (u == 0) __builtin_amdgcn_s_setprio(3);
-        else if (u == PK_PRIO) __builtin_amdgcn_s_setprio(2);
-        else if (u == 2 * PK_PRIO) __builtin_amdgcn_s_setprio(1);
-        else if (u == 3 * PK_PRIO) __builtin_amdgcn_s_setprio(0);
-#endif
         const uint32_t on = 0u - ((live >> u) & 1u);
         const int32_t col = pk_next_col(t, W) & (int32_t)on;
         if (col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
@@ -541,11 +532,7 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
                 g_pk_fault[13] = (unsigned long long)blockIdx.x | ((unsigned long long)threadIdx.x << 32);
             }
 #endif
-#ifdef PK_TILED_STALE   /* experiment: stale records from the tiled copy of the table */
-            C.rec[u] = pk_load_rec(tiled, (tp_px_tiled_row_part((uint32_t)first + (uint32_t)u * (uint32_t)C.TL, (uint32_t)pitch) & on) + tp_px_tiled_col_part((uint32_t)col));
-#else
             C.rec[u] = pk_load_rec(table, ((t.row + (uint32_t)u * t.rs) & on) + ((uint32_t)col << 4));
-#endif
 #endif
             C.col[u] = col;
         }

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
 #pragma unroll
             for (int i = 0; i < PK_NI; i++)
                 rows[i] = (it == 0 && tiled && !PK_EXP_NOFILL) ? pk_walk_fill<RR, RL>(cache[i], V, tid + i * PK_THREADS, A.px_pitch, tiled, table, A.vw.W)
-                                                                : pk_walk_pass<RR, RL>(cache[i], V, tid + i * PK_THREADS, A.px_pitch, table, A.vw.W, tiled);
+                                                                : pk_walk_pass<RR, RL>(cache[i], V, tid + i * PK_THREADS, A.px_pitch, table, A.vw.W);
             PK_STAMP(8); PK_WSTAMP(5);
             if (RL > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the records requested into LDS have landed: the compiler does not count those)
 #pragma unroll
