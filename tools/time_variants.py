@@ -16,7 +16,7 @@ out = []
 for steps in (256, 2048, 2048, 2048):
     t0 = time.perf_counter(); ctx.iterate(p, steps); ctx.synchronize()
     out.append("%%d: %%.2f" %% (steps, (time.perf_counter() - t0) / steps * 1e6))
-print(" | ".join(out), "| replans", ctx.info(capi.INFO_REPLANS))
+print(" | ".join(out), "| replans", ctx.info(capi.INFO_REPLANS), "given up", ctx.info(capi.INFO_PERSIST_FAILURES), "rows per lane", ctx.info(13))
 """ % ROOT
 for v in sys.argv[1:]:
     env = dict(os.environ)
