@@ -84,12 +84,12 @@ def test_iterate_until_at_the_metric_size(flavour):
     ctx.close()
 
 
-@pytest.mark.parametrize("flavour", [0, 1])
-def test_persistent_is_the_oracle_at_the_batch_size(flavour):
+@pytest.mark.parametrize("flavour,contrast", [(0, 0.1), (1, 0.1), (0, 1.0)])
+def test_persistent_is_the_oracle_at_the_batch_size(flavour, contrast):
     """4096^2 / 12 000 (BASELINE config 4's element): ~3400 lane-items per workgroup, more than its threads keep records
-    for -- the overflow path of the walk"""
+    for -- the overflow path of the walk; on bench.py's raster and on SURVEY 8(d)'s raster as written"""
     iters = 4
-    ctx, sweep, pts, tris, ratio, colors = _setup(4096, 4096, 12000, flavour, 0.1)
+    ctx, sweep, pts, tris, ratio, colors = _setup(4096, 4096, 12000, flavour, contrast)
     p = capi.default_params(flavour)
     ctx.iterate(p, iters)
     ctx.synchronize()
