@@ -482,7 +482,7 @@ TP_HD void pk_lds_fetch(const char* src, char* wave_run, int lane) {
 }
 template <int RR, int RL>
 TP_HD void pk_walk_lds_rows(const pk_view& V, int s, pk_rows& t, uint32_t live, bool moved, const char* table, int W) {
-    static_assert(RL == 0 || RL == 4, "a slot's crossing columns in LDS are one 64-bit word");
+    static_assert(RL == 0 || RL == 2 || RL == 4, "a slot's crossing columns in LDS are one 64-bit word");
     if (RL == 0) return;
     uint64_t* const word = reinterpret_cast<uint64_t*>(V.lcol) + s;
     uint64_t pc = *word;

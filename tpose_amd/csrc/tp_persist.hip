@@ -633,6 +633,7 @@ int tp_persist_set_lds(int bytes) {
     if (!rc) rc = set_lds_rr<PK_RR1>(bytes);
     if (!rc) rc = set_lds_rr<PK_RR2>(bytes);
     if (!rc) rc = set_lds_rr<PK_ROWS_PER_LANE>(bytes);
+    if (!rc) rc = set_lds_rr<PK_ROWS_MID>(bytes);
     if (!rc) rc = set_lds_rr<PK_ROWS_MAX>(bytes);
     return rc;
 }
@@ -644,6 +645,7 @@ void tp_launch_persist(const pk_args& A, int grid, int rows, int lds_bytes, hipS
         case PK_RR1: launch_rr<PK_RR1>(A, g, b, (size_t)lds_bytes, s); break;
         case PK_RR2: launch_rr<PK_RR2>(A, g, b, (size_t)lds_bytes, s); break;
         case PK_ROWS_PER_LANE: launch_rr<PK_ROWS_PER_LANE>(A, g, b, (size_t)lds_bytes, s); break;
+        case PK_ROWS_MID: launch_rr<PK_ROWS_MID>(A, g, b, (size_t)lds_bytes, s); break;
         default: launch_rr<PK_ROWS_MAX>(A, g, b, (size_t)lds_bytes, s); break;   // (rows beyond the registers in LDS: the plan has made the room)
     }
 }

@@ -59,6 +59,7 @@
    a row more in the same walk costs a seventh of what a lane-item more does */
 #define PK_LDS_ROWS 4
 #define PK_ROWS_MAX (PK_ROWS_PER_LANE + PK_LDS_ROWS)
+#define PK_ROWS_MID (PK_ROWS_PER_LANE + PK_LDS_ROWS / 2)   /* an instantiation between: the first plans beyond the registers need a row or two */
 #define PK_LDS_ROW_BYTES (PK_THREADS * PK_NI * (16 + 2))   /* per row: a record and its crossing column for every thread */
 #define PK_MAX_SLOTS 1023    /* position slots of a workgroup (10-bit fields of the corner records) */
 #define PK_MAX_TL 4095       /* chunks per line */
@@ -113,7 +114,7 @@ struct pk_plan {
 PK_HD int pk_align16(int v) { return (v + 15) & ~15; }
 // the instantiation that runs a plan whose patches take at most `rows` rows per lane: one row more than the plan's where
 // there is one (a line that has grown by a chunk's worth of rows since the plan was cut still fits the records its lanes keep)
-PK_HD int pk_rr_for(int rows) { return rows < PK_RR0 ? PK_RR0 : rows < PK_RR1 ? PK_RR1 : rows < PK_RR2 ? PK_RR2 : rows <= PK_ROWS_PER_LANE ? PK_ROWS_PER_LANE : PK_ROWS_MAX; }
+PK_HD int pk_rr_for(int rows) { return rows < PK_RR0 ? PK_RR0 : rows < PK_RR1 ? PK_RR1 : rows < PK_RR2 ? PK_RR2 : rows <= PK_ROWS_PER_LANE ? PK_ROWS_PER_LANE : rows <= PK_ROWS_MID ? PK_ROWS_MID : PK_ROWS_MAX; }
 // chunks of a line of `rows` pixel rows when a lane takes `rpl` of them
 PK_HD int pk_chunks(int rows, int rpl) {
     const int t = (rows + PK_SLACK_ROWS + rpl - 1) / rpl;
