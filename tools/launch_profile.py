@@ -29,3 +29,9 @@ for it in range(24):
     ph = [np.median(st[:, it, k + 1] - st[:, it, k]) / 100.0 for k in range(4)]
     print("%2d  %7.1f  %6.2f  %5.2f %5.2f %5.2f %5.2f" % (it, s, per, ph[0], ph[1], ph[2], ph[3]))
 print("grad-iters 0..19 end %.1f us after the first stamp (steady state would be %.1f)" % (np.median(st[:, 20, 0] - t0) / 100.0, 20 * np.median(st[:, 30:39, 0][:, 1:] - st[:, 30:39, 0][:, :-1]) / 100.0))
+
+# the cuts of the lines inside the stamped window: set-up (stamp 1 -> 6), pass A on one wave (6 -> 7), passes B-D (7 -> 2)
+for it in range(1, 40):
+    if (st[:, it, 7] > 0).all() and np.median(st[:, it, 2] - st[:, it, 1]) > 250:
+        print("cut in grad-iter %d: set-up %.2f us, pass A (what every line wants, one wave) %.2f, passes B-D (release, allocate, take + list) %.2f"
+              % (it, np.median(st[:, it, 6] - st[:, it, 1]) / 100.0, np.median(st[:, it, 7] - st[:, it, 6]) / 100.0, np.median(st[:, it, 2] - st[:, it, 7]) / 100.0))
