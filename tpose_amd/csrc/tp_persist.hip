@@ -417,7 +417,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         const bool back = (it & 1) != 0;
         const int extra = n_unc;
         const int parts = extra * PK_UNCACHED_PARTS <= PK_THREADS ? PK_UNCACHED_PARTS : 1;
-        // (each step for both lane-items of the thread before the next step: their fetches are in flight together)
+        // (each step for every lane-item of the thread -- PK_NI: one, since round 5 -- before the next step: the fetches are in flight together)
         {
             int rows[PK_NI];
 #pragma unroll
