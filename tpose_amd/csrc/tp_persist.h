@@ -521,6 +521,15 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
     const int n = t.n;
 #pragma unroll
     for (int u = 0; u < RR; u++) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PK_NO_PRIO)
+        // A wave that is behind its SIMD's other waves is issued first (round 5).  The hardware's order is oldest first: of the three waves
+        // of a SIMD the youngest got what the others left and finished its pass 0.4 us behind them, alone on the SIMD, at the latency of
+        // its own chain instead of the SIMD's issue rate (per-wave stamps).  The priority falls as a wave gets on with its rows, so the
+        // three stay together: 4.37-4.40 -> 4.26-4.32 us per grad-iter, A/B on one box, four alternations.
+        if (u == 0) __builtin_amdgcn_s_setprio(3);
+        else if (u == RR / 3) __builtin_amdgcn_s_setprio(2);
+        else if (u == 2 * (RR / 3)) __builtin_amdgcn_s_setprio(1);
+#endif
         const uint32_t on = 0u - ((live >> u) & 1u);
         const int32_t col = pk_next_col(t, W) & (int32_t)on;
         if (col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
@@ -539,6 +548,9 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
         }
     }
     pk_walk_lds_rows<RR, RL>(V, s, t, live, moved, table, W);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PK_NO_PRIO)
+    __builtin_amdgcn_s_setprio(0);
+#endif
     return n;
 }
 // step 1 in the FIRST grad-iter of a launch: nothing is cached yet, every row of every lane is fetched -- from the TILED copy of the table
