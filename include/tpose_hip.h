@@ -242,7 +242,9 @@ int tp_render(tp_context* ctx, int source, const float* points, uint8_t* dst_rgb
  * from tp_band_mailbox_alloc (fine-grained memory), 11 = persistent launches that started from what the launch before them left (the cut of the
  * patches' lines and the lanes' lane-items: same plan, image and dp -- a launch after tp_upload, tp_set_image or tp_set_dp never does),
  * 12 = milliseconds until persistent launches are tried again after one gave up (0: in use), 13 = rows a lane of the walk takes in the current
- * plan's largest patch (above 16: the records of the rows beyond 16 live in LDS) */
+ * plan's largest patch (above 16: the records of the rows beyond 16 live in LDS), 14 = plans cut again because the patches had gone out of balance
+ * under the speeds of their vertices (round 6: the kernel measures how far every vertex moves per grad-iter, the planner weighs its rows by it),
+ * 15 = heaviest patch / mean patch of the current plan under the weights it was cut with, x 1000 */
 int tp_get_info(tp_context* ctx, int what, int64_t* value);
 
 /* device self-test of the exact span walker (tp_raster.h): for each (N0, step, d), the 32 values

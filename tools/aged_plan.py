@@ -10,7 +10,10 @@ from tpose_amd import capi, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 contrast = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
 W = H = 2048
-img, pts, tris, he, ratio = synth.workload(W, H, 3000, contrast=contrast)
+os.environ.setdefault("TPOSE_CONTRAST", str(contrast))
+from tpose_amd import photos
+img, pts, tris, he, ratio, raster_label = photos.raster_from_env(W, H, 3000)
+print(raster_label)
 so = '/tmp/libtp_emul_persist_aged.so'
 subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, "tests/emul/emul_persist.cpp"])
 emp = C.CDLL(so)

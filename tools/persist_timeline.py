@@ -25,7 +25,8 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 W = H = int(args[0]) if args else 2048
 NT = int(args[1]) if len(args) > 1 else 3000
 contrast = float(os.environ.get("TPOSE_CONTRAST", "0.1"))
-img, pts, tris, he, ratio = synth.workload(W, H, NT, contrast=contrast)
+from tpose_amd import photos  # noqa: E402
+img, pts, tris, he, ratio, raster_label = photos.raster_from_env(W, H, NT)
 ctx = capi.Context(0, W, H)
 ctx.set_image(capi.IMAGE_A, img)
 ctx.upload(pts, tris, None)
@@ -45,7 +46,7 @@ buf = np.zeros(512 * IT * 16, np.uint64)
 assert lib.tp_debug_dump_persist(ctx.h, buf.ctypes.data, buf.size) == 0
 st = buf.reshape(512, IT, 16)[:parts].astype(np.int64)  # [workgroup, grad-iter, stamp]
 labels = ["P0 positions in (wait)", "P1 set-up + snap", "P3 walk", "P6 corners", "P7 step + post"]
-out = {"workload": "%dx%d / %d triangles, contrast %g, grad-iters %d.." % (W, H, tris.shape[0], contrast, first + 8), "patches": parts,
+out = {"workload": "%dx%d / %d triangles, %s, grad-iters %d.." % (W, H, tris.shape[0], raster_label, first + 8), "patches": parts,
        "units": "us; percentiles over workgroups x grad-iters 8..63 of one launch"}
 sel = st[:, 8:IT]
 for k, lab in enumerate(labels):

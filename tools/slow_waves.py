@@ -5,7 +5,8 @@ os.environ["TPOSE_HIP_LIB"] = os.path.join(os.getcwd(), "tpose_amd", "variants",
 import numpy as np
 from tpose_amd import capi, synth
 contrast=float(os.environ.get("TPOSE_CONTRAST","0.3"))
-img, pts, tris, he, ratio = synth.workload(2048, 2048, 3000, contrast=contrast)
+from tpose_amd import photos
+img, pts, tris, he, ratio, raster_label = photos.raster_from_env(2048, 2048, 3000, 0.3)
 ctx = capi.Context(0, 2048, 2048); ctx.set_image(capi.IMAGE_A, img); ctx.upload(pts, tris, None)
 p = capi.default_params(0)
 age = int(os.environ.get("TPOSE_AGE", "1024"))

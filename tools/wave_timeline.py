@@ -26,7 +26,8 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 W = H = int(args[0]) if args else 2048
 NT = int(args[1]) if len(args) > 1 else 3000
 WAVES = int(os.environ.get("TPOSE_WAVES", "8"))
-img, pts, tris, he, ratio = synth.workload(W, H, NT, contrast=float(os.environ.get("TPOSE_CONTRAST", "0.1")))
+from tpose_amd import photos  # noqa: E402
+img, pts, tris, he, ratio, raster_label = photos.raster_from_env(W, H, NT)
 ctx = capi.Context(0, W, H)
 ctx.set_image(capi.IMAGE_A, img)
 ctx.upload(pts, tris, None)
@@ -43,7 +44,7 @@ buf = np.zeros(base + 512 * WIT * 16 * 16, np.uint64)
 assert lib.tp_debug_dump_persist(ctx.h, buf.ctypes.data, buf.size) == 0
 st = buf[base: base + parts * WIT * WAVES * 16].reshape(parts, WIT, WAVES, 16).astype(np.int64)
 names = os.environ.get("TPOSE_STAMPS", "top,P0 polled,P0 barrier,P1 done,P1 barrier,P3 pass,P3 folded,P3 barrier,P6 done,P6 barrier,P7 end").split(",")
-out = {"workload": "%dx%d / %d triangles" % (W, H, tris.shape[0]), "patches": parts, "waves": WAVES,
+out = {"workload": "%dx%d / %d triangles, %s" % (W, H, tris.shape[0], raster_label), "patches": parts, "waves": WAVES,
        "units": "us, median over workgroups x grad-iters 8..31; per wave", "intervals": {}}
 sel = st[:, 8:WIT]
 for k in range(len(names) - 1):

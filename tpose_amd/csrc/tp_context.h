@@ -141,6 +141,15 @@ struct tp_context {
     int64_t warm_launches = 0;       // (tp_get_info 11: persistent launches enqueued with a carry of the same tag behind them)
     bool carry_written = false;      // a launch with the current tag has been enqueued: the next one finds its carry
     std::vector<float> plan_points;           // positions the current plan was cut from
+    // How far every vertex moves per grad-iter (round 6): the kernel itself averages |step| per vertex and axis over every launch (pk_args::vspeed)
+    // and the snapshot carries it to the host beside the positions.  The planner weighs a vertex's rows by it (tp_plan.h: pk_vertex_work) -- a row
+    // whose crossing column changes every grad-iter costs five times one that stands -- and a plan is cut again when the patches have gone out of
+    // balance under the speeds of the day, not only when vertices have drifted.
+    float* vspeed = nullptr; size_t cap_vspeed = 0;     // device, [NP][2], t-pose units per grad-iter
+    float* snap_speed[2] = {nullptr, nullptr};          // pinned, beside snap_host
+    double plan_balance = 1.0;                          // heaviest patch / mean patch of the current plan under the weights it was cut with
+    double plan_heaviest_vertex = 0.0;                  // heaviest VERTEX / mean patch, likewise (a patch owns whole vertices: the floor of plan_balance)
+    int64_t replans_balance = 0;                        // (tp_get_info 14: plans cut again because the patches were out of balance)
     float* snap_host[2] = {nullptr, nullptr};  // pinned: positions after a chunk
     size_t snap_cap = 0;
     hipEvent_t snap_ev[2] = {nullptr, nullptr};
@@ -158,12 +167,13 @@ struct tp_context {
         std::condition_variable cv;
         bool stop = false, go = false, busy = false, done = false, superseded = false;
         pk_plan plan;
-        std::vector<float> points;
+        std::vector<float> points, speed;   // (speed: pixels per grad-iter and vertex, or empty)
         std::vector<int32_t> tris, edge_uv, he_edge;
         int NP = 0, NT = 0, NE = 0, W = 0, H = 0, parts = 0;
         float ratio = 0.0f, dp = 0.0f;
         uint64_t generation = 0;
         bool base_every = false;
+        double balance = 1.0;
     };
     std::unique_ptr<replan_worker> worker;
     bool plan_base_every = false;   // the current plan walks every triangle's base lines in every grad-iter (tp_iterate_until)
@@ -245,6 +255,9 @@ int grow(tp_context* c, T** p, size_t* cap, size_t need) {
 #ifndef PK_REPLAN_PX
 #define PK_REPLAN_PX 2.0f     /* a vertex this far from where the plan saw it: cut a new plan */
 #endif
+#ifndef PK_REPLAN_BALANCE
+#define PK_REPLAN_BALANCE 1.15   /* the heaviest patch this far above the mean under today's speeds (and 8 % worse than when the plan was cut): cut a new plan */
+#endif
 #define PK_RING_FRAMES 256    /* frames of a chunk of tp_iterate_until a band's mailbox has rings for (two halves, used in turn) */
 
 // tp_context.hip
@@ -265,7 +278,7 @@ hipError_t wait_context(tp_context* c);   // wait for the context's stream
 int install_plan(tp_context* c, pk_plan& np, const float* points, int slot);
 void drop_carry(tp_context* c);   // what the last launch left for the next is not to be used (a new plan, image or dp)
 int plan_patches(const tp_context* c);
-int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok);
+int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok, const float* speed_px = nullptr);
 int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false);
 int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings = false);
 // tp_replan.hip

@@ -171,7 +171,7 @@ int tp_destroy(tp_context* c) {
     free_triangulation(c);
     hipFree(c->img[0]); hipFree(c->img[1]); hipFree(c->prefix[0]); hipFree(c->prefix[1]); hipFree(c->px[0]); hipFree(c->px[1]); hipFree(c->pxt[0]); hipFree(c->pxt[1]);
     hipFree(c->render_pic); hipFree(c->render_pts);
-    hipFree(c->d_wg); hipFree(c->d_pool); hipFree(c->posbox); hipFree(c->points_out); hipFree(c->d_status); hipFree(c->carry);
+    hipFree(c->d_wg); hipFree(c->d_pool); hipFree(c->posbox); hipFree(c->points_out); hipFree(c->d_status); hipFree(c->carry); hipFree(c->vspeed);
     if (c->h_status) hipHostFree(c->h_status);
     if (c->frame_mirror) hipHostFree(c->frame_mirror);
     hipFree(c->ering); hipFree(c->pring);
@@ -180,6 +180,7 @@ int tp_destroy(tp_context* c) {
         hipFree(c->plan_dev[k].wg); hipFree(c->plan_dev[k].pool);
         if (c->plan_dev[k].stage) hipHostFree(c->plan_dev[k].stage);
         if (c->snap_host[k]) hipHostFree(c->snap_host[k]);
+        if (c->snap_speed[k]) hipHostFree(c->snap_speed[k]);
         if (c->snap_ev[k]) hipEventDestroy(c->snap_ev[k]);
     }
     if (c->eval_host) hipHostFree(c->eval_host);
@@ -800,6 +801,9 @@ int tp_get_info(tp_context* c, int what, int64_t* value) {
             return TP_OK;
         }
         case 13: *value = (c->plan_generation == c->generation && c->plan.ok) ? c->plan.rows_max : 0; return TP_OK;
+        case 14: *value = c->replans_balance; return TP_OK;   // plans cut again because the patches were out of balance under the vertices' speeds
+        case 15: *value = (int64_t)(c->plan_balance * 1000.0); return TP_OK;
+        case 16: *value = (int64_t)(c->plan_heaviest_vertex * 1000.0); return TP_OK;   // heaviest vertex / mean patch, x 1000 (plans cut on the calling thread)   // heaviest patch / mean patch of the current plan, x 1000
         default: return fail(c, TP_ERR_INVALID, "unknown info %d", what);
     }
 }

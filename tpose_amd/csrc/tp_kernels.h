@@ -110,6 +110,9 @@ struct pk_args {
     // lane, lane-items, lane-items with the base lines, -, -, -}, the cut (first lane-item of every line), every thread's lane-item {line, chunk,
     // chunks}; null: none.  A workgroup whose words carry carry_tag starts from them (tp_persist.hip)
     int32_t* carry; int carry_stride; unsigned carry_tag; int carry_cut_cap;
+    // what the planner weighs a vertex's rows by (tp_plan.h: pk_vertex_work): [NP][2] the mean |step| per grad-iter of every vertex over THIS
+    // launch, per axis, in t-pose units -- written at the launch's end by the vertex's owner; null: not wanted
+    float* vspeed;
 #ifdef TPOSE_DEBUG
     unsigned long long* dbg;      // [parts][PK_DBG_ITERS][16] phase timestamps of the grad-iters dbg_first ...
     int dbg_first;

@@ -37,6 +37,7 @@ struct pk_view {
                                // adds (difference << 32) | 1, and the lane whose returned count completes the vertex (vdeg) holds the whole sum:
                                // it takes that axis' step right there, no workgroup barrier between the corners and the steps
     int32_t* vdeg;             // [n_own_v] corners of the vertex
+    float* spd;                // [n_own_v][2] sum over the launch's grad-iters of |step| of the vertex, per axis (t-pose units): what the planner weighs rows by
     int32_t* vid;              // static tables, copied from the plan's pool at the start of the launch
     int32_t* edges;
     int32_t* lines;
@@ -63,6 +64,7 @@ TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     V.pos = (pk_f2*)p; p += pk_align16(w.n_slots * 8);
     V.gacc = (unsigned long long*)p; p += pk_align16(w.n_own_v * 16);
     V.vdeg = (int32_t*)p; p += pk_align16(w.n_own_v * 4);
+    V.spd = (float*)p; p += pk_align16(w.n_own_v * 8);
     V.vid = (int32_t*)p; p += pk_align16(w.n_slots * 4);
     V.edges = (int32_t*)p; p += pk_align16(w.n_edges * 4);
     V.lines = (int32_t*)p; p += pk_align16(w.n_lines_all * 4);
@@ -435,7 +437,13 @@ struct pk_lane_cache {
 };
 // A slot (a thread's cached lane-item) through a cut of the lines -- passes B and D above.
 // where a slot stands in the free list when everything is cut afresh the OTHER way (PK_CHUNK_MAJOR 0: a line's chunks on lanes 64 / (slots / 64) apart)
-TP_HD int pk_place_of_slot(int s) { return (s & 63) * (PK_CACHED / 64) + (s >> 6); }
+#ifndef PK_PLACE_IDENTITY
+#define PK_PLACE_IDENTITY 0   /* 1 (experiment): a line's chunks on ADJACENT lanes -- consecutive rows of one line in one wave-load */
+#endif
+#ifndef PK_STALE_TILED
+#define PK_STALE_TILED 0      /* 1 (experiment): rows whose crossing column has changed are fetched from the tiled copy of the table */
+#endif
+TP_HD int pk_place_of_slot(int s) { return PK_PLACE_IDENTITY ? s : (s & 63) * (PK_CACHED / 64) + (s >> 6); }
 // (A slot's records and columns are never touched here: a slot that changes hands gets a first row that matches nothing -- row0 = ~0 -- and
 // the walk's own "the line's first row moved" path drops its columns and fetches; a slot without a lane-item has no rows, its columns
 // read 0 and its records the table's all-zero record.  Loops over a slot's 16 rows in three more places cost the kernel 160 registers.)
@@ -499,11 +507,12 @@ TP_HD void pk_walk_lds_rows(const pk_view& V, int s, pk_rows& t, uint32_t live, 
     *word = pc;
 }
 template <int RR, int RL, int R>
-TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, const char* table, int W) {
+TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, const char* table, int W, const char* tiled = nullptr) {
     static_assert(RR <= R && RR + RL <= 32, "one bit per row");
     pk_rows t;
+    int first = 0;
     if (C.TL == 0) { t.n = 0; t.x = 0; t.xs = 0; t.row = 0; t.rs = 0; }
-    else t = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch);
+    else t = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch, PK_STALE_TILED ? &first : nullptr);
     const uint32_t live = t.n >= 32 ? 0xffffffffu : ((1u << t.n) - 1u);   // bit u: row u exists
     const bool moved = t.row != C.row0;   // another first row: every record is another row's (an endpoint crossed a pixel row)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -542,7 +551,10 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
                 g_pk_fault[13] = (unsigned long long)blockIdx.x | ((unsigned long long)threadIdx.x << 32);
             }
 #endif
-            C.rec[u] = pk_load_rec(table, ((t.row + (uint32_t)u * t.rs) & on) + ((uint32_t)col << 4));
+            if (PK_STALE_TILED && tiled)
+                C.rec[u] = pk_load_rec(tiled, tp_px_tiled_row_part(((uint32_t)first + (uint32_t)u * (uint32_t)C.TL) & on, (uint32_t)pitch) + tp_px_tiled_col_part((uint32_t)col));
+            else
+                C.rec[u] = pk_load_rec(table, ((t.row + (uint32_t)u * t.rs) & on) + ((uint32_t)col << 4));
 #endif
             C.col[u] = col;
         }

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             V.pos[i].x = p.x; V.pos[i].y = p.y;
         }
         for (int i = tid; i < PK_SUM_STRIDE * w.n_lines_all; i += PK_THREADS) V.sums[i] = 0ull;
-        for (int k = tid; k < w.n_own_v; k += PK_THREADS) { V.gacc[2 * k] = 0ull; V.gacc[2 * k + 1] = 0ull; V.vdeg[k] = 0; }
+        for (int k = tid; k < w.n_own_v; k += PK_THREADS) { V.gacc[2 * k] = 0ull; V.gacc[2 * k + 1] = 0ull; V.vdeg[k] = 0; V.spd[2 * k] = 0.0f; V.spd[2 * k + 1] = 0.0f; }
         if (tid < 16) V.flags[tid] = 0;   // ([3]: a lane gave up; [8]: the lines want cutting again; [9]: free slots filed while they are)
         for (int i = tid; i < PK_CACHED; i += PK_THREADS) V.st[i] = -1;
     }
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
 #pragma unroll
             for (int i = 0; i < PK_NI; i++)
                 rows[i] = (it == 0 && tiled && !PK_EXP_NOFILL) ? pk_walk_fill<RR, RL>(cache[i], V, tid + i * PK_THREADS, A.px_pitch, tiled, table, A.vw.W)
-                                                                : pk_walk_pass<RR, RL>(cache[i], V, tid + i * PK_THREADS, A.px_pitch, table, A.vw.W);
+                                                                : pk_walk_pass<RR, RL>(cache[i], V, tid + i * PK_THREADS, A.px_pitch, table, A.vw.W, tiled);
             PK_STAMP(8); PK_WSTAMP(5);
             if (RL > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the records requested into LDS have landed: the compiler does not count those)
 #pragma unroll
@@ -526,10 +526,11 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                     const int v = V.vid[own];
                     float* const pc = ax ? &V.pos[own].y : &V.pos[own].x;
                     if (emit) reinterpret_cast<int32_t*>(A.gr + v)[ax] = g;
+                    const float po = *pc;
 #if defined(PK_EXP_FREEZE)  // timing experiments only: the mesh stands still
-                    const float pn = *pc;
+                    const float pn = po;
 #else
-                    const float pn = v < 4 ? *pc : pk_step_axis(*pc, g, ax ? 1.0f : A.vw.ratio, A.rate);   // (vertices 0..3 never move: shift.cs:20)
+                    const float pn = v < 4 ? po : pk_step_axis(po, g, ax ? 1.0f : A.vw.ratio, A.rate);   // (vertices 0..3 never move: shift.cs:20)
 #endif
                     *pc = pn;
                     if (last) reinterpret_cast<float*>(A.points_out + v)[ax] = pn;
@@ -548,6 +549,8 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                             __hip_atomic_store(posbox + at, gw, PK_RLX_AGENT);
                         }
                     }
+                    // (behind the post: how far the vertex went, for the planner -- one lane per vertex and axis and grad-iter, so a plain add)
+                    if (A.vspeed) V.spd[2 * own + ax] += fabsf(pn - po);
                 }
             }
         }
@@ -564,6 +567,12 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         PK_STAMP(4); PK_WSTAMP(8);
         PK_STAMP(5); PK_WSTAMP(10);
         // (no barrier here: P0 of the next grad-iter touches foreign position slots only, and its barrier orders the rest)
+    }
+    // ---- what the planner wants to know: the mean step of every own vertex over this launch
+    if (A.vspeed) {
+        __syncthreads();
+        const float inv = 1.0f / (float)A.n_iters;
+        for (int k = tid; k < 2 * w.n_own_v; k += PK_THREADS) A.vspeed[2 * (size_t)V.vid[k >> 1] + (k & 1)] = V.spd[k] * inv;
     }
     // ---- carry for the next launch on this plan (no fence: it is work on the same stream, ordered behind the end of this kernel)
     if (carry) {

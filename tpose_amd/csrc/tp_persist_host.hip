@@ -196,11 +196,19 @@ void drop_carry(tp_context* c) { c->carry_tag = ++c->carry_seq ? c->carry_seq : 
 int plan_patches(const tp_context* c) { return c->n_bands > 1 ? c->n_bands * c->band_patches : c->num_cus * PK_WG_PER_CU; }
 
 // cut a plan from `points` and install it in plan buffer `slot`.  c->plan is replaced only when the new plan is usable.
-int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok) {
+int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok, const float* speed_px) {
     pk_plan np;
     pk_build_plan(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
                   c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, plan_patches(c), PK_LDS_LIMIT, np,
-                  c->plan_base_every);
+                  c->plan_base_every, PK_ROWS_MAX, speed_px);
+    if (np.ok) {
+        std::vector<float> rows; std::vector<double> wv; std::vector<int> deg;
+        pk_vertex_work(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(), c->H, speed_px, rows, wv, deg);
+        c->plan_balance = pk_imbalance(np.owner_v, wv, np.parts);
+        double total = 0.0, most = 0.0;
+        for (double x : wv) { total += x; most = std::max(most, x); }
+        c->plan_heaviest_vertex = total > 0.0 ? most * (double)np.parts / total : 0.0;
+    }
     // (a band split runs equal shares of the patches: a plan with fewer patches than asked for -- a tiny mesh -- is not split)
     if (np.ok && c->n_bands > 1 && np.parts != c->n_bands * c->band_patches) { np.ok = false; np.why = "fewer patches than the bands need"; }
     *ok = np.ok;
@@ -247,11 +255,16 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every) {
             if (int rc = grow(c, &c->points_out, &c->cap_points_out, np)) return rc;
             if (np > c->snap_cap) {
                 for (int k = 0; k < 2; k++) { if (c->snap_host[k]) hipHostFree(c->snap_host[k]); c->snap_host[k] = nullptr; }
+                for (int k = 0; k < 2; k++) { if (c->snap_speed[k]) hipHostFree(c->snap_speed[k]); c->snap_speed[k] = nullptr; }
                 c->snap_cap = 0;
                 const size_t n = np + np / 2 + 64;
                 for (int k = 0; k < 2; k++) HIP_TRY(c, hipHostMalloc((void**)&c->snap_host[k], n * 2 * sizeof(float), hipHostMallocDefault));
+                for (int k = 0; k < 2; k++) HIP_TRY(c, hipHostMalloc((void**)&c->snap_speed[k], n * 2 * sizeof(float), hipHostMallocDefault));
                 c->snap_cap = n;
             }
+            // (a new triangulation: nothing is known about how its vertices move)
+            if (int rc = grow(c, &c->vspeed, &c->cap_vspeed, 2 * np)) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->vspeed, 0, 2 * np * sizeof(float), c->stream));
             for (int k = 0; k < 2; k++) if (!c->snap_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->snap_ev[k], hipEventDisableTiming));
         }
     }
@@ -322,6 +335,7 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
             c->carry_written = true;
         }
         A.emit = n == k && !rings; A.ten = c->ten; A.cn = c->cn; A.ca_out = c->ca; A.gr = c->gr;
+        A.vspeed = banded ? nullptr : c->vspeed;   // (bands keep the plan they cut together)
         if (rings && !banded_rings(c)) { A.ering = c->ering; A.pring = c->pring; }
         if (rings && banded_rings(c)) {
             // (the half of the rings this chunk writes: the next chunk's frame 0 needs nothing from the other bands, so a band that is
@@ -372,6 +386,7 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
             const int sl = c->snap_next;
             c->tail_is_finish = false;
             HIP_TRY(c, hipMemcpyAsync(c->snap_host[sl], c->points, sizeof(float) * 2 * (size_t)c->NP, hipMemcpyDeviceToHost, c->stream));
+            if (c->vspeed && c->snap_speed[sl]) HIP_TRY(c, hipMemcpyAsync(c->snap_speed[sl], c->vspeed, sizeof(float) * 2 * (size_t)c->NP, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipEventRecord(c->snap_ev[sl], c->stream));
             c->snap_pending[sl] = true;
             c->snap_next = sl ^ 1;

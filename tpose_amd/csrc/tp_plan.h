@@ -66,6 +66,11 @@
 #ifndef PK_SLACK_ROWS
 #define PK_SLACK_ROWS 3      /* rows a line may grow before its chunks are cut again */
 #endif
+#ifndef PK_STALE_COST
+#define PK_STALE_COST 4.0f   /* what a table look-up costs MORE when its row's crossing column has changed since the last grad-iter (the record is fetched
+                                again: a cache line through the CU's texture path; profiles/r06_ta_bench.txt, r06_meninas_timeline_2000.json: a patch whose
+                                rows are all stale walks for 9 us, one whose rows stand for 1.7) -- the planner's weight of a row is 1 + this x P(stale) */
+#endif
 #ifndef PK_RECUT
 #define PK_RECUT 64          /* grad-iters between two looks at the chunks of a patch's lines (a power of two) */
 #endif
@@ -101,7 +106,7 @@ struct pk_plan {
     std::vector<pk_wg> wg;
     std::vector<int32_t> pool;
     std::vector<int32_t> owner_v;           // (kept for tests and statistics)
-    double work_max = 0.0, work_mean = 0.0; // table look-ups per workgroup at upload
+    double work_max = 0.0, work_mean = 0.0; // weighted table look-ups per workgroup when the plan was cut (pk_edge_costs)
     int64_t lines_total = 0, foreign_total = 0;  // lines walked by all patches (9 NE if nothing were walked twice); foreign position slots
 };
 
@@ -127,6 +132,7 @@ inline int pk_lds_bytes(const pk_wg& w) {
     b += pk_align16(w.n_slots * 8);                 // positions
     b += pk_align16(w.n_own_v * 16);                // gradient: per own vertex and axis {corners counted : 32, sum of their central differences : 32}
     b += pk_align16(w.n_own_v * 4);                 // corners of every own vertex
+    b += pk_align16(w.n_own_v * 8);                 // how far every own vertex has moved during the launch, per axis (for the planner)
     b += pk_align16(w.n_slots * 4);                 // vid
     b += pk_align16(w.n_edges * 4);                 // edges
     b += pk_align16(w.n_lines_all * 4);             // lines
@@ -174,32 +180,32 @@ inline void rcb(std::vector<rcb_vertex>& a, int lo, int hi, int p0, int p1, std:
 }
 }  // namespace pk_detail
 
-// Build the plan.  tris: ivec4[NT]; points: vec2[NP] (upload-time positions); edge_uv: int[2 NE] endpoint ids (the low
-// 30 bits; tp_upload keeps flags above); he_edge: int[3 NT] edge * 2 + direction; W, H: raster; dp_px: a hint, the size
-// of the moves in pixels (lines get a few rows longer or shorter).  max_parts: workgroups that can be resident at once.
-// base_every: the base lines of every triangle are walked in every grad-iter (not only in the last one of a call).
-inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* points, int NE, const int32_t* edge_uv,
-                          const int32_t* he_edge, int W, int H, float ratio, float dp_px, int max_parts, int lds_limit,
-                          pk_plan& P, bool base_every = false, int rows_cap = PK_ROWS_MAX) {
-    P = pk_plan();
-    if (NT < 1 || NE < 1 || max_parts < 1) { P.why = "empty triangulation"; return; }
-    auto EU = [&](int e) { return edge_uv[2 * (size_t)e] & 0x3fffffff; };
-    auto EV = [&](int e) { return edge_uv[2 * (size_t)e + 1] & 0x3fffffff; };
-    for (int e = 0; e < NE; e++)
-        if (EU(e) == EV(e)) { P.why = "an edge names one vertex twice"; return; }
-
-    // rows of every edge at upload: table look-ups per line
-    std::vector<float> rows((size_t)NE);
+// What the planner balances.  rows[e]: the table look-ups of ONE line of edge e per grad-iter -- its pixel rows at `points`, each weighted by
+// 1 + PK_STALE_COST x P(its crossing column changes from one grad-iter to the next), where P = min(1, mean over the edge's endpoints of
+// vspeed[v]) and vspeed[v] is how far the vertex moves per grad-iter in PIXELS (|dx| + |dy|, averaged over the last launch by the kernel
+// itself: tp_persist.hip, `vspeed`; null: nothing is known, every row counts 1).  The reference's fixed-step descent (shift.cs:45) makes
+// vertices in high-contrast regions jump a pixel or more per grad-iter for as long as it runs: their rows are fetched again every time and
+// a patch made of such vertices took five times as long as its neighbours, who waited (profiles/r06_meninas_timeline_2000.json).
+// wv[v]: a vertex's work -- per corner the four moves of its two edges (each edge at the vertex is shared by two corners) and the opposite
+// base line (shared with the corner across the edge, if that one is in the same patch), plus the corner itself.  Returns the sum of wv.
+inline double pk_vertex_work(int NP, int NT, const int32_t* tris, const float* points, int NE, const int32_t* edge_uv, const int32_t* he_edge, int H,
+                             const float* vspeed, std::vector<float>& rows, std::vector<double>& wv, std::vector<int>& deg) {
+    rows.assign((size_t)NE, 0.0f);
     for (int e = 0; e < NE; e++) {
-        const float ya = points[2 * (size_t)EU(e) + 1], yb = points[2 * (size_t)EV(e) + 1];
+        const int u = edge_uv[2 * (size_t)e] & 0x3fffffff, v = edge_uv[2 * (size_t)e + 1] & 0x3fffffff;
+        const float ya = points[2 * (size_t)u + 1], yb = points[2 * (size_t)v + 1];
         float r = fabsf(ya - yb) * 0.5f * (float)H;
         if (!(r >= 0.0f)) r = 0.0f;                   // NaN positions: no rows
-        rows[e] = std::min(r, (float)H) + 1.0f;
+        r = std::min(r, (float)H) + 1.0f;
+        if (vspeed) {
+            float st = 0.5f * (vspeed[u] + vspeed[v]);
+            if (!(st >= 0.0f)) st = 0.0f;
+            r *= 1.0f + PK_STALE_COST * std::min(st, 1.0f);
+        }
+        rows[e] = r;
     }
-    // a vertex's work: per corner the four moves of its two edges (each edge at the vertex is shared by two corners) and the
-    // opposite base line (shared with the corner across the edge, if that one is in the same patch), plus the corner itself
-    std::vector<double> wv((size_t)NP, 0.0);
-    std::vector<int> deg((size_t)NP, 0);
+    wv.assign((size_t)NP, 0.0);
+    deg.assign((size_t)NP, 0);
     double total = 0.0;
     for (int t = 0; t < NT; t++)
         for (int s = 0; s < 3; s++) {
@@ -209,6 +215,39 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
                              0.75 * rows[he_edge[3 * (size_t)t + sn] >> 1] + 40.0;
             deg[v]++; wv[v] += w; total += w;
         }
+    return total;
+}
+// how far the heaviest patch of an assignment of vertices to patches lies above the mean, under the weights wv
+inline double pk_imbalance(const std::vector<int32_t>& owner_v, const std::vector<double>& wv, int parts) {
+    if (parts < 1) return 1.0;
+    std::vector<double> load((size_t)parts, 0.0);
+    double total = 0.0;
+    for (size_t v = 0; v < owner_v.size() && v < wv.size(); v++)
+        if (owner_v[v] >= 0 && owner_v[v] < parts) { load[(size_t)owner_v[v]] += wv[v]; total += wv[v]; }
+    double most = 0.0;
+    for (double l : load) most = std::max(most, l);
+    return total > 0.0 ? most * (double)parts / total : 1.0;
+}
+
+// Build the plan.  tris: ivec4[NT]; points: vec2[NP] (upload-time positions); edge_uv: int[2 NE] endpoint ids (the low
+// 30 bits; tp_upload keeps flags above); he_edge: int[3 NT] edge * 2 + direction; W, H: raster; dp_px: a hint, the size
+// of the moves in pixels (lines get a few rows longer or shorter).  max_parts: workgroups that can be resident at once.
+// base_every: the base lines of every triangle are walked in every grad-iter (not only in the last one of a call).
+inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* points, int NE, const int32_t* edge_uv,
+                          const int32_t* he_edge, int W, int H, float ratio, float dp_px, int max_parts, int lds_limit,
+                          pk_plan& P, bool base_every = false, int rows_cap = PK_ROWS_MAX, const float* vspeed = nullptr) {
+    P = pk_plan();
+    if (NT < 1 || NE < 1 || max_parts < 1) { P.why = "empty triangulation"; return; }
+    auto EU = [&](int e) { return edge_uv[2 * (size_t)e] & 0x3fffffff; };
+    auto EV = [&](int e) { return edge_uv[2 * (size_t)e + 1] & 0x3fffffff; };
+    for (int e = 0; e < NE; e++)
+        if (EU(e) == EV(e)) { P.why = "an edge names one vertex twice"; return; }
+
+    // rows of every edge at upload: table look-ups per line -- weighted by how often a row's record has to be fetched again (vspeed)
+    std::vector<float> rows;
+    std::vector<double> wv;
+    std::vector<int> deg;
+    const double total = pk_vertex_work(NP, NT, tris, points, NE, edge_uv, he_edge, H, vspeed, rows, wv, deg);
 
     // workgroups: at least ~4 look-ups per lane each, at most one per used vertex
     int used = 0;
@@ -402,7 +441,7 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
     if (P.rows_max > PK_ROWS_PER_LANE) {   // rows beyond the registers: in LDS, if the tables leave the room -- or the plan again without them
         if (P.lds_bytes + PK_LDS_ROWS * PK_LDS_ROW_BYTES > lds_limit) {
             P = pk_plan();
-            pk_build_plan(NP, NT, tris, points, NE, edge_uv, he_edge, W, H, ratio, dp_px, max_parts, lds_limit, P, base_every, PK_ROWS_PER_LANE);
+            pk_build_plan(NP, NT, tris, points, NE, edge_uv, he_edge, W, H, ratio, dp_px, max_parts, lds_limit, P, base_every, PK_ROWS_PER_LANE, vspeed);
             return;
         }
         P.lds_bytes = 0;
