@@ -24,6 +24,10 @@ img = synth.voronoi_raster(W, H, seed=1234, sites=160)
 CONTRAST = float(os.environ.get("CONFIG2_CONTRAST", "0.1"))
 rgb = img[:, :, :3].astype(np.float32)
 img[:, :, :3] = np.clip(128.0 + (rgb - 128.0) * CONTRAST + 0.5, 0, 255).astype(np.uint8)
+if os.environ.get("CONFIG2_PHOTO"):   # the picture config 2 names: resource/meninas.png (tests/golden/photos)
+    from tpose_amd import photos
+    img = photos.load(os.environ["CONFIG2_PHOTO"])
+    H, W = img.shape[:2]
 ppm = os.path.join(out, "config2.ppm")
 with open(ppm, "wb") as f:
     f.write(b"P6\n%d %d\n255\n" % (W, H))
@@ -33,9 +37,9 @@ levels = "50,100,200,300,400,500,600,700,800,900,1000,1500,2000,2500,3000"
 t0 = time.perf_counter()
 extra = sys.argv[2:]  # e.g. -maxframes 20000
 r = subprocess.run([os.path.join(HOST, "triangulate"), "-i", ppm, "-o", os.path.join(out, "config2.tri"), "-levels", levels,
-                    "-window", "1.5", "-quiet"] + extra, capture_output=True, text=True, timeout=int(sys.argv[1]) if len(sys.argv) > 1 else 900)
+                    "-window", "1.5"] + ([] if os.environ.get("CONFIG2_VERBOSE") else ["-quiet"]) + extra, capture_output=True, text=True, timeout=int(sys.argv[1]) if len(sys.argv) > 1 else 900)
 dt = time.perf_counter() - t0
-print(r.stdout.strip().splitlines()[-1])
+print("\n".join(r.stdout.strip().splitlines()[-(40 if os.environ.get("CONFIG2_VERBOSE") else 1):]))
 for line in r.stderr.strip().splitlines()[-3:]:
     print(line)
 print("wall incl. start-up %.1f s" % dt)

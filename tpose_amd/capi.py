@@ -42,6 +42,7 @@ PERSIST_OFF, PERSIST_AUTO = 0, 1
 INFO_PATCHES, INFO_PATCH_LDS, INFO_PATCH_LINES, INFO_PERSIST_LAUNCHES, INFO_PERSIST_ITERS, INFO_CENSUS, INFO_REPLANS = 2, 3, 4, 5, 6, 7, 8
 INFO_PERSIST_FAILURES, INFO_BOX_FINEGRAINED, INFO_WARM_LAUNCHES = 9, 10, 11
 INFO_RETRY_MS, INFO_PLAN_ROWS = 12, 13
+INFO_REPLANS_BALANCE, INFO_PLAN_BALANCE_X1000, INFO_HEAVIEST_VERTEX_X1000 = 14, 15, 16
 
 
 class Params(C.Structure):

@@ -149,6 +149,7 @@ struct tp_context {
     float* snap_speed[2] = {nullptr, nullptr};          // pinned, beside snap_host
     double plan_balance = 1.0;                          // heaviest patch / mean patch of the current plan under the weights it was cut with
     double plan_heaviest_vertex = 0.0;                  // heaviest VERTEX / mean patch, likewise (a patch owns whole vertices: the floor of plan_balance)
+    uint64_t probed_generation = 0;                     // the triangulation tp_prepare has probed the speeds of
     int64_t replans_balance = 0;                        // (tp_get_info 14: plans cut again because the patches were out of balance)
     float* snap_host[2] = {nullptr, nullptr};  // pinned: positions after a chunk
     size_t snap_cap = 0;
@@ -258,6 +259,9 @@ int grow(tp_context* c, T** p, size_t* cap, size_t need) {
 #ifndef PK_REPLAN_BALANCE
 #define PK_REPLAN_BALANCE 1.15   /* the heaviest patch this far above the mean under today's speeds (and 8 % worse than when the plan was cut): cut a new plan */
 #endif
+#ifndef PK_PROBE_ITERS
+#define PK_PROBE_ITERS 8      /* grad-iters of tp_prepare's probe of the vertices' speeds */
+#endif
 #define PK_RING_FRAMES 256    /* frames of a chunk of tp_iterate_until a band's mailbox has rings for (two halves, used in turn) */
 
 // tp_context.hip
@@ -280,7 +284,8 @@ void drop_carry(tp_context* c);   // what the last launch left for the next is n
 int plan_patches(const tp_context* c);
 int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok, const float* speed_px = nullptr);
 int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false);
-int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings = false);
+int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings = false, bool probe = false);
+int probe_speeds(tp_context* c, const tp_params& p, float dp);   // tp_prepare: a few grad-iters nobody keeps, for the planner
 // tp_replan.hip
 int take_replan(tp_context* c);
 void join_device(tp_context* c);    // a context came to / left a device: persistent launches of the contexts of ONE device take turns

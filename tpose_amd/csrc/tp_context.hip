@@ -627,7 +627,7 @@ int tp_prepare(tp_context* c, const tp_params* p) {
     HIP_TRY(c, hipSetDevice(c->device));
     bool use = false;
     if (int rc = ensure_plan(c, resolve_dp(c, p->flavour, p->dp), &use)) return rc;
-    if (use) return TP_OK;
+    if (use) return probe_speeds(c, *p, resolve_dp(c, p->flavour, p->dp));
     graph_entry* g = nullptr;
     return chunk_graph(c, p, resolve_dp(c, p->flavour, p->dp), &g);
 }

@@ -300,11 +300,30 @@ TP_HD void pk_add_unpacked(uint64_t lo, uint64_t hi, pk_acc& a) {
 // lines of an edge have the same chunks: adjacent lanes work ON THE SAME ROWS, and their crossing columns lie within a few
 // pixels of each other, so what they fetch shares cache lines.  Residues are absolute (not counted from the line's first
 // row): when an endpoint crosses a pixel row, one lane of the line gains or loses a row and the others keep theirs.
+#ifndef PK_CONTIG_ALL
+#define PK_CONTIG_ALL 0   /* 1 (experiment): chunk c of TL takes a BLOCK of consecutive rows instead of a residue class */
+#endif
+TP_HD int pk_row_step(int TL) { return PK_CONTIG_ALL ? 1 : TL; }   // image rows between two rows of a lane
 struct pk_rows { int n; int64_t x, xs; uint32_t row, rs; };
 TP_HD pk_rows pk_lane_rows(const pk_walker& ln, int c, int TL, uint32_t magic, int pitch, int* first_row = nullptr) {
     pk_rows r; r.n = 0; r.x = 0; r.xs = 0; r.row = 0; r.rs = 0;
     if (first_row) *first_row = 0;
     if (ln.ra > ln.rb) return r;
+#if PK_CONTIG_ALL
+    {
+        const int rows = ln.rb - ln.ra + 1;
+        const int B = (int)pk_div((uint32_t)(rows + TL - 1), magic);   // ceil(rows / TL) rows per chunk
+        const int first = ln.ra + c * B;
+        if (ln.rb < first) return r;
+        r.n = ln.rb - first + 1 < B ? ln.rb - first + 1 : B;
+        r.x = (int64_t)((uint64_t)ln.x + (uint64_t)ln.s * (uint64_t)(uint32_t)(c * B));
+        r.xs = ln.s;
+        r.row = pk_mul24((uint32_t)first, (uint32_t)pitch * 16u);
+        r.rs = (uint32_t)pitch * 16u;
+        if (first_row) *first_row = first;
+        return r;
+    }
+#endif
     int d = c - (ln.ra - (int)pk_mul24(pk_div((uint32_t)ln.ra, magic), (uint32_t)TL));   // c - ra mod TL (rows and chunks < 2^13)
     d += d < 0 ? TL : 0;
     const int first = ln.ra + d;
@@ -411,10 +430,10 @@ TP_HD int pk_walk_lane(const pk_view& V, const char* table, const char* tiled, i
     if (parts > 1) {
         const int skip = part * PK_UNCACHED_BATCH;
         if (skip >= r.n) return l;   // (nothing left for this part)
-        r.n -= skip; r.x = (int64_t)((uint64_t)r.x + (uint64_t)skip * (uint64_t)r.xs); r.row += (uint32_t)skip * r.rs; first += skip * TL;
+        r.n -= skip; r.x = (int64_t)((uint64_t)r.x + (uint64_t)skip * (uint64_t)r.xs); r.row += (uint32_t)skip * r.rs; first += skip * pk_row_step(TL);
         if (part + 1 < parts && r.n > PK_UNCACHED_BATCH) r.n = PK_UNCACHED_BATCH;
     }
-    if (tiled) pk_walk_rows_tiled<PK_UNCACHED_BATCH>(r, (uint32_t)first, (uint32_t)TL, (uint32_t)pitch, tiled, W, a);
+    if (tiled) pk_walk_rows_tiled<PK_UNCACHED_BATCH>(r, (uint32_t)first, (uint32_t)pk_row_step(TL), (uint32_t)pitch, tiled, W, a);
     else pk_walk_rows<PK_UNCACHED_BATCH>(r, table, W, a);
     return l;
 }
@@ -552,7 +571,7 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
             }
 #endif
             if (PK_STALE_TILED && tiled)
-                C.rec[u] = pk_load_rec(tiled, tp_px_tiled_row_part(((uint32_t)first + (uint32_t)u * (uint32_t)C.TL) & on, (uint32_t)pitch) + tp_px_tiled_col_part((uint32_t)col));
+                C.rec[u] = pk_load_rec(tiled, tp_px_tiled_row_part(((uint32_t)first + (uint32_t)u * (uint32_t)pk_row_step(C.TL)) & on, (uint32_t)pitch) + tp_px_tiled_col_part((uint32_t)col));
             else
                 C.rec[u] = pk_load_rec(table, ((t.row + (uint32_t)u * t.rs) & on) + ((uint32_t)col << 4));
 #endif
@@ -587,7 +606,7 @@ TP_HD int pk_walk_fill(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
         const int32_t col = pk_next_col(t, W) & (int32_t)on;
         C.rec[u] = pk_load_rec(tiled, (tp_px_tiled_row_part(row, (uint32_t)pitch) & on) + tp_px_tiled_col_part((uint32_t)col));
         C.col[u] = col;
-        row += (uint32_t)C.TL;
+        row += (uint32_t)pk_row_step(C.TL);
     }
     pk_walk_lds_rows<RR, RL>(V, s, t, live, true, table, W);
     return n;

@@ -299,9 +299,9 @@ void leave_device(tp_context* c) {   // (the caller has waited for the context's
 
 // n grad-iters of the persistent kernel -- the last one writes `tenergy`, `colnum`, `colacc`, `gradient` --, then
 // `points_out` -> `points` / `epos`
-int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings) {
+int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings, bool probe) {
     while (n > 0) {
-        if (int rc = take_replan(c)) return rc;   // (a plan cut on the side since an earlier call, if it is ready)
+        if (!probe) if (int rc = take_replan(c)) return rc;   // (a plan cut on the side since an earlier call, if it is ready)
         // long calls go chunk by chunk (a chunk and a half rather than a short tail)
         const int k = n <= PK_CHUNK + PK_CHUNK / 2 ? n : PK_CHUNK;   // (rings: the caller's chunks are shorter than this)
         if (c->epoch + (uint32_t)k > PK_MAX_EPOCH) {
@@ -334,7 +334,7 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
             if (c->carry_written) c->warm_launches++;
             c->carry_written = true;
         }
-        A.emit = n == k && !rings; A.ten = c->ten; A.cn = c->cn; A.ca_out = c->ca; A.gr = c->gr;
+        A.emit = n == k && !rings && !probe; A.ten = c->ten; A.cn = c->cn; A.ca_out = c->ca; A.gr = c->gr;
         A.vspeed = banded ? nullptr : c->vspeed;   // (bands keep the plan they cut together)
         if (rings && !banded_rings(c)) { A.ering = c->ering; A.pring = c->pring; }
         if (rings && banded_rings(c)) {
@@ -352,6 +352,7 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         // a plain launch over a mesh without unused vertices finishes itself: it writes the positions it ends with into the other position
         // buffer, its last workgroup counts it as completed, and the host swaps the buffers -- no small kernel behind it
         const bool self = !banded && !rings && !c->has_loose && c->points_out && c->cap_points_out >= (size_t)c->NP;
+        if (probe && !self) return TP_OK;   // (a probe leaves `points` alone because it writes the OTHER buffer and nobody swaps the two)
         if (self) A.host_status = c->h_status;
         if (c->inject_give_up > 0 && --c->inject_give_up == 0) A.inject_give_up = 1;
         device_turn* T = banded ? nullptr : turn_of(c);
@@ -366,8 +367,8 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         if (banded) tp_launch_band_collect(make_launch(c, p.image_slot, dp), A, c->points_out, c->stream);
         if (!self) tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->h_status, 0, c->stream);
         c->epos_stale = true; c->tail_is_finish = true;
-        c->journal.push_back({p, rings ? 0 : k, self ? c->points : nullptr});   // (a chunk of tp_iterate_until is checked by its caller: nothing to replay)
-        if (self) std::swap(c->points, c->points_out);
+        c->journal.push_back({p, rings || probe ? 0 : k, self && !probe ? c->points : nullptr});   // (a chunk of tp_iterate_until is checked by its caller: nothing to replay)
+        if (self && !probe) std::swap(c->points, c->points_out);
         // A marker behind every launch (round 5): the runtime raises a completion signal for the LAST command of a stream only when somebody
         // asks -- a caller's hipStreamSynchronize / hipDeviceSynchronize behind a bare kernel submits a barrier packet of its own and waits
         // for the round trip (13.6 us behind a 20-step launch; 6.4 with the marker already queued: tools/host_call_cost.py).  0.6 us of
@@ -379,9 +380,10 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         HIP_TRY(c, hipGetLastError());
         c->epoch += (uint32_t)k;
         c->persist_unchecked = true;
+        n -= k;
+        if (probe) { drop_carry(c); continue; }   // (what the probe left is of positions nobody keeps)
         c->persist_launches++; c->persist_iters += k;
         c->iters_since_snap += k; c->iters_since_cut += k;
-        n -= k;
         if (c->iters_since_snap >= PK_CHUNK / 2) {   // the positions after this chunk, for a later maybe_replan
             const int sl = c->snap_next;
             c->tail_is_finish = false;
@@ -395,6 +397,33 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
         // with this chunk on the stream (the GPU has work while the host cuts): does the mesh want a new plan?
         if (int rc = maybe_replan(c, dp, n > 0)) return rc;
     }
+    return TP_OK;
+}
+
+// tp_prepare, behind the first plan of a triangulation: how fast do its vertices move?  PK_PROBE_ITERS grad-iters of the persistent kernel that
+// nobody keeps -- the launch writes the positions it ends with into the context's OTHER position buffer and the host does not swap the two, no
+// buffer of the reference is written -- tell the planner what the first launches of a descent cannot know yet: on a photograph a tenth of
+// the patches hold the vertices that jump a pixel or more per grad-iter, walk five times as long as the others, and everybody waits for
+// them (profiles/r06_meninas_timeline_first_launch.json: period 13.4 us, median patch 4.8).  The plan is cut again with the speeds measured.
+int probe_speeds(tp_context* c, const tp_params& p, float dp) {
+    static const bool off = getenv("TPOSE_NO_PROBE") != nullptr || getenv("TPOSE_NO_SPEED_PLAN") != nullptr;
+    if (off || !c->plan.ok || c->n_bands > 1 || !c->vspeed || c->probed_generation == c->generation) return TP_OK;
+    c->probed_generation = c->generation;
+    if (int rc = enqueue_persistent(c, p, dp, PK_PROBE_ITERS, false, true)) return rc;
+    HIP_TRY(c, wait_context(c));
+    const int64_t before = c->persist_failures;
+    if (int rc = check_persist_status(c)) return rc;
+    if (c->persist_failures != before) return TP_OK;   // (the probe gave up: nothing was measured)
+    std::vector<float> sp(2 * (size_t)c->NP), speed((size_t)c->NP);
+    HIP_TRY(c, hipMemcpy(sp.data(), c->vspeed, sp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    const float sx = 0.5f * (float)c->W / c->ratio, sy = 0.5f * (float)c->H;
+    for (size_t v = 0; v < speed.size(); v++) { const float q = sp[2 * v] * sx + sp[2 * v + 1] * sy; speed[v] = q >= 0.0f ? q : 0.0f; }
+    std::vector<float> rows; std::vector<double> wv; std::vector<int> deg;
+    pk_vertex_work(c->NP, c->NT, c->h_tris.data(), c->h_points.data(), c->NE, c->h_edge_uv.data(), c->h_he_edge.data(), c->H, speed.data(), rows, wv, deg);
+    if (pk_imbalance(c->plan.owner_v, wv, c->plan.parts) <= PK_REPLAN_BALANCE) return TP_OK;   // (balanced as it is)
+    bool ok = false;
+    if (int rc = build_plan(c, c->h_points.data(), dp, c->plan_slot ^ 1, &ok, speed.data())) return rc;
+    if (ok) c->replans_balance++;
     return TP_OK;
 }
 

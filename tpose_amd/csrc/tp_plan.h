@@ -22,6 +22,7 @@
 
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <string>
 #include <unordered_map>
@@ -67,9 +68,11 @@
 #define PK_SLACK_ROWS 3      /* rows a line may grow before its chunks are cut again */
 #endif
 #ifndef PK_STALE_COST
-#define PK_STALE_COST 4.0f   /* what a table look-up costs MORE when its row's crossing column has changed since the last grad-iter (the record is fetched
-                                again: a cache line through the CU's texture path; profiles/r06_ta_bench.txt, r06_meninas_timeline_2000.json: a patch whose
-                                rows are all stale walks for 9 us, one whose rows stand for 1.7) -- the planner's weight of a row is 1 + this x P(stale) */
+#define PK_STALE_COST 2.5f   /* what a table look-up costs MORE when its row's crossing column has changed since the last grad-iter (the record is fetched
+                                again: a cache line through the CU's texture path; profiles/r06_ta_bench.txt, r06_meninas_timeline_2000_rows_only_plan.json: a
+                                patch whose rows are all stale walks for 9 us, one whose rows stand for 1.7) -- the planner's weight of a row is
+                                1 + this x P(stale).  Swept on four rasters (profiles/r06_experiments.txt): 1.5 / 2.5 / 4 / 6 -> meninas 8.3 / 8.0 / 8.3 /
+                                9.4 us per grad-iter: beyond 2.5 the patches of standing vertices get more rows than their threads keep records for */
 #endif
 #ifndef PK_RECUT
 #define PK_RECUT 64          /* grad-iters between two looks at the chunks of a patch's lines (a power of two) */
@@ -188,6 +191,10 @@ inline void rcb(std::vector<rcb_vertex>& a, int lo, int hi, int p0, int p1, std:
 // a patch made of such vertices took five times as long as its neighbours, who waited (profiles/r06_meninas_timeline_2000.json).
 // wv[v]: a vertex's work -- per corner the four moves of its two edges (each edge at the vertex is shared by two corners) and the opposite
 // base line (shared with the corner across the edge, if that one is in the same patch), plus the corner itself.  Returns the sum of wv.
+inline float pk_stale_cost() {   // (TPOSE_STALE_COST: tuning runs only -- tools/photo_timing.py)
+    static const float v = [] { const char* e = getenv("TPOSE_STALE_COST"); return e ? (float)atof(e) : PK_STALE_COST; }();
+    return v;
+}
 inline double pk_vertex_work(int NP, int NT, const int32_t* tris, const float* points, int NE, const int32_t* edge_uv, const int32_t* he_edge, int H,
                              const float* vspeed, std::vector<float>& rows, std::vector<double>& wv, std::vector<int>& deg) {
     rows.assign((size_t)NE, 0.0f);
@@ -200,7 +207,7 @@ inline double pk_vertex_work(int NP, int NT, const int32_t* tris, const float* p
         if (vspeed) {
             float st = 0.5f * (vspeed[u] + vspeed[v]);
             if (!(st >= 0.0f)) st = 0.0f;
-            r *= 1.0f + PK_STALE_COST * std::min(st, 1.0f);
+            r *= 1.0f + pk_stale_cost() * std::min(st, 1.0f);
         }
         rows[e] = r;
     }
