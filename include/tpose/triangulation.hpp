@@ -13,6 +13,7 @@
 #pragma once
 
 #include <cmath>
+#include <cstring>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -475,6 +476,27 @@ inline long descend(triangulation* tr, double threshold, long maxframes) {
     newerr = toterr; relerr = rel;
     retrieve(tr);
     return frames;
+}
+// Frames WITHOUT a read-back each (tp_iterate_frames, round 6): up to maxframes frames of { computecolors; doenergy; doshift } run in chunks on
+// the device; after every frame, in order, `terr[0, NT)` and `tr->points` hold what the reference's four retrieves would have left (the
+// frame's base energies; the positions after its shift) and fn(k) decides: TP_FRAME_GO_ON, TP_FRAME_STOP_REPLAY (the device is brought to
+// the state the frame left -- all buffers readable, as after doframe()), or TP_FRAME_STOP (the caller uploads next).  Returns the frames run.
+// `cn` and `perr` are NOT refreshed per frame (the reference's loop looks at them at an export only, which follows a replayed frame).
+template <class F>
+inline long frames(triangulation* tr, long maxframes, F&& fn) {
+    struct pack { triangulation* tr; F* fn; } pk = {tr, &fn};
+    tp_params p;
+    tp_default_params(flavour, &p);
+    p.image_slot = swept_slot();
+    int n = 0;
+    check(tp_iterate_frames(ctx, &p, (int)(maxframes > 0x3fffffff ? 0x3fffffff : maxframes),
+                            [](void* user, int k, const int32_t* ten, const float* pts) -> int {
+                                pack* q = static_cast<pack*>(user);
+                                std::memcpy(terr, ten, sizeof(int) * (size_t)q->tr->NT);
+                                std::memcpy(&q->tr->points[0].x, pts, sizeof(float) * 2 * (size_t)q->tr->NP);
+                                return (*q->fn)(k);
+                            }, &pk, &n), "frames");
+    return n;
 }
 inline float gettoterr(triangulation* tr) { sum_energy(tr); return std::fabs(toterr); }
 inline int maxerrid(triangulation* tr) {

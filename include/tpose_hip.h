@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TP_ABI_VERSION 4
+#define TP_ABI_VERSION 5
 #define TP_MAXT (2 << 18) /* tpose::triangulation::MAXT, source/triangulation.hpp:95; 13*NT <= MAXT */
 
 typedef struct tp_context tp_context;
@@ -182,6 +182,27 @@ int tp_iterate(tp_context* ctx, const tp_params* p, int n_iters);
  * against a double literal (`geterr(&tr) < 1E-4`).  Synchronous. */
 int tp_iterate_until(tp_context* ctx, const tp_params* p, int max_frames, double threshold, float* toterr, int* frames,
                      float* relerr /* may be NULL */);
+/* The reference's frame loop with the HOST in it, but off the device's critical path (round 6).  software/triangulate/main.cpp:196-346 looks
+ * at EVERY frame: geterr over the base energies (:210), then the prune / wide-angle-flip / collapse sweeps over the positions the frame
+ * ended with (:316-346) -- four read-backs and a wait per frame.  tp_iterate_frames runs up to max_frames frames of { accumulate; energy;
+ * shift } in chunks inside persistent launches that keep every frame's base energies and positions on the device, and hands them to the
+ * caller frame by frame, in order:  fn(user, k, tenergy, points)  with k the frame's number within this call, tenergy = int32[NT] (the
+ * entries [0, NT) of `tenergy` as the frame's doenergy left them) and points = float[2 NP] (the positions after the frame's shift).
+ * fn returns
+ *   TP_FRAME_GO_ON      the next frame, please;
+ *   TP_FRAME_STOP_REPLAY  the run ends WITH this frame and the caller wants the device as the frame left it: the positions of the frame's
+ *                       start are restored and the frame is run once more on the two-kernel path -- `tenergy`, `colnum`, `colacc`,
+ *                       `gradient` and the positions are then exactly what the reference's frame leaves (as tp_iterate_until's last frame);
+ *   TP_FRAME_STOP       the run ends with this frame and the caller will upload next: the positions the frame ended with are restored,
+ *                       the other buffers are unspecified.
+ * Frames the device ran beyond the one that stops the run are discarded.  *frames = frames handed to fn.  When the run ends because
+ * max_frames were handed over, the device holds the positions of the last frame; the other buffers are unspecified (the next
+ * tp_iterate / tp_accumulate recomputes them).  What fn does to the caller's own copy of the mesh between frames -- the reference's
+ * wide-angle flips, which it never uploads (main.cpp:322-331 does not set `updated`) -- is the caller's business: the device runs on the
+ * mesh of the last tp_upload, as the reference's does.  Synchronous; not available to bands (TP_ERR_STATE). */
+enum { TP_FRAME_GO_ON = 0, TP_FRAME_STOP_REPLAY = 1, TP_FRAME_STOP = 2 };
+typedef int (*tp_frame_fn)(void* user, int frame, const int32_t* tenergy, const float* points);
+int tp_iterate_frames(tp_context* ctx, const tp_params* p, int max_frames, tp_frame_fn fn, void* user, int* frames);
 /* Optional: build the launch graph tp_iterate replays for these parameters now (it is otherwise built by the
  * first tp_iterate of >= 16 iterations after an upload), so that no later call pays for it.  Runs nothing.
  * The reference has no counterpart -- its frame loop issues GL calls one by one (triangulate/main.cpp:190-204). */

@@ -173,6 +173,19 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
     return TP_OK;
 }
 
+/* the frame loop with the host in it: frame by frame, the caller's verdict after each (the frame has just run: everything stands as it left it) */
+int tp_iterate_frames(tp_context* c, const tp_params* p, int max_frames, tp_frame_fn fn, void* user, int* frames) {
+    int done = 0;
+    while (done < max_frames) {
+        tp_iterate(c, p, 1);
+        const int verdict = fn(user, done, c->ten, c->points);
+        done++;
+        if (verdict != TP_FRAME_GO_ON) break;
+    }
+    *frames = done;
+    return TP_OK;
+}
+
 /* band split (tp_band_attach): the stand-in runs every band's descents whole -- the same results, nothing shared */
 size_t tp_band_mailbox_bytes(int points, int triangles) { (void)triangles; return (size_t)(points > 0 ? points : 0) * 64 + 64; }
 int tp_band_attach(tp_context* c, int band, int n_bands, void* const* mailboxes, size_t bytes_each, int points, int triangles, int patches_per_band) {

@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(lib, name), "libtpose_hip.so does not export %s" % name
     assert sorted(capi.SYMBOLS) == decl
-    assert lib.tp_abi_version() == 4
+    assert lib.tp_abi_version() == 5
 
 
 def test_no_device_fails_loudly():

@@ -112,7 +112,14 @@ def test_bench_line_contract_one_gpu():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["higher_is_better"] is True
-    assert line["unit"] == "triangles*grad-iters/s" and line["vs_baseline"] is None and line["data"] == "synthetic"
+    assert line["unit"] == "triangles*grad-iters/s" and line["vs_baseline"] is None
+    # round 6: the headline workload is the reference's own picture (meninas.png at the metric's 2048 x 2048), the synthetic raster's figures beside it
+    assert line["data"].startswith("reference photograph") and "meninas" in line["data"] and "meninas" in line["config"]["workload"]
+    ph = line["ms_per_step_on_reference_photos"]
+    assert abs(ph["meninas"] - line["ms_per_step"]) < 1e-12 and all(isinstance(ph[k], float) and ph[k] > 0 for k in ("fruit", "imageA", "shoeA"))
+    assert line["value_synthetic_contrast_0.10"] > 0 and 0 < line["roofline_frac_synthetic_contrast_0.10"] < 1
+    assert set(line["ms_per_step_by_contrast"]) == {"0.10", "0.14", "0.30", "1.00"}
+    assert line["value_all_13_variants"] > 0 and 0 < line["roofline_frac_all_13_variants_by_bench_clock"] < 1
     assert abs(line["value"] - 3000 * 20 / (line["ms_per_step"] * 20e-3)) < 1e-6 * line["value"]
     assert line["config"]["raster"] == [2048, 2048] and line["config"]["triangles"] == 3000 and "workload" in line["config"]
     rf = line["roofline"]

@@ -25,7 +25,7 @@ SYMBOLS = [
     "tp_get_stream", "tp_profile_iterate", "tp_profile_accumulate", "tp_get_info", "tp_selftest_walker", "tp_render",
     "tp_prepare", "tp_selftest_line", "tp_timer_start", "tp_timer_stop", "tp_iterate_until", "tp_band_mailbox_bytes",
     "tp_band_attach", "tp_band_mailbox_alloc", "tp_band_mailbox_free", "tp_band_mailbox_export", "tp_band_mailbox_import",
-    "tp_band_mailbox_close", "tp_evaluate_triangles", "tp_selftest_variant",
+    "tp_band_mailbox_close", "tp_evaluate_triangles", "tp_selftest_variant", "tp_iterate_frames",
 ]
 
 
@@ -39,6 +39,7 @@ def band_mailbox_bytes(points, triangles):
 RENDER_AVERAGE, RENDER_STORED = 0, 1
 OPT_PERSISTENT, OPT_INJECT_GIVE_UP = 1, 3
 PERSIST_OFF, PERSIST_AUTO = 0, 1
+FRAME_GO_ON, FRAME_STOP_REPLAY, FRAME_STOP = 0, 1, 2
 INFO_PATCHES, INFO_PATCH_LDS, INFO_PATCH_LINES, INFO_PERSIST_LAUNCHES, INFO_PERSIST_ITERS, INFO_CENSUS, INFO_REPLANS = 2, 3, 4, 5, 6, 7, 8
 INFO_PERSIST_FAILURES, INFO_BOX_FINEGRAINED, INFO_WARM_LAUNCHES = 9, 10, 11
 INFO_RETRY_MS, INFO_PLAN_ROWS = 12, 13
@@ -332,6 +333,20 @@ class Context:
         tot, n, rel = C.c_float(toterr), C.c_int(0), C.c_float(0.0)
         self._ck(self.lib.tp_iterate_until(self.h, C.byref(params), max_frames, C.c_double(threshold), C.byref(tot), C.byref(n), C.byref(rel)))
         return n.value, tot.value, rel.value
+
+    def iterate_frames(self, params, max_frames, fn):
+        """tp_iterate_frames: fn(k, tenergy int32[NT], points float32[NP, 2]) -> FRAME_GO_ON / FRAME_STOP_REPLAY / FRAME_STOP after every frame
+        (the arrays are views of the library's buffers: copy what is kept); returns the frames handed over"""
+        NT, NP = self.NT, self.NP
+        FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float))
+
+        def tramp(_user, k, ten, pts):
+            return int(fn(k, np.ctypeslib.as_array(ten, shape=(NT,)), np.ctypeslib.as_array(pts, shape=(NP, 2))))
+        cb = FN(tramp)
+        n = C.c_int(0)
+        self.lib.tp_iterate_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, FN, C.c_void_p, C.POINTER(C.c_int)]
+        self._ck(self.lib.tp_iterate_frames(self.h, C.byref(params), max_frames, cb, None, C.byref(n)))
+        return n.value
 
     def timer_start(self):
         self._ck(self.lib.tp_timer_start(self.h))

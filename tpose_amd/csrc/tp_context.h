@@ -181,6 +181,7 @@ struct tp_context {
     int32_t* ering = nullptr; float2* pring = nullptr;   // tp_iterate_until: per-frame base energies / positions of a chunk
     size_t cap_ering = 0, cap_pring = 0;
     int32_t* ering_host = nullptr; size_t cap_ering_host = 0;   // pinned
+    float2* pring_host = nullptr; size_t cap_pring_host = 0;    // pinned: tp_iterate_frames hands every frame's positions to the caller
     unsigned long long* posbox = nullptr;
     size_t cap_posbox = 0;   // (in vertices)
     // band split (tp_band_attach): this context runs band `band` of `n_bands` -- the patches [band, band + 1) * band_patches of a

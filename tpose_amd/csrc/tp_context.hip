@@ -176,6 +176,7 @@ int tp_destroy(tp_context* c) {
     if (c->frame_mirror) hipHostFree(c->frame_mirror);
     hipFree(c->ering); hipFree(c->pring);
     if (c->ering_host) hipHostFree(c->ering_host);
+    if (c->pring_host) hipHostFree(c->pring_host);
     for (int k = 0; k < 2; k++) {
         hipFree(c->plan_dev[k].wg); hipFree(c->plan_dev[k].pool);
         if (c->plan_dev[k].stage) hipHostFree(c->plan_dev[k].stage);

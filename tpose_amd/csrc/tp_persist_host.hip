@@ -556,6 +556,105 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
     return TP_OK;
 }
 
+int tp_iterate_frames(tp_context* c, const tp_params* p, int max_frames, tp_frame_fn fn, void* user, int* frames) {
+    api_guard api_lock;
+    if (!c) return TP_ERR_INVALID;
+    if (int rc = validate_params(c, p, max_frames)) return rc;
+    if (!fn || !frames) return fail(c, TP_ERR_INVALID, "iterate_frames: fn / frames is NULL");
+    *frames = 0;
+    if (max_frames == 0) return TP_OK;
+    if (c->n_bands > 1) return fail(c, TP_ERR_STATE, "iterate_frames: not available to the bands of a split descent");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->mutations++; c->tail_is_finish = false;
+    if (int rc = settle_persistent(c)) return rc;
+    const float dp = resolve_dp(c, p->flavour, p->dp);
+    const int NT = c->NT;
+    const size_t NP = (size_t)c->NP;
+    auto host_rings = [&](size_t frames_cap) -> int {
+        const size_t ints = frames_cap * (size_t)NT, pts = (frames_cap + 1) * NP;
+        if (ints > c->cap_ering_host || !c->ering_host) {
+            if (c->ering_host) hipHostFree(c->ering_host);
+            c->ering_host = nullptr; c->cap_ering_host = 0;
+            HIP_TRY(c, hipHostMalloc((void**)&c->ering_host, ints * sizeof(int32_t), hipHostMallocDefault));
+            c->cap_ering_host = ints;
+        }
+        if (pts > c->cap_pring_host || !c->pring_host) {
+            if (c->pring_host) hipHostFree(c->pring_host);
+            c->pring_host = nullptr; c->cap_pring_host = 0;
+            HIP_TRY(c, hipHostMalloc((void**)&c->pring_host, pts * sizeof(float2), hipHostMallocDefault));
+            c->cap_pring_host = pts;
+        }
+        return TP_OK;
+    };
+    bool use = false;
+    if (max_frames >= PK_MIN_ITERS) { if (int rc = ensure_plan(c, dp, &use, true)) return rc; }
+    // vertices no triangle uses (the schedule's prune leaves some): the persistent kernel never writes their ring entries -- they are clamped
+    // once by whatever ends the launch (k_persist_finish; shift.cs:25-43 runs for every i >= 4) and stand still from then on
+    std::vector<int> loose;
+    if (c->has_loose) {
+        std::vector<char> used(NP, 0);
+        for (int t = 0; t < NT; t++) for (int s = 0; s < 3; s++) used[(size_t)c->h_tris[4 * (size_t)t + s]] = 1;
+        for (size_t v = 0; v < NP; v++) if (!used[v]) loose.push_back((int)v);
+    }
+    int done = 0;
+    bool stopped = false;
+    while (done < max_frames && !stopped) {
+        const int left = max_frames - done;
+        if (!use || left < PK_MIN_ITERS) {
+            // frame by frame on the two-kernel path: the frame, then its base energies and positions come back
+            if (int rc = host_rings(1)) return rc;
+            if (int rc = settle_epos(c)) return rc;
+            enqueue_iter(c, *p, dp);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(c->ering_host, c->ten, sizeof(int32_t) * (size_t)NT, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->pring_host, c->points, sizeof(float2) * NP, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, wait_stream(c->stream));
+            const int verdict = fn(user, done, c->ering_host, reinterpret_cast<const float*>(c->pring_host));
+            done++;
+            stopped = verdict != TP_FRAME_GO_ON;   // (the frame has just run on the two-kernel path: everything stands as it left it)
+            continue;
+        }
+        // a chunk of frames inside one persistent launch: every frame leaves its base energies and its starting positions
+        const int C = left < 256 ? left : 256;
+        if (int rc = grow(c, &c->ering, &c->cap_ering, (size_t)C * NT)) return rc;
+        if (int rc = grow(c, &c->pring, &c->cap_pring, (size_t)C * NP)) return rc;
+        if (int rc = host_rings(256)) return rc;   // (for the longest chunk at once: freeing pinned memory waits for the device)
+        if (int rc = enqueue_persistent(c, *p, dp, C, true)) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->ering_host, c->ering, sizeof(int32_t) * (size_t)C * NT, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->pring_host, c->pring, sizeof(float2) * (size_t)C * NP, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->pring_host + (size_t)C * NP, c->points, sizeof(float2) * NP, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, wait_stream(c->stream));
+        {
+            const int64_t fails = c->persist_failures;
+            if (int rc = check_persist_status(c)) return rc;
+            if (c->persist_failures != fails) { use = false; continue; }   // the chunk gave up (nothing changed): frame by frame from here
+        }
+        for (int v : loose)
+            for (int j = 1; j < C; j++) c->pring_host[(size_t)j * NP + (size_t)v] = c->pring_host[(size_t)C * NP + (size_t)v];
+        for (int j = 0; j < C; j++) {
+            // (frame j started from pring[j] and ended with pring[j + 1] -- the chunk's last one with the positions the launch ended with)
+            const int verdict = fn(user, done, c->ering_host + (size_t)j * NT, reinterpret_cast<const float*>(c->pring_host + (size_t)(j + 1) * NP));
+            done++;
+            if (verdict == TP_FRAME_GO_ON) continue;
+            stopped = true;
+            if (verdict == TP_FRAME_STOP_REPLAY) {
+                tp_launch_persist_finish(make_launch(c, p->image_slot, dp), c->pring + (size_t)j * NP, nullptr, nullptr, 1, c->stream);
+                c->epos_stale = false; c->tail_is_finish = false;
+                enqueue_iter(c, *p, dp);
+            } else if (j + 1 < C) {
+                tp_launch_persist_finish(make_launch(c, p->image_slot, dp), c->pring + (size_t)(j + 1) * NP, nullptr, nullptr, 1, c->stream);
+                c->epos_stale = false; c->tail_is_finish = false;
+            }
+            HIP_TRY(c, hipGetLastError());
+            break;
+        }
+    }
+    c->acc_slot = p->image_slot; c->last_flavour = p->flavour;
+    c->accumulated = c->energized = false;
+    *frames = done;
+    return TP_OK;
+}
+
 #ifdef PK_DBG_BOUNDS
 int tp_debug_persist_faults(tp_context* c, unsigned long long* out) {
     api_guard api_lock;

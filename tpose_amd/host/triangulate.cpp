@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     long maxframes = 1L << 40;
     int maxtris = 1 << 30, device = 0;
     std::string levels;  // export list override (the reference hard-codes 50..1000; its showcase uses 3000)
-    bool quiet = false, literal = false;
+    bool quiet = false, literal = false, nochunks = false;
     for (int a = 1; a < argc; a++) {
         const std::string k = argv[a];
         auto val = [&]() -> const char* { if (a + 1 >= argc) { std::cerr << "missing value for " << k << "\n"; std::exit(2); } return argv[++a]; };
@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
         else if (k == "-device") device = std::atoi(val());
         else if (k == "-quiet") quiet = true;
         else if (k == "-literal") literal = true;
+        else if (k == "-nochunks") nochunks = true;   // frame by frame with the shortcuts of round 5, no tp_iterate_frames
         else { std::cerr << "unknown option " << k << "\n"; return 2; }
     }
     if (input.empty()) { std::cout << "Please specify an input image with -i." << std::endl; return 0; }
@@ -100,21 +101,78 @@ int main(int argc, char** argv) {
     // does change the mesh, the upload that follows overwrites everything that frame touched (positions, topology, colour sums), and the frame
     // is simply never read back.  Decisions, states and bytes are the reference's (`-literal` keeps its order of calls as written).
     bool ahead = false;   // the device is already running the frame the loop is about to count
-    while (!done && frame < maxframes) {
-        frame++;
-        const auto t0 = now();
-        if (!ahead) {
-            if (fresh) { tpose::doenergy(); tpose::doshift(); }
-            else tpose::doframe();
+    // the per-frame sweeps of software/triangulate/main.cpp:316-346 over tr as it stands (positions of the frame just read): true when the mesh
+    // changed in a way the device has to hear of (prune, collapse; the wide-angle flips stay on the host, as in the reference)
+    auto sweeps = [&]() {
+        bool changed = false;
+        for (size_t t = 0; t < (size_t)tr.NT; t++)
+            if (tr.boundary((int)t) == 3)
+                if (tr.prune((int)t)) changed = true;
+        for (size_t t = 0; t < (size_t)tr.NT; t++) {
+            int maybe = literal ? 7 : tr.sweep_candidates((int)t);   // (bit k: angle(3 t + k) may exceed 0.8 PI)
+            for (int k = 0; k < 3; k++)
+                if (((maybe >> k) & 1) && tr.angle(3 * (int)t + k) > 0.8 * tpose::PI) {
+                    tr.flip(3 * (int)t + k, 0.0);
+                    if (!literal) maybe = tr.sweep_candidates((int)t);   // (the flip may have changed triangle t)
+                }
         }
-        ahead = false;
-        fresh = false;
-        tpose::retrieve(&tr, !literal);   // (the reference reads all 13 NT entries of three buffers every frame and looks at the first NT)
+        for (size_t t = 0; t < tr.triangles.size(); t++) {
+            if (!literal && !(tr.sweep_candidates((int)t) & 8)) continue;   // (collapse() would refuse whichever half-edge is the shortest)
+            int h = 3 * (int)t;
+            float shortest = tr.hlength(h);
+            if (tr.hlength(h + 1) < shortest) shortest = tr.hlength(++h);
+            if (tr.hlength(h + 1) < shortest) shortest = tr.hlength(++h);
+            if (tr.collapse(h)) changed = true;
+        }
+        return changed;
+    };
+    // Frames in chunks (round 6, tp_iterate_frames).  On a photograph the reference's convergence test holds a level for thousands of frames --
+    // resource/meninas.png: ~10 000 frames per split below 50 triangles -- and every one of them was a device round trip (17 us) for a host
+    // that looks, finds nothing to do and asks for the next.  After QUIET_MIN frames in a row without a convergence step or a change of the
+    // mesh, frames run in chunks on the device and the host replays its part -- geterr, then the sweeps, frame by frame in the reference's
+    // order -- over the energies and positions every frame left in the device's rings; the first frame that converges or changes the mesh
+    // ends the run (the frames the device ran beyond it are dropped), and the loop goes on from exactly the state the frame-by-frame
+    // loop would be in.  Decisions, frame counts and .tri bytes are those of `-literal` (tests/test_configs.py, tests/test_harness.py).
+    const long QUIET_MIN = 16;
+    long calm = 0, budget = 64;
+    double t_chunks = 0; long chunk_frames = 0, chunk_calls = 0;
+    while (!done && frame < maxframes) {
+        bool have_frame = false, conv = false, swept = false, updated = false, device_stale = false;
+        // (a chunk's first launch cuts a plan of the mesh -- about a microsecond per triangle on the host -- where a frame on its own costs 20: a
+        // big mesh has to have been calm for long before its frames go in chunks)
+        if (!literal && !nochunks && !ahead && !fresh && calm >= std::max<long>(QUIET_MIN, tr.NT / 4) && maxframes - frame >= 4) {
+            const auto c0 = now();
+            int kind = 0;   // 1: the last frame handed over converged (replayed on the device), 2: its sweeps changed the mesh
+            const long n = tpose::frames(&tr, std::min(budget, maxframes - frame), [&](int) {
+                frame++;
+                if (tpose::geterr(&tr) < 1E-4) { kind = 1; return (int)TP_FRAME_STOP_REPLAY; }
+                if (sweeps()) { kind = 2; return (int)TP_FRAME_STOP; }
+                return (int)TP_FRAME_GO_ON;
+            });
+            t_chunks += secs(c0, now()); chunk_frames += n; chunk_calls++;
+            if (kind == 0) { budget = std::min<long>(budget * 2, 4096); continue; }   // (nothing happened: the device holds the last frame's positions)
+            calm = 0; budget = 64;
+            have_frame = true;
+            if (kind == 1) { conv = true; tpose::retrieve(&tr, true); }   // (the frame once more on the device: its buffers, as after doframe())
+            else { swept = true; updated = true; }
+        }
+        const auto t0 = now();
+        if (!have_frame) {
+            frame++;
+            if (!ahead) {
+                if (fresh) { tpose::doenergy(); tpose::doshift(); }
+                else tpose::doframe();
+            }
+            ahead = false;
+            fresh = false;
+            tpose::retrieve(&tr, !literal);   // (the reference reads all 13 NT entries of three buffers every frame and looks at the first NT)
+            conv = tpose::geterr(&tr) < 1E-4;
+        }
         const auto t1 = now();
         t_device += secs(t0, t1);
+        if (conv) calm = 0; else calm++;
 
-        bool updated = false, device_stale = false;
-        if (tpose::geterr(&tr) < 1E-4) {
+        if (conv) {
             if (exportlist.empty() || tr.NT > maxtris) { done = true; break; }
             if (tr.NT >= exportlist.back()) {
                 tpose::retrieve_colors(&tr);
@@ -229,31 +287,14 @@ int main(int argc, char** argv) {
             const int worst = tpose::maxerrid(&tr);
             if (worst >= 0 && tr.split(worst)) updated = true;
         }
-        else if (!literal && frame < maxframes) { tpose::doframe(); ahead = true; }   // (no convergence step: the next frame, ahead of the sweeps)
+        else if (!literal && frame < maxframes && !swept && (nochunks || calm < std::max<long>(QUIET_MIN, tr.NT / 4))) { tpose::doframe(); ahead = true; }   // (no convergence step: the next frame, ahead of the sweeps -- unless the next frames run in a chunk)
         const auto t2 = now();
         t_converged += secs(t1, t2);
 
-        for (size_t t = 0; t < (size_t)tr.NT; t++)
-            if (tr.boundary((int)t) == 3)
-                if (tr.prune((int)t)) updated = true;
-        for (size_t t = 0; t < (size_t)tr.NT; t++) {
-            int maybe = literal ? 7 : tr.sweep_candidates((int)t);   // (bit k: angle(3 t + k) may exceed 0.8 PI)
-            for (int k = 0; k < 3; k++)
-                if (((maybe >> k) & 1) && tr.angle(3 * (int)t + k) > 0.8 * tpose::PI) {
-                    tr.flip(3 * (int)t + k, 0.0);
-                    if (!literal) maybe = tr.sweep_candidates((int)t);   // (the flip may have changed triangle t)
-                }
-        }
-        for (size_t t = 0; t < tr.triangles.size(); t++) {
-            if (!literal && !(tr.sweep_candidates((int)t) & 8)) continue;   // (collapse() would refuse whichever half-edge is the shortest)
-            int h = 3 * (int)t;
-            float shortest = tr.hlength(h);
-            if (tr.hlength(h + 1) < shortest) shortest = tr.hlength(++h);
-            if (tr.hlength(h + 1) < shortest) shortest = tr.hlength(++h);
-            if (tr.collapse(h)) updated = true;
-        }
+        if (!swept && sweeps()) updated = true;
         const auto t3 = now();
         if (updated) {
+            calm = 0;
             const float e = tpose::gettoterr(&tr);
             if (!quiet) std::cout << tr.NT << " " << std::setprecision(16) << e << std::endl;
             tpose::upload(&tr, false);
@@ -273,6 +314,7 @@ int main(int argc, char** argv) {
               << " s, per-frame host loops (prune, angle, collapse) " << t_loops << " s, re-upload + computecolors after a change " << t_reup << " s" << std::endl;
     std::cerr << "inside the convergence steps: ranking + flips " << t_rank << " s (the flips and flip-backs themselves " << t_flip << "), uploads " << t_upload << " s, computecolors + doenergy + read-back "
               << t_energy << " s" << std::endl;
+    std::cerr << "frames in chunks on the device (tp_iterate_frames) " << chunk_frames << " of " << frame << " in " << chunk_calls << " calls, " << t_chunks << " s" << std::endl;
     std::cerr << "seconds " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
     tpose::quit();
     return 0;
