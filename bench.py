@@ -570,23 +570,35 @@ def main():
     ev_samples.sort()
     kern_us_events = ev_samples[len(ev_samples) // 2]
     # the two-kernel path (k_lines + k_update per grad-iter: what every call ran through before round 3, and what calls
-    # of fewer than 4 grad-iters and rasters wider than 4096 columns still use), same state, for comparison
-    ctx.set_persistent(False)
-    ctx.prepare(params)
-    ctx.iterate(params, 64)
-    ctx.synchronize()
+    # of fewer than 4 grad-iters and rasters wider than 4096 columns still use) and the reference's frame (software/triangulate/main.cpp:
+    # 196-204: one grad-iter, then terr, perr, cn and the points read back whole) -- beside the fused figure, never as
+    # `value`.  On a context of their own, `warmup` grad-iters into the descent like the timed regions (rounds 4-5 took them on the main
+    # context after everything else: both kernels walk every row of every line, so their time follows the mesh's age -- which is what the
+    # round-5 review read as a regression, 50.3 -> 58.2 us; the figure's state is now the same from round to round)
+    cr = capi.Context(local_rank, W, H)
+    cr.set_image(capi.IMAGE_A, img)
+    if args.flavour == 1:
+        cr.set_image(capi.IMAGE_B, imgB)
+    cr.upload(pts, tris, colors)
+    cr.set_persistent(False)
+    cr.prepare(params)
+    cr.iterate(params, max(args.warmup, 16))
+    cr.synchronize()
     t0 = time.perf_counter()
-    ctx.iterate(params, 512)
-    ctx.synchronize()
+    cr.iterate(params, 512)
+    cr.synchronize()
     two_kernel_ms = (time.perf_counter() - t0) / 512 * 1e3
-    # the reference's frame (software/triangulate/main.cpp:196-204): one grad-iter, then terr, perr, cn and the points
-    # read back -- reported beside the fused figure, never as `value`
+    cr.upload(pts, tris, colors)
+    cr.iterate(params, max(args.warmup, 16))
+    for _ in range(8):
+        cr.iterate(params, 1)
+        cr.retrieve_many([capi.BUF_TENERGY, capi.BUF_PENERGY, capi.BUF_COLNUM, capi.BUF_POINTS])
     t0 = time.perf_counter()
     for _ in range(256):
-        ctx.iterate(params, 1)
-        ctx.retrieve_many([capi.BUF_TENERGY, capi.BUF_PENERGY, capi.BUF_COLNUM, capi.BUF_POINTS])
+        cr.iterate(params, 1)
+        cr.retrieve_many([capi.BUF_TENERGY, capi.BUF_PENERGY, capi.BUF_COLNUM, capi.BUF_POINTS])
     readback_ms = (time.perf_counter() - t0) / 256 * 1e3
-    ctx.set_persistent(True)
+    cr.close()
     # how the figure ages: LONG_RUN grad-iters more on the same context (calls of 4096), the last LONG_RUN / 4 of them timed
     if rank == 0 and world == 1 and not args.no_extra:
         try:

@@ -426,6 +426,7 @@ extern "C" int emul_plan(const float* points, int NP, const int32_t* tris, int N
         int ml = 0, mc = 0, ms = 0, mit = 0;
         for (auto& w : P.wg) { ml = tp_max(ml, w.n_lines); mc = tp_max(mc, w.n_corners); ms = tp_max(ms, w.n_slots); mit = tp_max(mit, w.n_li); }
         stats[8] = ml; stats[9] = mc; stats[10] = ms; stats[11] = mit;
+        stats[12] = P.rows_max;   // rows per lane of the largest patch (above PK_ROWS_PER_LANE: the rows beyond the registers live in LDS)
     }
     if (!P.ok) return -1;
     if (owner_v) memcpy(owner_v, P.owner_v.data(), sizeof(int32_t) * NP);

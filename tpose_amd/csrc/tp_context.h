@@ -285,7 +285,7 @@ void drop_carry(tp_context* c);   // what the last launch left for the next is n
 int plan_patches(const tp_context* c);
 int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok, const float* speed_px = nullptr);
 int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false);
-int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings = false, bool probe = false);
+int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings = false, bool probe = false, bool rings_emit = false);
 int probe_speeds(tp_context* c, const tp_params& p, float dp);   // tp_prepare: a few grad-iters nobody keeps, for the planner
 // tp_replan.hip
 int take_replan(tp_context* c);

@@ -438,17 +438,19 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
             PK_WNOTE(9, (unsigned long long)__popcll(__ballot(rows[0] > RT)) | ((unsigned long long)extra << 16));
         }
         for (int k = tid; k < extra * parts; k += PK_THREADS) {
-            const int kk = parts > 1 ? k / PK_UNCACHED_PARTS : k, part = parts > 1 ? k % PK_UNCACHED_PARTS : 0;
+            const int kk = parts > 1 ? k / PK_UNCACHED_PARTS : k, sub = parts > 1 ? k % PK_UNCACHED_PARTS : 0;   // (sub: which part of the lane-item; `part` is the patch)
             const int j = back ? extra - 1 - kk : kk;
             pk_acc a;
-            const int l = pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, 0, w.li_cap, j, a, part, parts);
+            const int l = pk_walk_lane(V, table, tiled, A.px_pitch, A.vw.W, w.n_lines_all, 0, w.li_cap, j, a, sub, parts);
             fold(l, a);
         }
         PK_WSTAMP(6);
         __syncthreads();
         PK_STAMP(3); PK_WSTAMP(7);
         if (ering && !emit) {   // tp_iterate_until: the energy of the base variants, frame by frame (the plan walks their lines every grad-iter)
-            for (int k = tid; k < w.n_base; k += PK_THREADS) {
+            // (by the LAST threads of the workgroup, round 6: the first ones form the corners right below, and a thread that did both had a
+            // base variant's chain -- three line sums, an average, an energy: 0.4 us -- in front of its corner's, on the path to the step)
+            for (int k = PK_THREADS - 1 - tid; k < w.n_base; k += PK_THREADS) {
                 int t;
                 const pk_var mv = pk_base_var(V, k, t);
                 pk_i4 col = {0, 0, 0, 0};
@@ -554,14 +556,17 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 }
             }
         }
-        if (emit) {   // base variants (i = 0) of the triangles whose first vertex this patch owns
-            for (int k = tid; k < w.n_base; k += PK_THREADS) {
+        if (emit) {   // base variants (i = 0) of the triangles whose first vertex this patch owns (the last threads: beside the corners, not behind them)
+            for (int k = PK_THREADS - 1 - tid; k < w.n_base; k += PK_THREADS) {
                 int t;
                 const pk_var mv = pk_base_var(V, k, t);
                 pk_i4 col = {0, 0, 0, 0};
                 if (A.flavour == 1) { const int4 c = A.ca[t]; col.x = c.x; col.y = c.y; col.z = c.z; }
                 if (A.flavour == 0) A.ca_out[t] = make_int4((int32_t)mv.r, (int32_t)mv.g, (int32_t)mv.b, 0);
-                A.ten[t] = pk_energy_var(mv, A.flavour, col); A.cn[t] = (int32_t)mv.n;
+                const int32_t en = pk_energy_var(mv, A.flavour, col);
+                A.ten[t] = en; A.cn[t] = (int32_t)mv.n;
+                // (tp_iterate_until's last chunk: its last frame leaves the reference's buffers AND its ring entry -- no frame run twice)
+                if (ering && !banded) ering[(size_t)it * A.NT + t] = en;
             }
         }
         PK_STAMP(4); PK_WSTAMP(8);

@@ -54,6 +54,9 @@ int check_persist_status(tp_context* c) {
     c->mutations++; c->tail_is_finish = false;  // (what a retrieve returns is about to change)
     // (snapshots taken behind launches that did nothing hold a half-written buffer: no plan is cut from them)
     c->snap_pending[0] = c->snap_pending[1] = false; c->iters_since_snap = 0;
+    // (what the launches that gave up left for the next one is of positions the replay below discards, and its age counts grad-iters that never
+    // took effect: a hint only -- tl / nc / cut / items stay self-consistent per workgroup -- but nothing is gained by keeping it)
+    drop_carry(c);
     if (c->worker) { std::lock_guard<std::mutex> lk(c->worker->m); c->worker->superseded = true; }
     std::vector<tp_context::journal_entry> todo(c->journal.begin() + (completed < c->journal.size() ? completed : c->journal.size()), c->journal.end());
     c->journal.clear();
@@ -299,7 +302,7 @@ void leave_device(tp_context* c) {   // (the caller has waited for the context's
 
 // n grad-iters of the persistent kernel -- the last one writes `tenergy`, `colnum`, `colacc`, `gradient` --, then
 // `points_out` -> `points` / `epos`
-int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings, bool probe) {
+int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings, bool probe, bool rings_emit) {
     while (n > 0) {
         if (!probe) if (int rc = take_replan(c)) return rc;   // (a plan cut on the side since an earlier call, if it is ready)
         // long calls go chunk by chunk (a chunk and a half rather than a short tail)
@@ -334,7 +337,8 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
             if (c->carry_written) c->warm_launches++;
             c->carry_written = true;
         }
-        A.emit = n == k && !rings && !probe; A.ten = c->ten; A.cn = c->cn; A.ca_out = c->ca; A.gr = c->gr;
+        // (rings_emit: a chunk of tp_iterate_until that is the call's last -- its last frame writes the reference's buffers as a tp_iterate call's does)
+        A.emit = n == k && !probe && (!rings || (rings_emit && c->n_bands == 1)); A.ten = c->ten; A.cn = c->cn; A.ca_out = c->ca; A.gr = c->gr;
         A.vspeed = banded ? nullptr : c->vspeed;   // (bands keep the plan they cut together)
         if (rings && !banded_rings(c)) { A.ering = c->ering; A.pring = c->pring; }
         if (rings && banded_rings(c)) {
@@ -515,7 +519,10 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
         const int32_t* ering = shared ? band_ering(c, c->band) + (size_t)c->ring_half * (PK_RING_FRAMES / 2) * (size_t)NT : c->ering;
         const float2* pring = shared ? band_pring(c, c->band) + (size_t)c->ring_half * (PK_RING_FRAMES / 2) * (size_t)c->NP : c->pring;
         if (int rc = host_ring((size_t)256 * NT)) return rc;   // (for the longest chunk at once: freeing pinned memory waits for the device)
-        if (int rc = enqueue_persistent(c, *p, dp, C, true)) return rc;
+        // (the chunk that ends the call: its last frame leaves the buffers itself, so that a call that runs out of frames -- or converges in
+        // its very last one -- runs no frame twice; 25 us of a 20-frame call)
+        const bool emits = !shared && C == left;
+        if (int rc = enqueue_persistent(c, *p, dp, C, true, false, emits)) return rc;
         // the frames' sums: on the device for the long chunks of a context on its own (one wave per frame, written into the pinned buffer:
         // 256 frames of 3000 energies are 3 MB across the link and 0.1 ms of host additions otherwise); short chunks and a band split's
         // rings (the bands' shared mailboxes) are read back and summed on the host -- a launch more would cost a short chunk more than it saves
@@ -540,10 +547,12 @@ int tp_iterate_until(tp_context* c, const tp_params* p, int max_frames, double t
             // back to the start of the last frame that counts, and that frame once more on the two-kernel path: it writes the
             // buffers the reference reads back (`tenergy`, `colnum`, `colacc`, `gradient`) and takes the step
             const int last = converged ? j : C - 1;
-            tp_launch_persist_finish(make_launch(c, p->image_slot, dp), pring + (size_t)last * c->NP, nullptr, nullptr, 1, c->stream);
-            c->epos_stale = false; c->tail_is_finish = false;
-            enqueue_iter(c, *p, dp);
-            HIP_TRY(c, hipGetLastError());
+            if (!(emits && last == C - 1)) {   // (the chunk's own last frame left everything in place)
+                tp_launch_persist_finish(make_launch(c, p->image_slot, dp), pring + (size_t)last * c->NP, nullptr, nullptr, 1, c->stream);
+                c->epos_stale = false; c->tail_is_finish = false;
+                enqueue_iter(c, *p, dp);
+                HIP_TRY(c, hipGetLastError());
+            }
             break;
         }
         if (chunk < 256) chunk *= 2;

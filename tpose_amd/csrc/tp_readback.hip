@@ -6,6 +6,9 @@ namespace tpctx {
 
 // the frame mirror of this triangulation (pinned; grown when the triangulation outgrows it) into a launch
 int frame_mirror_into(tp_context* c, tp_launch& L) {
+    // (NT + 64 entries: what the schedules' shortcuts look at.  Mirroring all 13 NT entries for callers that read whole buffers back, as the
+    // reference's loop does, was tried in round 6: the frame's kernels then store 312 KB more across the link four bytes at a time, and the
+    // frame went from 60 to 95 us -- the copy kernel's 16-byte stores behind the frame are the faster way)
     const int fn = (int)std::min<size_t>((size_t)13 * c->NT, (size_t)c->NT + 64);
     const size_t need = (size_t)8 * fn + (size_t)8 * c->NP;
     if (need > c->frame_mirror_bytes) {
