@@ -25,6 +25,7 @@ cpif $S/photo_timing.txt $D/r06_photo_timing.txt
 cpif $S/ta_bench.txt $D/r06_ta_bench.txt
 cpif $S/pmc_traffic_4096_12000.json $D/r06_pmc_traffic_4096_12000.json
 cpif $S/pmc_traffic_2048_3000.json $D/r06_pmc_traffic_2048_3000.json
+cpif $S/pmc_traffic_2048_3000_synthetic.json $D/r06_pmc_traffic_2048_3000_synthetic_x0.10.json
 cpif $S/pmc_persist.json $D/r06_pmc_persist.json
 cpif $S/ipc_handover.txt $D/r06_ipc_handover.txt
 cpif $S/band_timing_4096_12000.json $D/r06_band_timing_4096_12000.json
