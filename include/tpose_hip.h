@@ -203,9 +203,12 @@ int tp_iterate_until(tp_context* ctx, const tp_params* p, int max_frames, double
 enum { TP_FRAME_GO_ON = 0, TP_FRAME_STOP_REPLAY = 1, TP_FRAME_STOP = 2 };
 typedef int (*tp_frame_fn)(void* user, int frame, const int32_t* tenergy, const float* points);
 int tp_iterate_frames(tp_context* ctx, const tp_params* p, int max_frames, tp_frame_fn fn, void* user, int* frames);
-/* Optional: build the launch graph tp_iterate replays for these parameters now (it is otherwise built by the
- * first tp_iterate of >= 16 iterations after an upload), so that no later call pays for it.  Runs nothing.
- * The reference has no counterpart -- its frame loop issues GL calls one by one (triangulate/main.cpp:190-204). */
+/* Optional: build what tp_iterate needs for these parameters now -- the plan of the persistent launches (or the launch graph of the two-kernel
+ * path) -- so that no later call pays for it.  Round 6: where persistent launches are in use it also PROBES how far the mesh's vertices move per
+ * grad-iter (8 grad-iters of the persistent kernel whose results nobody keeps: positions and every buffer of the context stay as they are) and
+ * cuts the plan weighted by that -- on a photograph a tenth of the patches hold the vertices that jump a pixel per grad-iter, and a plan balanced
+ * by rows alone makes everybody wait for them.  The reference has no counterpart -- its frame loop issues GL calls one by one
+ * (triangulate/main.cpp:190-204). */
 int tp_prepare(tp_context* ctx, const tp_params* p);
 
 /* Buffer::retrieve (triangulate/main.cpp:201-204, 221): copies `count` elements (int32 / float /
