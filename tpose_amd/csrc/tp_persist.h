@@ -526,12 +526,12 @@ TP_HD void pk_walk_lds_rows(const pk_view& V, int s, pk_rows& t, uint32_t live, 
     *word = pc;
 }
 template <int RR, int RL, int R>
-TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, const char* table, int W, const char* tiled = nullptr) {
+TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, const char* table, int W, const char* tiled = nullptr, bool hot = false) {
     static_assert(RR <= R && RR + RL <= 32, "one bit per row");
     pk_rows t;
     int first = 0;
     if (C.TL == 0) { t.n = 0; t.x = 0; t.xs = 0; t.row = 0; t.rs = 0; }
-    else t = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch, PK_STALE_TILED ? &first : nullptr);
+    else t = pk_lane_rows(V.wk[C.l], C.c, C.TL, C.magic, pitch, &first);
     const uint32_t live = t.n >= 32 ? 0xffffffffu : ((1u << t.n) - 1u);   // bit u: row u exists
     const bool moved = t.row != C.row0;   // another first row: every record is another row's (an endpoint crossed a pixel row)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -570,7 +570,7 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
                 g_pk_fault[13] = (unsigned long long)blockIdx.x | ((unsigned long long)threadIdx.x << 32);
             }
 #endif
-            if (PK_STALE_TILED && tiled)
+            if ((PK_STALE_TILED || hot) && tiled)   // (hot: one answer per workgroup -- a scalar branch)
                 C.rec[u] = pk_load_rec(tiled, tp_px_tiled_row_part(((uint32_t)first + (uint32_t)u * (uint32_t)pk_row_step(C.TL)) & on, (uint32_t)pitch) + tp_px_tiled_col_part((uint32_t)col));
             else
                 C.rec[u] = pk_load_rec(table, ((t.row + (uint32_t)u * t.rs) & on) + ((uint32_t)col << 4));

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 for (int i = 0; i < PK_NI; i++)
                     if (pk_slot_release(cache[i], V, how == 2)) {
                         if (how != 2) V.freel[__hip_atomic_fetch_add(&V.flags[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = tid + i * PK_THREADS;
-                        else if (!PK_CHUNK_MAJOR) V.freel[pk_place_of_slot(tid + i * PK_THREADS)] = tid + i * PK_THREADS;
+                        else if (!PK_CHUNK_MAJOR) V.freel[w.hot ? tid + i * PK_THREADS : pk_place_of_slot(tid + i * PK_THREADS)] = tid + i * PK_THREADS;   // (hot: a line's chunks on adjacent lanes)
                     }
                 __syncthreads();
                 // pass C: free slots to the chunks that want one; the uncached lane-items numbered
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
 #pragma unroll
             for (int i = 0; i < PK_NI; i++)
                 rows[i] = (it == 0 && tiled && !PK_EXP_NOFILL) ? pk_walk_fill<RR, RL>(cache[i], V, tid + i * PK_THREADS, A.px_pitch, tiled, table, A.vw.W)
-                                                                : pk_walk_pass<RR, RL>(cache[i], V, tid + i * PK_THREADS, A.px_pitch, table, A.vw.W, tiled);
+                                                                : pk_walk_pass<RR, RL>(cache[i], V, tid + i * PK_THREADS, A.px_pitch, table, A.vw.W, tiled, w.hot != 0);
             PK_STAMP(8); PK_WSTAMP(5);
             if (RL > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the records requested into LDS have landed: the compiler does not count those)
 #pragma unroll

@@ -98,7 +98,14 @@ struct pk_wg {
     int32_t off_base;          // [n_base] {t, own | slot_1 << 10 | slot_2 << 20, line of edge 0 | edge 1 << 16, line of edge 2 | flips of edges 0, 1, 2 << 16}
     int32_t lds_bytes;         // dynamic LDS of this workgroup (pk_lds_bytes)
     int32_t lds_rows;          // rows per lane whose records live in LDS: 0, or PK_LDS_ROWS when some patch of the plan takes more than PK_ROWS_PER_LANE (the same for every patch)
+    int32_t hot;               // 1 (round 6): most of this patch's rows change their crossing column every grad-iter (the planner knows from the vertices'
+                               // speeds) -- its slots are handed out line by line onto ADJACENT lanes and stale rows come from the tiled table, so that
+                               // the lanes of a wave-load ask for consecutive rows of one line: one cache line for up to four of them
 };
+#ifndef PK_HOT_FRACTION
+#define PK_HOT_FRACTION 0.4    /* share of a patch's rows expected stale per grad-iter from which the patch counts as hot (swept 0.25 ... 0.75: calls of 20 on
+                                  meninas 10.4 / 10.5 / 10.6 / 10.6 us, on fruit 10.7 / 10.8 / 11.3 / 11.1; long calls the same within the noise) */
+#endif
 
 struct pk_plan {
     bool ok = false;
@@ -297,6 +304,10 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
         }
     }
 
+    // which patches are hot: the share of their rows expected stale, from the weights with and without the speeds
+    std::vector<double> wcold;
+    static const bool no_hot = getenv("TPOSE_NO_HOT_LAYOUT") != nullptr;   // (A/B)
+    if (vspeed && !no_hot) { std::vector<float> r0; std::vector<int> d0; pk_vertex_work(NP, NT, tris, points, NE, edge_uv, he_edge, H, nullptr, r0, wcold, d0); }
     std::vector<std::vector<int>> own_v((size_t)parts);
     for (auto& q : a) own_v[P.owner_v[q.v]].push_back(q.v);   // (a is in bisection order: neighbours stay neighbours)
     // vertex -> corners (t, s), in triangle order
@@ -330,6 +341,12 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
         };
         for (int v : own_v[p]) slot(v);
         w.n_own_v = (int)own_v[p].size();
+        if (!wcold.empty()) {
+            double a = 0.0, b = 0.0;
+            for (int v : own_v[p]) { a += wv[v]; b += wcold[v]; }
+            static const double hot_from = [] { const char* e = getenv("TPOSE_HOT_FRACTION"); return e ? atof(e) : (double)PK_HOT_FRACTION; }();   // (tuning runs only)
+            w.hot = (b > 0.0 && (a / b - 1.0) / (double)pk_stale_cost() > hot_from) ? 1 : 0;
+        }
         for (int v : own_v[p])
             for (int j = voff[v]; j < voff[v + 1]; j++) {
                 const int h = vadj[j], t = h / 3, s = h - 3 * t;
