@@ -7,9 +7,15 @@ sys.path.insert(0, ROOT)
 os.environ["TPOSE_HIP_LIB"] = os.path.join(ROOT, "tpose_amd", "variants", "libtpose_hip_debug.so")
 import numpy as np
 from tpose_amd import capi, synth
-img, pts, tris, he, ratio = synth.workload(2048, 2048, 3000, contrast=0.1)
+from tpose_amd import photos
+img, pts, tris, he, ratio, label = photos.raster_from_env(2048, 2048, 3000)   # (TPOSE_PHOTO=meninas: the headline picture)
+print(label)
 ctx = capi.Context(0, 2048, 2048); ctx.set_image(capi.IMAGE_A, img); ctx.upload(pts, tris, None)
-p = capi.default_params(0); ctx.iterate(p, 300); ctx.iterate(p, 40); ctx.synchronize()
+p = capi.default_params(0); ctx.prepare(p)
+# TPOSE_LAUNCH_AFTER=n: n grad-iters before the stamped launch (default 300; the driver's shape: 5, then calls of 20)
+for n in [int(v) for v in os.environ.get("TPOSE_LAUNCH_AFTER", "300").split(",")]:
+    ctx.iterate(p, n)
+ctx.iterate(p, 40); ctx.synchronize()
 lib = ctx.lib; lib.tp_debug_dump_persist.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 buf = np.zeros(512 * 64 * 16, np.uint64); assert lib.tp_debug_dump_persist(ctx.h, buf.ctypes.data, buf.size) == 0
 st = buf.reshape(512, 64, 16)[:256, :40].astype(np.int64)
@@ -22,12 +28,12 @@ if (e > 0).all():
 if (st[:, 0, 6] > 0).all() and (st[:, 0, 7] > 0).all():
     print("grad-iter 0, P1 in parts (us, medians): line set-up + barrier %.2f, the cut of the lines on one wave + barrier %.2f, lane-item table + the lanes' items + barrier %.2f"
           % (np.median(st[:, 0, 6] - st[:, 0, 1]) / 100.0, np.median(st[:, 0, 7] - st[:, 0, 6]) / 100.0, np.median(st[:, 0, 2] - st[:, 0, 7]) / 100.0))
-print("it  start(med, us after the first workgroup's first stamp)  period  P0  P1  P3  P6")
+print("it  start(med, us after the first workgroup's first stamp)  period  P0  P1  P3  P6 (medians over workgroups) | P1 max, P3 max")
 for it in range(24):
     s = np.median(st[:, it, 0] - t0) / 100.0
     per = np.median(st[:, it + 1, 0] - st[:, it, 0]) / 100.0
     ph = [np.median(st[:, it, k + 1] - st[:, it, k]) / 100.0 for k in range(4)]
-    print("%2d  %7.1f  %6.2f  %5.2f %5.2f %5.2f %5.2f" % (it, s, per, ph[0], ph[1], ph[2], ph[3]))
+    print("%2d  %7.1f  %6.2f  %5.2f %5.2f %5.2f %5.2f | %5.2f %5.2f" % (it, s, per, ph[0], ph[1], ph[2], ph[3], (st[:, it, 2] - st[:, it, 1]).max() / 100.0, (st[:, it, 3] - st[:, it, 2]).max() / 100.0))
 print("grad-iters 0..19 end %.1f us after the first stamp (steady state would be %.1f)" % (np.median(st[:, 20, 0] - t0) / 100.0, 20 * np.median(st[:, 30:39, 0][:, 1:] - st[:, 30:39, 0][:, :-1]) / 100.0))
 
 # the cuts of the lines inside the stamped window: set-up (stamp 1 -> 6), pass A on one wave (6 -> 7), passes B-D (7 -> 2)
