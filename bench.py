@@ -548,6 +548,7 @@ def main():
             if args.flavour == 1:
                 cu.set_image(capi.IMAGE_B, imgB)
             cu.upload(pts, tris, colors)
+            cu.prepare(params)   # (like the timed context: census, and the probe of the vertices' speeds for the first plan)
 
             def one_until():
                 n, state["tot"], _ = cu.iterate_until(params, args.steps, 0.0, state["tot"])   # (a threshold nothing meets: exactly `steps` frames)

@@ -147,6 +147,7 @@ struct tp_context {
     // balance under the speeds of the day, not only when vertices have drifted.
     float* vspeed = nullptr; size_t cap_vspeed = 0;     // device, [NP][2], t-pose units per grad-iter
     float* snap_speed[2] = {nullptr, nullptr};          // pinned, beside snap_host
+    std::vector<float> last_speed_px; uint64_t speed_generation = 0;   // the speeds the last plan of this triangulation was weighted with (pixels per grad-iter)
     double plan_balance = 1.0;                          // heaviest patch / mean patch of the current plan under the weights it was cut with
     double plan_heaviest_vertex = 0.0;                  // heaviest VERTEX / mean patch, likewise (a patch owns whole vertices: the floor of plan_balance)
     uint64_t probed_generation = 0;                     // the triangulation tp_prepare has probed the speeds of

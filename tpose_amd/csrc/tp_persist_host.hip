@@ -200,6 +200,7 @@ int plan_patches(const tp_context* c) { return c->n_bands > 1 ? c->n_bands * c->
 
 // cut a plan from `points` and install it in plan buffer `slot`.  c->plan is replaced only when the new plan is usable.
 int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok, const float* speed_px) {
+    if (speed_px && speed_px != c->last_speed_px.data()) { c->last_speed_px.assign(speed_px, speed_px + c->NP); c->speed_generation = c->generation; }
     pk_plan np;
     pk_build_plan(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
                   c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, plan_patches(c), PK_LDS_LIMIT, np,
@@ -231,11 +232,13 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every) {
     if (c->census == -6 && c->n_bands == 1 && std::chrono::steady_clock::now() >= c->persist_retry_at)
         c->census = 1;   // (the census itself had passed: a launch gave up later, check_persist_status)
     if (c->census != 1) return TP_OK;
+    bool recut_same_mesh = false;
     if (c->plan_generation == c->generation && base_every && !c->plan_base_every) {
         // the plan of this triangulation does not walk the base lines in every grad-iter yet: cut it again (from the
         // upload-time positions; a later re-plan follows the mesh) -- nothing in flight reads the plan buffers by then
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->plan_generation = 0;
+        recut_same_mesh = true;
     }
     if (c->plan_generation != c->generation) {
         c->plan_generation = c->generation;
@@ -243,7 +246,10 @@ int ensure_plan(tp_context* c, float dp, bool* use, bool base_every) {
         c->plan_base_every = base_every;
         c->snap_pending[0] = c->snap_pending[1] = false;   // (uploads synchronise the stream: nothing is in flight)
         bool ok = false;
-        if (int rc = build_plan(c, c->h_points.data(), dp, 0, &ok)) return rc;
+        // (the same mesh cut again for the other kind of plan: what is known about its vertices' speeds -- tp_prepare's probe, a re-plan -- still holds)
+        const bool keep_speed = recut_same_mesh && c->speed_generation == c->generation && c->last_speed_px.size() == (size_t)c->NP;
+        if (!keep_speed) c->last_speed_px.clear();
+        if (int rc = build_plan(c, c->h_points.data(), dp, 0, &ok, keep_speed ? c->last_speed_px.data() : nullptr)) return rc;
         if (ok) {
             const size_t np = (size_t)c->NP;
             if (c->n_bands > 1 && np > c->band_cap) { c->plan.ok = false; c->plan.why = "more vertices than the bands' mailboxes hold"; *use = false; return TP_OK; }

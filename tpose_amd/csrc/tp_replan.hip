@@ -50,6 +50,7 @@ int take_replan(tp_context* c) {
     w->done = false;
     if (w->superseded || w->generation != c->generation || c->plan_generation != c->generation || w->base_every != c->plan_base_every || !w->plan.ok || c->n_bands > 1) return TP_OK;
     if (int rc = install_plan(c, w->plan, w->points.data(), c->plan_slot ^ 1)) return rc;
+    if (!w->speed.empty()) { c->last_speed_px = w->speed; c->speed_generation = c->generation; }
     c->plan_balance = w->balance;
     c->replans++;
     return TP_OK;
