@@ -401,13 +401,24 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
         const int n_unc = emit ? n_unc_all_now : n_unc_now;
         PK_STAMP(2);
         // ---- P3: walk -- one table record per (line, row); chunks of a line meet in LDS
-        auto fold = [&](int l, const pk_acc& a) {
+        auto fold = [&](int l, const pk_acc& a, int rot = 0) {
             if (a.xs | a.nodd | a.r | a.q) {
                 unsigned long long* s = V.sums + (size_t)l * PK_SUM_STRIDE;
                 unsigned long long wd[PK_SUM_WORDS];
                 pk_fold_words(a, wd);
+                if (w.hot) {
+                    // (a hot patch keeps a line's chunks on ADJACENT lanes: word q of all of them in one instruction is one address, and same-address
+                    // LDS atomics serialise -- so lane k starts with word k mod 4: four neighbours, four words)
 #pragma unroll
-                for (int q = 0; q < PK_SUM_WORDS; q++) atomicAdd(&s[q], wd[q]);
+                    for (int q = 0; q < PK_SUM_WORDS; q++) {
+                        const int k = (q + rot) & 3;
+                        const unsigned long long v = k == 0 ? wd[0] : k == 1 ? wd[1] : k == 2 ? wd[2] : wd[3];
+                        atomicAdd(&s[k], v);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < PK_SUM_WORDS; q++) atomicAdd(&s[q], wd[q]);
+                }
             }
         };
         // Lane-items WITHOUT a slot (a patch with more chunks than slots; the base lines of a call's last grad-iter), every other grad-iter
@@ -431,7 +442,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 pk_acc a;
                 pk_walk_sum<RR, RL>(cache[i], rows[i], V, tid + i * PK_THREADS, A.px_pitch, table, A.vw.W, a);
                 if (rows[i] > RT) V.flags[8] = 1;   // (the lines want cutting again)
-                fold(cache[i].l, a);
+                fold(cache[i].l, a, tid);
             }
             PK_STAMP(9); PK_WSTAMP(15);
             // (how many of the wave's lanes have more rows than records | lane-items without a slot beyond those in LDS << 16 | those in LDS << 32)
