@@ -103,8 +103,9 @@ struct pk_wg {
                                // the lanes of a wave-load ask for consecutive rows of one line: one cache line for up to four of them
 };
 #ifndef PK_HOT_FRACTION
-#define PK_HOT_FRACTION 0.4    /* share of a patch's rows expected stale per grad-iter from which the patch counts as hot (swept 0.25 ... 0.75: calls of 20 on
-                                  meninas 10.4 / 10.5 / 10.6 / 10.6 us, on fruit 10.7 / 10.8 / 11.3 / 11.1; long calls the same within the noise) */
+#define PK_HOT_FRACTION 0.1    /* share of a patch's rows expected stale per grad-iter from which the patch counts as hot.  Swept before the hot patches folded
+                                  in rotated word order (0.25 ... 0.75: little difference) and after (0.03 / 0.07 / 0.1 / 0.15 / every patch hot: meninas' long calls 7.35 /
+                                  7.3 / 7.3 / 7.35 / 7.35 us against 7.6-7.8 at 0.4; every patch hot costs the synthetic x0.10 raster 0.2 us, 0.03-0.15 nothing) */
 #endif
 
 struct pk_plan {
