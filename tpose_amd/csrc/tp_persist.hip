@@ -36,6 +36,9 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 #define PK_CHUNK_MAJOR 0   /* 1: a cut of everything hands slots out chunk-major (tp_persist.h) -- measured: 5 % faster on the full-contrast raster, 2 % slower on
                              the bench's; 0: line by line, a line's chunks on lanes far apart */
 #endif
+#ifndef PK_ROT_ALL
+#define PK_ROT_ALL 0       /* 1 (experiment): every patch folds in rotated word order, not only the hot ones */
+#endif
 #ifndef PK_UNCACHED_PARTS
 #define PK_UNCACHED_PARTS 4   /* lanes that share a lane-item without cached records when a patch has few of those */
 #endif
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(PK_T
                 unsigned long long* s = V.sums + (size_t)l * PK_SUM_STRIDE;
                 unsigned long long wd[PK_SUM_WORDS];
                 pk_fold_words(a, wd);
-                if (w.hot) {
+                if (w.hot || PK_ROT_ALL) {
                     // (a hot patch keeps a line's chunks on ADJACENT lanes: word q of all of them in one instruction is one address, and same-address
                     // LDS atomics serialise -- so lane k starts with word k mod 4: four neighbours, four words)
 #pragma unroll
