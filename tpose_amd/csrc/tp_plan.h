@@ -68,11 +68,13 @@
 #define PK_SLACK_ROWS 3      /* rows a line may grow before its chunks are cut again */
 #endif
 #ifndef PK_STALE_COST
-#define PK_STALE_COST 2.5f   /* what a table look-up costs MORE when its row's crossing column has changed since the last grad-iter (the record is fetched
+#define PK_STALE_COST 1.8f   /* what a table look-up costs MORE when its row's crossing column has changed since the last grad-iter (the record is fetched
                                 again: a cache line through the CU's texture path; profiles/r06_ta_bench.txt, r06_meninas_timeline_2000_rows_only_plan.json: a
                                 patch whose rows are all stale walks for 9 us, one whose rows stand for 1.7) -- the planner's weight of a row is
                                 1 + this x P(stale).  Swept on four rasters (profiles/r06_experiments.txt): 1.5 / 2.5 / 4 / 6 -> meninas 8.3 / 8.0 / 8.3 /
-                                9.4 us per grad-iter: beyond 2.5 the patches of standing vertices get more rows than their threads keep records for */
+                                9.4 us per grad-iter: beyond 2.5 the patches of standing vertices get more rows than their threads keep records for -- and again once hot
+                                patches fetched their stale rows from shared cache lines (experiments 17-19): 1.2 / 1.8 / 2.5 / 3.5 -> meninas 6.9 / 7.0 / 7.35 / 8.1 in long
+                                calls, 10.5 / 9.8 / 10.4 / 10.9 in calls of 20; 1.8 kept */
 #endif
 #ifndef PK_RECUT
 #define PK_RECUT 64          /* grad-iters between two looks at the chunks of a patch's lines (a power of two) */
