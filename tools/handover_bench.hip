@@ -27,6 +27,7 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 #define NF 13
 
 struct args {
+    unsigned long long* lbox;  // local == 2: a second mailbox of the same shape, written with PLAIN stores and polled with sc1 loads by readers on the owner's XCD
     unsigned long long* box;   // [2][256 * NV][pad * 2]
     unsigned* xcc;             // [256] XCC id of every patch's workgroup; [256]: arrival counter
     int turns, work, wide, pad, depth, presleep, local;
@@ -39,6 +40,17 @@ __device__ __forceinline__ int patch_of_block(int b) { return (b & 7) * 32 + (b 
 __device__ __forceinline__ void place(int p, int& px, int& py) { const int r = p >> 5, i = p & 31; px = (r & 3) * 4 + (i & 3); py = (r >> 2) * 8 + (i >> 2); }
 __device__ __forceinline__ int patch_at(int px, int py) { return ((py >> 3) * 4 + (px >> 2)) * 32 + (py & 7) * 4 + (px & 3); }
 
+// local == 2 (round 6, the round-5 review's item 2a): sc1 loads of a granule the owner wrote with a PLAIN store -- if an agent-scope load is served by
+// the XCD's L2 and the plain store leaves the line there, a same-XCD hand-over never goes to the memory side
+__device__ __forceinline__ void poll_plain_sc1(gu64* g, uint32_t tag, uint32_t& va, uint32_t& vb, unsigned long long limit_ticks, bool& timed_out) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned long long a = __hip_atomic_load(g, RLX_AGENT), b = __hip_atomic_load(g + 1, RLX_AGENT);
+        if ((uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag) { va = (uint32_t)a; vb = (uint32_t)b; return; }
+        if (wall_clock64() - t0 > limit_ticks) { timed_out = true; va = vb = 0; return; }   // (the store never became visible: fall back is the caller's)
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
 template <int DEPTH, int WIDE>
 __device__ __forceinline__ void poll(gu64* g, uint32_t tag, bool local, uint32_t& va, uint32_t& vb) {
     unsigned long long ra[DEPTH], rb[DEPTH];
@@ -108,7 +120,12 @@ __global__ __launch_bounds__(64) void k_bench(args A) {
         if (e > 1 && q >= 0) {
             for (int z = 0; z < A.presleep; z++) __builtin_amdgcn_s_sleep(1);
             uint32_t va, vb;
-            poll<DEPTH, WIDE>(box + (size_t)(e & 1) * stride + ((size_t)q * NV + k) * A.pad * 2, tag, local, va, vb);
+            const size_t at = (size_t)(e & 1) * stride + ((size_t)q * NV + k) * A.pad * 2;
+            if (A.local == 2 && local) {
+                bool timed_out = false;
+                poll_plain_sc1((gu64*)A.lbox + at, tag, va, vb, 2000ull, timed_out);   // (20 us: then the global mailbox)
+                if (timed_out) { atomicAdd(&A.stats[2], 1); poll<DEPTH, WIDE>(box + at, tag, false, va, vb); }
+            } else poll<DEPTH, WIDE>(box + at, tag, A.local == 1 && local, va, vb);
             acc += va + vb;
         }
         __syncthreads();
@@ -116,7 +133,9 @@ __global__ __launch_bounds__(64) void k_bench(args A) {
         if (A.work) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < (unsigned long long)A.work) __builtin_amdgcn_s_sleep(1); }
         if (tid < 2 * NV) {
             const unsigned long long w = ((unsigned long long)(0x80000000u | (uint32_t)(e + 1)) << 32) | (uint32_t)(acc + e);
-            __hip_atomic_store(box + (size_t)((e + 1) & 1) * stride + ((size_t)p * NV + (tid >> 1)) * A.pad * 2 + (tid & 1), w, RLX_AGENT);
+            const size_t at = (size_t)((e + 1) & 1) * stride + ((size_t)p * NV + (tid >> 1)) * A.pad * 2 + (tid & 1);
+            if (A.local == 2) A.lbox[at] = w;   // (a plain store: it stays in this XCD's L2)
+            __hip_atomic_store(box + at, w, RLX_AGENT);
         }
     }
     if (tid == 0) A.out[b] = wall_clock64() - t_start;
@@ -127,7 +146,8 @@ static double run(args A, int lds) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_bench<DEPTH, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipMemset(A.box, 0, (size_t)2 * 256 * NV * A.pad * 2 * 8);
     hipMemset(A.xcc, 0, 257 * 4);
-    hipMemset(A.stats, 0, 8);
+    hipMemset(A.stats, 0, 12);
+    hipMemset(A.lbox, 0, (size_t)2 * 256 * NV * A.pad * 2 * 8);
     hipLaunchKernelGGL((k_bench<DEPTH, WIDE>), dim3(256), dim3(64), lds, 0, A);
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); exit(1); }
     std::vector<unsigned long long> t(256);
@@ -143,7 +163,8 @@ int main(int argc, char** argv) {
     hipMalloc(&A.box, (size_t)2 * 256 * NV * maxpad * 2 * 8);
     hipMalloc(&A.xcc, 257 * 4);
     hipMalloc(&A.out, 256 * 8);
-    hipMalloc(&A.stats, 8);
+    hipMalloc(&A.stats, 12);
+    hipMalloc(&A.lbox, (size_t)2 * 256 * NV * maxpad * 2 * 8);
     A.turns = 20000;
     const int lds = 100 * 1024;   // one workgroup per CU
     struct cfg { int work, wide, pad, depth, presleep, local; };
@@ -153,7 +174,8 @@ int main(int argc, char** argv) {
         {380, 0, 8, 1, 0, 0}, {380, 0, 16, 1, 0, 0}, {380, 1, 16, 1, 0, 0}, {380, 1, 64, 1, 0, 0},   // a line / 256 bytes / 1 KB per vertex
         {380, 0, 1, 2, 0, 0}, {380, 0, 1, 4, 0, 0},                  // requests in flight
         {380, 0, 1, 1, 2, 0}, {380, 0, 1, 1, 4, 0}, {380, 0, 1, 1, 8, 0}, {380, 1, 1, 1, 4, 0},     // wait before the first poll
-        {380, 0, 1, 1, 0, 1}, {380, 1, 1, 1, 0, 1}, {380, 1, 16, 1, 0, 1}, {0, 1, 1, 1, 0, 1},       // same-XCD granules from that XCD's L2
+        // (local == 1, round 5: sc0 loads of the global mailbox for same-XCD granules -- served by the CU's own L1, they never see the post: the run hangs; left out)
+        {380, 0, 1, 1, 0, 2}, {0, 0, 1, 1, 0, 2}, {380, 0, 16, 1, 0, 2},   // same-XCD granules: plain store + sc1 loads of an XCD-local copy
         {380, 0, 1, 1, 0, 0},
     };
     printf("work wide pad depth presleep local | period us | hand-over us\n");
@@ -164,10 +186,10 @@ int main(int argc, char** argv) {
         else if (c.depth == 1) us = run<1, 0>(A, lds);
         else if (c.depth == 2) us = run<2, 0>(A, lds);
         else us = run<4, 0>(A, lds);
-        int st[2];
-        hipMemcpy(st, A.stats, 8, hipMemcpyDeviceToHost);
-        printf("%4d %4d %3d %5d %8d %5d | %9.3f | %6.3f   (neighbour reads on the owner's XCD: %d of %d)\n", c.work, c.wide, c.pad, c.depth, c.presleep, c.local, us,
-               us - c.work / 100.0, st[0], st[1]);
+        int st[3];
+        hipMemcpy(st, A.stats, 12, hipMemcpyDeviceToHost);
+        printf("%4d %4d %3d %5d %8d %5d | %9.3f | %6.3f   (neighbour reads on the owner's XCD: %d of %d; local polls that timed out: %d)\n", c.work, c.wide, c.pad, c.depth, c.presleep, c.local, us,
+               us - c.work / 100.0, st[0], st[1], st[2]);
         fflush(stdout);
     }
     return 0;
