@@ -207,7 +207,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             }
             memset(V.sums, 0, sizeof(unsigned long long) * PK_SUM_STRIDE * (size_t)w.n_lines_all);
             if (recut) {   // the four passes of a cut (tp_persist.h, "SLOTS"): the wave's lanes / the slots one after the other
-                const int RRk = pk_rr_for(P.rows_max);   // tp_launch_persist's choice
+                const int RRk = w.lds_rows == PK_LDS_ROWS_BIG ? PK_ROWS_BIG : pk_rr_for(P.rows_max);   // tp_launch_persist's choice (tp_persist_host.hip)
                 int changed = 0;
                 int rpl = it == 0 ? w.rows : S[p].rpl;
                 bool first = it == 0;
@@ -268,7 +268,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             // P3
             if (g_walk_stats && it < g_walk_stats_iters) {
                 int64_t* ws = g_walk_stats + 6 * (size_t)it;
-                const int RRk = pk_rr_for(P.rows_max);   // tp_launch_persist's choice
+                const int RRk = w.lds_rows == PK_LDS_ROWS_BIG ? PK_ROWS_BIG : pk_rr_for(P.rows_max);   // tp_launch_persist's choice (tp_persist_host.hip)
                 int64_t over_rows = 0, stale = 0;
                 for (int j = 0; j < PK_CACHED; j++) {   // (what pk_walk_pass is about to find, without changing anything)
                     const auto& C = S[p].cache[j];
@@ -289,7 +289,8 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
             }
             for (int j = 0; j < PK_CACHED; j++) {   // the cached slots (a slot without a lane-item walks nothing)
                 pk_acc a;
-                if (w.lds_rows) pk_walk_cached<PK_ROWS_PER_LANE, PK_LDS_ROWS>(S[p].cache[j], V, j, table, pitch, W, a);
+                if (w.lds_rows == PK_LDS_ROWS_BIG) pk_walk_cached<PK_ROWS_PER_LANE, PK_LDS_ROWS_BIG>(S[p].cache[j], V, j, table, pitch, W, a);
+                else if (w.lds_rows) pk_walk_cached<PK_ROWS_PER_LANE, PK_LDS_ROWS>(S[p].cache[j], V, j, table, pitch, W, a);
                 else pk_walk_cached<PK_ROWS_PER_LANE, 0>(S[p].cache[j], V, j, table, pitch, W, a);
                 if (S[p].cache[j].TL != 0) {   // what the slot keeps now -- in registers and in LDS -- is the record of every row's CURRENT crossing column
                     const auto& C = S[p].cache[j];
@@ -300,7 +301,7 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
                         const uint32_t col = u < n ? (uint32_t)pk_next_col(r, W) : 0u;
                         const uint32_t off = (u < n ? r.row + (uint32_t)u * r.rs : 0u) + (col << 4);
                         const int v = u - PK_ROWS_PER_LANE;
-                        const uint32_t have = v < 0 ? (uint32_t)C.col[u] : (uint32_t)V.lcol[(size_t)j * PK_LDS_ROWS + v];
+                        const uint32_t have = v < 0 ? (uint32_t)C.col[u] : (uint32_t)V.lcol[(size_t)j * 8 + v];
                         const void* rec = v < 0 ? (const void*)&C.rec[u] : (const void*)(V.lrec + 16 * ((size_t)v * PK_CACHED + j));
                         if (have != col || memcmp(rec, table + off, 16) != 0) return -14;
                     }

@@ -79,7 +79,7 @@ TP_HD void pk_carve(char* base, const pk_wg& w, pk_view& V) {
     V.ldir = (int32_t*)p; p += pk_align16(w.n_lines_all * 4);
     V.flags = (int32_t*)p; p += 64;
     V.lrec = p; p += (size_t)w.lds_rows * 16 * PK_CACHED;
-    V.lcol = (uint16_t*)p;
+    V.lcol = (uint16_t*)p; p += w.lds_rows ? (size_t)16 * PK_CACHED : 0;   // (eight 16-bit columns per slot: two 64-bit words of four)
 }
 
 // P1b, lane l < n_lines: line l = (local edge, version) -- the walker of the whole line
@@ -507,42 +507,41 @@ TP_HD void pk_lds_fetch(const char* src, char* wave_run, int lane) {
     memcpy(wave_run + 16 * (size_t)lane, src, 16);
 #endif
 }
-template <int RR, int RL>
-TP_HD void pk_walk_lds_rows(const pk_view& V, int s, pk_rows& t, uint32_t live, bool moved, const char* table, int W) {
-    static_assert(RL == 0 || RL == 2 || RL == 4, "a slot's crossing columns in LDS are one 64-bit word");
-    if (RL == 0) return;
-    uint64_t* const word = reinterpret_cast<uint64_t*>(V.lcol) + s;
-    uint64_t pc = *word;
-    char* const run = V.lrec + 16 * (size_t)(s & ~63);
-#pragma unroll
-    for (int u = 0; u < RL; u++) {
-        const uint32_t on = 0u - ((live >> (RR + u)) & 1u);
-        const uint32_t col = (uint32_t)pk_next_col(t, W) & on;
-        if (moved || col != (uint32_t)((pc >> (16 * u)) & 0xffffu)) {
-            pk_lds_fetch(table + (((t.row + (uint32_t)(RR + u) * t.rs) & on) + (col << 4)), run + 16 * (size_t)u * PK_CACHED, s & 63);
-            pc = (pc & ~(0xffffull << (16 * u))) | ((uint64_t)col << (16 * u));
-        }
-    }
-    *word = pc;
-}
 // (round 6) A plan's instantiation follows its LARGEST patch: on a photograph one patch in ten takes 17-20 rows per lane and every workgroup ran the
 // rows beyond the registers -- 60 instructions of the pass, 16 of the sums, 0.35 us -- for lanes that have no such rows.  A WAVE none of whose lanes
-// has more than RR rows skips them (device only: the CPU replay keeps checking every slot), and marks its slots' columns in LDS as belonging
-// to no row (0xffff: no raster has that many columns), so that whatever the slot finds there when a lane-item of more rows arrives is fetched again.
+// has more than RR rows skips them -- and one none of whose lanes has more than RR + 4 the second four of eight -- (device only: the CPU replay
+// keeps checking every slot), and marks its slots' columns in LDS as belonging to no row (0xffff: no raster has that many columns), so that
+// whatever the slot finds there when a lane-item of more rows arrives is fetched again.  h: which four of the rows
 template <int RR>
-TP_HD bool pk_lds_rows_idle(int n) {
+TP_HD bool pk_lds_rows_idle(int n, int h = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return !__any(n > RR);
+    return !__any(n > RR + 4 * h);
 #else
-    (void)n; return false;
+    (void)n; (void)h; return false;
 #endif
 }
 template <int RR, int RL>
-TP_HD bool pk_lds_rows_skipped(const pk_view& V, int s, int n) {
-    if (RL == 0) return true;
-    if (!pk_lds_rows_idle<RR>(n)) return false;
-    reinterpret_cast<uint64_t*>(V.lcol)[s] = ~0ull;
-    return true;
+TP_HD void pk_walk_lds_rows(const pk_view& V, int s, int n, pk_rows& t, uint32_t live, bool moved, const char* table, int W) {
+    static_assert(RL == 0 || RL == 2 || RL == 4 || RL == 8, "a slot's crossing columns in LDS are two 64-bit words of four");
+    if (RL == 0) return;
+    char* const run = V.lrec + 16 * (size_t)(s & ~63);
+#pragma unroll
+    for (int h = 0; h < (RL + 3) / 4; h++) {
+        uint64_t* const word = reinterpret_cast<uint64_t*>(V.lcol) + 2 * (size_t)s + h;
+        if (pk_lds_rows_idle<RR>(n, h)) { *word = ~0ull; continue; }   // (idle at h: idle beyond)
+        uint64_t pc = *word;
+#pragma unroll
+        for (int v = 0; v < 4 && 4 * h + v < RL; v++) {
+            const int u = 4 * h + v;
+            const uint32_t on = 0u - ((live >> (RR + u)) & 1u);
+            const uint32_t col = (uint32_t)pk_next_col(t, W) & on;
+            if (moved || col != (uint32_t)((pc >> (16 * v)) & 0xffffu)) {
+                pk_lds_fetch(table + (((t.row + (uint32_t)(RR + u) * t.rs) & on) + (col << 4)), run + 16 * (size_t)u * PK_CACHED, s & 63);
+                pc = (pc & ~(0xffffull << (16 * v))) | ((uint64_t)col << (16 * v));
+            }
+        }
+        *word = pc;
+    }
 }
 template <int RR, int RL, int R>
 TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, const char* table, int W, const char* tiled = nullptr, bool hot = false) {
@@ -597,7 +596,7 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
             C.col[u] = col;
         }
     }
-    if (!pk_lds_rows_skipped<RR, RL>(V, s, n)) pk_walk_lds_rows<RR, RL>(V, s, t, live, moved, table, W);
+    pk_walk_lds_rows<RR, RL>(V, s, n, t, live, moved, table, W);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PK_NO_PRIO)
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -627,7 +626,7 @@ TP_HD int pk_walk_fill(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
         C.col[u] = col;
         row += (uint32_t)pk_row_step(C.TL);
     }
-    if (!pk_lds_rows_skipped<RR, RL>(V, s, n)) pk_walk_lds_rows<RR, RL>(V, s, t, live, true, table, W);
+    pk_walk_lds_rows<RR, RL>(V, s, n, t, live, true, table, W);
     return n;
 }
 // step 2: the line's partial sums of this lane (the crossing columns are the cached ones by now: they are added up here,
@@ -646,13 +645,18 @@ TP_HD void pk_walk_sum(const pk_lane_cache<R>& C, int n, const pk_view& V, int s
         pk_add_unpacked(lo, hi, a);
     }
     if (RL > 0 && !pk_lds_rows_idle<RR>(n)) {
-        const uint64_t pc = reinterpret_cast<const uint64_t*>(V.lcol)[s];
         uint64_t lo = 0, hi = 0;
 #pragma unroll
-        for (int u = 0; u < RL; u++) {
-            a.xs += (uint32_t)((pc >> (16 * u)) & 0xffffu);
-            const pk_rec d = *reinterpret_cast<const pk_rec*>(V.lrec + 16 * ((size_t)u * PK_CACHED + s));
-            lo += d.lo; hi += d.hi;
+        for (int h = 0; h < (RL + 3) / 4; h++) {
+            if (h && pk_lds_rows_idle<RR>(n, h)) continue;
+            const uint64_t pc = reinterpret_cast<const uint64_t*>(V.lcol)[2 * (size_t)s + h];
+#pragma unroll
+            for (int v = 0; v < 4 && 4 * h + v < RL; v++) {
+                const int u = 4 * h + v;
+                a.xs += (uint32_t)((pc >> (16 * v)) & 0xffffu);
+                const pk_rec d = *reinterpret_cast<const pk_rec*>(V.lrec + 16 * ((size_t)u * PK_CACHED + s));
+                lo += d.lo; hi += d.hi;
+            }
         }
         pk_add_unpacked(lo, hi, a);
     }

@@ -663,11 +663,13 @@ int tp_persist_set_lds(int bytes) {
     if (!rc) rc = set_lds_rr<PK_ROWS_PER_LANE>(bytes);
     if (!rc) rc = set_lds_rr<PK_ROWS_MID>(bytes);
     if (!rc) rc = set_lds_rr<PK_ROWS_MAX>(bytes);
+    if (!rc) rc = set_lds_rr<PK_ROWS_BIG>(bytes);
     return rc;
 }
 // rows: the most rows per lane of any patch of the plan (pk_plan::rows_max); the census passes PK_ROWS_PER_LANE
 void tp_launch_persist(const pk_args& A, int grid, int rows, int lds_bytes, hipStream_t s) {
     const dim3 g((unsigned)grid), b(PK_THREADS);
+    if (rows > PK_ROWS_MAX) { launch_rr<PK_ROWS_BIG>(A, g, b, (size_t)lds_bytes, s); return; }   // (eight rows per lane in LDS: the plan has made the room)
     switch (pk_rr_for(rows)) {
         case PK_RR0: launch_rr<PK_RR0>(A, g, b, (size_t)lds_bytes, s); break;
         case PK_RR1: launch_rr<PK_RR1>(A, g, b, (size_t)lds_bytes, s); break;

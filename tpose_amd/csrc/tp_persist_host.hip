@@ -204,7 +204,7 @@ int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok,
     pk_plan np;
     pk_build_plan(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
                   c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, plan_patches(c), PK_LDS_LIMIT, np,
-                  c->plan_base_every, PK_ROWS_MAX, speed_px);
+                  c->plan_base_every, PK_ROWS_BIG, speed_px);
     if (np.ok) {
         std::vector<float> rows; std::vector<double> wv; std::vector<int> deg;
         pk_vertex_work(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(), c->H, speed_px, rows, wv, deg);
@@ -373,7 +373,8 @@ int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool 
             shared_device = T->contexts > 1;
             if (shared_device && T->last && T->owner != c) HIP_TRY(c, hipStreamWaitEvent(c->stream, T->last, 0));
         }
-        tp_launch_persist(A, grid, c->plan.rows_max, c->plan.lds_bytes, c->stream);
+        // (a plan with eight LDS rows per lane runs the 24-row instantiation whatever its largest patch takes today: its lines may grow)
+        tp_launch_persist(A, grid, !c->plan.wg.empty() && c->plan.wg[0].lds_rows == PK_LDS_ROWS_BIG ? PK_ROWS_BIG : c->plan.rows_max, c->plan.lds_bytes, c->stream);
         if (banded) tp_launch_band_collect(make_launch(c, p.image_slot, dp), A, c->points_out, c->stream);
         if (!self) tp_launch_persist_finish(make_launch(c, p.image_slot, dp), c->points_out, c->d_status, c->h_status, 0, c->stream);
         c->epos_stale = true; c->tail_is_finish = true;

@@ -61,7 +61,15 @@
 #define PK_LDS_ROWS 4
 #define PK_ROWS_MAX (PK_ROWS_PER_LANE + PK_LDS_ROWS)
 #define PK_ROWS_MID (PK_ROWS_PER_LANE + PK_LDS_ROWS / 2)   /* an instantiation between: the first plans beyond the registers need a row or two */
-#define PK_LDS_ROW_BYTES (PK_THREADS * PK_NI * (16 + 2))   /* per row: a record and its crossing column for every thread */
+/* Round 6: EIGHT rows in LDS (24 per lane) for the plans that need them.  On a photograph the patches of standing vertices take the rows the
+   fast ones shed and outgrow 768 slots x 20 rows between two plans; the lane-items without a slot they then walk cost such a patch 1.4-2.1 us of
+   every grad-iter and made them the slowest of the grid (profiles/r06_persist_timeline_after4000.json).  Since a wave whose lanes all have at
+   most 16 rows skips the LDS rows, and one whose lanes have at most 20 the second four (tp_persist.h: pk_lds_rows_idle), the extra rows cost only the
+   waves that have them. */
+#define PK_LDS_ROWS_BIG 8
+#define PK_ROWS_BIG (PK_ROWS_PER_LANE + PK_LDS_ROWS_BIG)
+#define PK_LDS_ROW_BYTES (PK_THREADS * PK_NI * 16)         /* per row: a record for every thread */
+#define PK_LDS_COL_BYTES (PK_THREADS * PK_NI * 16)         /* ... and, once, the crossing columns of up to eight such rows for every thread (two 64-bit words of four) */
 #define PK_MAX_SLOTS 1023    /* position slots of a workgroup (10-bit fields of the corner records) */
 #define PK_MAX_TL 4095       /* chunks per line */
 #ifndef PK_SLACK_ROWS
@@ -157,7 +165,7 @@ inline int pk_lds_bytes(const pk_wg& w) {
     b += pk_align16(w.n_base * 16);                 // base variants
     b += pk_align16(w.n_lines_all * 4);             // which way every line runs down the raster (this grad-iter's)
     b += 64;                                        // flags
-    return b + w.lds_rows * PK_LDS_ROW_BYTES;       // records and crossing columns of the rows beyond the registers
+    return b + w.lds_rows * PK_LDS_ROW_BYTES + (w.lds_rows ? PK_LDS_COL_BYTES : 0);   // records and crossing columns of the rows beyond the registers
 }
 
 namespace pk_detail {
@@ -252,7 +260,7 @@ inline double pk_imbalance(const std::vector<int32_t>& owner_v, const std::vecto
 // base_every: the base lines of every triangle are walked in every grad-iter (not only in the last one of a call).
 inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* points, int NE, const int32_t* edge_uv,
                           const int32_t* he_edge, int W, int H, float ratio, float dp_px, int max_parts, int lds_limit,
-                          pk_plan& P, bool base_every = false, int rows_cap = PK_ROWS_MAX, const float* vspeed = nullptr) {
+                          pk_plan& P, bool base_every = false, int rows_cap = PK_ROWS_BIG, const float* vspeed = nullptr) {
     P = pk_plan();
     if (NT < 1 || NE < 1 || max_parts < 1) { P.why = "empty triangulation"; return; }
     auto EU = [&](int e) { return edge_uv[2 * (size_t)e] & 0x3fffffff; };
@@ -465,14 +473,21 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
         P.work_max = std::max(P.work_max, work); P.work_mean += work / parts;
     }
     if (P.lds_bytes > lds_limit) { P.why = "a patch does not fit the LDS"; return; }
-    if (P.rows_max > PK_ROWS_PER_LANE) {   // rows beyond the registers: in LDS, if the tables leave the room -- or the plan again without them
-        if (P.lds_bytes + PK_LDS_ROWS * PK_LDS_ROW_BYTES > lds_limit) {
+    if (P.rows_max > PK_ROWS_PER_LANE) {   // rows beyond the registers: in LDS, if the tables leave the room -- or the plan again with fewer rows per lane
+        // (eight rows from 19 rows per lane on: lines grow between two plans, and the workgroup may take a row more per lane by itself up to what
+        // its instantiation keeps -- tp_persist.hip, the cut)
+        const int want = P.rows_max > PK_ROWS_MID ? PK_LDS_ROWS_BIG : PK_LDS_ROWS;
+        int have = want;
+        if (P.lds_bytes + have * PK_LDS_ROW_BYTES + PK_LDS_COL_BYTES > lds_limit) have = P.rows_max <= PK_ROWS_MAX ? PK_LDS_ROWS : 0;
+        if (have && P.lds_bytes + have * PK_LDS_ROW_BYTES + PK_LDS_COL_BYTES > lds_limit) have = 0;
+        if (!have || PK_ROWS_PER_LANE + have < P.rows_max) {
+            const int cap = have ? PK_ROWS_PER_LANE + have : (rows_cap > PK_ROWS_MAX && P.lds_bytes + PK_LDS_ROWS * PK_LDS_ROW_BYTES + PK_LDS_COL_BYTES <= lds_limit ? PK_ROWS_MAX : PK_ROWS_PER_LANE);
             P = pk_plan();
-            pk_build_plan(NP, NT, tris, points, NE, edge_uv, he_edge, W, H, ratio, dp_px, max_parts, lds_limit, P, base_every, PK_ROWS_PER_LANE, vspeed);
+            pk_build_plan(NP, NT, tris, points, NE, edge_uv, he_edge, W, H, ratio, dp_px, max_parts, lds_limit, P, base_every, cap, vspeed);
             return;
         }
         P.lds_bytes = 0;
-        for (auto& w : P.wg) { w.lds_rows = PK_LDS_ROWS; w.lds_bytes = pk_lds_bytes(w); P.lds_bytes = std::max(P.lds_bytes, w.lds_bytes); }
+        for (auto& w : P.wg) { w.lds_rows = have; w.lds_bytes = pk_lds_bytes(w); P.lds_bytes = std::max(P.lds_bytes, w.lds_bytes); }
     }
     P.ok = true;
 }

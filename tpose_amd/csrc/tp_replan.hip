@@ -14,7 +14,7 @@ void replan_worker_main(tp_context::replan_worker* w) {
         w->go = false;
         lk.unlock();
         pk_build_plan(w->NP, w->NT, w->tris.data(), w->points.data(), w->NE, w->edge_uv.data(), w->he_edge.data(), w->W, w->H, w->ratio,
-                      w->dp * 0.5f * (float)w->H, w->parts, PK_LDS_LIMIT, w->plan, w->base_every, PK_ROWS_MAX, w->speed.empty() ? nullptr : w->speed.data());
+                      w->dp * 0.5f * (float)w->H, w->parts, PK_LDS_LIMIT, w->plan, w->base_every, PK_ROWS_BIG, w->speed.empty() ? nullptr : w->speed.data());
         if (w->plan.ok) {
             std::vector<float> rows; std::vector<double> wv; std::vector<int> deg;
             pk_vertex_work(w->NP, w->NT, w->tris.data(), w->points.data(), w->NE, w->edge_uv.data(), w->he_edge.data(), w->H, w->speed.empty() ? nullptr : w->speed.data(), rows, wv, deg);
