@@ -28,12 +28,13 @@ if (e > 0).all():
 if (st[:, 0, 6] > 0).all() and (st[:, 0, 7] > 0).all():
     print("grad-iter 0, P1 in parts (us, medians): line set-up + barrier %.2f, the cut of the lines on one wave + barrier %.2f, lane-item table + the lanes' items + barrier %.2f"
           % (np.median(st[:, 0, 6] - st[:, 0, 1]) / 100.0, np.median(st[:, 0, 7] - st[:, 0, 6]) / 100.0, np.median(st[:, 0, 2] - st[:, 0, 7]) / 100.0))
-print("it  start(med, us after the first workgroup's first stamp)  period  P0  P1  P3  P6 (medians over workgroups) | P1 max, P3 max")
+print("it  start(med, us after the first workgroup's first stamp)  period  P0  P1  P3  P6 (medians over workgroups) | P1 max, P3 max | P3 of thread 0 in parts: scan + fetch, sums + atomics, barrier (medians)")
 for it in range(24):
     s = np.median(st[:, it, 0] - t0) / 100.0
     per = np.median(st[:, it + 1, 0] - st[:, it, 0]) / 100.0
     ph = [np.median(st[:, it, k + 1] - st[:, it, k]) / 100.0 for k in range(4)]
-    print("%2d  %7.1f  %6.2f  %5.2f %5.2f %5.2f %5.2f | %5.2f %5.2f" % (it, s, per, ph[0], ph[1], ph[2], ph[3], (st[:, it, 2] - st[:, it, 1]).max() / 100.0, (st[:, it, 3] - st[:, it, 2]).max() / 100.0))
+    sub = [np.median(st[:, it, b] - st[:, it, a]) / 100.0 for a, b in ((2, 8), (8, 9), (9, 3))]
+    print("%2d  %7.1f  %6.2f  %5.2f %5.2f %5.2f %5.2f | %5.2f %5.2f | %5.2f %5.2f %5.2f" % (it, s, per, ph[0], ph[1], ph[2], ph[3], (st[:, it, 2] - st[:, it, 1]).max() / 100.0, (st[:, it, 3] - st[:, it, 2]).max() / 100.0, sub[0], sub[1], sub[2]))
 print("grad-iters 0..19 end %.1f us after the first stamp (steady state would be %.1f)" % (np.median(st[:, 20, 0] - t0) / 100.0, 20 * np.median(st[:, 30:39, 0][:, 1:] - st[:, 30:39, 0][:, :-1]) / 100.0))
 
 # the cuts of the lines inside the stamped window: set-up (stamp 1 -> 6), pass A on one wave (6 -> 7), passes B-D (7 -> 2)

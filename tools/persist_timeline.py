@@ -34,6 +34,8 @@ p = capi.default_params(capi.TRIANGULATE)
 # TPOSE_TIMELINE_AFTER=n: n grad-iters first (their launches stamp too; the last launch's stamps are the ones read)
 after = int(os.environ.get("TPOSE_TIMELINE_AFTER", "0"))
 first = after + int(os.environ.get("TPOSE_DBG_FIRST", "0"))   # (TPOSE_DBG_FIRST: first stamped grad-iter of a launch, read by the library)
+if os.environ.get("TPOSE_TIMELINE_PREPARE"):   # (the bench's shape: tp_prepare first -- the plan with the probe's speeds)
+    ctx.prepare(p)
 if after:
     ctx.iterate(p, after)
 ctx.iterate(p, int(os.environ.get("TPOSE_DBG_FIRST", "0")) + 130)
