@@ -47,6 +47,8 @@ IT = 64
 buf = np.zeros(512 * IT * 16, np.uint64)
 assert lib.tp_debug_dump_persist(ctx.h, buf.ctypes.data, buf.size) == 0
 st = buf.reshape(512, IT, 16)[:parts].astype(np.int64)  # [workgroup, grad-iter, stamp]
+if os.environ.get("TPOSE_TIMELINE_DUMP"):   # the stamps themselves, [workgroup][grad-iter][16] (100 MHz ticks), for tools that want them per patch
+    np.save(os.environ["TPOSE_TIMELINE_DUMP"], st)
 labels = ["P0 positions in (wait)", "P1 set-up + snap", "P3 walk", "P6 corners", "P7 step + post"]
 out = {"workload": "%dx%d / %d triangles, %s, grad-iters %d.." % (W, H, tris.shape[0], raster_label, first + 8), "patches": parts,
        "units": "us; percentiles over workgroups x grad-iters 8..63 of one launch"}

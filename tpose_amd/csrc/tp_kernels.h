@@ -121,6 +121,9 @@ struct pk_args {
 #ifdef PK_DBG_BOUNDS
 int tp_persist_debug_faults(unsigned long long out[16]);   // debug flavour: table offsets beyond the table seen by k_persist
 #endif
+#ifdef PK_DBG_STALE
+int tp_persist_debug_counts(unsigned long long* out, int reset);   // counting flavour: what k_persist counted, [512][4]
+#endif
 int tp_persist_set_lds(int bytes);  // hipFuncSetAttribute(max dynamic LDS); returns the hipError_t
 void tp_launch_persist(const pk_args& A, int grid, int rows, int lds_bytes, hipStream_t s);   // grid: workgroups = patches of this launch
 // band split: the positions the launch ended with, from the own mailbox (every band posted there) into points_out; raises

@@ -272,8 +272,14 @@ struct pk_acc {
 
 struct pk_rec { uint64_t lo, hi; };   // one pixel record (tp_raster.h, "Pixel records")
 
+#if defined(PK_DBG_STALE) && defined(__HIPCC__)
+// Counting flavour (tools/stale_counts.py; never in the product): per workgroup, summed over a launch's grad-iters -- {rows of cached lane-items whose record
+// was fetched again, wave-loads that fetched them (rows x waves with at least one such lane), lane-items whose first row moved, rows walked}
+static __device__ unsigned long long g_pk_cnt[512 * 4];
+#endif
 // a record of the table at byte offset `off`.  (-DTPOSE_DEBUG -DPK_DBG_BOUNDS flavour of the library only -- tools/hostile_repro.py: offsets beyond the table are counted, the
 // first one is kept -- g_pk_fault = {table bytes, faults, offset, block | thread << 32} -- and the load is not made.)
+
 #if defined(PK_DBG_BOUNDS) && defined(__HIPCC__)
 static __device__ unsigned long long g_pk_fault[16];   // (one per translation unit; the kernel's and its reader are both in tp_persist.hip)
 #endif
@@ -565,6 +571,9 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
         }
     }
     const int n = t.n;
+#if defined(PK_DBG_STALE) && defined(__HIP_DEVICE_COMPILE__)
+    unsigned dbg_stale = 0, dbg_loads = 0;
+#endif
 #pragma unroll
     for (int u = 0; u < RR; u++) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PK_NO_PRIO)
@@ -578,6 +587,9 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
 #endif
         const uint32_t on = 0u - ((live >> u) & 1u);
         const int32_t col = pk_next_col(t, W) & (int32_t)on;
+#if defined(PK_DBG_STALE) && defined(__HIP_DEVICE_COMPILE__)
+        dbg_stale += col != C.col[u]; dbg_loads += __any(col != C.col[u]) ? 1u : 0u;
+#endif
         if (col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
 #if !defined(PK_EXP_NOLOAD)   // timing experiments only (tools/build_variants.py); never defined in the product
 #if defined(PK_DBG_BOUNDS) && defined(__HIP_DEVICE_COMPILE__)
@@ -599,6 +611,12 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
     pk_walk_lds_rows<RR, RL>(V, s, n, t, live, moved, table, W);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PK_NO_PRIO)
     __builtin_amdgcn_s_setprio(0);
+#endif
+#if defined(PK_DBG_STALE) && defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(&g_pk_cnt[4 * blockIdx.x + 0], (unsigned long long)dbg_stale);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_pk_cnt[4 * blockIdx.x + 1], (unsigned long long)dbg_loads);
+    atomicAdd(&g_pk_cnt[4 * blockIdx.x + 2], (unsigned long long)(moved && C.TL != 0));
+    atomicAdd(&g_pk_cnt[4 * blockIdx.x + 3], (unsigned long long)(n < RR ? n : RR));
 #endif
     return n;
 }

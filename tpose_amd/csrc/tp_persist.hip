@@ -656,6 +656,13 @@ void launch_rr(const pk_args& A, dim3 g, dim3 b, size_t lds, hipStream_t s) {
 #ifdef PK_DBG_BOUNDS
 int tp_persist_debug_faults(unsigned long long out[16]) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_fault), 16 * sizeof(unsigned long long)); }
 #endif
+#ifdef PK_DBG_STALE
+int tp_persist_debug_counts(unsigned long long* out, int reset) {   // counting flavour: g_pk_cnt, [512][4]
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_cnt), 512 * 4 * sizeof(unsigned long long));
+    if (!rc && reset) { static unsigned long long zero[512 * 4]; rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pk_cnt), zero, sizeof(zero)); }
+    return rc;
+}
+#endif
 int tp_persist_set_lds(int bytes) {
     int rc = set_lds_rr<PK_RR0>(bytes);
     if (!rc) rc = set_lds_rr<PK_RR1>(bytes);

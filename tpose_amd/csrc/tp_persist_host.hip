@@ -679,6 +679,22 @@ int tp_debug_persist_faults(tp_context* c, unsigned long long* out) {
 }
 #endif
 
+#ifdef PK_DBG_STALE
+// counting flavour only (tools/stale_counts.py): [512][4] what k_persist counted since the last reset; what the planner weighed the plan's patches with
+int tp_debug_persist_counts(tp_context* c, unsigned long long* out, int reset) {
+    api_guard api_lock;
+    hipStreamSynchronize(c->stream);
+    return tp_persist_debug_counts(out, reset);
+}
+int tp_debug_plan_weights(tp_context* c, float* out, int n) {   // [patch][4]: work, rows, hot, rows per lane
+    api_guard api_lock;
+    const pk_plan& P = c->plan;
+    if (!P.ok || (int)P.patch_work.size() != P.parts || n < 4 * P.parts) return TP_ERR_STATE;
+    for (int p = 0; p < P.parts; p++) { out[4 * p] = P.patch_work[p]; out[4 * p + 1] = P.patch_rows[p]; out[4 * p + 2] = (float)P.wg[p].hot; out[4 * p + 3] = (float)P.wg[p].rows; }
+    return TP_OK;
+}
+#endif
+
 #ifdef TPOSE_DEBUG
 // debug flavour only (tools/persist_timeline.py): [workgroup][grad-iter < 64][8] phase timestamps of the last persistent launch
 int tp_debug_dump_persist(tp_context* c, unsigned long long* out, int n) {

@@ -127,6 +127,7 @@ struct pk_plan {
     std::vector<pk_wg> wg;
     std::vector<int32_t> pool;
     std::vector<int32_t> owner_v;           // (kept for tests and statistics)
+    std::vector<float> patch_work, patch_rows;   // (likewise: what the planner weighed every patch with -- rows with and without the stale rows' cost)
     double work_max = 0.0, work_mean = 0.0; // weighted table look-ups per workgroup when the plan was cut (pk_edge_costs)
     int64_t lines_total = 0, foreign_total = 0;  // lines walked by all patches (9 NE if nothing were walked twice); foreign position slots
 };
@@ -357,6 +358,7 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
             for (int v : own_v[p]) { a += wv[v]; b += wcold[v]; }
             static const double hot_from = [] { const char* e = getenv("TPOSE_HOT_FRACTION"); return e ? atof(e) : (double)PK_HOT_FRACTION; }();   // (tuning runs only)
             w.hot = (b > 0.0 && (a / b - 1.0) / (double)pk_stale_cost() > hot_from) ? 1 : 0;
+            P.patch_work.push_back((float)a); P.patch_rows.push_back((float)b);
         }
         for (int v : own_v[p])
             for (int j = voff[v]; j < voff[v + 1]; j++) {
