@@ -175,6 +175,7 @@ struct tp_context {
         float ratio = 0.0f, dp = 0.0f;
         uint64_t generation = 0;
         bool base_every = false;
+        int rows_cap = PK_ROWS_BIG;   // (tp_persist_host.hip: plan_rows_cap)
         double balance = 1.0;
     };
     std::unique_ptr<replan_worker> worker;
@@ -285,6 +286,7 @@ int install_plan(tp_context* c, pk_plan& np, const float* points, int slot);
 void drop_carry(tp_context* c);   // what the last launch left for the next is not to be used (a new plan, image or dp)
 int plan_patches(const tp_context* c);
 int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok, const float* speed_px = nullptr);
+int plan_rows_cap(const tp_context* c);   // rows per lane the next cut of this triangulation starts from
 int ensure_plan(tp_context* c, float dp, bool* use, bool base_every = false);
 int enqueue_persistent(tp_context* c, const tp_params& p, float dp, int n, bool rings = false, bool probe = false, bool rings_emit = false);
 int probe_speeds(tp_context* c, const tp_params& p, float dp);   // tp_prepare: a few grad-iters nobody keeps, for the planner

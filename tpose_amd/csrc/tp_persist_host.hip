@@ -198,13 +198,18 @@ int install_plan(tp_context* c, pk_plan& np, const float* points, int slot) {
 void drop_carry(tp_context* c) { c->carry_tag = ++c->carry_seq ? c->carry_seq : ++c->carry_seq; c->carry_written = false; }
 int plan_patches(const tp_context* c) { return c->n_bands > 1 ? c->n_bands * c->band_patches : c->num_cus * PK_WG_PER_CU; }
 
+// the rows per lane a cut of this triangulation may start from: what its last plan ended with (a plan that finds no room in LDS for the rows it
+// took is cut again with fewer -- twice the planner's time, which at 4096^2 / 12 000 is milliseconds inside a call)
+int plan_rows_cap(const tp_context* c) {
+    return c->plan.ok && c->plan_generation == c->generation && c->plan.rows_cap > 0 ? c->plan.rows_cap : PK_ROWS_BIG;
+}
 // cut a plan from `points` and install it in plan buffer `slot`.  c->plan is replaced only when the new plan is usable.
 int build_plan(tp_context* c, const float* points, float dp, int slot, bool* ok, const float* speed_px) {
     if (speed_px && speed_px != c->last_speed_px.data()) { c->last_speed_px.assign(speed_px, speed_px + c->NP); c->speed_generation = c->generation; }
     pk_plan np;
     pk_build_plan(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(),
                   c->W, c->H, c->ratio, dp * 0.5f * (float)c->H, plan_patches(c), PK_LDS_LIMIT, np,
-                  c->plan_base_every, PK_ROWS_BIG, speed_px);
+                  c->plan_base_every, plan_rows_cap(c), speed_px);
     if (np.ok) {
         std::vector<float> rows; std::vector<double> wv; std::vector<int> deg;
         pk_vertex_work(c->NP, c->NT, c->h_tris.data(), points, c->NE, c->h_edge_uv.data(), c->h_he_edge.data(), c->H, speed_px, rows, wv, deg);

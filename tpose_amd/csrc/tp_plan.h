@@ -124,6 +124,7 @@ struct pk_plan {
     int parts = 0;             // workgroups (grid size)
     int lds_bytes = 0;         // max over workgroups
     int rows_max = 0;          // most rows per lane of any patch
+    int rows_cap = 0;          // the most a lane was allowed when this plan was cut (what the LDS left room for: the next cut of the same mesh starts there)
     std::vector<pk_wg> wg;
     std::vector<int32_t> pool;
     std::vector<int32_t> owner_v;           // (kept for tests and statistics)
@@ -263,6 +264,7 @@ inline void pk_build_plan(int NP, int NT, const int32_t* tris, const float* poin
                           const int32_t* he_edge, int W, int H, float ratio, float dp_px, int max_parts, int lds_limit,
                           pk_plan& P, bool base_every = false, int rows_cap = PK_ROWS_BIG, const float* vspeed = nullptr) {
     P = pk_plan();
+    P.rows_cap = rows_cap;
     if (NT < 1 || NE < 1 || max_parts < 1) { P.why = "empty triangulation"; return; }
     auto EU = [&](int e) { return edge_uv[2 * (size_t)e] & 0x3fffffff; };
     auto EV = [&](int e) { return edge_uv[2 * (size_t)e + 1] & 0x3fffffff; };

@@ -14,7 +14,7 @@ void replan_worker_main(tp_context::replan_worker* w) {
         w->go = false;
         lk.unlock();
         pk_build_plan(w->NP, w->NT, w->tris.data(), w->points.data(), w->NE, w->edge_uv.data(), w->he_edge.data(), w->W, w->H, w->ratio,
-                      w->dp * 0.5f * (float)w->H, w->parts, PK_LDS_LIMIT, w->plan, w->base_every, PK_ROWS_BIG, w->speed.empty() ? nullptr : w->speed.data());
+                      w->dp * 0.5f * (float)w->H, w->parts, PK_LDS_LIMIT, w->plan, w->base_every, w->rows_cap, w->speed.empty() ? nullptr : w->speed.data());
         if (w->plan.ok) {
             std::vector<float> rows; std::vector<double> wv; std::vector<int> deg;
             pk_vertex_work(w->NP, w->NT, w->tris.data(), w->points.data(), w->NE, w->edge_uv.data(), w->he_edge.data(), w->H, w->speed.empty() ? nullptr : w->speed.data(), rows, wv, deg);
@@ -36,7 +36,7 @@ void start_replan(tp_context* c, const float* points, float dp, const std::vecto
     w->speed = speed_px;
     w->tris = c->h_tris; w->edge_uv = c->h_edge_uv; w->he_edge = c->h_he_edge;
     w->NP = c->NP; w->NT = c->NT; w->NE = c->NE; w->W = c->W; w->H = c->H; w->parts = plan_patches(c);
-    w->ratio = c->ratio; w->dp = dp; w->generation = c->generation; w->base_every = c->plan_base_every;
+    w->ratio = c->ratio; w->dp = dp; w->generation = c->generation; w->base_every = c->plan_base_every; w->rows_cap = plan_rows_cap(c);
     w->superseded = false; w->busy = true; w->go = true;
     w->cv.notify_one();
 }
