@@ -100,18 +100,20 @@ def test_persistent_is_the_oracle_at_the_batch_size(flavour, contrast):
     ctx.close()
 
 
-@pytest.mark.parametrize("size,contrast", [(3072, 0.1), (3072, 1.0), (2300, 0.1)])
+@pytest.mark.parametrize("size,contrast", [(3072, 0.1), (3072, 1.0), (2300, 0.1), (2700, 0.1), (3500, 1.0)])
 def test_rows_beyond_the_registers_are_the_oracle(size, contrast):
-    """3072^2 / 3000: edge lines half again as long as at the metric size -- a plan of more than 16 rows per lane (k_persist<20, 0>): rows 16..19
-    of every thread's lane-item keep their records in LDS (pk_walk_lds_rows), and some lane-items have no slot at all.  14 grad-iters in one
-    launch, then 6 in a second, warm one: records kept, dropped and fetched again under the oracle.  2300^2: 17 rows per lane, the
-    instantiation with two rows in LDS (k_persist<18, 0>)."""
+    """3072^2 / 3000: edge lines half again as long as at the metric size -- a plan of more than 16 rows per lane: rows 16..23 of every thread's
+    lane-item keep their records in LDS (pk_walk_lds_rows; k_persist<24, 0>, 23 rows per lane: both words of a slot's crossing columns), and
+    at 3500^2 (24 rows per lane) some lane-items have no slot at all.  14 grad-iters in one launch, then 6 in a second, warm one: records
+    kept, dropped and fetched again under the oracle.  2300^2: 17-18 rows per lane, the instantiation with two rows in LDS (k_persist<18, 0>);
+    2700^2: 20 rows per lane in the 24-row instantiation (its waves skip the second four LDS rows)."""
     ctx, sweep, pts, tris, ratio, colors = _setup(size, size, 3000, 0, contrast)
     p = capi.default_params(0)
     ctx.iterate(p, 14)
     ctx.synchronize()
     assert ctx.info(capi.INFO_PERSIST_ITERS) == 14 and ctx.info(9) == 0
-    assert ctx.info(capi.INFO_PLAN_ROWS) > 18 if size == 3072 else ctx.info(capi.INFO_PLAN_ROWS) in (17, 18)
+    rows = ctx.info(capi.INFO_PLAN_ROWS)
+    assert {2300: rows in (17, 18), 2700: rows in (19, 20), 3072: rows > 20, 3500: rows == 24}[size], rows
     ref = O.iterate(sweep, pts, tris, 0, ratio, RATE[0], 14, colors=colors, literal=False)
     _compare(ctx, ref, 0)
     ctx.iterate(p, 6)
