@@ -160,7 +160,8 @@ static int emul_persist_impl(const uint8_t* img, size_t stride, int W, int H, fl
     const int NE = (int)(edge_uv.size() / 2);
     pk_plan P;
     pk_build_plan(NP, NT, tris, points, NE, edge_uv.data(), he_edge.data(), W, H, ratio, dp * 0.5f * (float)H, max_parts, lds_limit, P);
-    if (stats) { stats[0] = P.ok; stats[1] = P.parts; stats[2] = P.lds_bytes; stats[3] = P.lines_total; stats[4] = P.foreign_total; stats[5] = NE; }
+    if (stats) { stats[0] = P.ok; stats[1] = P.parts; stats[2] = P.lds_bytes; stats[3] = P.lines_total; stats[4] = P.foreign_total; stats[5] = NE;
+                 stats[12] = P.rows_max; stats[13] = P.wg.empty() ? 0 : P.wg[0].lds_rows; }   // (rows per lane of the largest patch; of which in LDS)
     if (!P.ok) return -1;
     if (P.parts % n_bands) return -3;
     const int p_lo = band * (P.parts / n_bands), p_hi = (band + 1) * (P.parts / n_bands);

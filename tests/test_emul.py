@@ -272,11 +272,15 @@ def test_persistent_record_cache_over_many_grad_iters(emp):
     the rows a lane keeps) over 60 grad-iters"""
     W, H, grid = 300, 200, (15, 5)
     img, _, pts, tris, ratio, _ = case(W, H, grid)
-    for rate in (0.00005, 0.0004):
-        rc, p, stats = emul_persist(emp, img, pts, tris, 0, ratio, rate, 60, max_parts=7)
+    seen = set()
+    for rate, max_parts in ((0.00005, 7), (0.0004, 7), (0.0004, 12)):
+        rc, p, stats = emul_persist(emp, img, pts, tris, 0, ratio, rate, 60, max_parts=max_parts)
         assert rc == 0
+        seen.add(int(stats[13]))
         ref = O.iterate(img, pts, tris, 0, ratio, rate, 60, literal=False)
         assert np.array_equal(p.view(np.uint32), ref["points"].view(np.uint32)), rate
+    # (the replay of the rows beyond the registers: eight rows per lane in LDS -- both words of a slot's crossing columns -- with seven patches)
+    assert 8 in seen, seen
 
 
 def test_persistent_lines_are_cut_again_on_the_device(emp):
@@ -350,8 +354,10 @@ def test_persistent_plan_statistics(emp):
     assert stats[3] <= 1.15 * 9 * stats[5]          # lines walked vs 9 per edge
     assert stats[6] <= 1.3 * stats[7]               # heaviest patch vs the mean
     # LDS per workgroup: the tables alone when no patch takes more than 16 rows per lane (this mesh: stats[12] = rows per lane of the largest patch), and
-    # PK_LDS_ROWS (4) rows of 768 records + crossing columns (18 bytes each) on top when the plan keeps rows beyond the registers in LDS
-    assert stats[2] <= 64 * 1024 + (0 if stats[12] <= 16 else 4 * 768 * 18)
+    # on top, when the plan keeps rows beyond the registers in LDS: four rows (plans of up to 18 rows per lane) or eight of 768 records of 16 bytes,
+    # plus 16 bytes of crossing columns per slot (tp_plan.h: PK_LDS_ROW_BYTES, PK_LDS_COL_BYTES)
+    lds_rows = 0 if stats[12] <= 16 else 4 if stats[12] <= 18 else 8
+    assert stats[2] <= 64 * 1024 + (lds_rows * 768 * 16 + 768 * 16 if lds_rows else 0)
     assert (np.bincount(owner[owner >= 0], minlength=256) > 0).all()
 
 
