@@ -25,10 +25,20 @@ cnt = np.zeros((512, 4), np.uint64)
 lib.tp_debug_persist_counts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 lib.tp_debug_plan_weights.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 assert lib.tp_debug_persist_counts(c.h, cnt.ctypes.data, 1) == 0
+lib.tp_debug_persist_vcounts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+lib.tp_debug_plan_owner.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+vc = np.zeros((pts.shape[0], 2), np.uint64)
+assert lib.tp_debug_persist_vcounts(c.h, vc.ctypes.data, 1) == 0
+pts0 = c.retrieve(capi.BUF_POINTS).copy()
 c.iterate(p, n); c.synchronize()
 wts = np.zeros((512, 4), np.float32)
 rc = lib.tp_debug_plan_weights(c.h, wts.ctypes.data, wts.size)   # (the plan the launch ran on, unless it was cut again inside the call)
 assert lib.tp_debug_persist_counts(c.h, cnt.ctypes.data, 1) == 0
+assert lib.tp_debug_persist_vcounts(c.h, vc.ctypes.data, 1) == 0
+if os.environ.get("TPOSE_COUNT_DUMP"):   # for tools that try other weights on the same mesh: positions at the window's start and end, what every vertex's lines fetched and walked, its patch
+    owner = np.zeros(pts.shape[0], np.int32)
+    lib.tp_debug_plan_owner(c.h, owner.ctypes.data, owner.size)
+    np.savez(os.environ["TPOSE_COUNT_DUMP"], pts0=pts0, pts1=c.retrieve(capi.BUF_POINTS), tris=tris, vstale=vc[:, 0] / float(n), vrows=vc[:, 1] / float(n), owner=owner, ratio=ratio, W=W, H=H, iters=n)
 parts = c.info(capi.INFO_PATCHES)
 blk = np.arange(parts); patch = (blk & 7) * (parts >> 3) + (blk >> 3) if parts % 8 == 0 else blk
 out = {"workload": "%dx%d / %d triangles, %s; grad-iters %d..%d" % (W, H, NT, label, after, after + n - 1), "patches": parts, "plan_weights_rc": rc,

@@ -123,6 +123,7 @@ int tp_persist_debug_faults(unsigned long long out[16]);   // debug flavour: tab
 #endif
 #ifdef PK_DBG_STALE
 int tp_persist_debug_counts(unsigned long long* out, int reset);   // counting flavour: what k_persist counted, [512][4]
+int tp_persist_debug_vcounts(unsigned long long* out, int n, int reset);   // ... and per vertex, [n][2]
 #endif
 int tp_persist_set_lds(int bytes);  // hipFuncSetAttribute(max dynamic LDS); returns the hipError_t
 void tp_launch_persist(const pk_args& A, int grid, int rows, int lds_bytes, hipStream_t s);   // grid: workgroups = patches of this launch

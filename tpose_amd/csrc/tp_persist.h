@@ -276,6 +276,9 @@ struct pk_rec { uint64_t lo, hi; };   // one pixel record (tp_raster.h, "Pixel r
 // Counting flavour (tools/stale_counts.py; never in the product): per workgroup, summed over a launch's grad-iters -- {rows of cached lane-items whose record
 // was fetched again, wave-loads that fetched them (rows x waves with at least one such lane), lane-items whose first row moved, rows walked}
 static __device__ unsigned long long g_pk_cnt[512 * 4];
+// ... and per vertex {rows fetched again, rows walked} of the lines displaced at the vertex (a base line: at its endpoint of the lower slot)
+#define PK_DBG_VCNT 65536
+static __device__ unsigned long long g_pk_vcnt[2 * PK_DBG_VCNT];
 #endif
 // a record of the table at byte offset `off`.  (-DTPOSE_DEBUG -DPK_DBG_BOUNDS flavour of the library only -- tools/hostile_repro.py: offsets beyond the table are counted, the
 // first one is kept -- g_pk_fault = {table bytes, faults, offset, block | thread << 32} -- and the load is not made.)
@@ -572,7 +575,7 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
     }
     const int n = t.n;
 #if defined(PK_DBG_STALE) && defined(__HIP_DEVICE_COMPILE__)
-    unsigned dbg_stale = 0, dbg_loads = 0;
+    unsigned dbg_stale = 0, dbg_loads = 0, dbg_live = 0;
 #endif
 #pragma unroll
     for (int u = 0; u < RR; u++) {
@@ -588,7 +591,7 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
         const uint32_t on = 0u - ((live >> u) & 1u);
         const int32_t col = pk_next_col(t, W) & (int32_t)on;
 #if defined(PK_DBG_STALE) && defined(__HIP_DEVICE_COMPILE__)
-        dbg_stale += col != C.col[u]; dbg_loads += __any(col != C.col[u]) ? 1u : 0u;
+        dbg_stale += col != C.col[u]; dbg_loads += __any(col != C.col[u]) ? 1u : 0u; dbg_live += (col != C.col[u]) && on;
 #endif
         if (col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
 #if !defined(PK_EXP_NOLOAD)   // timing experiments only (tools/build_variants.py); never defined in the product
@@ -617,6 +620,12 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
     if ((threadIdx.x & 63) == 0) atomicAdd(&g_pk_cnt[4 * blockIdx.x + 1], (unsigned long long)dbg_loads);
     atomicAdd(&g_pk_cnt[4 * blockIdx.x + 2], (unsigned long long)(moved && C.TL != 0));
     atomicAdd(&g_pk_cnt[4 * blockIdx.x + 3], (unsigned long long)(n < RR ? n : RR));
+    if (C.TL != 0) {
+        const int le = V.lines[C.l] & 0xffff, q = V.lines[C.l] >> 16;
+        const int su = V.edges[le] & 0xffff, sv = (V.edges[le] >> 16) & 0xffff;
+        const int v = V.vid[q >= 5 ? sv : q >= 1 ? su : (su < sv ? su : sv)];
+        if (v >= 0 && v < PK_DBG_VCNT) { atomicAdd(&g_pk_vcnt[2 * v], (unsigned long long)dbg_live); atomicAdd(&g_pk_vcnt[2 * v + 1], (unsigned long long)(n < RR ? n : RR)); }
+    }
 #endif
     return n;
 }

@@ -662,6 +662,12 @@ int tp_persist_debug_counts(unsigned long long* out, int reset) {   // counting 
     if (!rc && reset) { static unsigned long long zero[512 * 4]; rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pk_cnt), zero, sizeof(zero)); }
     return rc;
 }
+int tp_persist_debug_vcounts(unsigned long long* out, int n, int reset) {   // g_pk_vcnt, [n][2]
+    if (n > PK_DBG_VCNT) n = PK_DBG_VCNT;
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pk_vcnt), 2 * (size_t)n * sizeof(unsigned long long));
+    if (!rc && reset) { static unsigned long long zero[2 * PK_DBG_VCNT]; rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pk_vcnt), zero, sizeof(zero)); }
+    return rc;
+}
 #endif
 int tp_persist_set_lds(int bytes) {
     int rc = set_lds_rr<PK_RR0>(bytes);

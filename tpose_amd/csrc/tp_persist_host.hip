@@ -691,6 +691,17 @@ int tp_debug_persist_counts(tp_context* c, unsigned long long* out, int reset) {
     hipStreamSynchronize(c->stream);
     return tp_persist_debug_counts(out, reset);
 }
+int tp_debug_persist_vcounts(tp_context* c, unsigned long long* out, int reset) {   // [NP][2]: rows fetched again, rows walked
+    api_guard api_lock;
+    hipStreamSynchronize(c->stream);
+    return tp_persist_debug_vcounts(out, c->NP, reset);
+}
+int tp_debug_plan_owner(tp_context* c, int32_t* out, int n) {   // [NP]: the patch that owns the vertex in the current plan (-1: none)
+    api_guard api_lock;
+    if (!c->plan.ok || n < c->NP || (int)c->plan.owner_v.size() < c->NP) return TP_ERR_STATE;
+    for (int v = 0; v < c->NP; v++) out[v] = c->plan.owner_v[v];
+    return TP_OK;
+}
 int tp_debug_plan_weights(tp_context* c, float* out, int n) {   // [patch][4]: work, rows, hot, rows per lane
     api_guard api_lock;
     const pk_plan& P = c->plan;
