@@ -33,7 +33,6 @@ CONTRAST = 0.1          # contrast of the synthetic raster of rounds 3-5 (tpose_
 # review asked for exactly that unless the kernel's speed stopped depending on how fast the mesh moves; it still does (ms_per_step_by_contrast).
 PHOTO = "meninas"
 PHOTOS_BESIDE = ("fruit", "imageA", "shoeA")   # the other pictures the configs name, same flags (ms_per_step_on_reference_photos)
-REPLICA_PHOTOS = ("meninas", "fruit", "imageA", "imageB", "shoeA", "shoeB")   # N > 1: rank r sweeps picture r mod 6
 CHILD_ITERS = 256       # grad-iters per k_persist launch in the profiler passes
 LONG_RUN = 131072       # grad-iters of the ageing figure (ms_per_step_long_run)
 PAIR_SPLIT_DEADLINE_S = 150   # the one-pair-on-all-GPUs figure runs under this deadline (bench.py --gpus N)
@@ -414,10 +413,11 @@ def main():
     if args.share_gpu:
         local_rank = 0
 
-    # independent replica per rank: its own picture and triangulation (the same jittered grid: the pictures differ)
+    # independent replica per rank: its own context, raster tables and triangulation (its own jitter of the grid) on the headline picture -- the work of a
+    # GPU is the same at every N (weak scaling), so that the driver's efficiency compares like with like; the other pictures are timed at N = 1
     from tpose_amd import photos
     img_syn, pts, tris, he, ratio = synth.workload(W, H, NT, seed=dist_util.replica_seed(rank), contrast=CONTRAST)
-    picture = REPLICA_PHOTOS[rank % len(REPLICA_PHOTOS)] if world > 1 else PHOTO
+    picture = PHOTO
     img = photos.resample_int(photos.load(picture), W, H)
     NP = pts.shape[0]
     ctx = capi.Context(local_rank, W, H)
@@ -695,7 +695,7 @@ def main():
                 "workload": "2048x2048 RGBA8 raster = the reference's %s.png (%s) resampled by tpose_amd/photos.py: resample_int, 3000-triangle jittered grid "
                             "(50x30x2), %s flavour, one replica per GPU%s" % (picture, "BASELINE config 2's picture" if picture == "meninas" else "one of the configs' pictures",
                                                                             "warp" if args.flavour else "triangulate",
-                                                                            "" if world == 1 else " (rank r sweeps picture r mod 6 of meninas, fruit, imageA, imageB, shoeA, shoeB)"),
+                                                                            "" if world == 1 else " (every rank the same picture, its own jitter of the grid)"),
                 "raster": [W, H], "triangles": NT, "points": NP, "variants": 13 * NT,
                 "parallelism": "replicas x%d (no data-path collective)" % world,
                 "path": "persistent launches: %d patches (workgroups), %d grad-iters ran inside them.  Inside a tp_iterate call the intermediate "
