@@ -22,6 +22,7 @@ python tools/launch_profile.py > $O/launch_profile.txt 2>> $O/persist_timeline.e
 python tools/persist_check.py > $O/persist_check.txt 2>&1
 python tools/time_big.py product > $O/time_4096.txt 2>&1
 python tools/long_parity.py > $O/long_parity.txt 2>&1
+TPOSE_PHOTO=meninas python tools/long_mixed_calls.py > $O/long_mixed_calls_meninas.txt 2>&1   # 120 000 grad-iters of the photograph in calls of mixed lengths against the two-kernel path
 python tools/time_variants.py product > $O/long_run_timing.txt 2>&1
 python tools/call_length.py > $O/call_length.txt 2>&1
 python tools/contrast_sweep.py > $O/contrast_sweep.txt 2>&1

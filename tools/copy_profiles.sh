@@ -35,5 +35,6 @@ cpif $S/config2_meninas.txt $D/r06_config2_meninas.txt
 cpif $S/config3.txt $D/r06_config3_warp.txt
 cpif $S/config4.json $D/r06_config4_batch.json
 cpif $S/coop.txt $D/r06_coop.txt
+cpif $S/long_mixed_calls_meninas.txt $D/r06_long_mixed_calls_meninas.txt
 if [ -f $S/bench_two_ranks_one_gpu.json ]; then grep '^{' $S/bench_two_ranks_one_gpu.json > $D/r06_bench_two_ranks_one_gpu.json || true; fi
 ls -la $D/r06_*
