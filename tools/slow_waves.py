@@ -9,6 +9,7 @@ from tpose_amd import photos
 img, pts, tris, he, ratio, raster_label = photos.raster_from_env(2048, 2048, 3000, 0.3)
 ctx = capi.Context(0, 2048, 2048); ctx.set_image(capi.IMAGE_A, img); ctx.upload(pts, tris, None)
 p = capi.default_params(0)
+if os.environ.get("TPOSE_TIMELINE_PREPARE"): ctx.prepare(p)   # (the bench's shape: the plan with the probe's speeds)
 age = int(os.environ.get("TPOSE_AGE", "1024"))
 while age > 0:
     ctx.iterate(p, min(age, 4096)); age -= 4096
@@ -25,7 +26,7 @@ dur = (st[:, 8:, :, 6].max(axis=2) - st[:, 8:, :, 4].min(axis=2)) / 100.0
 med = np.median(dur, axis=1)
 order = np.argsort(-med)
 names = {4: "P1 barrier", 14: "LDS pass", 5: "pass", 15: "sums", 6: "folded", 7: "P3 barrier"}
-for b in list(order[:3]) + [order[-1]]:
+for b in list(order[:6]) + [order[len(order) // 2], order[-1]]:
     it = 12
     t0 = st[b, it, :, 4].min()
     print("block", b, "median P3 %.2f" % med[b])
