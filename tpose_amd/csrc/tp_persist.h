@@ -279,6 +279,9 @@ static __device__ unsigned long long g_pk_cnt[512 * 4];
 // ... and per vertex {rows fetched again, rows walked} of the lines displaced at the vertex (a base line: at its endpoint of the lower slot)
 #define PK_DBG_VCNT 65536
 static __device__ unsigned long long g_pk_vcnt[2 * PK_DBG_VCNT];
+// ... and the crossing column every (workgroup, thread, row) had BEFORE its current one: how many of the rows fetched again go back to it (a second record
+// per row would have had them) -- counted in g_pk_cnt[4 b + 1] in place of the wave-loads when PK_DBG_VICTIM is defined
+static __device__ int g_pk_prevcol[256 * PK_THREADS * 16];
 #endif
 // a record of the table at byte offset `off`.  (-DTPOSE_DEBUG -DPK_DBG_BOUNDS flavour of the library only -- tools/hostile_repro.py: offsets beyond the table are counted, the
 // first one is kept -- g_pk_fault = {table bytes, faults, offset, block | thread << 32} -- and the load is not made.)
@@ -591,7 +594,16 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
         const uint32_t on = 0u - ((live >> u) & 1u);
         const int32_t col = pk_next_col(t, W) & (int32_t)on;
 #if defined(PK_DBG_STALE) && defined(__HIP_DEVICE_COMPILE__)
-        dbg_stale += col != C.col[u]; dbg_loads += __any(col != C.col[u]) ? 1u : 0u; dbg_live += (col != C.col[u]) && on;
+        dbg_stale += col != C.col[u]; dbg_live += (col != C.col[u]) && on;
+#if defined(PK_DBG_VICTIM)
+        if (RR <= 16 && blockIdx.x < 256 && col != C.col[u]) {
+            int* pc = &g_pk_prevcol[((size_t)blockIdx.x * PK_THREADS + threadIdx.x) * 16 + u];
+            dbg_loads += (on && !moved && *pc == col && col != 0) ? 1u : 0u;   // (lane-local count here: summed by every lane below)
+            *pc = moved ? -2 : C.col[u];
+        }
+#else
+        dbg_loads += __any(col != C.col[u]) ? 1u : 0u;
+#endif
 #endif
         if (col != C.col[u]) {   // (a row beyond the line's end: the record of row 0, column 0)
 #if !defined(PK_EXP_NOLOAD)   // timing experiments only (tools/build_variants.py); never defined in the product
@@ -617,7 +629,11 @@ TP_HD int pk_walk_pass(pk_lane_cache<R>& C, const pk_view& V, int s, int pitch, 
 #endif
 #if defined(PK_DBG_STALE) && defined(__HIP_DEVICE_COMPILE__)
     atomicAdd(&g_pk_cnt[4 * blockIdx.x + 0], (unsigned long long)dbg_stale);
+#if defined(PK_DBG_VICTIM)
+    atomicAdd(&g_pk_cnt[4 * blockIdx.x + 1], (unsigned long long)dbg_loads);
+#else
     if ((threadIdx.x & 63) == 0) atomicAdd(&g_pk_cnt[4 * blockIdx.x + 1], (unsigned long long)dbg_loads);
+#endif
     atomicAdd(&g_pk_cnt[4 * blockIdx.x + 2], (unsigned long long)(moved && C.TL != 0));
     atomicAdd(&g_pk_cnt[4 * blockIdx.x + 3], (unsigned long long)(n < RR ? n : RR));
     if (C.TL != 0) {
